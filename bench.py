@@ -1,0 +1,199 @@
+#!/usr/bin/env python3
+"""bench.py -- edge-relaxations/s (N^3/t) of the max-product Floyd-Warshall hot path on MI355X.
+
+Contract (one JSON line from rank 0):
+  python bench.py --gpus N --steps K --warmup W
+  N > 1 is launched by the driver as
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+A "step" is ONE FULL SOLVE (all N pivots of runAlgo, /root/reference/src/lib/Algorithms.hs:42-61)
+of the synthetic dense matrix, restarted from the pristine input (a device-to-device copy inside
+the timed region, ~0.03 % of a step).  Workload = BASELINE.json's metric configuration:
+N = 16384, fp32, dense D1 input (floydwarshall_amd/synth.py), matrices resident in HBM.
+
+  value     = K * N^3 / t      t = wall time of the K steps, barrier + synchronize on both sides,
+                               max over ranks
+  roofline  = per-k kernel `relax_k` against HBM: algorithmic bytes per launch
+              (s*N^2 + s*U/N + 2*s*N) / average launch duration measured
+              live with HIP events on the launch stream over the timed region
+  cpu_baseline = the oracle's multithreaded dense loop (a C restatement of the reference loop --
+              the Haskell reference cannot be built here) on a bounded k-slice of the same matrix
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBPS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
+
+
+def parse_args():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=2)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--n", type=int, default=16384)
+    ap.add_argument("--dtype", default="f32", choices=["f32", "f64"])
+    ap.add_argument("--dist", default="d1", choices=["d1", "d2"])
+    ap.add_argument("--with-next", action="store_true", help="carry the next-hop matrix")
+    ap.add_argument("--block", type=int, default=64, help="pivots per broadcast (N > 1)")
+    ap.add_argument("--no-serpentine", action="store_true")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    ap.add_argument("--kslice", type=int, default=0,
+                    help="DEBUG: run only this many pivots per step (result flagged invalid)")
+    return ap.parse_args()
+
+
+def cpu_baseline(rate_host, cpu_seconds):
+    """Oracle (port of the reference loop) on a bounded k-slice, all host cores of this process."""
+    import oracle
+    n = rate_host.shape[0]
+    cores = len(os.sched_getaffinity(0))
+    work = rate_host.copy()
+    done, t_total, chunk = 0, 0.0, 8
+    while t_total < cpu_seconds and done < n:
+        k1 = min(n, done + chunk)
+        t0 = time.perf_counter()
+        oracle.relax_mt(work, None, done, k1, threads=cores)
+        t_total += time.perf_counter() - t0
+        done = k1
+    relax = float(done) * n * n
+    return {"value": relax / t_total, "unit": "edge-relaxations/s", "cores": cores,
+            "kind": "port",
+            "sample": "pivots [0,%d) of the same N=%d %s matrix (%.1f s); oracle/fw_oracle.c "
+                      "fwo_relax_mt, a C restatement of Algorithms.hs:42-61 -- the Haskell "
+                      "reference cannot be built in this image" % (done, n, rate_host.dtype, t_total)}
+
+
+def main():
+    args = parse_args()
+    import torch
+    import torch.distributed as dist
+    from floydwarshall_amd import engine, synth
+    from floydwarshall_amd import dist as fwdist
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("--gpus %d needs torch.distributed.run with %d ranks" % (args.gpus, args.gpus))
+        args.gpus = world
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+
+    n = args.n
+    np_dtype = np.float32 if args.dtype == "f32" else np.float64
+    es = np.dtype(np_dtype).itemsize
+    cfg_index = 3  # BASELINE.json configs[3]: N=16384 fp32
+    rate_host, next_host = synth.GENERATORS[args.dist](n, np_dtype, synth.BASE_SEED + cfg_index)
+
+    bounds = fwdist.row_bounds(n, world)
+    r0, r1 = bounds[rank], bounds[rank + 1]
+    pristine = torch.from_numpy(rate_host[r0:r1]).to(dev)
+    rate = torch.empty_like(pristine)
+    pristine_next = nxt = None
+    if args.with_next:
+        pristine_next = torch.from_numpy(next_host[r0:r1]).to(dev)
+        nxt = torch.empty_like(pristine_next)
+    del next_host
+    if not (rank == 0 and world == 1 and not args.no_cpu_baseline):
+        rate_host = None
+    upd = torch.zeros(engine.FWX_UPDATE_SHARDS, dtype=torch.int64, device=dev)
+    k_end = args.kslice if args.kslice > 0 else n
+    serp = not args.no_serpentine
+
+    ev_pairs = []
+
+    def step(count=False, timed=False):
+        rate.copy_(pristine)
+        if nxt is not None:
+            nxt.copy_(pristine_next)
+        if world == 1:
+            if timed:
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+            engine.dev_relax(rate, n, 0, 0, k_end, next_t=nxt, serpentine=serp,
+                             updates_t=upd if count else None)
+            if timed:
+                e1.record()
+                ev_pairs.append((e0, e1))
+        else:
+            fwdist.solve_partitioned(rate, n, rank, world, nxt=nxt, block=args.block)
+
+    def fence():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    updates = None
+    for w in range(args.warmup):
+        first = (w == 0 and world == 1)
+        if first:
+            upd.zero_()
+        step(count=first)
+        if first:
+            torch.cuda.synchronize()
+            updates = int(upd.sum().item())
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step(timed=True)
+    fence()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+
+    relax_per_step = float(k_end) * n * n
+    value = args.steps * relax_per_step / dt
+    out = {
+        "metric": "edge-relaxations/sec (N^3/t), N=%d %s" % (n, "fp32" if es == 4 else "fp64"),
+        "value": value, "unit": "edge-relaxations/s", "n_gpus": world, "steps": args.steps,
+        "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True,
+        "scaling": "strong", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
+        "config": {"workload": "N=%d dense %s rate matrix (%s), full solve = %d pivot steps per "
+                               "step, per-k engine%s" % (n, args.dtype, args.dist.upper(), k_end,
+                                                         ", with next-hop matrix" if args.with_next else ""),
+                   "n": n, "engine": "perk", "serpentine": serp,
+                   "partition": "single GPU" if world == 1 else
+                   "row-block x%d, %d-pivot snapshot panels broadcast on RCCL" % (world, args.block)},
+    }
+    if args.kslice > 0:
+        out["INVALID_debug_kslice"] = args.kslice
+
+    if world == 1 and ev_pairs:
+        launches = args.steps * k_end
+        kern_ms = sum(a.elapsed_time(b) for a, b in ev_pairs)
+        avg_us = 1e3 * kern_ms / launches
+        u_per_launch = (updates / float(k_end)) if updates is not None else 0.0
+        # B_alg = s*N^3 + s*U + 2*s*N^2 per solve (+4*U with next)
+        alg_bytes = es * n * n + (es + (4 if args.with_next else 0)) * u_per_launch + 2 * es * n
+        achieved = alg_bytes / (avg_us * 1e-6) / 1e9
+        out["roofline"] = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS,
+                           "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS, "traffic": None,
+                           "kernel": "fwx::relax_k", "avg_launch_us": avg_us,
+                           "alg_bytes_per_launch": alg_bytes, "updates_per_solve": updates,
+                           "frac_of_measured_copy_peak_6290": achieved / 6290.0}
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline(rate_host, args.cpu_seconds)
+    if rank == 0:
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,99 @@
+"""ctypes loader for libfwx.so (the C ABI of include/fwx.h).  Fails loudly: there is no fallback."""
+import ctypes
+import os
+
+PKG = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(PKG, "libfwx.so")
+
+FWX_OK = 0
+FWX_ERR_INVALID = -1
+FWX_ERR_NO_DEVICE = -2
+FWX_ERR_HIP = -3
+FWX_ERR_OOM = -4
+FWX_ERR_CYCLE = -5
+FWX_ERR_CAPACITY = -6
+FWX_ERR_UNSUPPORTED = -7
+
+FWX_F32, FWX_F64 = 0, 1
+FWX_ENGINE_AUTO, FWX_ENGINE_PERK, FWX_ENGINE_FUSED = 0, 1, 2
+FWX_UPDATE_SHARDS = 256
+
+c_i32 = ctypes.c_int32
+c_vp = ctypes.c_void_p
+
+
+class FwxOpts(ctypes.Structure):
+    _fields_ = [("struct_size", ctypes.c_uint32), ("device", c_i32), ("engine", c_i32),
+                ("k_begin", c_i32), ("k_end", c_i32), ("block", c_i32), ("serpentine", c_i32),
+                ("updates_out", ctypes.POINTER(ctypes.c_uint64))]
+
+
+class FwxSlab(ctypes.Structure):
+    _fields_ = [("n", c_i32), ("row0", c_i32), ("rows", c_i32), ("dtype", c_i32),
+                ("rate", c_vp), ("next", c_vp), ("hops", c_vp)]
+
+
+class FwxPivots(ctypes.Structure):
+    _fields_ = [("k_begin", c_i32), ("k_end", c_i32), ("rate", c_vp), ("hops", c_vp),
+                ("stride", ctypes.c_int64)]
+
+
+class FwxError(RuntimeError):
+    def __init__(self, status, what):
+        self.status = status
+        msg = lib().fwx_strerror(status).decode()
+        extra = ""
+        if status == FWX_ERR_HIP:
+            extra = " (hipError_t %d)" % lib().fwx_last_hip_error()
+        super().__init__("%s: %s%s" % (what, msg, extra))
+
+
+# Every symbol include/fwx.h declares, with its ctypes signature.
+SIGNATURES = {
+    "fwx_abi_version": (ctypes.c_int, []),
+    "fwx_device_count": (ctypes.c_int, []),
+    "fwx_strerror": (ctypes.c_char_p, [ctypes.c_int]),
+    "fwx_last_hip_error": (ctypes.c_int, []),
+    "fwx_solve_f64": (ctypes.c_int, [c_i32, c_vp, c_vp, c_vp, ctypes.POINTER(FwxOpts)]),
+    "fwx_solve_f32": (ctypes.c_int, [c_i32, c_vp, c_vp, c_vp, ctypes.POINTER(FwxOpts)]),
+    "fwx_follow_path": (ctypes.c_int, [c_i32, c_vp, c_i32, c_i32, c_vp, c_i32]),
+    "fwx_matrix_create": (ctypes.c_int, [ctypes.POINTER(c_vp), c_i32, c_i32, c_i32, c_i32, c_i32]),
+    "fwx_matrix_upload": (ctypes.c_int, [c_vp, c_vp, c_vp, c_vp]),
+    "fwx_matrix_solve": (ctypes.c_int, [c_vp, ctypes.POINTER(FwxOpts)]),
+    "fwx_matrix_download": (ctypes.c_int, [c_vp, c_vp, c_vp, c_vp]),
+    "fwx_matrix_query": (ctypes.c_int, [c_vp, c_i32, c_i32, ctypes.POINTER(ctypes.c_double), c_vp,
+                                        c_i32]),
+    "fwx_matrix_destroy": (ctypes.c_int, [c_vp]),
+    "fwx_dev_relax": (ctypes.c_int, [ctypes.POINTER(FwxSlab), ctypes.POINTER(FwxPivots), c_i32,
+                                     c_vp, c_vp]),
+    "fwx_dev_panel": (ctypes.c_int, [ctypes.POINTER(FwxSlab), c_vp, c_vp, c_vp, c_vp]),
+    "fwx_dev_relax_fused": (ctypes.c_int, [ctypes.POINTER(FwxSlab), ctypes.POINTER(FwxPivots), c_vp,
+                                           c_vp, c_vp, c_vp]),
+}
+
+_LIB = None
+
+
+def lib():
+    """Load libfwx.so from the package directory.  Raises if it has not been built."""
+    global _LIB
+    if _LIB is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                "libfwx.so is missing at %s -- build it with `python -m floydwarshall_amd.build` "
+                "(hipcc, gfx950).  floydwarshall_amd has no CPU fallback." % LIB_PATH)
+        L = ctypes.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(L, name)  # AttributeError here = header/library mismatch
+            fn.restype = res
+            fn.argtypes = args
+        if L.fwx_abi_version() != 1:
+            raise RuntimeError("libfwx ABI version mismatch")
+        _LIB = L
+    return _LIB
+
+
+def check(status, what):
+    if status < 0:
+        raise FwxError(status, what)
+    return status

@@ -1,0 +1,71 @@
+"""In-tree build of libfwx.so for gfx950 (MI355X).  hipcc cross-compiles without a GPU.
+
+    python -m floydwarshall_amd.build        # build if sources are newer than the library
+    python -m floydwarshall_amd.build -f     # force
+
+The library is git-ignored (history stays source-only) but travels with the repo snapshot to the
+GPU box, where the tests load exactly this file.
+"""
+import os
+import shutil
+import subprocess
+import sys
+
+PKG = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(PKG)
+CSRC = os.path.join(PKG, "csrc")
+LIB = os.path.join(PKG, "libfwx.so")
+
+HIP_SOURCES = ["fwx_kernels.hip", "fwx_api.hip"]
+CXX_SOURCES = []  # host mirror sources are appended below when present
+HOST_DIR = os.path.join(CSRC, "host")
+
+HIPCC_FLAGS = [
+    "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
+    "-ffp-contract=off",          # never fuse; the path has no add anyway
+    "-fno-fast-math", "-fno-gpu-rdc",
+    "-Wall", "-Wextra", "-Wno-unused-parameter",
+    "-I" + os.path.join(ROOT, "include"), "-I" + CSRC,
+]
+
+
+def _sources():
+    srcs = [os.path.join(CSRC, s) for s in HIP_SOURCES]
+    if os.path.isdir(HOST_DIR):
+        srcs += sorted(os.path.join(HOST_DIR, f) for f in os.listdir(HOST_DIR)
+                       if f.endswith(".cpp"))
+    return srcs
+
+
+def _deps():
+    deps = _sources() + [os.path.join(ROOT, "include", f)
+                         for f in os.listdir(os.path.join(ROOT, "include"))]
+    for d in (CSRC, HOST_DIR):
+        if os.path.isdir(d):
+            deps += [os.path.join(d, f) for f in os.listdir(d) if f.endswith((".h", ".hpp"))]
+    return deps
+
+
+def needs_build():
+    if not os.path.exists(LIB):
+        return True
+    t = os.path.getmtime(LIB)
+    return any(os.path.getmtime(d) > t for d in _deps())
+
+
+def build_lib(force=False, verbose=False):
+    if not force and not needs_build():
+        return LIB
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc):
+        raise RuntimeError("hipcc not found: libfwx can only be built with the ROCm toolchain")
+    cmd = [hipcc] + HIPCC_FLAGS + ["-x", "hip"] + _sources() + ["-o", LIB + ".tmp"]
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.run(cmd, check=True)
+    os.replace(LIB + ".tmp", LIB)
+    return LIB
+
+
+if __name__ == "__main__":
+    print(build_lib(force="-f" in sys.argv, verbose=True))

@@ -1,0 +1,457 @@
+// fwx_api.hip -- the C ABI of libfwx (include/fwx.h) over the gfx950 kernels.
+//
+// Replaces runAlgo (/root/reference/src/lib/Algorithms.hs:42-61) behind floydWarshall (:19-20).
+// No CPU fallback: every solve entry point needs a HIP device and says so when there is none.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include <new>
+
+#include "fwx.h"
+#include "fwx_kernels.h"
+
+static_assert(FWX_UPDATE_SHARDS == FWX_UPDATE_SHARDS_K, "shard count mismatch");
+
+namespace {
+
+thread_local int g_last_hip = 0;
+
+#define FWX_HIP(call)                                                                              \
+    do {                                                                                           \
+        hipError_t e__ = (call);                                                                   \
+        if (e__ != hipSuccess) {                                                                   \
+            g_last_hip = (int)e__;                                                                 \
+            (void)hipGetLastError();                                                               \
+            return e__ == hipErrorOutOfMemory ? FWX_ERR_OOM : FWX_ERR_HIP;                         \
+        }                                                                                          \
+    } while (0)
+
+int device_count()
+{
+    int c = 0;
+    if (hipGetDeviceCount(&c) != hipSuccess) {
+        (void)hipGetLastError();
+        return 0;
+    }
+    return c;
+}
+
+// Sets the requested device for the scope of one ABI call and restores the caller's.
+struct DeviceGuard {
+    int prev = -1;
+    bool changed = false;
+    int enter(int device)
+    {
+        const int cnt = device_count();
+        if (cnt <= 0) return FWX_ERR_NO_DEVICE;
+        if (hipGetDevice(&prev) != hipSuccess) return FWX_ERR_HIP;
+        if (device < 0) return FWX_OK;
+        if (device >= cnt) return FWX_ERR_INVALID;
+        if (device != prev) {
+            FWX_HIP(hipSetDevice(device));
+            changed = true;
+        }
+        return FWX_OK;
+    }
+    ~DeviceGuard()
+    {
+        if (changed) (void)hipSetDevice(prev);
+    }
+};
+
+struct Opts {
+    int device = -1, engine = FWX_ENGINE_AUTO, k_begin = 0, k_end = 0, block = 0, serpentine = 1;
+    uint64_t *updates_out = nullptr;
+};
+
+int read_opts(const fwx_opts *o, int n, Opts &out)
+{
+    if (o) {
+        if (o->struct_size < sizeof(fwx_opts)) return FWX_ERR_INVALID;
+        out.device = o->device;
+        out.engine = o->engine;
+        out.k_begin = o->k_begin;
+        out.k_end = o->k_end;
+        out.block = o->block;
+        out.serpentine = o->serpentine == 0 ? 1 : 0;
+        out.updates_out = o->updates_out;
+    }
+    if (out.k_end <= 0) out.k_end = n;
+    if (out.k_begin < 0 || out.k_begin > out.k_end || out.k_end > n) return FWX_ERR_INVALID;
+    if (out.engine != FWX_ENGINE_AUTO && out.engine != FWX_ENGINE_PERK &&
+        out.engine != FWX_ENGINE_FUSED)
+        return FWX_ERR_INVALID;
+    return FWX_OK;
+}
+
+// One launch per pivot over a slab; pivot rows from `prow0 + (k-k_begin)*stride`.
+template <typename T>
+int relax_range(T *rate, int32_t *next, int32_t *hops, int rows, int n, int row0, const T *prow0,
+                const int32_t *phops0, int64_t stride, int k_begin, int k_end, int serpentine,
+                unsigned long long *d_updates, hipStream_t s)
+{
+    fwx::RelaxArgs<T> a;
+    a.rate = rate; a.next = next; a.hops = hops;
+    a.rows = rows; a.n = n; a.row0 = row0; a.updates = d_updates;
+    for (int k = k_begin; k < k_end; ++k) {
+        a.prow = prow0 + (int64_t)(k - k_begin) * stride;
+        a.phops = phops0 ? phops0 + (int64_t)(k - k_begin) * stride : nullptr;
+        a.k = k;
+        a.flip = serpentine ? (k & 1) : 0;
+        FWX_HIP(fwx::launch_relax<T>(a, s));
+    }
+    return FWX_OK;
+}
+
+int sum_updates(unsigned long long *d_updates, uint64_t *out, hipStream_t s)
+{
+    unsigned long long h[FWX_UPDATE_SHARDS];
+    FWX_HIP(hipMemcpyAsync(h, d_updates, sizeof(h), hipMemcpyDeviceToHost, s));
+    FWX_HIP(hipStreamSynchronize(s));
+    uint64_t u = 0;
+    for (int i = 0; i < FWX_UPDATE_SHARDS; ++i) u += h[i];
+    *out = u;
+    return FWX_OK;
+}
+
+struct DevBuf {
+    void *p = nullptr;
+    ~DevBuf() { if (p) (void)hipFree(p); }
+    int alloc(size_t bytes)
+    {
+        FWX_HIP(hipMalloc(&p, bytes ? bytes : 1));
+        return FWX_OK;
+    }
+};
+
+template <typename T>
+int solve_host(int32_t n, T *rate, int32_t *next, int32_t *hops, const fwx_opts *o)
+{
+    if (n < 0) return FWX_ERR_INVALID;
+    if (n == 0) return FWX_OK;  // empty map -> empty matrix (AlgorithmsTest.hs:62-64)
+    if (!rate) return FWX_ERR_INVALID;
+    if (hops && !next) return FWX_ERR_INVALID;
+    Opts op;
+    int rc = read_opts(o, n, op);
+    if (rc) return rc;
+    DeviceGuard g;
+    if ((rc = g.enter(op.device))) return rc;
+
+    const size_t nn = (size_t)n * (size_t)n;
+    DevBuf d_rate, d_next, d_hops, d_upd;
+    if ((rc = d_rate.alloc(nn * sizeof(T)))) return rc;
+    if (next && (rc = d_next.alloc(nn * sizeof(int32_t)))) return rc;
+    if (hops && (rc = d_hops.alloc(nn * sizeof(int32_t)))) return rc;
+    if ((rc = d_upd.alloc(FWX_UPDATE_SHARDS * sizeof(unsigned long long)))) return rc;
+
+    hipStream_t s = nullptr;
+    FWX_HIP(hipMemcpyAsync(d_rate.p, rate, nn * sizeof(T), hipMemcpyHostToDevice, s));
+    if (next) FWX_HIP(hipMemcpyAsync(d_next.p, next, nn * sizeof(int32_t), hipMemcpyHostToDevice, s));
+    if (hops) FWX_HIP(hipMemcpyAsync(d_hops.p, hops, nn * sizeof(int32_t), hipMemcpyHostToDevice, s));
+    FWX_HIP(hipMemsetAsync(d_upd.p, 0, FWX_UPDATE_SHARDS * sizeof(unsigned long long), s));
+
+    T *dr = (T *)d_rate.p;
+    int32_t *dh = (int32_t *)d_hops.p;
+    rc = relax_range<T>(dr, (int32_t *)d_next.p, dh, n, n, 0, dr + (size_t)op.k_begin * n,
+                        dh ? dh + (size_t)op.k_begin * n : nullptr, n, op.k_begin, op.k_end,
+                        op.serpentine, op.updates_out ? (unsigned long long *)d_upd.p : nullptr, s);
+    if (rc) return rc;
+
+    FWX_HIP(hipMemcpyAsync(rate, d_rate.p, nn * sizeof(T), hipMemcpyDeviceToHost, s));
+    if (next) FWX_HIP(hipMemcpyAsync(next, d_next.p, nn * sizeof(int32_t), hipMemcpyDeviceToHost, s));
+    if (hops) FWX_HIP(hipMemcpyAsync(hops, d_hops.p, nn * sizeof(int32_t), hipMemcpyDeviceToHost, s));
+    FWX_HIP(hipStreamSynchronize(s));
+    if (op.updates_out) {
+        if ((rc = sum_updates((unsigned long long *)d_upd.p, op.updates_out, s))) return rc;
+    }
+    return FWX_OK;
+}
+
+// Single-thread device walk of the next-hop matrix (fwx_matrix_query).
+__global__ void follow_path_kernel(const int32_t *next, int n, int src, int dst, int32_t *out,
+                                   int cap, int32_t *len_out)
+{
+    int len = 0, cur = src;
+    if (next[(size_t)src * n + dst] < 0) { *len_out = 0; return; }
+    while (cur != dst || len == 0) {
+        const int nx = next[(size_t)cur * n + dst];
+        if (nx < 0 || len >= n) { *len_out = FWX_ERR_CYCLE; return; }
+        if (len >= cap) { *len_out = FWX_ERR_CAPACITY; return; }
+        out[len++] = nx;
+        cur = nx;
+    }
+    *len_out = len;
+}
+
+int check_slab(const fwx_slab *s)
+{
+    if (!s || s->n < 0 || s->rows < 0 || s->row0 < 0 || (int64_t)s->row0 + s->rows > s->n ||
+        (s->dtype != FWX_F32 && s->dtype != FWX_F64) || (s->hops && !s->next))
+        return FWX_ERR_INVALID;
+    if (s->rows > 0 && s->n > 0 && !s->rate) return FWX_ERR_INVALID;
+    return FWX_OK;
+}
+
+template <typename T>
+int panel_impl(const fwx_slab *b, T *w, int32_t *w_hops, unsigned long long *d_updates,
+                      hipStream_t s)
+{
+    const int n = b->n, k0 = b->row0, B = b->rows;
+    T *rows = (T *)b->rate;
+    fwx::RelaxArgs<T> a;
+    a.rate = rows; a.next = b->next; a.hops = b->hops;
+    a.rows = B; a.n = n; a.row0 = k0; a.updates = d_updates; a.flip = 0;
+    for (int t = 0; t < B; ++t) {
+        // Time-k snapshot of pivot row k = k0+t: every pivot < k has been applied, pivot k
+        // leaves row k unchanged (Algorithms.hs:50), later pivots will change it.
+        FWX_HIP(fwx::launch_snapshot_row<T>(w + (size_t)t * n, rows + (size_t)t * n,
+                                            b->hops ? w_hops + (size_t)t * n : nullptr,
+                                            b->hops ? b->hops + (size_t)t * n : nullptr, n, s));
+        a.prow = w + (size_t)t * n;
+        a.phops = b->hops ? w_hops + (size_t)t * n : nullptr;
+        a.k = k0 + t;
+        FWX_HIP(fwx::launch_relax<T>(a, s));
+    }
+    return FWX_OK;
+}
+
+}  // namespace
+
+struct fwx_matrix {
+    int32_t n, dtype, device;
+    void *rate;
+    int32_t *next, *hops, *scratch;
+    unsigned long long *upd;
+};
+
+extern "C" {
+
+int fwx_abi_version(void) { return FWX_ABI_VERSION; }
+
+int fwx_device_count(void) { return device_count(); }
+
+int fwx_last_hip_error(void) { return g_last_hip; }
+
+const char *fwx_strerror(int status)
+{
+    switch (status) {
+    case FWX_OK: return "ok";
+    case FWX_ERR_INVALID: return "invalid argument";
+    case FWX_ERR_NO_DEVICE: return "no HIP device visible (libfwx has no CPU fallback)";
+    case FWX_ERR_HIP: return "HIP runtime error";
+    case FWX_ERR_OOM: return "out of memory";
+    case FWX_ERR_CYCLE: return "next-hop walk does not reach the destination (cycle)";
+    case FWX_ERR_CAPACITY: return "output buffer too small";
+    case FWX_ERR_UNSUPPORTED: return "unsupported option combination";
+    default: return "unknown status";
+    }
+}
+
+int fwx_solve_f64(int32_t n, double *rate, int32_t *next, int32_t *hops, const fwx_opts *opts)
+{
+    try { return solve_host<double>(n, rate, next, hops, opts); } catch (...) { return FWX_ERR_OOM; }
+}
+
+int fwx_solve_f32(int32_t n, float *rate, int32_t *next, int32_t *hops, const fwx_opts *opts)
+{
+    try { return solve_host<float>(n, rate, next, hops, opts); } catch (...) { return FWX_ERR_OOM; }
+}
+
+int fwx_follow_path(int32_t n, const int32_t *next, int32_t src, int32_t dst, int32_t *out,
+                    int32_t cap)
+{
+    if (n < 0 || !next || src < 0 || dst < 0 || src >= n || dst >= n || cap < 0 ||
+        (cap > 0 && !out))
+        return FWX_ERR_INVALID;
+    const size_t N = (size_t)n;
+    if (next[(size_t)src * N + dst] < 0) return 0;
+    int32_t len = 0, cur = src;
+    while (cur != dst || len == 0) {
+        const int32_t nx = next[(size_t)cur * N + dst];
+        if (nx < 0 || nx >= n || len >= n) return FWX_ERR_CYCLE;
+        if (len >= cap) return FWX_ERR_CAPACITY;
+        out[len++] = nx;
+        cur = nx;
+    }
+    return len;
+}
+
+int fwx_matrix_create(fwx_matrix **out, int32_t n, int32_t dtype, int32_t with_next,
+                      int32_t with_hops, int32_t device)
+{
+    if (!out || n < 0 || (dtype != FWX_F32 && dtype != FWX_F64) || (with_hops && !with_next))
+        return FWX_ERR_INVALID;
+    *out = nullptr;
+    DeviceGuard g;
+    int rc = g.enter(device);
+    if (rc) return rc;
+    int dev = 0;
+    FWX_HIP(hipGetDevice(&dev));
+    fwx_matrix *m = new (std::nothrow) fwx_matrix();
+    if (!m) return FWX_ERR_OOM;
+    memset(m, 0, sizeof(*m));
+    m->n = n; m->dtype = dtype; m->device = dev;
+    const size_t nn = (size_t)n * (size_t)n;
+    const size_t es = dtype == FWX_F64 ? 8 : 4;
+    hipError_t e = hipMalloc(&m->rate, nn * es ? nn * es : 1);
+    if (e == hipSuccess && with_next) e = hipMalloc((void **)&m->next, nn * 4 ? nn * 4 : 1);
+    if (e == hipSuccess && with_hops) e = hipMalloc((void **)&m->hops, nn * 4 ? nn * 4 : 1);
+    if (e == hipSuccess) e = hipMalloc((void **)&m->scratch, ((size_t)n + 2) * 4);
+    if (e == hipSuccess) e = hipMalloc((void **)&m->upd, FWX_UPDATE_SHARDS * 8);
+    if (e != hipSuccess) {
+        g_last_hip = (int)e;
+        (void)hipGetLastError();
+        fwx_matrix_destroy(m);
+        return e == hipErrorOutOfMemory ? FWX_ERR_OOM : FWX_ERR_HIP;
+    }
+    *out = m;
+    return FWX_OK;
+}
+
+int fwx_matrix_destroy(fwx_matrix *m)
+{
+    if (!m) return FWX_OK;
+    DeviceGuard g;
+    (void)g.enter(m->device);
+    if (m->rate) (void)hipFree(m->rate);
+    if (m->next) (void)hipFree(m->next);
+    if (m->hops) (void)hipFree(m->hops);
+    if (m->scratch) (void)hipFree(m->scratch);
+    if (m->upd) (void)hipFree(m->upd);
+    delete m;
+    return FWX_OK;
+}
+
+int fwx_matrix_upload(fwx_matrix *m, const void *rate, const int32_t *next, const int32_t *hops)
+{
+    if (!m) return FWX_ERR_INVALID;
+    if (m->n == 0) return FWX_OK;
+    if (!rate || (m->next && !next) || (m->hops && !hops)) return FWX_ERR_INVALID;
+    DeviceGuard g;
+    int rc = g.enter(m->device);
+    if (rc) return rc;
+    const size_t nn = (size_t)m->n * (size_t)m->n, es = m->dtype == FWX_F64 ? 8 : 4;
+    FWX_HIP(hipMemcpy(m->rate, rate, nn * es, hipMemcpyHostToDevice));
+    if (m->next) FWX_HIP(hipMemcpy(m->next, next, nn * 4, hipMemcpyHostToDevice));
+    if (m->hops) FWX_HIP(hipMemcpy(m->hops, hops, nn * 4, hipMemcpyHostToDevice));
+    return FWX_OK;
+}
+
+int fwx_matrix_download(fwx_matrix *m, void *rate, int32_t *next, int32_t *hops)
+{
+    if (!m) return FWX_ERR_INVALID;
+    if (m->n == 0) return FWX_OK;
+    if ((next && !m->next) || (hops && !m->hops)) return FWX_ERR_INVALID;
+    DeviceGuard g;
+    int rc = g.enter(m->device);
+    if (rc) return rc;
+    const size_t nn = (size_t)m->n * (size_t)m->n, es = m->dtype == FWX_F64 ? 8 : 4;
+    if (rate) FWX_HIP(hipMemcpy(rate, m->rate, nn * es, hipMemcpyDeviceToHost));
+    if (next) FWX_HIP(hipMemcpy(next, m->next, nn * 4, hipMemcpyDeviceToHost));
+    if (hops) FWX_HIP(hipMemcpy(hops, m->hops, nn * 4, hipMemcpyDeviceToHost));
+    return FWX_OK;
+}
+
+int fwx_matrix_solve(fwx_matrix *m, const fwx_opts *opts)
+{
+    if (!m) return FWX_ERR_INVALID;
+    if (m->n == 0) return FWX_OK;
+    Opts op;
+    int rc = read_opts(opts, m->n, op);
+    if (rc) return rc;
+    DeviceGuard g;
+    if ((rc = g.enter(m->device))) return rc;
+    hipStream_t s = nullptr;
+    const int n = m->n;
+    unsigned long long *upd = op.updates_out ? m->upd : nullptr;
+    if (upd) FWX_HIP(hipMemsetAsync(upd, 0, FWX_UPDATE_SHARDS * 8, s));
+    if (m->dtype == FWX_F64) {
+        double *r = (double *)m->rate;
+        rc = relax_range<double>(r, m->next, m->hops, n, n, 0, r + (size_t)op.k_begin * n,
+                                 m->hops ? m->hops + (size_t)op.k_begin * n : nullptr, n,
+                                 op.k_begin, op.k_end, op.serpentine, upd, s);
+    } else {
+        float *r = (float *)m->rate;
+        rc = relax_range<float>(r, m->next, m->hops, n, n, 0, r + (size_t)op.k_begin * n,
+                                m->hops ? m->hops + (size_t)op.k_begin * n : nullptr, n,
+                                op.k_begin, op.k_end, op.serpentine, upd, s);
+    }
+    if (rc) return rc;
+    FWX_HIP(hipStreamSynchronize(s));
+    if (upd) return sum_updates(upd, op.updates_out, s);
+    return FWX_OK;
+}
+
+int fwx_matrix_query(fwx_matrix *m, int32_t src, int32_t dst, double *rate_out, int32_t *path_out,
+                     int32_t cap)
+{
+    if (!m || src < 0 || dst < 0 || src >= m->n || dst >= m->n || cap < 0 || (cap > 0 && !path_out))
+        return FWX_ERR_INVALID;
+    DeviceGuard g;
+    int rc = g.enter(m->device);
+    if (rc) return rc;
+    const size_t idx = (size_t)src * m->n + dst;
+    if (rate_out) {
+        if (m->dtype == FWX_F64) {
+            FWX_HIP(hipMemcpy(rate_out, (double *)m->rate + idx, 8, hipMemcpyDeviceToHost));
+        } else {
+            float f = 0;
+            FWX_HIP(hipMemcpy(&f, (float *)m->rate + idx, 4, hipMemcpyDeviceToHost));
+            *rate_out = (double)f;
+        }
+    }
+    if (!m->next) return FWX_ERR_INVALID;
+    const int dcap = cap < m->n ? cap : m->n;
+    hipLaunchKernelGGL(follow_path_kernel, dim3(1), dim3(1), 0, nullptr, m->next, m->n, src, dst,
+                       m->scratch + 1, dcap, m->scratch);
+    FWX_HIP(hipGetLastError());
+    int32_t len = 0;
+    FWX_HIP(hipMemcpy(&len, m->scratch, 4, hipMemcpyDeviceToHost));
+    if (len > 0) FWX_HIP(hipMemcpy(path_out, m->scratch + 1, (size_t)len * 4, hipMemcpyDeviceToHost));
+    return len;
+}
+
+int fwx_dev_relax(const fwx_slab *slab, const fwx_pivots *piv, int32_t serpentine,
+                  unsigned long long *d_updates, void *stream)
+{
+    int rc = check_slab(slab);
+    if (rc) return rc;
+    if (!piv || piv->k_begin < 0 || piv->k_end < piv->k_begin || piv->k_end > slab->n)
+        return FWX_ERR_INVALID;
+    if (slab->rows == 0 || slab->n == 0 || piv->k_end == piv->k_begin) return FWX_OK;
+    if (!piv->rate || (slab->hops && !piv->hops)) return FWX_ERR_INVALID;
+    if (device_count() <= 0) return FWX_ERR_NO_DEVICE;
+    hipStream_t s = (hipStream_t)stream;
+    if (slab->dtype == FWX_F64)
+        return relax_range<double>((double *)slab->rate, slab->next, slab->hops, slab->rows,
+                                   slab->n, slab->row0, (const double *)piv->rate, piv->hops,
+                                   piv->stride, piv->k_begin, piv->k_end, serpentine, d_updates, s);
+    return relax_range<float>((float *)slab->rate, slab->next, slab->hops, slab->rows, slab->n,
+                              slab->row0, (const float *)piv->rate, piv->hops, piv->stride,
+                              piv->k_begin, piv->k_end, serpentine, d_updates, s);
+}
+
+int fwx_dev_panel(const fwx_slab *block, void *w_rate, int32_t *w_hops,
+                  unsigned long long *d_updates, void *stream)
+{
+    int rc = check_slab(block);
+    if (rc) return rc;
+    if (block->rows == 0 || block->n == 0) return FWX_OK;
+    if (!w_rate || (block->hops && !w_hops)) return FWX_ERR_INVALID;
+    if (device_count() <= 0) return FWX_ERR_NO_DEVICE;
+    hipStream_t s = (hipStream_t)stream;
+    if (block->dtype == FWX_F64)
+        return panel_impl<double>(block, (double *)w_rate, w_hops, d_updates, s);
+    return panel_impl<float>(block, (float *)w_rate, w_hops, d_updates, s);
+}
+
+int fwx_dev_relax_fused(const fwx_slab *slab, const fwx_pivots *piv, void *col_rate,
+                        int32_t *col_next, unsigned long long *d_updates, void *stream)
+{
+    (void)slab; (void)piv; (void)col_rate; (void)col_next; (void)d_updates; (void)stream;
+    return FWX_ERR_UNSUPPORTED;
+}
+
+}  // extern "C"

@@ -1,0 +1,120 @@
+"""Row-block partitioned solve: one process per GPU, torch.distributed (RCCL over xGMI).
+
+The reference is single-threaded; this is the multi-GPU shape of the same
+loop.  Rank r owns the contiguous rows [bounds[r], bounds[r+1]) of `rate`
+(and of `next`).  Step k of runAlgo (/root/reference/src/lib/Algorithms.hs:42-61) needs, for a
+local row i, only r[i][k] / next[i][k] (local) and the pivot row r[k][.] AS IT STANDS AT THE START
+OF STEP k, which lives on one rank.  That is the only exchange, so the only collective is a
+broadcast of pivot rows.
+
+Latency, not bandwidth, is the problem (N messages of N*4 bytes): pivots are therefore exchanged
+B at a time.  The owner of pivots [k0, k0+B) runs the PANEL phase -- it evolves just those B rows
+through those B pivots in exact k order and exports the time-k snapshot of each pivot row -- and
+broadcasts the B x N snapshot panel once; every rank then applies the B pivots to its slab using
+the snapshots.  No operand and no order changes, so the result is bit-identical to the
+single-GPU solve (tests/test_dist_gloo.py, tests/test_gpu_parity.py).
+
+Look-ahead: while a rank relaxes its slab with panel b, the owner of panel b+1 first brings just
+those B rows up to date, runs their panel phase and starts the broadcast, so the exchange of
+panel b+1 overlaps the bulk of step b.
+"""
+import torch
+import torch.distributed as dist
+
+from . import engine
+
+
+def row_bounds(n, world):
+    """Contiguous, balanced row blocks: rank r owns [bounds[r], bounds[r+1])."""
+    return [(n * r) // world for r in range(world + 1)]
+
+
+def pivot_blocks(n, world, block):
+    """[(k0, B, owner)]: pivot panels never straddle two owners."""
+    bounds = row_bounds(n, world)
+    out = []
+    for r in range(world):
+        k0 = bounds[r]
+        while k0 < bounds[r + 1]:
+            b = min(block, bounds[r + 1] - k0)
+            out.append((k0, b, r))
+            k0 += b
+    return out
+
+
+class HipBackend:
+    """The product backend: libfwx kernels on torch-owned device memory, current stream."""
+
+    def panel(self, block_rate, n, k0, w, block_next=None):
+        engine.dev_panel(block_rate, n, k0, w, next_t=block_next)
+
+    def relax(self, slab_rate, n, row0, k0, k1, w, slab_next=None):
+        if slab_rate.shape[0] > 0:
+            engine.dev_relax(slab_rate, n, row0, k0, k1, pivots_t=w, next_t=slab_next)
+
+
+def solve_partitioned(rate, n, rank, world, *, nxt=None, block=64, backend=None, group=None,
+                      lookahead=True):
+    """In-place solve of this rank's slab `rate` (rows row_bounds(n, world)[rank]...).
+
+    All ranks must call this with the same n / world / block / lookahead.  Works on any device the
+    backend and the process group support (HIP + RCCL in production; the tests drive it on
+    CPU + gloo with an oracle-backed backend to check the schedule).
+
+    Schedule per panel b (pivots [k0, k0+B), snapshots W_b):
+        wait for W_b
+        owner of panel b+1: relax ONLY the rows of panel b+1 with W_b, run their panel phase
+        everyone:           start the broadcast of W_{b+1} (async, other buffer)
+        everyone:           relax the rest of the slab with W_b   <- overlaps the broadcast
+    """
+    backend = backend or HipBackend()
+    bounds = row_bounds(n, world)
+    row0, rows = bounds[rank], bounds[rank + 1] - bounds[rank]
+    assert tuple(rate.shape) == (rows, n)
+    blocks = pivot_blocks(n, world, block)
+    if not blocks:
+        return
+    bufs = [torch.empty((block, n), dtype=rate.dtype, device=rate.device) for _ in range(2)]
+
+    def sub(t, lo, hi):
+        return None if t is None else t[lo:hi]
+
+    def panel_and_broadcast(idx):
+        k0, b, owner = blocks[idx]
+        w = bufs[idx & 1][:b]
+        if rank == owner:
+            lo = k0 - row0
+            backend.panel(rate[lo:lo + b], n, k0, w, sub(nxt, lo, lo + b))
+        work = None
+        if world > 1:
+            src = owner if group is None else dist.get_global_rank(group, owner)
+            work = dist.broadcast(w, src=src, group=group, async_op=True)
+        return w, work
+
+    def relax_rows_except(skips, k0, k1, w):
+        pos = 0
+        for lo, hi in sorted(skips) + [(rows, rows)]:
+            if lo > pos:
+                backend.relax(rate[pos:lo], n, row0 + pos, k0, k1, w, sub(nxt, pos, lo))
+            pos = max(pos, hi)
+
+    w, work = panel_and_broadcast(0)
+    for idx, (k0, b, owner) in enumerate(blocks):
+        if work is not None:
+            work.wait()
+        k1 = k0 + b
+        skips = [(k0 - row0, k0 - row0 + b)] if rank == owner else []
+        nxt_w = nxt_work = None
+        if idx + 1 < len(blocks) and lookahead:
+            nk0, nb, nowner = blocks[idx + 1]
+            if rank == nowner:
+                nlo = nk0 - row0
+                backend.relax(rate[nlo:nlo + nb], n, nk0, k0, k1, w, sub(nxt, nlo, nlo + nb))
+                skips.append((nlo, nlo + nb))
+            nxt_w, nxt_work = panel_and_broadcast(idx + 1)
+            relax_rows_except(skips, k0, k1, w)
+        else:
+            relax_rows_except(skips, k0, k1, w)
+            if idx + 1 < len(blocks):
+                nxt_w, nxt_work = panel_and_broadcast(idx + 1)
+        w, work = nxt_w, nxt_work

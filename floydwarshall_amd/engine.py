@@ -1,0 +1,195 @@
+"""Python binding over the libfwx C ABI (include/fwx.h).
+
+This is plumbing for the tests, the benchmark and the multi-GPU driver: numpy arrays for the
+host-buffer entry points, raw device pointers (from torch tensors) for the device step API.
+The functions mirror the reference's seam, floydWarshall = runAlgo 0 . buildMatrix
+(/root/reference/src/lib/Algorithms.hs:19-20): `solve` IS runAlgo on the dense form.
+"""
+import ctypes
+
+import numpy as np
+
+from . import _lib
+from ._lib import (FWX_ENGINE_AUTO, FWX_ENGINE_FUSED, FWX_ENGINE_PERK, FWX_F32, FWX_F64,
+                   FWX_UPDATE_SHARDS, FwxError, FwxOpts, FwxPivots, FwxSlab, check, lib)
+
+__all__ = ["solve", "follow_path", "DeviceMatrix", "dev_relax", "dev_panel", "device_count",
+           "FwxError", "FWX_ENGINE_AUTO", "FWX_ENGINE_PERK", "FWX_ENGINE_FUSED",
+           "FWX_UPDATE_SHARDS"]
+
+
+def device_count():
+    return lib().fwx_device_count()
+
+
+def _np_ptr(a):
+    return None if a is None else a.ctypes.data_as(ctypes.c_void_p)
+
+
+def _check_arrays(rate, nxt, hops):
+    if not (isinstance(rate, np.ndarray) and rate.ndim == 2 and rate.shape[0] == rate.shape[1]):
+        raise ValueError("rate must be a square 2-D numpy array")
+    if rate.dtype not in (np.float32, np.float64) or not rate.flags.c_contiguous:
+        raise ValueError("rate must be C-contiguous float32 or float64")
+    for name, a in (("next", nxt), ("hops", hops)):
+        if a is not None and not (isinstance(a, np.ndarray) and a.shape == rate.shape
+                                  and a.dtype == np.int32 and a.flags.c_contiguous):
+            raise ValueError("%s must be a C-contiguous int32 array shaped like rate" % name)
+    if hops is not None and nxt is None:
+        raise ValueError("hops requires next")
+
+
+def _opts(device=-1, engine=FWX_ENGINE_AUTO, k_begin=0, k_end=0, block=0, serpentine=True,
+          want_updates=False):
+    o = FwxOpts()
+    o.struct_size = ctypes.sizeof(FwxOpts)
+    o.device, o.engine, o.k_begin, o.k_end, o.block = device, engine, k_begin, k_end, block
+    o.serpentine = 0 if serpentine else 1
+    u = ctypes.c_uint64(0)
+    if want_updates:
+        o.updates_out = ctypes.pointer(u)
+    return o, u
+
+
+def solve(rate, nxt=None, hops=None, *, device=-1, engine=FWX_ENGINE_AUTO, k_begin=0, k_end=0,
+          block=0, serpentine=True, count_updates=False):
+    """runAlgo (Algorithms.hs:42-61) in place on host numpy arrays, on the GPU.
+
+    Returns U (number of successful relaxations) if count_updates else None."""
+    _check_arrays(rate, nxt, hops)
+    o, u = _opts(device, engine, k_begin, k_end, block, serpentine, count_updates)
+    fn = lib().fwx_solve_f64 if rate.dtype == np.float64 else lib().fwx_solve_f32
+    check(fn(rate.shape[0], _np_ptr(rate), _np_ptr(nxt), _np_ptr(hops), ctypes.byref(o)),
+          "fwx_solve")
+    return int(u.value) if count_updates else None
+
+
+def follow_path(nxt, src, dst):
+    """Vertex indices after src up to and including dst; [] when there is no route."""
+    n = nxt.shape[0]
+    out = np.empty(max(n, 1), dtype=np.int32)
+    ln = check(lib().fwx_follow_path(n, _np_ptr(nxt), int(src), int(dst), _np_ptr(out), n),
+               "fwx_follow_path")
+    return [int(x) for x in out[:ln]]
+
+
+class DeviceMatrix:
+    """fwx_matrix handle: the solved matrix stays in HBM across queries (InSync, Types.hs:35-37)."""
+
+    def __init__(self, n, dtype=np.float64, with_next=True, with_hops=False, device=-1):
+        self.n = int(n)
+        self.dtype = np.dtype(dtype)
+        self.with_next, self.with_hops = bool(with_next), bool(with_hops)
+        h = ctypes.c_void_p()
+        check(lib().fwx_matrix_create(ctypes.byref(h), self.n,
+                                      FWX_F64 if self.dtype == np.float64 else FWX_F32,
+                                      int(self.with_next), int(self.with_hops), device),
+              "fwx_matrix_create")
+        self._h = h
+
+    def upload(self, rate, nxt=None, hops=None):
+        _check_arrays(rate, nxt, hops)
+        assert rate.shape[0] == self.n and rate.dtype == self.dtype
+        check(lib().fwx_matrix_upload(self._h, _np_ptr(rate), _np_ptr(nxt), _np_ptr(hops)),
+              "fwx_matrix_upload")
+
+    def solve(self, **kw):
+        count = kw.pop("count_updates", False)
+        o, u = _opts(want_updates=count, **kw)
+        check(lib().fwx_matrix_solve(self._h, ctypes.byref(o)), "fwx_matrix_solve")
+        return int(u.value) if count else None
+
+    def download(self):
+        rate = np.empty((self.n, self.n), dtype=self.dtype)
+        nxt = np.empty((self.n, self.n), dtype=np.int32) if self.with_next else None
+        hops = np.empty((self.n, self.n), dtype=np.int32) if self.with_hops else None
+        check(lib().fwx_matrix_download(self._h, _np_ptr(rate), _np_ptr(nxt), _np_ptr(hops)),
+              "fwx_matrix_download")
+        return rate, nxt, hops
+
+    def query(self, src, dst):
+        """(rate, [path indices]) of one entry, read back from the device."""
+        r = ctypes.c_double(0.0)
+        out = np.empty(max(self.n, 1), dtype=np.int32)
+        ln = check(lib().fwx_matrix_query(self._h, int(src), int(dst), ctypes.byref(r),
+                                          _np_ptr(out), self.n), "fwx_matrix_query")
+        return float(r.value), [int(x) for x in out[:ln]]
+
+    def close(self):
+        if self._h:
+            lib().fwx_matrix_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+# ---- device-pointer step API (torch tensors own the memory) -----------------------------------
+
+def _tensor_dtype_code(t):
+    import torch
+    if t.dtype == torch.float32:
+        return FWX_F32
+    if t.dtype == torch.float64:
+        return FWX_F64
+    raise ValueError("rate tensor must be float32 or float64")
+
+
+def _slab(rate_t, next_t, hops_t, n, row0):
+    import torch
+    assert rate_t.is_cuda and rate_t.is_contiguous() and rate_t.dim() == 2 and rate_t.shape[1] == n
+    for t in (next_t, hops_t):
+        assert t is None or (t.is_cuda and t.is_contiguous() and t.dtype == torch.int32
+                             and t.shape == rate_t.shape)
+    s = FwxSlab()
+    s.n, s.row0, s.rows, s.dtype = n, row0, rate_t.shape[0], _tensor_dtype_code(rate_t)
+    s.rate = rate_t.data_ptr()
+    s.next = next_t.data_ptr() if next_t is not None else None
+    s.hops = hops_t.data_ptr() if hops_t is not None else None
+    return s
+
+
+def _stream_ptr():
+    import torch
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def dev_relax(rate_t, n, row0, k_begin, k_end, *, pivots_t=None, pivot_hops_t=None, next_t=None,
+              hops_t=None, serpentine=True, updates_t=None):
+    """Apply pivots [k_begin,k_end) to the slab `rate_t` (rows [row0,row0+rows) of the n x n
+    matrix) on torch's current stream, asynchronously.
+
+    pivots_t None: the slab holds the pivot rows itself (single-GPU solve).  Otherwise pivots_t is
+    the (k_end-k_begin) x n panel of time-k snapshots from dev_panel."""
+    s = _slab(rate_t, next_t, hops_t, n, row0)
+    p = FwxPivots()
+    p.k_begin, p.k_end = k_begin, k_end
+    if pivots_t is None:
+        assert row0 <= k_begin and k_end <= row0 + rate_t.shape[0]
+        es = rate_t.element_size()
+        p.rate = rate_t.data_ptr() + (k_begin - row0) * n * es
+        p.hops = hops_t.data_ptr() + (k_begin - row0) * n * 4 if hops_t is not None else None
+        p.stride = n
+    else:
+        assert pivots_t.is_cuda and pivots_t.is_contiguous() and pivots_t.dtype == rate_t.dtype
+        assert pivots_t.shape == (k_end - k_begin, n)
+        p.rate = pivots_t.data_ptr()
+        p.hops = pivot_hops_t.data_ptr() if pivot_hops_t is not None else None
+        p.stride = n
+    upd = ctypes.c_void_p(updates_t.data_ptr()) if updates_t is not None else None
+    check(lib().fwx_dev_relax(ctypes.byref(s), ctypes.byref(p), int(bool(serpentine)), upd,
+                              _stream_ptr()), "fwx_dev_relax")
+
+
+def dev_panel(block_rate_t, n, k0, w_rate_t, *, next_t=None, hops_t=None, w_hops_t=None,
+              updates_t=None):
+    """Owner-side panel phase: evolve pivot rows [k0,k0+B) in place, export time-k snapshots."""
+    s = _slab(block_rate_t, next_t, hops_t, n, k0)
+    assert w_rate_t.is_cuda and w_rate_t.is_contiguous() and w_rate_t.shape == block_rate_t.shape
+    upd = ctypes.c_void_p(updates_t.data_ptr()) if updates_t is not None else None
+    wh = ctypes.c_void_p(w_hops_t.data_ptr()) if w_hops_t is not None else None
+    check(lib().fwx_dev_panel(ctypes.byref(s), ctypes.c_void_p(w_rate_t.data_ptr()), wh, upd,
+                              _stream_ptr()), "fwx_dev_panel")

@@ -1,0 +1,161 @@
+/*
+ * fwx.h -- C ABI of libfwx, the MI355X (gfx950) max-product Floyd-Warshall engine.
+ *
+ * Drop-in boundary.  The reference has no FFI; its seam is the pure function
+ *     floydWarshall :: Map (Vertex,Vertex) Double -> Matrix RateEntry
+ *         /root/reference/src/lib/Algorithms.hs:19-20   (= runAlgo 0 . buildMatrix)
+ * whose replaceable core is
+ *     runAlgo :: Int -> Matrix RateEntry -> Matrix RateEntry
+ *         /root/reference/src/lib/Algorithms.hs:42-61
+ * The host keeps buildMatrix (:26-40) and optimum (:65-78); this library replaces runAlgo on the
+ * dense structure-of-arrays form of `Matrix RateEntry` (Types.hs:24-29, :39):
+ *
+ *     rate[n*n]  row-major, T = double (the reference's precision, Types.hs:26) or float
+ *     next[n*n]  int32: index of `head _path`, -1 for the empty path        (optional)
+ *     hops[n*n]  int32: `length _path`                                      (optional)
+ *
+ * `_start` of row i is implicit (vertex i).  "No route" is rate 0.0 / next -1 / hops 0
+ * (isolatedEntry, Utils.hs:13-14).
+ *
+ * Semantics preserved exactly: k ascending (:44); row k copied (:50);
+ * entries j==i or j==k untouched (:54); operands from the state at the start of step k (:58-60);
+ * one IEEE multiply (:61) and one strict ordered compare (:55) per relaxation -- no fast-math, no
+ * FMA, denormals kept, NaN compares false.  Results are bit-identical to the reference loop.
+ *
+ * Errors: every entry point returns FWX_OK (0) or a negative fwx_status; no C++ exception or
+ * abort crosses this boundary.  n == 0 is success and touches nothing (the reference returns the
+ * empty matrix: src/test/AlgorithmsTest.hs:45-47, :62-64).  There is NO CPU fallback: without a
+ * HIP device the solve entry points return FWX_ERR_NO_DEVICE.
+ *
+ * Threading: calls are blocking unless a stream is passed explicitly (fwx_dev_*), may come from any
+ * OS thread, keep no global mutable state, and restore the caller's current HIP device.
+ */
+#ifndef FWX_H
+#define FWX_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define FWX_ABI_VERSION 1
+
+typedef enum fwx_status {
+    FWX_OK = 0,
+    FWX_ERR_INVALID = -1,     /* bad argument (null pointer, negative size, bad range, misaligned) */
+    FWX_ERR_NO_DEVICE = -2,   /* no HIP device visible: the engine has no CPU fallback            */
+    FWX_ERR_HIP = -3,         /* a HIP runtime call failed (fwx_last_hip_error gives the code)    */
+    FWX_ERR_OOM = -4,         /* device or host allocation failed                                 */
+    FWX_ERR_CYCLE = -5,       /* fwx_follow_path: next-hops do not reach dst within n hops        */
+    FWX_ERR_CAPACITY = -6,    /* fwx_follow_path: output buffer too small                         */
+    FWX_ERR_UNSUPPORTED = -7  /* option combination not implemented                               */
+} fwx_status;
+
+typedef enum fwx_dtype { FWX_F32 = 0, FWX_F64 = 1 } fwx_dtype;
+
+/* Which relaxation engine runs the pivots.  Both are bit-exact with the reference loop. */
+typedef enum fwx_engine {
+    FWX_ENGINE_AUTO = 0,
+    FWX_ENGINE_PERK = 1,  /* one N x N launch per pivot k (HBM-bound streaming kernel)            */
+    FWX_ENGINE_FUSED = 2  /* B pivots per launch from time-k snapshots of the pivot panels         */
+} fwx_engine;
+
+/* Options; zero-initialise and set struct_size = sizeof(fwx_opts).  NULL means all defaults. */
+typedef struct fwx_opts {
+    uint32_t struct_size;
+    int32_t device;        /* HIP device ordinal; -1 = the caller's current device                 */
+    int32_t engine;        /* fwx_engine                                                           */
+    int32_t k_begin;       /* first pivot (default 0): a solve over [k_begin,k_end) is resumable   */
+    int32_t k_end;         /* one past the last pivot; <= 0 means n                                */
+    int32_t block;         /* pivots per launch for FWX_ENGINE_FUSED (0 = default)                 */
+    int32_t serpentine;    /* 0 = default (on): alternate sweep direction per pivot so the tail of */
+                           /* one launch is re-read from the Infinity Cache; 1 = off               */
+    uint64_t *updates_out; /* host pointer, optional: receives U = number of successful updates    */
+} fwx_opts;
+
+int fwx_abi_version(void);
+int fwx_device_count(void);              /* number of HIP devices, 0 if none (never an error)      */
+const char *fwx_strerror(int status);
+int fwx_last_hip_error(void);            /* hipError_t of the last FWX_ERR_HIP on this thread      */
+
+/* ---- one-shot host-buffer entry points: what the reference-side FFI binds --------------------
+ * Replace runAlgo (Algorithms.hs:42-61) for a matrix produced by buildMatrix (:26-40).
+ * rate/next/hops are n*n row-major HOST arrays, updated IN PLACE; next and hops may be NULL
+ * (rates only).  The caller owns all buffers; no pointer is retained after return.            */
+int fwx_solve_f64(int32_t n, double *rate, int32_t *next, int32_t *hops, const fwx_opts *opts);
+int fwx_solve_f32(int32_t n, float *rate, int32_t *next, int32_t *hops, const fwx_opts *opts);
+
+/* Index form of the `_path` list that optimum returns (Algorithms.hs:74-75): follow next-hops
+ * from src until dst.  Returns the number of vertices written to out (dst included, src not), 0 if
+ * next[src][dst] == -1 (empty path, "no exchange"), or a negative fwx_status.  Host arrays.      */
+int fwx_follow_path(int32_t n, const int32_t *next, int32_t src, int32_t dst, int32_t *out,
+                    int32_t cap);
+
+/* ---- device-resident handle: keeps the solved matrix in HBM across queries --------------------
+ * Host counterpart of `InSync exRates matrix` (Types.hs:35-37): upload once per rate change,
+ * solve once, then answer any number of (src,dst) queries without re-solving.                   */
+typedef struct fwx_matrix fwx_matrix;
+
+int fwx_matrix_create(fwx_matrix **out, int32_t n, int32_t dtype, int32_t with_next,
+                      int32_t with_hops, int32_t device);
+int fwx_matrix_upload(fwx_matrix *m, const void *rate, const int32_t *next, const int32_t *hops);
+int fwx_matrix_solve(fwx_matrix *m, const fwx_opts *opts);
+int fwx_matrix_download(fwx_matrix *m, void *rate, int32_t *next, int32_t *hops);
+/* One entry + its path, read back from the device (8 + 4*len bytes instead of the matrix).      */
+int fwx_matrix_query(fwx_matrix *m, int32_t src, int32_t dst, double *rate_out, int32_t *path_out,
+                     int32_t cap);
+int fwx_matrix_destroy(fwx_matrix *m);
+
+/* ---- device-pointer step API (caller-owned DEVICE memory, caller's stream) --------------------
+ * Used by the benchmark and by the row-partitioned multi-GPU driver, which own their buffers
+ * through torch / torch.distributed.  All launches are asynchronous on `stream` (a hipStream_t,
+ * NULL = default stream); nothing is synchronised.                                              */
+
+/* `rows` consecutive rows [row0, row0+rows) of the global n x n matrix, rows*n elements each. */
+typedef struct fwx_slab {
+    int32_t n;       /* order of the global matrix = row length                                   */
+    int32_t row0;    /* global index of the slab's first row                                      */
+    int32_t rows;    /* rows held in this slab                                                    */
+    int32_t dtype;   /* fwx_dtype                                                                 */
+    void *rate;      /* device, rows*n                                                            */
+    int32_t *next;   /* device, rows*n, or NULL                                                   */
+    int32_t *hops;   /* device, rows*n, or NULL                                                   */
+} fwx_slab;
+
+/* Pivot rows for steps [k_begin, k_end): row k AS IT STANDS AT THE START OF STEP k is at
+ * rate + (k - k_begin) * stride (elements).  For a single-GPU solve this is the matrix itself
+ * (rate = matrix + k_begin*n, stride = n: row k is not modified by step k).  For a partitioned
+ * solve it is the panel of time-k snapshots produced by fwx_dev_panel on the owner.             */
+typedef struct fwx_pivots {
+    int32_t k_begin;
+    int32_t k_end;
+    const void *rate;
+    const int32_t *hops; /* same layout; required iff slab.hops != NULL                            */
+    int64_t stride;
+} fwx_pivots;
+
+/* Apply pivots [k_begin,k_end) in order to every row of the slab (one launch per pivot).
+ * d_updates: optional device array of FWX_UPDATE_SHARDS uint64 counters, incremented by U.      */
+#define FWX_UPDATE_SHARDS 256
+int fwx_dev_relax(const fwx_slab *slab, const fwx_pivots *piv, int32_t serpentine,
+                  unsigned long long *d_updates, void *stream);
+
+/* Owner-side panel phase for a partitioned solve.  `block` holds the pivot rows
+ * [block->row0, block->row0 + block->rows) at time k = block->row0.  Evolves them in place through
+ * those pivots and writes the time-k snapshot of each pivot row to w_rate (rows x n) (and its hops
+ * row to w_hops if the slab carries hops).  Afterwards the block rows are at time row0+rows and
+ * every other row of the matrix must be relaxed with fwx_dev_relax(pivots = w_rate).            */
+int fwx_dev_panel(const fwx_slab *block, void *w_rate, int32_t *w_hops,
+                  unsigned long long *d_updates, void *stream);
+
+/* Fused engine (B pivots per launch), see DESIGN.md "Kernels".  Same contract as fwx_dev_relax
+ * but `piv` must be a snapshot panel (not the matrix itself) and the slab must not contain the
+ * pivot rows.  col_* are device scratch of rows*(k_end-k_begin) elements.                       */
+int fwx_dev_relax_fused(const fwx_slab *slab, const fwx_pivots *piv, void *col_rate,
+                        int32_t *col_next, unsigned long long *d_updates, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* FWX_H */

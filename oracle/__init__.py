@@ -1,0 +1,106 @@
+"""CPU ORACLE for the max-product Floyd-Warshall hot path -- TEST INFRASTRUCTURE ONLY.
+
+Only tests/, __graft_entry__.smoke() and bench.py's `cpu_baseline` leg may import this package.
+The product (floydwarshall_amd/) never imports, links or calls anything here, and has no CPU
+fallback: it fails loudly when the HIP library is missing.
+
+Contents
+  fw_oracle.c / libfworacle.so   dense in-place restatement of runAlgo
+                                 (/root/reference/src/lib/Algorithms.hs:42-61), f64 and f32,
+                                 single- and multi-threaded; copy-per-k literal form.
+  list_faithful.py               entry-for-entry restatement with whole `_path` lists of
+                                 buildMatrix / runAlgo / floydWarshall / optimum
+                                 (Algorithms.hs:19-78).
+  host_oracle.py                 restatement of the request layer (Parsers.hs, ProcessRequests.hs,
+                                 Main.hs) used to pin the C++ host mirror.
+
+Parity pinning: the reference is Haskell and cannot be built here (no GHC/cabal/nix in the
+image), so the oracle is pinned by the reference's own golden vectors committed as data under
+tests/golden/ (tests/test_oracle_golden.py), and above N=4 by agreement of the two independent
+restatements (dense C vs list-faithful Python).
+"""
+import ctypes
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = None
+
+
+def build():
+    """Compile libfworacle.so with oracle/Makefile (gcc only)."""
+    subprocess.run(["make", "-s", "-C", _HERE, "libfworacle.so"], check=True)
+
+
+def lib():
+    global _LIB
+    if _LIB is None:
+        path = os.path.join(_HERE, "libfworacle.so")
+        if not os.path.exists(path):
+            build()
+        L = ctypes.CDLL(path)
+        i32, u64, vp = ctypes.c_int32, ctypes.c_uint64, ctypes.c_void_p
+        for name in ("fwo_relax_f64", "fwo_relax_f32"):
+            getattr(L, name).restype = u64
+            getattr(L, name).argtypes = [i32, vp, vp, vp, i32, i32]
+        for name in ("fwo_relax_mt_f64", "fwo_relax_mt_f32"):
+            getattr(L, name).restype = u64
+            getattr(L, name).argtypes = [i32, vp, vp, i32, i32, i32]
+        for name in ("fwo_copy_per_k_f64", "fwo_copy_per_k_f32"):
+            getattr(L, name).restype = ctypes.c_int
+            getattr(L, name).argtypes = [i32, vp, vp, vp]
+        L.fwo_follow_path.restype = i32
+        L.fwo_follow_path.argtypes = [i32, vp, i32, i32, vp, i32]
+        _LIB = L
+    return _LIB
+
+
+def _ptr(a):
+    return None if a is None else a.ctypes.data_as(ctypes.c_void_p)
+
+
+def _check(rate, nxt, hops):
+    assert rate.ndim == 2 and rate.shape[0] == rate.shape[1]
+    assert rate.dtype in (np.float32, np.float64) and rate.flags.c_contiguous
+    for a in (nxt, hops):
+        if a is not None:
+            assert a.shape == rate.shape and a.dtype == np.int32 and a.flags.c_contiguous
+    return "f64" if rate.dtype == np.float64 else "f32"
+
+
+def relax(rate, nxt=None, hops=None, k_begin=0, k_end=None):
+    """In-place dense k-i-j over pivots [k_begin, k_end); returns U (successful relaxations)."""
+    sfx = _check(rate, nxt, hops)
+    n = rate.shape[0]
+    k_end = n if k_end is None else k_end
+    return int(getattr(lib(), "fwo_relax_" + sfx)(n, _ptr(rate), _ptr(nxt), _ptr(hops),
+                                                  k_begin, k_end))
+
+
+def relax_mt(rate, nxt=None, k_begin=0, k_end=None, threads=None):
+    """Same result as relax(), rows of each pivot step split over `threads` host threads."""
+    sfx = _check(rate, nxt, None)
+    n = rate.shape[0]
+    k_end = n if k_end is None else k_end
+    threads = threads or len(os.sched_getaffinity(0))
+    return int(getattr(lib(), "fwo_relax_mt_" + sfx)(n, _ptr(rate), _ptr(nxt), k_begin, k_end,
+                                                     threads))
+
+
+def copy_per_k(rate, nxt, hops):
+    """Literal new-matrix-per-k form (Algorithms.hs:44); small n."""
+    sfx = _check(rate, nxt, hops)
+    rc = getattr(lib(), "fwo_copy_per_k_" + sfx)(rate.shape[0], _ptr(rate), _ptr(nxt), _ptr(hops))
+    assert rc == 0
+
+
+def follow_path(nxt, src, dst):
+    """Index path src -> dst by following next-hops; [] if unreachable; None on a cycle."""
+    n = nxt.shape[0]
+    out = np.empty(max(n, 1), dtype=np.int32)
+    ln = lib().fwo_follow_path(n, _ptr(nxt), int(src), int(dst), _ptr(out), n)
+    if ln < 0:
+        return None
+    return [int(x) for x in out[:ln]]

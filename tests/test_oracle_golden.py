@@ -1,0 +1,170 @@
+"""Pins the ORACLE (CPU restatement) against the reference's own golden vectors, and the two
+independent restatements (dense C, list-faithful Python) against each other.  CPU only.
+
+Golden data: tests/golden/*.json, transcribed (inputs + expected outputs only) from
+/root/reference/src/test/AlgorithmsTest.hs and MockData.hs -- see each file's `_source`.
+"""
+import random
+
+import numpy as np
+import pytest
+
+import oracle
+from floydwarshall_amd import synth
+from oracle import list_faithful as lf
+
+from helpers import (assert_bits_equal, golden_dense, golden_rates_dict, load_golden)
+
+
+def test_build_matrix_4x4_matches_reference_golden():
+    # AlgorithmsTest.hs:49-60 (buildMatrix_4x4Matrix)
+    g = load_golden("algorithms_4x4.json")
+    m = lf.build_matrix(golden_rates_dict(g))
+    vertices, rate, nxt, hops = lf.to_dense(m)
+    assert [list(v) for v in vertices] == g["vertices"]
+    erate, enext, ehops, epaths = golden_dense(g["initial"])
+    assert_bits_equal(rate, erate, "initial rate")
+    assert np.array_equal(nxt, enext) and np.array_equal(hops, ehops)
+    assert lf.path_indices(m) == epaths
+
+
+def test_floyd_warshall_4x4_matches_reference_golden_list_faithful():
+    # AlgorithmsTest.hs:66-77 (floydWarshall_4x4Matrix)
+    g = load_golden("algorithms_4x4.json")
+    m = lf.floyd_warshall(golden_rates_dict(g))
+    _, rate, nxt, hops = lf.to_dense(m)
+    erate, enext, ehops, epaths = golden_dense(g["solved"])
+    assert_bits_equal(rate, erate, "solved rate")
+    assert lf.path_indices(m) == epaths
+    assert np.array_equal(nxt, enext) and np.array_equal(hops, ehops)
+
+
+@pytest.mark.parametrize("form", ["inplace", "copy_per_k", "mt"])
+def test_floyd_warshall_4x4_matches_reference_golden_dense_c(form):
+    g = load_golden("algorithms_4x4.json")
+    rate, nxt, hops, _ = golden_dense(g["initial"])
+    if form == "inplace":
+        u = oracle.relax(rate, nxt, hops)
+        assert u == 8
+    elif form == "copy_per_k":
+        oracle.copy_per_k(rate, nxt, hops)
+    else:
+        oracle.relax_mt(rate, nxt, threads=3)
+        hops = None
+    erate, enext, ehops, epaths = golden_dense(g["solved"])
+    assert_bits_equal(rate, erate, "solved rate")
+    assert np.array_equal(nxt, enext)
+    if hops is not None:
+        assert np.array_equal(hops, ehops)
+    # following next-hops reproduces every golden `_path` list
+    for i in range(4):
+        for j in range(4):
+            assert tuple(oracle.follow_path(nxt, i, j)) == epaths[i][j]
+
+
+def test_empty_map_gives_empty_matrix():
+    # AlgorithmsTest.hs:45-47, :62-64
+    assert lf.build_matrix({}) == []
+    assert lf.floyd_warshall({}) == []
+    rate = np.zeros((0, 0))
+    assert oracle.relax(rate) == 0
+
+
+def test_optimum_golden_cases():
+    g = load_golden("algorithms_4x4.json")
+    c = load_golden("optimum_cases.json")
+    m = lf.floyd_warshall(golden_rates_dict(g))
+    for case in c["not_exist"]:                                  # AlgorithmsTest.hs:82-91
+        assert lf.optimum(tuple(case["src"]), tuple(case["dst"]), m) == ("err", case["err"])
+    i, j = c["reachability"]["isolate"]                          # AlgorithmsTest.hs:93-110
+    m2 = [list(r) for r in m]
+    m2[i][j] = (0.0, m2[i][j][1], ())
+    for case in c["reachability"]["cases"]:
+        res = lf.optimum(tuple(case["src"]), tuple(case["dst"]), m2)
+        if "err" in case:
+            assert res == ("err", case["err"])
+        else:
+            assert res[0] == "ok"
+            assert res[1][0] == case["rate"]
+            assert [list(v) for v in res[1][2]] == case["path"]
+
+
+def test_optimum_error_precedence_property():
+    # AlgorithmsTest.hs:112-134 with the generators of MockData.hs:59-81, restated
+    c = load_golden("optimum_cases.json")
+    sample = [tuple(v) for v in c["sample_vertices"]]
+    rnd = random.Random(7)
+    for _ in range(400):
+        src, dest = rnd.choice(sample), rnd.choice(sample)
+        k = rnd.randint(0, len(sample) // 2 + 1)
+        vertices = sorted(set(rnd.choice(sample) for _ in range(k)))
+        if rnd.random() < 0.5:
+            matrix = [[] for _ in vertices]
+        else:
+            matrix = [[(0.0, s, ()) if s == d else (1.0, s, (d,)) for d in vertices]
+                      for s in vertices]
+        res = lf.optimum(src, dest, matrix)
+        sv, dv = lf.show_vertex(src), lf.show_vertex(dest)
+        if len(matrix) == 0:
+            assert res == ("err", sv + " is not entered before")
+        elif any(len(r) == 0 for r in matrix):
+            assert res == ("err", "The matrix is empty")
+        elif src not in vertices:
+            assert res == ("err", sv + " is not entered before")
+        elif dest not in vertices:
+            assert res == ("err", dv + " is not entered before")
+        elif src == dest:
+            assert res == ("err", "There is no exchange between " + sv + " and " + dv)
+        else:
+            assert res == ("ok", (1.0, src, (dest,)))
+
+
+@pytest.mark.parametrize("kind", ["d1", "d2", "t1", "t2", "t3"])
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+def test_dense_c_equals_list_faithful(kind, dtype):
+    """Above N=4 the reference pins nothing: the two restatements must agree bit for bit, in
+    rates, in head-of-path (next) and in path length (hops)."""
+    n = 24
+    rate, nxt, hops = synth.make(kind, n, dtype, seed=100 + n)
+    vertices = [("X", "C%03d" % i) for i in range(n)]
+    m = lf.run_algo(lf.from_dense(vertices, rate, nxt), dtype)
+    _, lrate, lnext, lhops = lf.to_dense(m, dtype)
+    r2, n2, h2 = rate.copy(), nxt.copy(), hops.copy()
+    oracle.relax(r2, n2, h2)
+    assert_bits_equal(r2, lrate, "rate %s" % kind)
+    assert np.array_equal(n2, lnext)
+    assert np.array_equal(h2, lhops)
+    if kind in ("d1", "d2", "t1", "t2"):
+        # no arbitrage: following the final next-hops reproduces every whole `_path` list
+        paths = lf.path_indices(m)
+        for i in range(n):
+            for j in range(n):
+                assert tuple(oracle.follow_path(n2, i, j)) == paths[i][j]
+
+
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+def test_inplace_equals_copy_per_k_and_mt(dtype):
+    for kind in ("d1", "t1", "t3"):
+        rate, nxt, hops = synth.make(kind, 61, dtype, seed=5)
+        a = (rate.copy(), nxt.copy(), hops.copy())
+        b = (rate.copy(), nxt.copy(), hops.copy())
+        c = (rate.copy(), nxt.copy())
+        ua = oracle.relax(*a)
+        oracle.copy_per_k(*b)
+        uc = oracle.relax_mt(*c, threads=4)
+        assert ua == uc
+        assert_bits_equal(a[0], b[0], "copy_per_k rate")
+        assert np.array_equal(a[1], b[1]) and np.array_equal(a[2], b[2])
+        assert_bits_equal(a[0], c[0], "mt rate")
+        assert np.array_equal(a[1], c[1])
+
+
+def test_k_range_is_resumable():
+    rate, nxt, hops = synth.make("d2", 50, np.float64, seed=9)
+    a = (rate.copy(), nxt.copy(), hops.copy())
+    b = (rate.copy(), nxt.copy(), hops.copy())
+    oracle.relax(*a)
+    oracle.relax(*b, k_begin=0, k_end=17)
+    oracle.relax(*b, k_begin=17, k_end=50)
+    assert_bits_equal(a[0], b[0])
+    assert np.array_equal(a[1], b[1]) and np.array_equal(a[2], b[2])
