@@ -30,6 +30,7 @@ import numpy as np
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
+SEGMENTS = 16
 HBM_PEAK_GBPS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
 
 
@@ -51,11 +52,23 @@ def parse_args():
     return ap.parse_args()
 
 
+def host_cores():
+    """Threads this process may actually run: CPU affinity capped by the cgroup CPU quota."""
+    cores = len(os.sched_getaffinity(0))
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            cores = max(1, min(cores, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        pass
+    return cores
+
+
 def cpu_baseline(rate_host, cpu_seconds):
     """Oracle (port of the reference loop) on a bounded k-slice, all host cores of this process."""
     import oracle
     n = rate_host.shape[0]
-    cores = len(os.sched_getaffinity(0))
+    cores = host_cores()
     work = rate_host.copy()
     done, t_total, chunk = 0, 0.0, 8
     while t_total < cpu_seconds and done < n:
@@ -120,14 +133,21 @@ def main():
         if nxt is not None:
             nxt.copy_(pristine_next)
         if world == 1:
+            # the pivots are issued in SEGMENTS back-to-back launches with a HIP event between
+            # segments (no synchronisation): per-segment launch time shows how the cost moves with k
+            segs = [k_end * i // SEGMENTS for i in range(SEGMENTS + 1)] if timed else [0, k_end]
+            evs = []
+            for a, b in zip(segs[:-1], segs[1:]):
+                if timed:
+                    evs.append(torch.cuda.Event(enable_timing=True))
+                    evs[-1].record()
+                if b > a:
+                    engine.dev_relax(rate, n, 0, a, b, next_t=nxt, serpentine=serp,
+                                     updates_t=upd if count else None)
             if timed:
-                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                e0.record()
-            engine.dev_relax(rate, n, 0, 0, k_end, next_t=nxt, serpentine=serp,
-                             updates_t=upd if count else None)
-            if timed:
-                e1.record()
-                ev_pairs.append((e0, e1))
+                evs.append(torch.cuda.Event(enable_timing=True))
+                evs[-1].record()
+                ev_pairs.append((evs, segs))
         else:
             fwdist.solve_partitioned(rate, n, rank, world, nxt=nxt, block=args.block)
 
@@ -176,7 +196,10 @@ def main():
 
     if world == 1 and ev_pairs:
         launches = args.steps * k_end
-        kern_ms = sum(a.elapsed_time(b) for a, b in ev_pairs)
+        kern_ms = sum(evs[0].elapsed_time(evs[-1]) for evs, _ in ev_pairs)
+        evs, segs = ev_pairs[-1]
+        seg_us = [round(1e3 * evs[i].elapsed_time(evs[i + 1]) / max(1, segs[i + 1] - segs[i]), 1)
+                  for i in range(len(evs) - 1)]
         avg_us = 1e3 * kern_ms / launches
         u_per_launch = (updates / float(k_end)) if updates is not None else 0.0
         # B_alg = s*N^3 + s*U + 2*s*N^2 per solve (+4*U with next)
@@ -186,7 +209,8 @@ def main():
                            "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS, "traffic": None,
                            "kernel": "fwx::relax_k", "avg_launch_us": avg_us,
                            "alg_bytes_per_launch": alg_bytes, "updates_per_solve": updates,
-                           "frac_of_measured_copy_peak_6290": achieved / 6290.0}
+                           "frac_of_measured_copy_peak_6290": achieved / 6290.0,
+                           "avg_launch_us_by_k_sixteenth": seg_us}
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(rate_host, args.cpu_seconds)
     if rank == 0:

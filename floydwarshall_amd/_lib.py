@@ -82,6 +82,14 @@ def lib():
             raise RuntimeError(
                 "libfwx.so is missing at %s -- build it with `python -m floydwarshall_amd.build` "
                 "(hipcc, gfx950).  floydwarshall_amd has no CPU fallback." % LIB_PATH)
+        # One HIP runtime per process: torch wheels bundle their own libamdhip64.so.7 (same
+        # SONAME as /opt/rocm's).  If torch is going to be used in this process it must be loaded
+        # FIRST, so that libfwx's DT_NEEDED resolves to the copy torch initialises; the other
+        # order leaves torch with "No HIP GPUs are available".  libfwx itself does not need torch.
+        try:
+            import torch  # noqa: F401
+        except ImportError:
+            pass
         L = ctypes.CDLL(LIB_PATH)
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(L, name)  # AttributeError here = header/library mismatch

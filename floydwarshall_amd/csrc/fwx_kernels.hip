@@ -41,6 +41,12 @@ template <typename T, int W> struct Lanes {
     static __device__ __forceinline__ void set(V &v, int c, T x) { v[c] = x; }
     static __device__ __forceinline__ V splat(T x) { V v; for (int c = 0; c < W; ++c) v[c] = x; return v; }
 };
+template <typename V, bool NT, typename T> __device__ __forceinline__ V load_vec(const T *p)
+{
+    if (NT) return __builtin_nontemporal_load(reinterpret_cast<const V *>(p));
+    return *reinterpret_cast<const V *>(p);
+}
+
 template <typename T> struct Lanes<T, 1> {
     using V = T;
     static __device__ __forceinline__ T get(const V &v, int) { return v; }
@@ -65,8 +71,9 @@ template <typename T> struct Lanes<T, 1> {
 // `flip` reverses the block order: launches alternate direction so that the rows streamed last
 // by pivot k are streamed first by pivot k+1 and are served from the 256 MiB Infinity Cache.
 // -------------------------------------------------------------------------------------------------
-template <typename T, int W, int NV, int RPB, int UNROLL, bool HAS_NEXT, bool HAS_HOPS, bool COUNT>
-__global__ __launch_bounds__(256) void relax_k(T *rate, int32_t *next, int32_t *hops,
+template <typename T, int W, int NV, int RPB, int UNROLL, bool HAS_NEXT, bool HAS_HOPS, bool COUNT,
+          int MINW = 1, bool NT = false>
+__global__ __launch_bounds__(256, MINW) void relax_k(T *rate, int32_t *next, int32_t *hops,
                                                const T *prow, const int32_t *phops, int rows,
                                                int n, int row0, int k, int nstrips, int flip,
                                                unsigned long long *updates)
@@ -98,18 +105,22 @@ __global__ __launch_bounds__(256) void relax_k(T *rate, int32_t *next, int32_t *
     }
     if (COUNT && t == 0) s_cnt = 0;
 
-    // Pivot row segment -> registers.  Column k gets NaN: skip j == k.
+    // Pivot row segment -> registers.  Column k gets NaN: skip j == k.  Columns past the end
+    // of the row are CLAMPED to the last in-range vector and their pivot set to NaN: the
+    // streaming loads stay unconditional (valid addresses) and such lanes can never update.
     V p[NV];
     int col[NV];
 #pragma unroll
     for (int v = 0; v < NV; ++v) {
-        col[v] = strip * SW + (v * 256 + t) * W;
-        if (col[v] < n) {
-            p[v] = *reinterpret_cast<const V *>(prow + col[v]);
+        const int c0 = strip * SW + (v * 256 + t) * W;
+        if (c0 < n) {
+            col[v] = c0;
+            p[v] = *reinterpret_cast<const V *>(prow + c0);
 #pragma unroll
             for (int c = 0; c < W; ++c)
-                if (col[v] + c == k) L::set(p[v], c, quiet_nan<T>());
+                if (c0 + c == k) L::set(p[v], c, quiet_nan<T>());
         } else {
+            col[v] = n - W;
             p[v] = L::splat(quiet_nan<T>());
         }
     }
@@ -118,49 +129,60 @@ __global__ __launch_bounds__(256) void relax_k(T *rate, int32_t *next, int32_t *
     unsigned int my_updates = 0;
     T *const base = rate + (size_t)r_begin * n;
 
-    for (int r = 0; r < r_cnt; r += UNROLL) {
+    // One row of one vector: compare, and in the rare case that something improves, store.
+    auto relax_vec = [&](const V &x, const V &pv, int r, int cv) {
+        const T rik = s_col[r];
+        bool any = false;
+        T cand[W];
+#pragma unroll
+        for (int c = 0; c < W; ++c) {
+            cand[c] = rik * L::get(pv, c);
+            any |= (L::get(x, c) < cand[c]);
+        }
+        if (any) {
+            // Rare path: some component improves.  The diagonal (j == i) is filtered here.
+            const int i = row0 + r_begin + r;
+            V nx = x;
+            bool changed = false;
+            const size_t off = (size_t)(r_begin + r) * n + cv;
+#pragma unroll
+            for (int c = 0; c < W; ++c) {
+                if (L::get(x, c) < cand[c] && cv + c != i) {
+                    L::set(nx, c, cand[c]);
+                    changed = true;
+                    if (HAS_NEXT) next[off + c] = s_ncol[r];
+                    if (HAS_HOPS) hops[off + c] = s_hcol[r] + phops[cv + c];
+                    if (COUNT) ++my_updates;
+                }
+            }
+            if (changed) *reinterpret_cast<V *>(rate + off) = nx;
+        }
+    };
+
+    int r = 0;
+    // Main loop: UNROLL rows x NV vectors of unconditional 16-byte loads in flight per thread.
+    for (; r + UNROLL <= r_cnt; r += UNROLL) {
         V x[UNROLL][NV];
 #pragma unroll
         for (int u = 0; u < UNROLL; ++u)
 #pragma unroll
             for (int v = 0; v < NV; ++v)
-                if (r + u < r_cnt && col[v] < n)
-                    x[u][v] = *reinterpret_cast<const V *>(base + (size_t)(r + u) * n + col[v]);
-
+                x[u][v] = load_vec<V, NT>(base + (size_t)(r + u) * n + col[v]);
 #pragma unroll
-        for (int u = 0; u < UNROLL; ++u) {
-            if (r + u >= r_cnt) break;
-            const T rik = s_col[r + u];
-            const int i = row0 + r_begin + r + u;
+        for (int u = 0; u < UNROLL; ++u)
 #pragma unroll
-            for (int v = 0; v < NV; ++v) {
-                if (col[v] >= n) continue;
-                bool any = false;
-                T cand[W];
+            for (int v = 0; v < NV; ++v)
+                relax_vec(x[u][v], p[v], r + u, col[v]);
+    }
+    // Row tail (slab height not a multiple of UNROLL).
+    for (; r < r_cnt; ++r) {
+        V x[NV];
 #pragma unroll
-                for (int c = 0; c < W; ++c) {
-                    cand[c] = rik * L::get(p[v], c);
-                    any |= (L::get(x[u][v], c) < cand[c]);
-                }
-                if (any) {
-                    // Rare path: some component improves.  Filter the diagonal (j == i) here.
-                    V nx = x[u][v];
-                    bool changed = false;
-                    const size_t off = (size_t)(r_begin + r + u) * n + col[v];
+        for (int v = 0; v < NV; ++v)
+            x[v] = *reinterpret_cast<const V *>(base + (size_t)r * n + col[v]);
 #pragma unroll
-                    for (int c = 0; c < W; ++c) {
-                        if (L::get(x[u][v], c) < cand[c] && col[v] + c != i) {
-                            L::set(nx, c, cand[c]);
-                            changed = true;
-                            if (HAS_NEXT) next[off + c] = s_ncol[r + u];
-                            if (HAS_HOPS) hops[off + c] = s_hcol[r + u] + phops[col[v] + c];
-                            if (COUNT) ++my_updates;
-                        }
-                    }
-                    if (changed) *reinterpret_cast<V *>(rate + off) = nx;
-                }
-            }
-        }
+        for (int v = 0; v < NV; ++v)
+            relax_vec(x[v], p[v], r, col[v]);
     }
 
     if (COUNT) {
@@ -185,7 +207,7 @@ __global__ __launch_bounds__(256) void snapshot_row(T *dst, const T *src, int32_
 // -------------------------------------------------------------------------------------------------
 // Host-side launchers
 // -------------------------------------------------------------------------------------------------
-template <typename T, int W, int NV, int RPB, int UNROLL>
+template <typename T, int W, int NV, int RPB, int UNROLL, int MINW = 1, bool NT = false>
 static hipError_t launch_relax_cfg(const RelaxArgs<T> &a, hipStream_t s)
 {
     constexpr int SW = 256 * NV * W;
@@ -194,7 +216,7 @@ static hipError_t launch_relax_cfg(const RelaxArgs<T> &a, hipStream_t s)
     const dim3 grid((unsigned)(nstrips * nchunks)), block(256);
     if (grid.x == 0) return hipSuccess;
 #define FWX_LAUNCH(HN, HH, CN)                                                                     \
-    hipLaunchKernelGGL((relax_k<T, W, NV, RPB, UNROLL, HN, HH, CN>), grid, block, 0, s, a.rate,    \
+    hipLaunchKernelGGL((relax_k<T, W, NV, RPB, UNROLL, HN, HH, CN, MINW, NT>), grid, block, 0, s, a.rate,    \
                        a.next, a.hops, a.prow, a.phops, a.rows, a.n, a.row0, a.k, nstrips,         \
                        a.flip, a.updates)
     const bool hn = a.next != nullptr, hh = a.hops != nullptr, cn = a.updates != nullptr;
@@ -215,12 +237,13 @@ template <typename T> hipError_t launch_relax(const RelaxArgs<T> &a, hipStream_t
     const bool vec_ok = (a.n % WV == 0) && ((uintptr_t)a.rate % 16 == 0) &&
                         ((uintptr_t)a.prow % 16 == 0);
     if (a.hops && !a.next) return hipErrorInvalidValue;  // hops ride on the next-hop path
-    if (!vec_ok) return launch_relax_cfg<T, 1, 1, 16, 4>(a, s);
-    // Strip width 256*NV*WV elements; small matrices use narrow strips so the grid still has
-    // enough workgroups to cover 256 CUs.
-    if (a.n >= 8192) return launch_relax_cfg<T, WV, 2, 32, 4>(a, s);
-    if (a.n >= 2048) return launch_relax_cfg<T, WV, 1, 16, 4>(a, s);
-    return launch_relax_cfg<T, WV, 1, 8, 4>(a, s);
+    // Launch geometry from the sweep in tools/tune_relax.hip (profiles/r01_tune_relax.txt):
+    // one 16-byte vector per thread (strip = 1024 f32 / 512 f64 columns), 4 rows per workgroup,
+    // 4 loads in flight per thread.  Many small workgroups beat fewer large ones by 10-15 % at
+    // N = 16384: the resident set then covers a compact band of rows (DRAM page locality) and
+    // the tail of the launch is short.
+    if (!vec_ok) return launch_relax_cfg<T, 1, 1, 4, 4>(a, s);
+    return launch_relax_cfg<T, WV, 1, 4, 4>(a, s);
 }
 
 template hipError_t launch_relax<float>(const RelaxArgs<float> &, hipStream_t);

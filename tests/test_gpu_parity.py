@@ -192,19 +192,22 @@ def test_torch_device_step_api_and_partition_emulation():
 
 
 def test_full_size_properties_n4096_fp32():
-    """Size-independent properties at a size the oracle cannot finish quickly:
-    idempotence (a solved no-arbitrage matrix is a fixed point: U == 0 on a second solve),
-    monotonicity (no rate decreases), and rate == product of edge rates along the next-hop path."""
+    """Properties at a size the oracle cannot finish quickly:
+      * monotonicity: no rate decreases (Algorithms.hs:55 only ever replaces by a larger value);
+      * rate == product of the input edge rates along the next-hop path (to fp32 rounding);
+      * a second solve moves no rate by more than rounding (exact idempotence does NOT hold in
+        floating point: re-associated products can win by an ulp);
+      * oracle parity on k-slices taken from the middle of the GPU solve, bit for bit."""
     n = 4096
     rate0, nxt0, _ = synth.make("d2", n, np.float32, seed=synth.BASE_SEED + 3)
     rate, nxt = rate0.copy(), nxt0.copy()
     u1 = engine.solve(rate, nxt, count_updates=True)
     assert u1 > 0
     assert np.all(rate >= rate0)
-    r2, n2 = rate.copy(), nxt.copy()
-    u2 = engine.solve(r2, n2, count_updates=True)
-    assert u2 == 0
-    assert_bits_equal(r2, rate) and np.array_equal(n2, nxt)
+    r2 = rate.copy()
+    engine.solve(r2)
+    assert np.all(r2 >= rate)
+    assert float(np.max((r2 - rate) / rate.clip(min=1e-30))) < 1e-5
     rnd = np.random.default_rng(1)
     for _ in range(300):
         s, d = (int(x) for x in rnd.integers(0, n, 2))
@@ -217,3 +220,23 @@ def test_full_size_properties_n4096_fp32():
             prod *= float(rate0[cur, v])
             cur = v
         assert abs(prod - float(rate[s, d])) <= 1e-5 * float(rate[s, d])
+    # mid-solve slices: GPU state at k=k0, then pivots [k0,k0+6) on both sides
+    for k0 in (0, 1531, n - 6):
+        r, nx = rate0.copy(), nxt0.copy()
+        if k0:
+            engine.solve(r, nx, k_begin=0, k_end=k0)
+        _solve_and_compare(r, nx, None, k_begin=k0, k_end=k0 + 6)
+
+
+def test_config4_n16384_fp32_k_slices_vs_oracle():
+    """BASELINE.json configs[3] size (1 GiB matrix, wide-strip launch configuration): oracle parity
+    on pivot slices at the start and in the middle of the solve; serpentine on == off."""
+    n = 16384
+    rate0, _ = synth.d1_uniform(n, np.float32, synth.BASE_SEED + 3)
+    _solve_and_compare(rate0, None, None, k_begin=0, k_end=3)
+    r = rate0.copy()
+    engine.solve(r, k_begin=0, k_end=301)
+    a = _solve_and_compare(r, None, None, k_begin=301, k_end=304)
+    b = r.copy()
+    engine.solve(b, k_begin=301, k_end=304, serpentine=False)
+    assert_bits_equal(a[0], b, "serpentine off")
