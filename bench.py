@@ -85,6 +85,19 @@ def cpu_baseline(rate_host, cpu_seconds):
                       "reference cannot be built in this image" % (done, n, rate_host.dtype, t_total)}
 
 
+def pmc_traffic(n, args):
+    """HBM bytes per relax_k launch from the committed rocprofv3 PMC passes (profiles/), which
+    cannot be collected inside this process.  Only quoted for the exact configuration they were
+    measured on (N=16384 fp32 rates-only single GPU); otherwise null."""
+    path = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
+    if n != 16384 or args.dtype != "f32" or args.with_next or args.kslice or not os.path.exists(path):
+        return None, None
+    with open(path) as f:
+        t = json.load(f)
+    return t["traffic_bytes_per_launch"], ("profiles/r01_pmc_traffic.json: rocprofv3 --pmc FETCH_SIZE "
+                                           "and --pmc WRITE_SIZE passes, FETCH_SIZE x2 (gfx950), KiB units")
+
+
 def main():
     args = parse_args()
     import torch
@@ -205,8 +218,10 @@ def main():
         # B_alg = s*N^3 + s*U + 2*s*N^2 per solve (+4*U with next)
         alg_bytes = es * n * n + (es + (4 if args.with_next else 0)) * u_per_launch + 2 * es * n
         achieved = alg_bytes / (avg_us * 1e-6) / 1e9
+        traffic, traffic_src = pmc_traffic(n, args)
         out["roofline"] = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS,
-                           "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS, "traffic": None,
+                           "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
+                           "traffic_source": traffic_src,
                            "kernel": "fwx::relax_k", "avg_launch_us": avg_us,
                            "alg_bytes_per_launch": alg_bytes, "updates_per_solve": updates,
                            "frac_of_measured_copy_peak_6290": achieved / 6290.0,

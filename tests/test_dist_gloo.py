@@ -1,0 +1,114 @@
+"""N > 1 path on CPU: world_size-2 (and 3) gloo process groups drive
+floydwarshall_amd.dist.solve_partitioned -- the row-block partition, the pivot-panel schedule, the
+look-ahead and the broadcast -- with an oracle-backed CPU backend standing in for the HIP kernels
+(the product backend is HIP only; this checks the schedule, not the kernels).  The gathered result
+must equal the oracle's single-process solve bit for bit."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+
+class OracleBackend:
+    """relax / panel restated with numpy for slabs with an explicit snapshot panel.
+    Step k on a slab (Algorithms.hs:42-61): c = r[i][k] * w_k[j]; update iff r[i][j] < c;
+    skip i == k (:50) and j in {i, k} (:54)."""
+
+    @staticmethod
+    def _apply(rate, nxt, n, row0, k, wk):
+        rows = rate.shape[0]
+        with np.errstate(all="ignore"):
+            c = rate[:, k:k + 1] * wk[None, :]
+        mask = rate < c
+        mask[:, k] = False
+        gi = np.arange(row0, row0 + rows)
+        mask[gi == k, :] = False
+        inside = (gi >= 0) & (gi < n)
+        mask[np.arange(rows)[inside], gi[inside]] = False
+        if nxt is not None:
+            nk = nxt[:, k].copy()
+            nxt[mask] = np.broadcast_to(nk[:, None], mask.shape)[mask]
+        rate[mask] = c[mask]
+
+    def relax(self, slab_rate, n, row0, k0, k1, w, slab_next=None):
+        r = slab_rate.numpy()
+        nx = None if slab_next is None else slab_next.numpy()
+        wn = w.numpy()
+        for k in range(k0, k1):
+            self._apply(r, nx, n, row0, k, wn[k - k0])
+
+    def panel(self, block_rate, n, k0, w, block_next=None):
+        r = block_rate.numpy()
+        nx = None if block_next is None else block_next.numpy()
+        wn = w.numpy()
+        for t in range(r.shape[0]):
+            wn[t] = r[t]                      # time-k snapshot of pivot row k0+t
+            self._apply(r, nx, n, k0, k0 + t, wn[t])
+
+
+def _worker(rank, world, port, n, block, lookahead, kind, with_next, outdir):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from floydwarshall_amd import dist as fwdist
+    from floydwarshall_amd import synth
+    rate, nxt, _ = synth.make(kind, n, np.float32, seed=4242)
+    b = fwdist.row_bounds(n, world)
+    slab = torch.from_numpy(rate[b[rank]:b[rank + 1]].copy())
+    nslab = torch.from_numpy(nxt[b[rank]:b[rank + 1]].copy()) if with_next else None
+    fwdist.solve_partitioned(slab, n, rank, world, nxt=nslab, block=block,
+                             backend=OracleBackend(), lookahead=lookahead)
+    np.save(os.path.join(outdir, "rate_%d.npy" % rank), slab.numpy())
+    if with_next:
+        np.save(os.path.join(outdir, "next_%d.npy" % rank), nslab.numpy())
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+@pytest.mark.parametrize("world,n,block,lookahead,kind", [
+    (2, 96, 16, True, "d1"),
+    (2, 96, 16, False, "d1"),
+    (2, 70, 8, True, "t1"),      # ties: earliest pivot must win on every rank
+    (3, 50, 7, True, "t3"),      # ragged partition, ragged panels, inf/NaN inputs
+])
+def test_partitioned_solve_equals_single_process_oracle(tmp_path, world, n, block, lookahead, kind):
+    import oracle
+    from floydwarshall_amd import synth
+    from helpers import assert_bits_equal
+    mp.spawn(_worker, args=(world, _free_port(), n, block, lookahead, kind, True, str(tmp_path)),
+             nprocs=world, join=True)
+    rate, nxt, _ = synth.make(kind, n, np.float32, seed=4242)
+    oracle.relax(rate, nxt)
+    got_r = np.concatenate([np.load(tmp_path / ("rate_%d.npy" % r)) for r in range(world)])
+    got_n = np.concatenate([np.load(tmp_path / ("next_%d.npy" % r)) for r in range(world)])
+    assert_bits_equal(got_r, rate, "partitioned rate")
+    assert_bits_equal(got_n, nxt, "partitioned next")
+
+
+def test_partition_helpers():
+    from floydwarshall_amd import dist as fwdist
+    assert fwdist.row_bounds(10, 3) == [0, 3, 6, 10]
+    blocks = fwdist.pivot_blocks(10, 3, 2)
+    assert [b[0] for b in blocks] == [0, 2, 3, 5, 6, 8]
+    assert sum(b[1] for b in blocks) == 10
+    for k0, b, owner in blocks:       # a panel never straddles two owners
+        lo, hi = fwdist.row_bounds(10, 3)[owner], fwdist.row_bounds(10, 3)[owner + 1]
+        assert lo <= k0 and k0 + b <= hi
+    assert fwdist.pivot_blocks(0, 2, 4) == []

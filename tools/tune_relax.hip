@@ -7,6 +7,7 @@
 
 #include <stdio.h>
 #include <stdlib.h>
+#include <string.h>
 #include <vector>
 
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s at %s:%d\n", hipGetErrorString(e), __FILE__, __LINE__); exit(1); } } while (0)
@@ -42,6 +43,31 @@ int main(int argc, char **argv)
     CK(hipMalloc(&d, n2 * sizeof(float)));
     hipLaunchKernelGGL(fill_uniform, dim3(4096), dim3(256), 0, 0, d, n2, n, 12345u);
     CK(hipDeviceSynchronize());
+
+    if (argc > 5 && !strcmp(argv[5], "solve")) {
+        // PMC probe mode: one full solve with the PRODUCTION launch path (fwx::launch_relax), so
+        // that `rocprofv3 --pmc FETCH_SIZE|WRITE_SIZE -- build/tune_relax 16384 0 0 0 solve` sees
+        // exactly the dispatches bench.py times (torch's bundled HIP runtime crashes under --pmc).
+        fwx::RelaxArgs<float> a;
+        a.rate = d; a.next = nullptr; a.hops = nullptr; a.phops = nullptr;
+        a.rows = n; a.n = n; a.row0 = 0; a.updates = nullptr;
+        hipEvent_t e0, e1;
+        CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+        CK(hipEventRecord(e0, 0));
+        const int kmax = argc > 6 ? atoi(argv[6]) : n;      // optional: only the first kmax pivots
+        const int sync_every = argc > 7 ? atoi(argv[7]) : 0; // optional: drain the queue regularly
+        for (int k = 0; k < kmax; ++k) {
+            a.k = k; a.prow = d + (size_t)k * n; a.flip = k & 1;
+            CK(fwx::launch_relax<float>(a, 0));
+            if (sync_every && (k + 1) % sync_every == 0) CK(hipDeviceSynchronize());
+        }
+        CK(hipEventRecord(e1, 0));
+        CK(hipEventSynchronize(e1));
+        float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+        printf("solve n=%d: %.3f ms, %.1f us/launch, %.3e relax/s\n", n, ms, 1e3 * ms / n,
+               (double)n * n * n / (ms * 1e-3));
+        return 0;
+    }
 
     std::vector<Cfg> cfgs = {
         {"NV1 RPB8 U8", run_cfg<1, 8, 8>},        {"NV1 RPB8 U8 w2", run_cfg<1, 8, 8, 2>},
