@@ -1,0 +1,171 @@
+// session.cpp -- AppState (InSync/OutSync) and the request layer over the GPU engine.
+//
+//   AppState / blankState   /root/reference/src/lib/Types.hs:35-37, Utils.hs:16-17
+//   updateRates             /root/reference/src/lib/ProcessRequests.hs:89-102
+//   findBestRate/syncMatrix /root/reference/src/lib/ProcessRequests.hs:70-85
+//   serveReq                /root/reference/src/lib/ProcessRequests.hs:31-63
+//   Main.run                /root/reference/src/app/Main.hs:26-37
+//
+// floydWarshall (Algorithms.hs:19-20) = build_matrix on the host + fwx_matrix_solve on the GPU.
+// The solved matrix stays resident in HBM (fwx_matrix) tagged with the rate-map version: queries
+// read back one rate and one path, not the matrix, and a query that fails in optimum does not
+// throw the solve away (the reference's lazy matrix costs nothing to rebuild; a GPU solve does).
+#include <cstring>
+
+#include "fwx.h"
+#include "host_types.hpp"
+
+namespace fwxh {
+
+Session::Session(int device) : device_(device) {}
+
+Session::~Session() { drop_device(); }
+
+void Session::drop_device()
+{
+    if (dev_) {
+        fwx_matrix_destroy(dev_);
+        dev_ = nullptr;
+    }
+}
+
+bool Session::update_rates(int64_t time, const Vertex &src, const Vertex &dest, double fwd, double bkd)
+{
+    // :97-98  rateOutdated = lookup (src,dest) <&> ((< time) . snd); update if Nothing or True
+    auto it = rates_.find(VertexPair(src, dest));
+    const bool update_required = it == rates_.end() || it->second.second < time;
+    if (!update_required) return false;
+    // :101-102 OutSync $ updateMap [((dest,src),(bkdR,time)), ((src,dest),(fwdR,time))] exRates
+    rates_[VertexPair(dest, src)] = std::make_pair(bkd, time);
+    rates_[VertexPair(src, dest)] = std::make_pair(fwd, time);
+    in_sync_ = false;
+    ++version_;
+    return true;
+}
+
+int Session::ensure_solved()
+{
+    if (solved_version_ == version_) return FWX_OK;
+    DenseMatrix m = build_matrix(rates_);
+    drop_device();
+    vertices_ = m.vertices;
+    if (m.n() > 0) {
+        int rc = fwx_matrix_create(&dev_, m.n(), FWX_F64, 1, 1, device_);
+        if (rc) return rc;
+        if ((rc = fwx_matrix_upload(dev_, m.rate.data(), m.next.data(), m.hops.data()))) return rc;
+        if ((rc = fwx_matrix_solve(dev_, nullptr))) return rc;      // runAlgo 0, on the GPU
+    }
+    solved_version_ = version_;
+    ++solves_;
+    return FWX_OK;
+}
+
+OptimumResult Session::find_best_rate(const Vertex &src, const Vertex &dest)
+{
+    OptimumResult res;
+    // :77-79  syncMatrix: OutSync -> floydWarshall, put InSync
+    const bool was_in_sync = in_sync_;
+    const int rc = ensure_solved();
+    if (rc) {
+        res.status = rc;
+        res.error = std::string("engine: ") + fwx_strerror(rc);
+        return res;
+    }
+    // :80  optimum src dest matrix -- index lookups on the host, entry + path from the device
+    const int32_t n = (int32_t)vertices_.size();
+    auto idx = [&](const Vertex &v) {
+        for (int32_t i = 0; i < n; ++i)
+            if (vertices_[i] == v) return i;
+        return (int32_t)-1;
+    };
+    const int32_t s = idx(src);
+    if (s < 0) { res.error = src.show() + " is not entered before"; }
+    const int32_t d = s < 0 ? -1 : idx(dest);
+    if (s >= 0 && d < 0) { res.error = dest.show() + " is not entered before"; }
+    if (s >= 0 && d >= 0) {
+        std::vector<int32_t> path((size_t)n);
+        double rate = 0.0;
+        const int len = fwx_matrix_query(dev_, s, d, &rate, path.data(), n);
+        if (len < 0) {
+            res.status = len;
+            res.error = std::string("engine: ") + fwx_strerror(len);
+            return res;
+        }
+        if (len == 0) {
+            res.error = "There is no exchange between " + src.show() + " and " + dest.show();
+        } else {
+            res.ok = true;
+            res.rate = rate;
+            res.start = src;
+            for (int i = 0; i < len; ++i) res.path.push_back(vertices_[path[i]]);
+        }
+    }
+    // The reference runs in RWST .. (Either e): when optimum fails the `put (InSync ..)` of :79
+    // is rolled back with everything else, so the visible state only advances on success.
+    in_sync_ = res.ok ? true : was_in_sync;
+    return res;
+}
+
+int Session::solved_matrix(DenseMatrix &out)
+{
+    const int rc = ensure_solved();
+    if (rc) return rc;
+    in_sync_ = true;
+    out.vertices = vertices_;
+    const size_t n = vertices_.size();
+    out.rate.assign(n * n, 0.0);
+    out.next.assign(n * n, -1);
+    out.hops.assign(n * n, 0);
+    if (n == 0) return FWX_OK;
+    return fwx_matrix_download(dev_, out.rate.data(), out.next.data(), out.hops.data());
+}
+
+std::vector<std::string> Session::serve_line(const std::string &line)
+{
+    std::vector<std::string> err, res;
+    // serveReq: catchError updateRatesM (\err1 -> ...)            ProcessRequests.hs:34-35
+    ParsedRates pr;
+    std::string e1;
+    if (parse_rates(line, pr, e1)) {
+        update_rates(pr.time, pr.src, pr.dest, pr.fwd, pr.bkd);
+        // :46-50 one line per stored rate, ascending key order
+        for (const auto &kv : rates_)
+            res.push_back(kv.first.first.show() + " -- " + show_double(kv.second.first) + " " +
+                          show_utctime(kv.second.second) + " --> " + kv.first.second.show());
+    } else {
+        // :36-38
+        err.push_back(e1);
+        err.push_back("Invalid request to update rates, probably a request for best rate");
+        // :39 catchError findBestRateM (\err2 -> tell err2)
+        Vertex src, dest;
+        std::string e2;
+        if (!parse_exch_pair(line, src, dest, e2)) {
+            err.push_back(e2);
+        } else {
+            OptimumResult r = find_best_rate(src, dest);
+            if (!r.ok) {
+                err.push_back(r.error);
+            } else {
+                // presentRateEntry :53-63
+                const Vertex &last = r.path.back();
+                res.push_back("BEST_RATES_BEGIN " + r.start.exch + " " + r.start.ccy + " " +
+                              last.exch + " " + last.ccy + " " + show_double(r.rate));
+                res.push_back(r.start.show());
+                for (const auto &v : r.path) res.push_back(v.show());
+                res.push_back("BEST_RATES_END");
+            }
+        }
+    }
+    // Main.run: Main.hs:34-37
+    std::vector<std::string> out;
+    if (res.empty()) {
+        out = err;
+        out.push_back("You neither enter exchange rates or request best rate, please enter a valid input\n");
+    } else {
+        out = res;
+        out.push_back("");
+    }
+    return out;
+}
+
+}  // namespace fwxh

@@ -1,0 +1,119 @@
+"""The drop-in demonstration: the reference's request layer on top of the GPU engine.
+
+BASELINE.json configs[0] (the 4-vertex KRAKEN/GDAX graph of the README) replayed line by line
+through the C++ host mirror, whose floydWarshall is the HIP path; plus the ProcessRequests
+known-answer tests that need a solve.  Golden data: tests/golden/readme_session.json
+(README.md:170-246) and process_requests.json (src/test/ProcessRequestsTest.hs)."""
+import numpy as np
+import pytest
+
+import oracle
+from floydwarshall_amd import host
+from oracle import list_faithful as lf
+
+from helpers import assert_bits_equal, golden_dense, load_golden
+
+pytestmark = pytest.mark.gpu
+
+
+def _session_with(rows):
+    s = host.Session(device=0)
+    for t, exch, a, b, fwd, bkd in rows:
+        assert s.update_rates(t, exch, a, b, fwd, bkd)
+    return s
+
+
+def test_readme_session_replays_byte_for_byte():
+    g = load_golden("readme_session.json")
+    s = host.Session(device=0)
+    for turn in g["turns"]:
+        assert s.serve_line(turn["in"]) == turn["out"], turn["in"]
+    # two distinct rate maps were queried: exactly two GPU solves, whatever the number of queries
+    assert s.solves == 2
+    assert s.state == host.INSYNC
+
+
+def test_floyd_warshall_golden_through_the_session():
+    # AlgorithmsTest.hs:66-77 via updateRates -> floydWarshall (GPU) -> download
+    g = load_golden("algorithms_4x4.json")
+    pr = load_golden("process_requests.json")
+    s = _session_with(pr["rates_ex2"])
+    rate, nxt, hops = s.solved_matrix()
+    erate, enext, ehops, _ = golden_dense(g["solved"])
+    assert_bits_equal(rate, erate, "solved rate")
+    assert np.array_equal(nxt, enext) and np.array_equal(hops, ehops)
+
+
+def test_serve_req_find_best_rate_and_state_transitions():
+    pr = load_golden("process_requests.json")
+    case = pr["serveReq_findBestRate"]                      # ProcessRequestsTest.hs:84-97
+    s = _session_with(pr["rates_ex2"])
+    assert s.state == host.OUTSYNC
+    out = s.serve_line(case["line"])
+    assert out == case["res"] + [""]                        # errs are dropped when res exists
+    assert s.state == host.INSYNC and s.solves == 1
+    # same query InSync: same answer, no new solve (ProcessRequestsTest.hs:154-162)
+    same = pr["findBestRate_sameUiSameResult"]
+    r, start, path = s.find_best_rate(("KRAKEN", "BTC"), ("KRAKEN", "USD"))
+    assert r == same["rate"] and list(start) == same["start"]
+    assert [list(v) for v in path] == same["path"]
+    assert s.solves == 1
+    # any accepted update turns the state OutSync again (ProcessRequestsTest.hs:108-115)
+    s.serve_line("2017-11-01T09:44:00+00:00 GDAX BTC USD 1002.0 0.0008")
+    assert s.state == host.OUTSYNC
+    r, _, path = s.find_best_rate(("KRAKEN", "BTC"), ("KRAKEN", "USD"))
+    assert r == 1002.0 and s.solves == 2 and s.state == host.INSYNC
+
+
+def test_find_best_rate_unknown_vertices_keep_state_and_cache():
+    pr = load_golden("process_requests.json")
+    s = _session_with(pr["rates_ex2"])
+    for name in ("findBestRate_srcNotExists", "findBestRate_destNotExists"):
+        case = pr[name]                                     # ProcessRequestsTest.hs:142-152
+        src, dst = host.parse_exch_pair(case["line"])
+        with pytest.raises(host.AlgoError) as e:
+            s.find_best_rate(src, dst)
+        assert str(e.value) == case["err"]
+        # the reference rolls the `put InSync` back with the failure (RWST over Either) ...
+        assert s.state == host.OUTSYNC
+    # ... but the GPU result is cached by rate-map version: the two failures cost one solve
+    assert s.solves == 1
+    s.find_best_rate(("KRAKEN", "BTC"), ("GDAX", "USD"))
+    assert s.solves == 1 and s.state == host.INSYNC
+
+
+def test_session_on_a_larger_market_matches_list_faithful_oracle():
+    """40 exchanges x 6 currencies, quotes with a spread (no arbitrage): every (src, dst) answer of
+    the GPU-backed session -- rate AND whole path -- equals the list-faithful restatement of
+    floydWarshall + optimum."""
+    rnd = np.random.default_rng(5)
+    ccys = ["AAA", "BBB", "CCC", "DDD", "EEE", "FFF"]
+    price = dict(zip(ccys, 0.5 + 1.5 * rnd.random(len(ccys))))
+    s = host.Session(device=0)
+    rates = {}
+    for e in range(8):
+        exch = "EX" + "ABCDEFGH"[e]
+        for i in range(len(ccys)):
+            for j in range(i + 1, len(ccys)):
+                if rnd.random() < 0.6:
+                    a, b = ccys[i], ccys[j]
+                    fwd = price[b] / price[a] * (0.97 + 0.03 * rnd.random())
+                    bkd = price[a] / price[b] * (0.97 + 0.03 * rnd.random())
+                    assert s.update_rates(1000 + e, exch, a, b, fwd, bkd)
+                    rates[((exch, a), (exch, b))] = fwd
+                    rates[((exch, b), (exch, a))] = bkd
+    m = lf.floyd_warshall(rates)
+    vertices = [row[0][1] for row in m]
+    grate, gnext, ghops = s.solved_matrix()
+    _, erate, enext, ehops = lf.to_dense(m)
+    assert_bits_equal(grate, erate, "rate")
+    assert np.array_equal(gnext, enext) and np.array_equal(ghops, ehops)
+    for _ in range(200):
+        a, b = (vertices[int(x)] for x in rnd.integers(0, len(vertices), 2))
+        exp = lf.optimum(a, b, m)
+        try:
+            r, start, path = s.find_best_rate(a, b)
+            assert exp[0] == "ok" and r == exp[1][0] and tuple(path) == exp[1][2]
+        except host.AlgoError as e:
+            assert exp == ("err", str(e))
+    assert s.solves == 1

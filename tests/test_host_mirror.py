@@ -1,0 +1,217 @@
+"""Host mirror (C++ in libfwx.so, include/fwx_host.h) against the reference's own known-answer
+tests -- parser strings, buildMatrix, optimum, the AppState FSM -- wherever no GPU solve is needed.
+Golden data: tests/golden/*.json (`_source` in each names the reference file:lines)."""
+import random
+
+import numpy as np
+import pytest
+
+from floydwarshall_amd import host
+from oracle import list_faithful as lf
+
+from helpers import golden_dense, load_golden
+
+
+def test_show_double_matches_ghc():
+    # values the reference prints: README.md:188-246, ParserTest.hs:54, ProcessRequestsTest.hs:77-78
+    cases = {1000.0: "1000.0", 0.0009: "9.0e-4", 1.0: "1.0", 1001.0: "1001.0", 0.0008: "8.0e-4",
+             0.434: "0.434", 1.1: "1.1", 0.0091: "9.1e-3", 0.1: "0.1", 0.05: "5.0e-2",
+             1e7: "1.0e7", 9999999.0: "9999999.0", 12345678.9: "1.23456789e7", 0.00089: "8.9e-4",
+             1001.1: "1001.1", 5e-324: "5.0e-324", 1.7976931348623157e308: "1.7976931348623157e308",
+             0.0: "0.0", -2.5: "-2.5", 123.456: "123.456", 100.0: "100.0", 1e21: "1.0e21",
+             0.30000000000000004: "0.30000000000000004", 2.0 / 3.0: "0.6666666666666666"}
+    for x, s in cases.items():
+        assert host.show_double(x) == s, x
+    assert host.show_double(float("inf")) == "Infinity"
+    assert host.show_double(float("nan")) == "NaN"
+
+
+def test_parse_rates_golden():
+    g = load_golden("parser_cases.json")
+    for case in g["parse_rates"]:
+        if "err" in case:
+            with pytest.raises(host.ParseError) as e:
+                host.parse_rates(case["line"])
+            assert str(e.value) == case["err"], case["ref"]
+        else:
+            t, src, dst, fwd, bkd = host.parse_rates(case["line"])
+            exp = case["ok"]
+            assert [t, src[0], src[1], dst[1], fwd, bkd] == exp, case["ref"]
+            assert src[0] == dst[0]
+
+
+def test_parse_exch_pair_golden():
+    g = load_golden("parser_cases.json")
+    for case in g["parse_exch_pair"]:
+        if "err" in case:
+            with pytest.raises(host.ParseError) as e:
+                host.parse_exch_pair(case["line"])
+            assert str(e.value) == case["err"], case["ref"]
+        else:
+            (a, b), (c, d) = host.parse_exch_pair(case["line"])
+            assert [a, b, c, d] == case["ok"], case["ref"]
+
+
+def test_parser_edge_cases_follow_attoparsec():
+    # not pinned by the reference's tests; these follow attoparsec's documented behaviour
+    for line, err in [("", "not enough input"), ("   ", "not enough input")]:
+        with pytest.raises(host.ParseError) as e:
+            host.parse_rates(line)
+        assert str(e.value) == err
+    with pytest.raises(host.ParseError) as e:
+        host.parse_exch_pair("KRAKEN BTC")
+    assert str(e.value) == "letter: not enough input"
+    with pytest.raises(host.ParseError) as e:
+        host.parse_exch_pair("KRAKEN BTC 12 USD")
+    assert str(e.value) == "letter: Failed reading: satisfy"
+    # timezone offsets are applied; "+0100" and "+01:00" both parse
+    assert host.parse_rates("2017-11-01T10:42:23+01:00 K A B 1 1")[0] == 1509529343
+    assert host.parse_rates("2017-11-01T10:42:23+0100 K A B 1 1")[0] == 1509529343
+    # trailing junk is ignored by parseOnly (README.md:170 feeds "0.434d")
+    assert host.parse_rates("2017-11-01T09:42:23+00:00 K A B 0.5 1.5zzz")[3:] == (0.5, 1.5)
+    # exponents; a malformed exponent backtracks and leaves the 'e' unread
+    assert host.parse_rates("2017-11-01T09:42:23+00:00 K A B 1e-3 2E2")[3:] == (0.001, 200.0)
+    with pytest.raises(host.ParseError) as e:
+        host.parse_rates("2017-11-01T09:42:23+00:00 K A B 0.5e 1")
+    assert str(e.value) == "Failed reading: takeWhile1"
+
+
+def _session_with(rows):
+    s = host.Session()
+    for t, exch, a, b, fwd, bkd in rows:
+        assert s.update_rates(t, exch, a, b, fwd, bkd)
+    return s
+
+
+def test_build_matrix_golden_through_the_session():
+    # AlgorithmsTest.hs:49-60 via updateRates + buildMatrix of the C++ mirror
+    g = load_golden("algorithms_4x4.json")
+    pr = load_golden("process_requests.json")
+    s = _session_with(pr["rates_ex2"])
+    vertices, rate, nxt = s.build_matrix()
+    assert [list(v) for v in vertices] == g["vertices"]
+    erate, enext, _, _ = golden_dense(g["initial"])
+    assert np.array_equal(rate, erate) and np.array_equal(nxt, enext)
+    # empty map -> empty matrix (AlgorithmsTest.hs:45-47)
+    v0, r0, n0 = host.Session().build_matrix()
+    assert v0 == [] and r0.shape == (0, 0)
+
+
+def test_build_matrix_same_currency_wins_over_map_entry():
+    # Algorithms.hs:35 is tested before the map lookup (:36)
+    s = host.Session()
+    s.update_rates(1, "A", "USD", "EUR", 0.5, 1.5)
+    s.update_rates(1, "B", "USD", "EUR", 0.25, 2.0)
+    vertices, rate, nxt = s.build_matrix()
+    rates = {(("A", "USD"), ("A", "EUR")): 0.5, (("A", "EUR"), ("A", "USD")): 1.5,
+             (("B", "USD"), ("B", "EUR")): 0.25, (("B", "EUR"), ("B", "USD")): 2.0}
+    m = lf.build_matrix(rates)
+    ev, er, en, _ = lf.to_dense(m)
+    assert vertices == ev and np.array_equal(rate, er) and np.array_equal(nxt, en)
+
+
+def test_optimum_dense_golden_cases():
+    g = load_golden("algorithms_4x4.json")
+    c = load_golden("optimum_cases.json")
+    vertices = [tuple(v) for v in g["vertices"]]
+    rate, nxt, _, _ = golden_dense(g["solved"])
+    for case in c["not_exist"]:                                   # AlgorithmsTest.hs:82-91
+        with pytest.raises(host.AlgoError) as e:
+            host.optimum_dense(vertices, rate, nxt, tuple(case["src"]), tuple(case["dst"]))
+        assert str(e.value) == case["err"]
+    i, j = c["reachability"]["isolate"]                           # AlgorithmsTest.hs:93-110
+    rate2, nxt2 = rate.copy(), nxt.copy()
+    rate2[i, j], nxt2[i, j] = 0.0, -1
+    for case in c["reachability"]["cases"]:
+        if "err" in case:
+            with pytest.raises(host.AlgoError) as e:
+                host.optimum_dense(vertices, rate2, nxt2, tuple(case["src"]), tuple(case["dst"]))
+            assert str(e.value) == case["err"]
+        else:
+            # The reference stores a whole `_path` list per entry, so its hand-edited matrix
+            # (entry [3][0] blanked) still answers [1][0] = [3,2,0] although that route crosses the
+            # blanked entry.  The dense form reconstructs paths from next-hops and needs a
+            # CONSISTENT matrix (every floydWarshall output is): entries whose route crosses the
+            # edit are therefore checked on the unedited solved matrix, where they are identical.
+            crosses = any(v == vertices[i] for v in map(tuple, case["path"][:-1]))
+            rr, nn = (rate, nxt) if crosses else (rate2, nxt2)
+            r, start, path = host.optimum_dense(vertices, rr, nn, tuple(case["src"]),
+                                                tuple(case["dst"]))
+            assert r == case["rate"] and start == tuple(case["src"])
+            assert [list(v) for v in path] == case["path"]
+
+
+def test_optimum_dense_error_precedence_property():
+    # AlgorithmsTest.hs:112-134 with MockData.hs:59-81 generators, against the C++ optimum
+    c = load_golden("optimum_cases.json")
+    sample = [tuple(v) for v in c["sample_vertices"]]
+    rnd = random.Random(11)
+    for _ in range(300):
+        src, dest = rnd.choice(sample), rnd.choice(sample)
+        k = rnd.randint(0, len(sample) // 2 + 1)
+        vertices = sorted(set(rnd.choice(sample) for _ in range(k)))
+        n = len(vertices)
+        empty_rows = rnd.random() < 0.5
+        rate = np.ones((n, n)) - np.eye(n)
+        nxt = np.tile(np.arange(n, dtype=np.int32), (n, 1))
+        np.fill_diagonal(nxt, -1)
+        sv, dv = "(%s, %s)" % src, "(%s, %s)" % dest
+        if n == 0:
+            exp = sv + " is not entered before"
+        elif empty_rows:
+            exp = "The matrix is empty"
+        elif src not in vertices:
+            exp = sv + " is not entered before"
+        elif dest not in vertices:
+            exp = dv + " is not entered before"
+        elif src == dest:
+            exp = "There is no exchange between " + sv + " and " + dv
+        else:
+            exp = None
+        try:
+            got = host.optimum_dense(vertices, rate, nxt, src, dest, n_cols=0 if empty_rows else n)
+            assert exp is None and got == (1.0, src, [dest])
+        except host.AlgoError as e:
+            assert str(e) == exp
+
+
+def test_update_rates_fsm_without_gpu():
+    pr = load_golden("process_requests.json")
+    s = host.Session()
+    assert s.state == host.OUTSYNC and s.rate_count == 0            # blankState, Utils.hs:16-17
+    out = s.serve_line(pr["serveReq_updateRates"]["line"])          # ProcessRequestsTest.hs:76-82
+    assert out == pr["serveReq_updateRates"]["res"] + [""]
+    assert s.state == host.OUTSYNC and s.rate_count == 2
+    # not newer / equal timestamp: ignored (ProcessRequestsTest.hs:131-137), rates still listed
+    for line in pr["updateRates_notNewerTs"]["lines"]:
+        s.serve_line(line)
+        _, rate, _ = s.build_matrix()
+        assert 1000.0 in rate and 0.00089 not in rate
+    # newer timestamp, case-insensitive (ProcessRequestsTest.hs:117-129)
+    for line in pr["updateRates_onlyUpdateByNewerTs"]["lines"]:
+        s2 = _session_with(pr["rates_ex2"])
+        s2.serve_line(line)
+        vertices, rate, _ = s2.build_matrix()
+        kb, ku = vertices.index(("KRAKEN", "BTC")), vertices.index(("KRAKEN", "USD"))
+        assert rate[kb, ku] == 1001.1 and rate[ku, kb] == 0.00089
+
+
+def test_serve_line_invalid_for_both_requests():
+    # ProcessRequestsTest.hs:64-74: no state change, three error lines + the hint
+    pr = load_golden("process_requests.json")
+    case = pr["serveReq_bothInvalid"]
+    s = _session_with(pr["rates_ex2"])
+    out = s.serve_line(case["line"])
+    assert out[:3] == case["err"]
+    assert out[3] == ("You neither enter exchange rates or request best rate, please enter a "
+                      "valid input")
+    assert out[4:] == [""]
+    assert s.state == host.OUTSYNC and s.rate_count == 4
+
+
+def test_readme_session_turns_that_need_no_solve():
+    # README.md:170-199: the first five turns never reach floydWarshall with a non-empty matrix
+    g = load_golden("readme_session.json")
+    s = host.Session()
+    for turn in g["turns"][:5]:
+        assert s.serve_line(turn["in"]) == turn["out"], turn["in"]
