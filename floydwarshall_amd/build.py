@@ -15,8 +15,9 @@ PKG = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(PKG)
 CSRC = os.path.join(PKG, "csrc")
 LIB = os.path.join(PKG, "libfwx.so")
+CLI = os.path.join(PKG, "fwx_cli")
 
-HIP_SOURCES = ["fwx_kernels.hip", "fwx_api.hip"]
+HIP_SOURCES = ["fwx_kernels.hip", "fwx_fused.hip", "fwx_api.hip"]
 CXX_SOURCES = []  # host mirror sources are appended below when present
 HOST_DIR = os.path.join(CSRC, "host")
 
@@ -40,6 +41,7 @@ def _sources():
 def _deps():
     deps = _sources() + [os.path.join(ROOT, "include", f)
                          for f in os.listdir(os.path.join(ROOT, "include"))]
+    deps.append(os.path.join(CSRC, "cli", "fwx_cli.cpp"))
     for d in (CSRC, HOST_DIR):
         if os.path.isdir(d):
             deps += [os.path.join(d, f) for f in os.listdir(d) if f.endswith((".h", ".hpp"))]
@@ -64,7 +66,21 @@ def build_lib(force=False, verbose=False):
         print(" ".join(cmd))
     subprocess.run(cmd, check=True)
     os.replace(LIB + ".tmp", LIB)
+    build_cli(hipcc, verbose)
     return LIB
+
+
+def build_cli(hipcc, verbose=False):
+    """fwx_cli: the reference's Main loop (src/app/Main.hs) over libfwx; host-only C++."""
+    src = os.path.join(CSRC, "cli", "fwx_cli.cpp")
+    if not os.path.exists(src):
+        return None
+    cmd = [hipcc, "-O2", "-std=c++17", "-I" + os.path.join(ROOT, "include"), src, "-o", CLI,
+           "-L" + PKG, "-lfwx", "-Wl,-rpath,$ORIGIN"]
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.run(cmd, check=True)
+    return CLI
 
 
 if __name__ == "__main__":

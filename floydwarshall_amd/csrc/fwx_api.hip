@@ -105,6 +105,59 @@ int relax_range(T *rate, int32_t *next, int32_t *hops, int rows, int n, int row0
     return FWX_OK;
 }
 
+template <typename T>
+int fused_block(T *rate, int32_t *next, int rows, int n, int row0, int k0, int bt, const T *w, T *ct,
+                int32_t *cnt, unsigned long long *d_updates, hipStream_t s)
+{
+    fwx::FusedArgs<T> a;
+    a.rate = rate; a.next = next; a.rows = rows; a.n = n; a.row0 = row0;
+    a.k0 = k0; a.bt = bt; a.w = w; a.ct = ct; a.cnt = cnt; a.updates = d_updates;
+    hipError_t e = fwx::launch_fused_relax<T>(a, s);
+    if (e == hipErrorInvalidValue) return FWX_ERR_INVALID;
+    FWX_HIP(e);
+    return FWX_OK;
+}
+
+// Can the fused engine run this matrix?  (16-byte vectors along rows, no hops.)
+template <typename T> bool fused_ok(int n, const void *rate, const int32_t *hops)
+{
+    return hops == nullptr && n % (16 / (int)sizeof(T)) == 0 && ((uintptr_t)rate % 16) == 0;
+}
+
+// Single-GPU solve of pivots [k_begin,k_end) with the fused engine: per block of <= 64 pivots,
+// snapshot panel (diag + rowpanel), then colpanel + main over all rows.  ws: see fused_ws_bytes.
+template <typename T>
+int fused_range(T *rate, int32_t *next, int n, int k_begin, int k_end, void *ws,
+                unsigned long long *d_updates, hipStream_t s)
+{
+    char *p = (char *)ws;
+    T *w = (T *)p;                 p += (size_t)FWX_FUSED_B * n * sizeof(T);
+    T *ct = (T *)p;                p += (size_t)FWX_FUSED_B * n * sizeof(T);
+    int32_t *cnt = (int32_t *)p;   p += (size_t)FWX_FUSED_B * n * sizeof(int32_t);
+    T *diag = (T *)p;
+    for (int k0 = k_begin; k0 < k_end; k0 += FWX_FUSED_B) {
+        const int bt = k_end - k0 < FWX_FUSED_B ? k_end - k0 : FWX_FUSED_B;
+        FWX_HIP(fwx::launch_fused_panel<T>(rate + (size_t)k0 * n, n, k0, bt, w, diag, s));
+        const int rc = fused_block<T>(rate, next, n, n, 0, k0, bt, w, ct, next ? cnt : nullptr,
+                                      d_updates, s);
+        if (rc) return rc;
+    }
+    return FWX_OK;
+}
+
+size_t fused_ws_bytes(int n, size_t es)
+{
+    return (size_t)FWX_FUSED_B * n * (2 * es + 4) + (size_t)2 * FWX_FUSED_B * FWX_FUSED_B * es + 256;
+}
+
+// AUTO: the fused engine wherever it applies and the matrix is big enough to fill the chip.
+template <typename T> bool pick_fused(int engine, int n, const void *rate, const int32_t *hops)
+{
+    if (engine == FWX_ENGINE_PERK) return false;
+    if (!fused_ok<T>(n, rate, hops)) return false;
+    return engine == FWX_ENGINE_FUSED || n >= 512;
+}
+
 int sum_updates(unsigned long long *d_updates, uint64_t *out, hipStream_t s)
 {
     unsigned long long h[FWX_UPDATE_SHARDS];
@@ -154,10 +207,20 @@ int solve_host(int32_t n, T *rate, int32_t *next, int32_t *hops, const fwx_opts 
 
     T *dr = (T *)d_rate.p;
     int32_t *dh = (int32_t *)d_hops.p;
-    rc = relax_range<T>(dr, (int32_t *)d_next.p, dh, n, n, 0, dr + (size_t)op.k_begin * n,
-                        dh ? dh + (size_t)op.k_begin * n : nullptr, n, op.k_begin, op.k_end,
-                        op.serpentine, op.updates_out ? (unsigned long long *)d_upd.p : nullptr, s);
-    if (rc) return rc;
+    unsigned long long *upd = op.updates_out ? (unsigned long long *)d_upd.p : nullptr;
+    if (op.engine == FWX_ENGINE_FUSED && !fused_ok<T>(n, dr, dh)) return FWX_ERR_UNSUPPORTED;
+    if (pick_fused<T>(op.engine, n, dr, dh)) {
+        DevBuf d_ws;
+        if ((rc = d_ws.alloc(fused_ws_bytes(n, sizeof(T))))) return rc;
+        rc = fused_range<T>(dr, (int32_t *)d_next.p, n, op.k_begin, op.k_end, d_ws.p, upd, s);
+        if (rc) return rc;
+        FWX_HIP(hipStreamSynchronize(s));   // d_ws is released at scope exit
+    } else {
+        rc = relax_range<T>(dr, (int32_t *)d_next.p, dh, n, n, 0, dr + (size_t)op.k_begin * n,
+                            dh ? dh + (size_t)op.k_begin * n : nullptr, n, op.k_begin, op.k_end,
+                            op.serpentine, upd, s);
+        if (rc) return rc;
+    }
 
     FWX_HIP(hipMemcpyAsync(rate, d_rate.p, nn * sizeof(T), hipMemcpyDeviceToHost, s));
     if (next) FWX_HIP(hipMemcpyAsync(next, d_next.p, nn * sizeof(int32_t), hipMemcpyDeviceToHost, s));
@@ -184,6 +247,9 @@ __global__ void follow_path_kernel(const int32_t *next, int n, int src, int dst,
     }
     *len_out = len;
 }
+
+template <typename T>
+int matrix_solve_typed(fwx_matrix *m, const Opts &op, unsigned long long *upd, hipStream_t s);
 
 int check_slab(const fwx_slab *s)
 {
@@ -225,6 +291,28 @@ struct fwx_matrix {
     int32_t *next, *hops, *scratch;
     unsigned long long *upd;
 };
+
+namespace {
+template <typename T>
+int matrix_solve_typed(fwx_matrix *m, const Opts &op, unsigned long long *upd, hipStream_t s)
+{
+    const int n = m->n;
+    T *r = (T *)m->rate;
+    if (op.engine == FWX_ENGINE_FUSED && !fused_ok<T>(n, r, m->hops)) return FWX_ERR_UNSUPPORTED;
+    if (pick_fused<T>(op.engine, n, r, m->hops)) {
+        DevBuf ws;
+        int rc = ws.alloc(fused_ws_bytes(n, sizeof(T)));
+        if (rc) return rc;
+        rc = fused_range<T>(r, m->next, n, op.k_begin, op.k_end, ws.p, upd, s);
+        if (rc) return rc;
+        FWX_HIP(hipStreamSynchronize(s));
+        return FWX_OK;
+    }
+    return relax_range<T>(r, m->next, m->hops, n, n, 0, r + (size_t)op.k_begin * n,
+                          m->hops ? m->hops + (size_t)op.k_begin * n : nullptr, n, op.k_begin,
+                          op.k_end, op.serpentine, upd, s);
+}
+}  // namespace
 
 extern "C" {
 
@@ -364,20 +452,12 @@ int fwx_matrix_solve(fwx_matrix *m, const fwx_opts *opts)
     DeviceGuard g;
     if ((rc = g.enter(m->device))) return rc;
     hipStream_t s = nullptr;
-    const int n = m->n;
     unsigned long long *upd = op.updates_out ? m->upd : nullptr;
     if (upd) FWX_HIP(hipMemsetAsync(upd, 0, FWX_UPDATE_SHARDS * 8, s));
-    if (m->dtype == FWX_F64) {
-        double *r = (double *)m->rate;
-        rc = relax_range<double>(r, m->next, m->hops, n, n, 0, r + (size_t)op.k_begin * n,
-                                 m->hops ? m->hops + (size_t)op.k_begin * n : nullptr, n,
-                                 op.k_begin, op.k_end, op.serpentine, upd, s);
-    } else {
-        float *r = (float *)m->rate;
-        rc = relax_range<float>(r, m->next, m->hops, n, n, 0, r + (size_t)op.k_begin * n,
-                                m->hops ? m->hops + (size_t)op.k_begin * n : nullptr, n,
-                                op.k_begin, op.k_end, op.serpentine, upd, s);
-    }
+    if (m->dtype == FWX_F64)
+        rc = matrix_solve_typed<double>(m, op, upd, s);
+    else
+        rc = matrix_solve_typed<float>(m, op, upd, s);
     if (rc) return rc;
     FWX_HIP(hipStreamSynchronize(s));
     if (upd) return sum_updates(upd, op.updates_out, s);
@@ -447,11 +527,49 @@ int fwx_dev_panel(const fwx_slab *block, void *w_rate, int32_t *w_hops,
     return panel_impl<float>(block, (float *)w_rate, w_hops, d_updates, s);
 }
 
+size_t fwx_fused_diag_ws_bytes(int32_t dtype)
+{
+    return (size_t)2 * FWX_FUSED_B * FWX_FUSED_B * (dtype == FWX_F64 ? 8 : 4);
+}
+
+int fwx_dev_panel_snap(const fwx_slab *block, void *w_rate, void *diag_ws, void *stream)
+{
+    int rc = check_slab(block);
+    if (rc) return rc;
+    if (block->rows == 0 || block->n == 0) return FWX_OK;
+    if (!w_rate || !diag_ws || block->rows > FWX_FUSED_B) return FWX_ERR_INVALID;
+    if (device_count() <= 0) return FWX_ERR_NO_DEVICE;
+    hipStream_t s = (hipStream_t)stream;
+    if (block->dtype == FWX_F64)
+        FWX_HIP(fwx::launch_fused_panel<double>((const double *)block->rate, block->n, block->row0,
+                                                block->rows, (double *)w_rate, (double *)diag_ws, s));
+    else
+        FWX_HIP(fwx::launch_fused_panel<float>((const float *)block->rate, block->n, block->row0,
+                                               block->rows, (float *)w_rate, (float *)diag_ws, s));
+    return FWX_OK;
+}
+
 int fwx_dev_relax_fused(const fwx_slab *slab, const fwx_pivots *piv, void *col_rate,
                         int32_t *col_next, unsigned long long *d_updates, void *stream)
 {
-    (void)slab; (void)piv; (void)col_rate; (void)col_next; (void)d_updates; (void)stream;
-    return FWX_ERR_UNSUPPORTED;
+    int rc = check_slab(slab);
+    if (rc) return rc;
+    if (!piv || piv->k_begin < 0 || piv->k_end < piv->k_begin || piv->k_end > slab->n ||
+        piv->k_end - piv->k_begin > FWX_FUSED_B)
+        return FWX_ERR_INVALID;
+    if (slab->rows == 0 || slab->n == 0 || piv->k_end == piv->k_begin) return FWX_OK;
+    if (slab->hops) return FWX_ERR_UNSUPPORTED;
+    if (!piv->rate || piv->stride != slab->n || !col_rate || (slab->next && !col_next))
+        return FWX_ERR_INVALID;
+    if (device_count() <= 0) return FWX_ERR_NO_DEVICE;
+    hipStream_t s = (hipStream_t)stream;
+    if (slab->dtype == FWX_F64)
+        return fused_block<double>((double *)slab->rate, slab->next, slab->rows, slab->n, slab->row0,
+                                   piv->k_begin, piv->k_end - piv->k_begin, (const double *)piv->rate,
+                                   (double *)col_rate, col_next, d_updates, s);
+    return fused_block<float>((float *)slab->rate, slab->next, slab->rows, slab->n, slab->row0,
+                              piv->k_begin, piv->k_end - piv->k_begin, (const float *)piv->rate,
+                              (float *)col_rate, col_next, d_updates, s);
 }
 
 }  // extern "C"

@@ -1,0 +1,392 @@
+// fwx_fused.hip -- the fused engine: B = 64 pivots of runAlgo
+// (/root/reference/src/lib/Algorithms.hs:42-61) per pass over the matrix, bit-identical to the
+// per-k loop.
+//
+// Why it is exact.  Step k only ever combines an entry with column k and row k AS THEY STAND AT
+// THE START OF STEP k (Algorithms.hs:58-60), and neither is modified by step k (:50, :54).  So for
+// pivots k0..k0+B-1 an entry's final value is the in-order fold
+//       x <- (x < C_k[i] * W_k[j]) ? C_k[i] * W_k[j] : x        k = k0, k0+1, ...
+// where W_k = row k at time k and C_k = column k at time k ("time-k snapshots").  Same operands,
+// same order, same single multiply and strict compare as the reference: no product is
+// re-associated (classic 3-phase blocked Floyd-Warshall is NOT exact: SURVEY.md Appendix B).
+// The snapshots themselves are produced by the same fold restricted to the pivot rows/columns:
+//
+//   fused_diag      the B x B diagonal block through its B pivots (one workgroup, LDS):
+//                   exports Wd[t][c] = D_t[k0+t][k0+c] and Cd[r][t] = D_t[k0+r][k0+t]
+//   fused_rowpanel  every column j of the B pivot rows (needs Cd): exports W[t][j]
+//   fused_colpanel  the B pivot columns of every row i (needs W's block columns): exports
+//                   Ct[t][i] (NaN where i == k: skip i==k) and CNt[t][i] = next_t[i][k0+t]
+//   fused_main      128 x 128 (f32) tile per workgroup, 8 x 8 entries per thread in registers,
+//                   W tile and C tile staged in LDS: B relaxations per entry per HBM round trip
+//
+// Skip set: i==k via NaN in Ct, j==k via NaN injected into the staged W tile, j==i by restoring
+// the diagonal entry at write-back.  Scratch copies of diagonal entries may go stale inside the
+// panel kernels; they are provably never consumed (every consumer is an i==k or j==k case).
+//
+// Roofline: per pass 4 B read + 4 B written per entry against 3*B = 192 VALU lane-ops per entry,
+// so this kernel is VALU-bound (about 3 lane-ops per relaxation), not HBM-bound.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "fwx_kernels.h"
+
+#pragma clang fp contract(off)
+
+namespace fwx {
+
+namespace {
+
+template <typename T> __device__ __forceinline__ T qnan();
+template <> __device__ __forceinline__ float qnan<float>() { return __builtin_nanf(""); }
+template <> __device__ __forceinline__ double qnan<double>() { return __builtin_nan(""); }
+
+template <typename T> struct Vec16;
+template <> struct Vec16<float> {
+    typedef float type __attribute__((ext_vector_type(4)));
+    static constexpr int W = 4;
+};
+template <> struct Vec16<double> {
+    typedef double type __attribute__((ext_vector_type(2)));
+    static constexpr int W = 2;
+};
+template <int W> struct IVec;
+template <> struct IVec<4> { typedef int type __attribute__((ext_vector_type(4))); };
+template <> struct IVec<2> { typedef int type __attribute__((ext_vector_type(2))); };
+
+constexpr int B = FWX_FUSED_B;
+
+// ------------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void fused_diag(const T *rows, int n, int k0, int bt, T *wd,
+                                                  T *cdt)
+{
+    __shared__ T blk[B][B + 1];
+    const int tid = threadIdx.x;
+    for (int idx = tid; idx < B * B; idx += 256) {
+        const int r = idx / B, c = idx % B;
+        blk[r][c] = (r < bt && c < bt) ? rows[(size_t)r * n + k0 + c] : qnan<T>();
+    }
+    __syncthreads();
+    for (int t = 0; t < bt; ++t) {
+        // row t and column t are fixed points of step t: record them, then relax the rest
+        if (tid < B) {
+            wd[t * B + tid] = blk[t][tid];      // Wd[t][c]
+            cdt[t * B + tid] = blk[tid][t];     // Cd[r][t], stored pivot-major
+        }
+        for (int idx = tid; idx < B * B; idx += 256) {
+            const int r = idx / B, c = idx % B;
+            if (r != t && c != t && r != c) {
+                const T cand = blk[r][t] * blk[t][c];
+                if (blk[r][c] < cand) blk[r][c] = cand;
+            }
+        }
+        __syncthreads();
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// 64 columns per workgroup; wave w keeps pivot rows 16w..16w+15 of its columns in registers.
+template <typename T>
+__global__ __launch_bounds__(256) void fused_rowpanel(const T *rows, int n, int k0, int bt,
+                                                      const T *cdt, T *w_out)
+{
+    constexpr int RPW = B / 4;
+    __shared__ T wrow[2][64];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int j = blockIdx.x * 64 + lane;
+    const bool valid = j < n;
+    const int jc = valid ? j : n - 1;
+
+    T p[RPW];
+#pragma unroll
+    for (int q = 0; q < RPW; ++q) {
+        const int r = wave * RPW + q;
+        p[q] = r < bt ? rows[(size_t)r * n + jc] : qnan<T>();
+    }
+    // a column inside the block carries one diagonal entry, which must be published untouched
+    const bool in_blk = valid && j >= k0 && j < k0 + bt;
+    const T dorig = in_blk ? rows[(size_t)(j - k0) * n + j] : T(0);
+
+#pragma unroll
+    for (int t = 0; t < B; ++t) {
+        if (t >= bt) continue;   // wave-uniform; `continue` keeps the loop fully unrollable so
+                                 // that every p[..] index below is a compile-time constant
+        const int ow = t / RPW, oq = t % RPW;
+        if (wave == ow) {
+            T v = p[oq];
+            if (j == k0 + t) v = dorig;
+            wrow[t & 1][lane] = v;
+            if (valid) w_out[(size_t)t * n + j] = v;
+        }
+        __syncthreads();
+        T w = wrow[t & 1][lane];
+        if (j == k0 + t) w = qnan<T>();                       // skip j == k
+        const T *cd = cdt + t * B + wave * RPW;               // wave-uniform -> scalar loads
+#pragma unroll
+        for (int q = 0; q < RPW; ++q) {
+            if (q == oq && wave == ow) continue;              // skip i == k
+            const T cand = cd[q] * w;
+            if (p[q] < cand) p[q] = cand;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// 64 rows per workgroup; wave w keeps block columns 16w..16w+15 of its rows in registers.
+template <typename T, bool HAS_NEXT>
+__global__ __launch_bounds__(256) void fused_colpanel(const T *rate, const int32_t *next, int rows,
+                                                      int n, int row0, int k0, int bt, const T *w,
+                                                      T *ct, int32_t *cnt)
+{
+    constexpr int CPW = B / 4;
+    __shared__ T ccol[2][64];
+    __shared__ int32_t ncol[2][64];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int il = blockIdx.x * 64 + lane;
+    const bool valid = il < rows;
+    const int ic = valid ? il : rows - 1;
+    const int gi = row0 + ic;
+
+    T d[CPW];
+    int32_t nx[CPW];
+#pragma unroll
+    for (int q = 0; q < CPW; ++q) {
+        const int c = wave * CPW + q;
+        const size_t off = (size_t)ic * n + k0 + (c < bt ? c : 0);
+        d[q] = c < bt ? rate[off] : qnan<T>();
+        nx[q] = (HAS_NEXT && c < bt) ? next[off] : -1;
+    }
+
+#pragma unroll
+    for (int t = 0; t < B; ++t) {
+        if (t >= bt) continue;   // wave-uniform (see fused_rowpanel)
+        const int ow = t / CPW, oq = t % CPW;
+        if (wave == ow) {
+            ccol[t & 1][lane] = d[oq];
+            if (HAS_NEXT) ncol[t & 1][lane] = nx[oq];
+        }
+        __syncthreads();
+        T c = ccol[t & 1][lane];
+        const int32_t cn = HAS_NEXT ? ncol[t & 1][lane] : 0;
+        if (gi == k0 + t) c = qnan<T>();                      // skip i == k
+        if (wave == ow && valid) {
+            ct[(size_t)t * rows + il] = c;
+            if (HAS_NEXT) cnt[(size_t)t * rows + il] = cn;
+        }
+        const T *wd = w + (size_t)t * n + k0;                 // Wd[t][.], wave-uniform
+#pragma unroll
+        for (int q = 0; q < CPW; ++q) {
+            if (q == oq && wave == ow) continue;              // skip j == k
+            const int cq = wave * CPW + q;
+            const T wv = cq < bt ? wd[cq] : qnan<T>();
+            const T cand = c * wv;
+            if (d[q] < cand) {
+                d[q] = cand;
+                if (HAS_NEXT) nx[q] = cn;
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+template <typename T, bool HAS_NEXT, bool COUNT>
+__global__ __launch_bounds__(256) void fused_main(T *rate, int32_t *next, int rows, int n,
+                                                  int row0, int k0, int bt, const T *w,
+                                                  const T *ct, const int32_t *cnt,
+                                                  unsigned long long *updates)
+{
+    using V = typename Vec16<T>::type;
+    using IV = typename IVec<Vec16<T>::W>::type;
+    constexpr int VW = Vec16<T>::W;
+    constexpr int RI = 8, TI = 16 * RI;       // 128 rows
+    constexpr int TJ = 16 * 2 * VW;           // 128 (f32) / 64 (f64) columns
+    constexpr int HJ = TJ / 2;
+
+    __shared__ __attribute__((aligned(16))) T sW[B][TJ];
+    __shared__ __attribute__((aligned(16))) T sC[B][TI];
+    __shared__ __attribute__((aligned(16))) int32_t sN[HAS_NEXT ? B : 1][HAS_NEXT ? TI : 4];
+    __shared__ unsigned int s_cnt;
+
+    const int tid = threadIdx.x;
+    const int i_base = blockIdx.y * TI;
+    const int j_base = blockIdx.x * TJ;
+    if (COUNT && tid == 0) s_cnt = 0;
+
+    // ---- stage the W tile (NaN at j == k: skip j==k) and the C tile --------------------------
+    constexpr int WV_PER_ROW = TJ / VW;
+    for (int idx = tid; idx < B * WV_PER_ROW; idx += 256) {
+        const int t = idx / WV_PER_ROW, jv = idx % WV_PER_ROW;
+        const int j = j_base + jv * VW;
+        V v;
+        if (t < bt && j < n) {
+            v = *reinterpret_cast<const V *>(w + (size_t)t * n + j);
+#pragma unroll
+            for (int e = 0; e < VW; ++e)
+                if (j + e == k0 + t) v[e] = qnan<T>();
+        } else {
+#pragma unroll
+            for (int e = 0; e < VW; ++e) v[e] = qnan<T>();
+        }
+        *reinterpret_cast<V *>(&sW[t][jv * VW]) = v;
+    }
+    for (int idx = tid; idx < B * TI; idx += 256) {
+        const int t = idx / TI, il = idx % TI;
+        const int i = i_base + il;
+        const bool ok = t < bt && i < rows;
+        sC[t][il] = ok ? ct[(size_t)t * rows + i] : qnan<T>();
+        if (HAS_NEXT) sN[t][il] = ok ? cnt[(size_t)t * rows + i] : -1;
+    }
+
+    // ---- this thread's 8 x (2 vectors) register tile -------------------------------------------
+    const int ti = tid >> 4, tj = tid & 15;
+    const int i0 = i_base + ti * RI;
+    int jcol[2];
+    bool jok[2];
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        const int j = j_base + h * HJ + tj * VW;
+        jok[h] = j < n;
+        jcol[h] = jok[h] ? j : n - VW;
+    }
+    V x[RI][2];
+    IV nx[HAS_NEXT ? RI : 1][2];
+#pragma unroll
+    for (int r = 0; r < RI; ++r) {
+        const int i = min(i0 + r, rows - 1);
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            x[r][h] = *reinterpret_cast<const V *>(rate + (size_t)i * n + jcol[h]);
+            if (HAS_NEXT) nx[r][h] = *reinterpret_cast<const IV *>(next + (size_t)i * n + jcol[h]);
+        }
+    }
+    __syncthreads();
+
+    // A diagonal tile holds entries with i == j, which no step may touch (Algorithms.hs:54).
+    const int gi_lo = row0 + i_base, gj_lo = j_base;
+    const bool diag_tile = gi_lo < gj_lo + TJ && gj_lo < gi_lo + TI;
+    unsigned int my_updates = 0;
+
+    // ---- B in-order relaxations per entry, operands from LDS ----------------------------------
+#pragma unroll 2
+    for (int t = 0; t < bt; ++t) {
+        T c[RI];
+        int32_t cn[HAS_NEXT ? RI : 1];
+        V wv[2];
+#pragma unroll
+        for (int q = 0; q < RI / VW; ++q) {
+            const V cv = *reinterpret_cast<const V *>(&sC[t][ti * RI + q * VW]);
+#pragma unroll
+            for (int e = 0; e < VW; ++e) c[q * VW + e] = cv[e];
+            if (HAS_NEXT) {
+                const IV nv = *reinterpret_cast<const IV *>(&sN[t][ti * RI + q * VW]);
+#pragma unroll
+                for (int e = 0; e < VW; ++e) cn[q * VW + e] = nv[e];
+            }
+        }
+        wv[0] = *reinterpret_cast<const V *>(&sW[t][tj * VW]);
+        wv[1] = *reinterpret_cast<const V *>(&sW[t][HJ + tj * VW]);
+#pragma unroll
+        for (int r = 0; r < RI; ++r)
+#pragma unroll
+            for (int h = 0; h < 2; ++h)
+#pragma unroll
+                for (int e = 0; e < VW; ++e) {
+                    const T cand = c[r] * wv[h][e];
+                    const bool up = x[r][h][e] < cand;
+                    if (COUNT) {
+                        const bool is_diag = diag_tile && (row0 + i0 + r == jcol[h] + e);
+                        my_updates += (up && !is_diag && jok[h] && i0 + r < rows) ? 1u : 0u;
+                    }
+                    x[r][h][e] = up ? cand : x[r][h][e];
+                    if (HAS_NEXT) nx[r][h][e] = up ? cn[r] : nx[r][h][e];
+                }
+    }
+
+    // ---- write back (the diagonal entry, if any, is restored from memory first) ---------------
+#pragma unroll
+    for (int r = 0; r < RI; ++r) {
+        const int i = i0 + r;
+        if (i >= rows) continue;
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            if (!jok[h]) continue;
+            const size_t off = (size_t)i * n + jcol[h];
+            if (diag_tile) {
+                const int gi = row0 + i;
+                if (gi >= jcol[h] && gi < jcol[h] + VW) {
+                    const int e = gi - jcol[h];
+                    x[r][h][e] = rate[off + e];
+                    if (HAS_NEXT) nx[r][h][e] = next[off + e];
+                }
+            }
+            *reinterpret_cast<V *>(rate + off) = x[r][h];
+            if (HAS_NEXT) *reinterpret_cast<IV *>(next + off) = nx[r][h];
+        }
+    }
+
+    if (COUNT) {
+        if (my_updates) atomicAdd(&s_cnt, my_updates);
+        __syncthreads();
+        if (tid == 0 && s_cnt)
+            atomicAdd(&updates[(blockIdx.x + blockIdx.y * 7) & (FWX_UPDATE_SHARDS_K - 1)],
+                      (unsigned long long)s_cnt);
+    }
+}
+
+}  // namespace
+
+template <typename T> hipError_t launch_fused_relax(const FusedArgs<T> &a, hipStream_t s)
+{
+    constexpr int VW = Vec16<T>::W;
+    constexpr int TI = 128, TJ = 16 * 2 * VW;
+    if (a.rows <= 0 || a.n <= 0 || a.bt <= 0) return hipSuccess;
+    if (a.bt > B || a.n % VW != 0 || ((uintptr_t)a.rate % 16) || ((uintptr_t)a.w % 16) ||
+        (a.next && ((uintptr_t)a.next % 16)))
+        return hipErrorInvalidValue;
+    const dim3 cgrid((unsigned)((a.rows + 63) / 64)), block(256);
+    if (a.next)
+        hipLaunchKernelGGL((fused_colpanel<T, true>), cgrid, block, 0, s, a.rate, a.next, a.rows,
+                           a.n, a.row0, a.k0, a.bt, a.w, a.ct, a.cnt);
+    else
+        hipLaunchKernelGGL((fused_colpanel<T, false>), cgrid, block, 0, s, a.rate, a.next, a.rows,
+                           a.n, a.row0, a.k0, a.bt, a.w, a.ct, a.cnt);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return e;
+    const dim3 grid((unsigned)((a.n + TJ - 1) / TJ), (unsigned)((a.rows + TI - 1) / TI));
+#define FWX_FUSED_LAUNCH(HN, CN)                                                                   \
+    hipLaunchKernelGGL((fused_main<T, HN, CN>), grid, block, 0, s, a.rate, a.next, a.rows, a.n,    \
+                       a.row0, a.k0, a.bt, a.w, a.ct, a.cnt, a.updates)
+    if (a.next) {
+        if (a.updates) FWX_FUSED_LAUNCH(true, true); else FWX_FUSED_LAUNCH(true, false);
+    } else {
+        if (a.updates) FWX_FUSED_LAUNCH(false, true); else FWX_FUSED_LAUNCH(false, false);
+    }
+#undef FWX_FUSED_LAUNCH
+    return hipGetLastError();
+}
+
+template <typename T>
+hipError_t launch_fused_panel(const T *rows_base, int n, int k0, int bt, T *w, T *diag_ws,
+                              hipStream_t s)
+{
+    if (n <= 0 || bt <= 0) return hipSuccess;
+    if (bt > B) return hipErrorInvalidValue;
+    T *wd = diag_ws, *cdt = diag_ws + B * B;
+    hipLaunchKernelGGL((fused_diag<T>), dim3(1), dim3(256), 0, s, rows_base, n, k0, bt, wd, cdt);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL((fused_rowpanel<T>), dim3((unsigned)((n + 63) / 64)), dim3(256), 0, s,
+                       rows_base, n, k0, bt, cdt, w);
+    return hipGetLastError();
+}
+
+template hipError_t launch_fused_relax<float>(const FusedArgs<float> &, hipStream_t);
+template hipError_t launch_fused_relax<double>(const FusedArgs<double> &, hipStream_t);
+template hipError_t launch_fused_panel<float>(const float *, int, int, int, float *, float *,
+                                              hipStream_t);
+template hipError_t launch_fused_panel<double>(const double *, int, int, int, double *, double *,
+                                               hipStream_t);
+
+}  // namespace fwx

@@ -26,5 +26,28 @@ template <typename T>
 hipError_t launch_snapshot_row(T *dst, const T *src, int32_t *hdst, const int32_t *hsrc, int n,
                                hipStream_t s);
 
+// ---- fused engine: FWX_FUSED_B pivots per launch from time-k snapshots ------------------------
+#define FWX_FUSED_B 64
+
+template <typename T> struct FusedArgs {
+    T *rate;               // slab: rows x n (all rows are relaxed, pivot rows included)
+    int32_t *next;         // or nullptr
+    int rows, n, row0;
+    int k0, bt;            // pivots [k0, k0+bt), bt <= FWX_FUSED_B
+    const T *w;            // snapshot panel: w[t*n + j] = row k0+t at time k0+t
+    T *ct;                 // scratch bt x rows: ct[t*rows + i] = column k0+t at time k0+t (NaN if i==k)
+    int32_t *cnt;          // scratch bt x rows (iff next)
+    unsigned long long *updates;
+};
+
+// colpanel + main: applies the bt pivots to every row of the slab.
+template <typename T> hipError_t launch_fused_relax(const FusedArgs<T> &a, hipStream_t s);
+
+// diag + rowpanel: snapshot panel of the pivot rows `rows_base` (bt x n, at time k0); the matrix
+// is not modified.  diag_ws: 2 * FWX_FUSED_B^2 elements of scratch.
+template <typename T>
+hipError_t launch_fused_panel(const T *rows_base, int n, int k0, int bt, T *w, T *diag_ws,
+                              hipStream_t s);
+
 }  // namespace fwx
 #endif

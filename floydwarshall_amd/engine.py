@@ -11,9 +11,11 @@ import numpy as np
 
 from . import _lib
 from ._lib import (FWX_ENGINE_AUTO, FWX_ENGINE_FUSED, FWX_ENGINE_PERK, FWX_F32, FWX_F64,
-                   FWX_UPDATE_SHARDS, FwxError, FwxOpts, FwxPivots, FwxSlab, check, lib)
+                   FWX_FUSED_BLOCK, FWX_UPDATE_SHARDS, FwxError, FwxOpts, FwxPivots, FwxSlab, check,
+                   lib)
 
-__all__ = ["solve", "follow_path", "DeviceMatrix", "dev_relax", "dev_panel", "device_count",
+__all__ = ["solve", "follow_path", "DeviceMatrix", "dev_relax", "dev_panel", "dev_panel_snap",
+           "dev_relax_fused", "FusedWorkspace", "FWX_FUSED_BLOCK", "device_count",
            "FwxError", "FWX_ENGINE_AUTO", "FWX_ENGINE_PERK", "FWX_ENGINE_FUSED",
            "FWX_UPDATE_SHARDS"]
 
@@ -193,3 +195,63 @@ def dev_panel(block_rate_t, n, k0, w_rate_t, *, next_t=None, hops_t=None, w_hops
     wh = ctypes.c_void_p(w_hops_t.data_ptr()) if w_hops_t is not None else None
     check(lib().fwx_dev_panel(ctypes.byref(s), ctypes.c_void_p(w_rate_t.data_ptr()), wh, upd,
                               _stream_ptr()), "fwx_dev_panel")
+
+
+class FusedWorkspace:
+    """Device scratch of the fused engine for slabs of up to `rows` rows: snapshot panels W (two,
+    for look-ahead), pivot-column snapshots Ct / CNt, and the diagonal-block scratch."""
+
+    def __init__(self, n, rows, dtype, device, with_next=False):
+        import torch
+        B = FWX_FUSED_BLOCK
+        self.w = [torch.empty((B, n), dtype=dtype, device=device) for _ in range(2)]
+        self.ct = torch.empty((B, max(rows, 1)), dtype=dtype, device=device)
+        self.cnt = torch.empty((B, max(rows, 1)), dtype=torch.int32, device=device) if with_next else None
+        code = FWX_F64 if dtype == torch.float64 else FWX_F32
+        self.diag = torch.empty(lib().fwx_fused_diag_ws_bytes(code), dtype=torch.uint8, device=device)
+
+
+def dev_panel_snap(block_rate_t, n, k0, w_rate_t, diag_ws_t):
+    """Snapshot panel of pivot rows [k0, k0+B) (B <= 64): w[t] = row k0+t at time k0+t.
+    The matrix is NOT modified (contrast dev_panel)."""
+    s = _slab(block_rate_t, None, None, n, k0)
+    assert w_rate_t.is_cuda and w_rate_t.is_contiguous()
+    assert tuple(w_rate_t.shape) == tuple(block_rate_t.shape) and w_rate_t.dtype == block_rate_t.dtype
+    check(lib().fwx_dev_panel_snap(ctypes.byref(s), ctypes.c_void_p(w_rate_t.data_ptr()),
+                                   ctypes.c_void_p(diag_ws_t.data_ptr()), _stream_ptr()),
+          "fwx_dev_panel_snap")
+
+
+def dev_relax_fused(rate_t, n, row0, k0, k1, w_t, ct_t, *, next_t=None, cnt_t=None, updates_t=None):
+    """Apply pivots [k0,k1) (at most 64) to EVERY row of the slab in one pass, from the snapshot
+    panel w_t ((k1-k0) x n).  ct_t / cnt_t: scratch of at least 64*rows elements."""
+    s = _slab(rate_t, next_t, None, n, row0)
+    p = FwxPivots()
+    p.k_begin, p.k_end = k0, k1
+    assert w_t.is_cuda and w_t.is_contiguous() and w_t.dtype == rate_t.dtype
+    assert tuple(w_t.shape) == (k1 - k0, n)
+    assert ct_t.numel() >= FWX_FUSED_BLOCK * rate_t.shape[0] and ct_t.dtype == rate_t.dtype
+    p.rate, p.hops, p.stride = w_t.data_ptr(), None, n
+    upd = ctypes.c_void_p(updates_t.data_ptr()) if updates_t is not None else None
+    cn = None
+    if next_t is not None:
+        assert cnt_t is not None and cnt_t.numel() >= FWX_FUSED_BLOCK * rate_t.shape[0]
+        cn = ctypes.c_void_p(cnt_t.data_ptr())
+    check(lib().fwx_dev_relax_fused(ctypes.byref(s), ctypes.byref(p),
+                                    ctypes.c_void_p(ct_t.data_ptr()), cn, upd, _stream_ptr()),
+          "fwx_dev_relax_fused")
+
+
+def dev_solve_fused(rate_t, n, k_begin=0, k_end=None, *, next_t=None, ws=None, updates_t=None):
+    """Single-GPU solve of pivots [k_begin,k_end) with the fused engine on a torch tensor holding
+    the whole n x n matrix; asynchronous on the current stream."""
+    k_end = n if k_end is None else k_end
+    ws = ws or FusedWorkspace(n, n, rate_t.dtype, rate_t.device, with_next=next_t is not None)
+    B = FWX_FUSED_BLOCK
+    for k0 in range(k_begin, k_end, B):
+        k1 = min(k_end, k0 + B)
+        w = ws.w[0][:k1 - k0]
+        dev_panel_snap(rate_t[k0:k1], n, k0, w, ws.diag)
+        dev_relax_fused(rate_t, n, 0, k0, k1, w, ws.ct, next_t=next_t, cnt_t=ws.cnt,
+                        updates_t=updates_t)
+    return ws

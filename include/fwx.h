@@ -33,6 +33,7 @@
 #ifndef FWX_H
 #define FWX_H
 
+#include <stddef.h>
 #include <stdint.h>
 
 #ifdef __cplusplus
@@ -149,9 +150,21 @@ int fwx_dev_relax(const fwx_slab *slab, const fwx_pivots *piv, int32_t serpentin
 int fwx_dev_panel(const fwx_slab *block, void *w_rate, int32_t *w_hops,
                   unsigned long long *d_updates, void *stream);
 
-/* Fused engine (B pivots per launch), see DESIGN.md "Kernels".  Same contract as fwx_dev_relax
- * but `piv` must be a snapshot panel (not the matrix itself) and the slab must not contain the
- * pivot rows.  col_* are device scratch of rows*(k_end-k_begin) elements.                       */
+/* ---- fused engine (FWX_FUSED_BLOCK pivots per pass; bit-identical to the per-k engine) --------
+ * fwx_dev_panel_snap: snapshot panel of the pivot rows in `block` (rows [row0,row0+rows), rows <=
+ *   FWX_FUSED_BLOCK, at time row0): writes the time-k snapshot of each pivot row to w_rate
+ *   (rows x n).  UNLIKE fwx_dev_panel THE MATRIX IS NOT MODIFIED: the pivot rows are then relaxed
+ *   like any other row.  diag_ws: device scratch, fwx_fused_diag_ws_bytes(dtype) bytes.
+ * fwx_dev_relax_fused: applies the pivots [piv->k_begin, piv->k_end) (at most FWX_FUSED_BLOCK,
+ *   piv->rate = snapshot panel, stride n) to EVERY row of the slab in one pass.  col_rate /
+ *   col_next: device scratch of FWX_FUSED_BLOCK * slab->rows elements (col_next only if the slab
+ *   carries next).  Slabs with hops are not supported (FWX_ERR_UNSUPPORTED); n must be a multiple
+ *   of 16 bytes worth of elements.
+ * The snapshot panel also feeds fwx_dev_relax (per-k engine), so fwx_dev_panel_snap +
+ * fwx_dev_relax over all rows is a valid (slower) combination.                                  */
+#define FWX_FUSED_BLOCK 64
+size_t fwx_fused_diag_ws_bytes(int32_t dtype);
+int fwx_dev_panel_snap(const fwx_slab *block, void *w_rate, void *diag_ws, void *stream);
 int fwx_dev_relax_fused(const fwx_slab *slab, const fwx_pivots *piv, void *col_rate,
                         int32_t *col_next, unsigned long long *d_updates, void *stream);
 

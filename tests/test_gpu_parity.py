@@ -240,3 +240,96 @@ def test_config4_n16384_fp32_k_slices_vs_oracle():
     b = r.copy()
     engine.solve(b, k_begin=301, k_end=304, serpentine=False)
     assert_bits_equal(a[0], b, "serpentine off")
+
+
+# ---------------------------------------------------------------------------------------------
+# Fused engine (64 pivots per pass): must be bit-identical to the per-k engine and the oracle
+# ---------------------------------------------------------------------------------------------
+
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+@pytest.mark.parametrize("n", [4, 8, 60, 64, 68, 128, 132, 200, 256, 388, 512, 1000])
+def test_fused_engine_ragged_sizes(n, dtype):
+    rate, nxt, _ = synth.make("d1", n, dtype, seed=2000 + n)
+    _solve_and_compare(rate, nxt, None, engine=engine.FWX_ENGINE_FUSED)
+    _solve_and_compare(rate, None, None, engine=engine.FWX_ENGINE_FUSED)
+
+
+@pytest.mark.parametrize("kind", ["d1", "d2", "t1", "t2", "t3"])
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+def test_fused_engine_distributions(kind, dtype):
+    """Ties (earliest pivot must win), sparse/unreachable, inf/NaN/negative inputs."""
+    rate, nxt, _ = synth.make(kind, 320, dtype, seed=78)
+    _solve_and_compare(rate, nxt, None, engine=engine.FWX_ENGINE_FUSED)
+
+
+def test_fused_engine_golden_4x4():
+    g = load_golden("algorithms_4x4.json")
+    rate, nxt, _, _ = golden_dense(g["initial"])
+    engine.solve(rate, nxt, engine=engine.FWX_ENGINE_FUSED)
+    erate, enext, _, epaths = golden_dense(g["solved"])
+    assert_bits_equal(rate, erate, "solved rate")
+    assert np.array_equal(nxt, enext)
+
+
+def test_fused_engine_k_range_and_unsupported():
+    rate, nxt, hops = synth.make("d2", 300, np.float64, seed=22)
+    _solve_and_compare(rate, nxt, None, engine=engine.FWX_ENGINE_FUSED, k_begin=37, k_end=211)
+    with pytest.raises(engine.FwxError) as e:           # hops ride on the per-k engine only
+        engine.solve(rate.copy(), nxt.copy(), hops.copy(), engine=engine.FWX_ENGINE_FUSED)
+    assert e.value.status == -7
+    odd, _, _ = synth.make("d1", 63, np.float32, seed=1)  # n not a multiple of the vector width
+    with pytest.raises(engine.FwxError):
+        engine.solve(odd, engine=engine.FWX_ENGINE_FUSED)
+    engine.solve(odd)                                     # AUTO falls back to the per-k engine
+
+
+def test_config3_n8192_fp32_fused_vs_perk_and_oracle_slices():
+    """BASELINE.json configs[2]: N=8192 fp32 blocked (LDS-tiled).  Full solve with the fused
+    engine == full solve with the per-k engine, bit for bit (rates and next-hops); oracle parity on
+    pivot slices taken mid-solve."""
+    n = 8192
+    rate0, nxt0 = synth.d1_uniform(n, np.float32, synth.BASE_SEED + 2)
+    a_r, a_n = rate0.copy(), nxt0.copy()
+    ua = engine.solve(a_r, a_n, engine=engine.FWX_ENGINE_FUSED, count_updates=True)
+    b_r, b_n = rate0.copy(), nxt0.copy()
+    ub = engine.solve(b_r, b_n, engine=engine.FWX_ENGINE_PERK, count_updates=True)
+    assert ua == ub
+    assert_bits_equal(a_r, b_r, "fused vs per-k rate")
+    assert_bits_equal(a_n, b_n, "fused vs per-k next")
+    r, nx = rate0.copy(), nxt0.copy()
+    engine.solve(r, nx, engine=engine.FWX_ENGINE_FUSED, k_begin=0, k_end=1000)
+    _solve_and_compare(r, nx, None, engine=engine.FWX_ENGINE_FUSED, k_begin=1000, k_end=1003)
+    _solve_and_compare(rate0, nxt0, None, engine=engine.FWX_ENGINE_FUSED, k_begin=0, k_end=2)
+
+
+def test_fused_device_api_partition_emulation():
+    """fwx_dev_panel_snap + fwx_dev_relax_fused on P logical partitions of one GPU."""
+    import torch
+    n, P = 640, 3
+    rate, nxt, _ = synth.make("t1", n, np.float32, seed=33)
+    er, en = rate.copy(), nxt.copy()
+    eu = oracle.relax(er, en)
+    dev = torch.device("cuda:0")
+    bounds = [n * p // P for p in range(P + 1)]
+    slabs = [torch.from_numpy(rate[bounds[p]:bounds[p + 1]].copy()).to(dev) for p in range(P)]
+    nslabs = [torch.from_numpy(nxt[bounds[p]:bounds[p + 1]].copy()).to(dev) for p in range(P)]
+    wss = [engine.FusedWorkspace(n, bounds[p + 1] - bounds[p], torch.float32, dev, with_next=True)
+           for p in range(P)]
+    upd = torch.zeros(engine.FWX_UPDATE_SHARDS, dtype=torch.int64, device=dev)
+    B = engine.FWX_FUSED_BLOCK
+    for owner in range(P):
+        k0 = bounds[owner]
+        while k0 < bounds[owner + 1]:
+            k1 = min(k0 + B, bounds[owner + 1])
+            lo = k0 - bounds[owner]
+            w = wss[owner].w[0][:k1 - k0]
+            engine.dev_panel_snap(slabs[owner][lo:lo + k1 - k0], n, k0, w, wss[owner].diag)
+            for p in range(P):
+                wp = w.clone()                           # stands in for the broadcast
+                engine.dev_relax_fused(slabs[p], n, bounds[p], k0, k1, wp, wss[p].ct,
+                                       next_t=nslabs[p], cnt_t=wss[p].cnt, updates_t=upd)
+            k0 = k1
+    torch.cuda.synchronize()
+    assert_bits_equal(torch.cat(slabs).cpu().numpy(), er, "partitioned fused rate")
+    assert_bits_equal(torch.cat(nslabs).cpu().numpy(), en, "partitioned fused next")
+    assert int(upd.sum().item()) == eu
