@@ -43,6 +43,9 @@ def parse_args():
     ap.add_argument("--dtype", default="f32", choices=["f32", "f64"])
     ap.add_argument("--dist", default="d1", choices=["d1", "d2"])
     ap.add_argument("--with-next", action="store_true", help="carry the next-hop matrix")
+    ap.add_argument("--engine", default="perk", choices=["perk", "fused"],
+                    help="perk: one launch per pivot (the HBM-roofline kernel the metric is defined "
+                         "on); fused: 64 pivots per pass (VALU-bound, same bits)")
     ap.add_argument("--block", type=int, default=64, help="pivots per broadcast (N > 1)")
     ap.add_argument("--no-serpentine", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -140,12 +143,24 @@ def main():
     serp = not args.no_serpentine
 
     ev_pairs = []
+    fused_ws = None
+    if args.engine == "fused" and world == 1:
+        fused_ws = engine.FusedWorkspace(n, n, rate.dtype, dev, with_next=args.with_next)
 
     def step(count=False, timed=False):
         rate.copy_(pristine)
         if nxt is not None:
             nxt.copy_(pristine_next)
-        if world == 1:
+        if world == 1 and fused_ws is not None:
+            if timed:
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+            engine.dev_solve_fused(rate, n, 0, k_end, next_t=nxt, ws=fused_ws,
+                                   updates_t=upd if count else None)
+            if timed:
+                e1.record()
+                ev_pairs.append(([e0, e1], [0, k_end]))
+        elif world == 1:
             # the pivots are issued in SEGMENTS back-to-back launches with a HIP event between
             # segments (no synchronisation): per-segment launch time shows how the cost moves with k
             segs = [k_end * i // SEGMENTS for i in range(SEGMENTS + 1)] if timed else [0, k_end]
@@ -207,7 +222,17 @@ def main():
     if args.kslice > 0:
         out["INVALID_debug_kslice"] = args.kslice
 
-    if world == 1 and ev_pairs:
+    out["config"]["engine"] = args.engine
+    if world == 1 and ev_pairs and args.engine == "fused":
+        passes = args.steps * ((k_end + 63) // 64)
+        kern_ms = sum(evs[0].elapsed_time(evs[-1]) for evs, _ in ev_pairs)
+        out["config"]["workload"] = out["config"]["workload"].replace("per-k engine", "fused engine (64 pivots per pass)")
+        out["fused"] = {"passes_per_solve": (k_end + 63) // 64, "avg_pass_us": 1e3 * kern_ms / passes,
+                        "effective_GBps_at_4B_per_relaxation": 4.0 * relax_per_step * args.steps / (kern_ms * 1e-3) / 1e9,
+                        "note": "VALU-bound kernel (3 lane-ops per relaxation); the GB/s figure is "
+                                "'effective' (algorithmic bytes of the per-k form), not an HBM roofline "
+                                "fraction", "updates_per_solve": updates}
+    elif world == 1 and ev_pairs:
         launches = args.steps * k_end
         kern_ms = sum(evs[0].elapsed_time(evs[-1]) for evs, _ in ev_pairs)
         evs, segs = ev_pairs[-1]

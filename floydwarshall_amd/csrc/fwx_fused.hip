@@ -56,31 +56,57 @@ template <> struct IVec<2> { typedef int type __attribute__((ext_vector_type(2))
 constexpr int B = FWX_FUSED_B;
 
 // ------------------------------------------------------------------------------------------------
+// The three panel kernels share one shape: 256 threads = 4 waves, each thread keeps 16 entries
+// in registers (indices are compile-time constants: the t loop is fully unrolled), and the
+// pivot row / pivot column of step t is exchanged through a double-buffered LDS line with ONE
+// barrier per step.  All per-step operands come from LDS (latency ~100 cycles), never from L2.
+// ------------------------------------------------------------------------------------------------
+
+// Diagonal block: thread (r = tid/4, cg = tid%4) owns blk[r][16cg .. 16cg+15].
 template <typename T>
 __global__ __launch_bounds__(256) void fused_diag(const T *rows, int n, int k0, int bt, T *wd,
                                                   T *cdt)
 {
-    __shared__ T blk[B][B + 1];
+    constexpr int Q = B / 4;
+    __shared__ __attribute__((aligned(16))) T rowbuf[2][B];
+    __shared__ T colbuf[2][B];
     const int tid = threadIdx.x;
-    for (int idx = tid; idx < B * B; idx += 256) {
-        const int r = idx / B, c = idx % B;
-        blk[r][c] = (r < bt && c < bt) ? rows[(size_t)r * n + k0 + c] : qnan<T>();
+    const int r = tid >> 2, cg = tid & 3;
+
+    T d[Q];
+#pragma unroll
+    for (int q = 0; q < Q; ++q) {
+        const int c = cg * Q + q;
+        d[q] = (r < bt && c < bt) ? rows[(size_t)r * n + k0 + c] : qnan<T>();
     }
-    __syncthreads();
-    for (int t = 0; t < bt; ++t) {
-        // row t and column t are fixed points of step t: record them, then relax the rest
-        if (tid < B) {
-            wd[t * B + tid] = blk[t][tid];      // Wd[t][c]
-            cdt[t * B + tid] = blk[tid][t];     // Cd[r][t], stored pivot-major
-        }
-        for (int idx = tid; idx < B * B; idx += 256) {
-            const int r = idx / B, c = idx % B;
-            if (r != t && c != t && r != c) {
-                const T cand = blk[r][t] * blk[t][c];
-                if (blk[r][c] < cand) blk[r][c] = cand;
+
+#pragma unroll
+    for (int t = 0; t < B; ++t) {
+        if (t >= bt) continue;                    // uniform
+        const int og = t / Q, oq = t % Q;         // compile-time owner of column t
+        if (r == t) {
+            // publish row t (time-t snapshot); its own column-t entry is the diagonal: NaN there
+            // makes every candidate of column t NaN (skip j == k)
+#pragma unroll
+            for (int q = 0; q < Q; ++q) {
+                const int c = cg * Q + q;
+                rowbuf[t & 1][c] = (c == t) ? qnan<T>() : d[q];
+                if (c != t) wd[t * B + c] = d[q];
             }
+            if (cg == og) wd[t * B + t] = rows[(size_t)t * n + k0 + t];   // diagonal: never changed
+        }
+        if (cg == og) {
+            colbuf[t & 1][r] = d[oq];             // column t at time t
+            cdt[t * B + r] = d[oq];               // (entry r == t is the diagonal: never consumed)
         }
         __syncthreads();
+        T cval = colbuf[t & 1][r];
+        if (r == t) cval = qnan<T>();             // skip i == k
+#pragma unroll
+        for (int q = 0; q < Q; ++q) {
+            const T cand = cval * rowbuf[t & 1][cg * Q + q];
+            d[q] = (d[q] < cand) ? cand : d[q];   // the r == c entry may go stale: never consumed
+        }
     }
 }
 
@@ -92,11 +118,16 @@ __global__ __launch_bounds__(256) void fused_rowpanel(const T *rows, int n, int 
 {
     constexpr int RPW = B / 4;
     __shared__ T wrow[2][64];
+    __shared__ __attribute__((aligned(16))) T s_cd[B][B];     // s_cd[t][r] = D_t[k0+r][k0+t]
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int j = blockIdx.x * 64 + lane;
     const bool valid = j < n;
     const int jc = valid ? j : n - 1;
+
+    for (int idx = threadIdx.x; idx < B * B; idx += 256)
+        s_cd[idx / B][idx % B] = (idx / B) < bt ? cdt[idx] : qnan<T>();
+    __syncthreads();
 
     T p[RPW];
 #pragma unroll
@@ -119,15 +150,17 @@ __global__ __launch_bounds__(256) void fused_rowpanel(const T *rows, int n, int 
             wrow[t & 1][lane] = v;
             if (valid) w_out[(size_t)t * n + j] = v;
         }
+        T cd[RPW];
+#pragma unroll
+        for (int q = 0; q < RPW; ++q) cd[q] = s_cd[t][wave * RPW + q];
         __syncthreads();
         T w = wrow[t & 1][lane];
         if (j == k0 + t) w = qnan<T>();                       // skip j == k
-        const T *cd = cdt + t * B + wave * RPW;               // wave-uniform -> scalar loads
 #pragma unroll
         for (int q = 0; q < RPW; ++q) {
             if (q == oq && wave == ow) continue;              // skip i == k
             const T cand = cd[q] * w;
-            if (p[q] < cand) p[q] = cand;
+            p[q] = (p[q] < cand) ? cand : p[q];
         }
     }
 }
@@ -142,12 +175,18 @@ __global__ __launch_bounds__(256) void fused_colpanel(const T *rate, const int32
     constexpr int CPW = B / 4;
     __shared__ T ccol[2][64];
     __shared__ int32_t ncol[2][64];
+    __shared__ __attribute__((aligned(16))) T s_wd[B][B];     // s_wd[t][c] = D_t[k0+t][k0+c]
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int il = blockIdx.x * 64 + lane;
     const bool valid = il < rows;
     const int ic = valid ? il : rows - 1;
     const int gi = row0 + ic;
+
+    for (int idx = threadIdx.x; idx < B * B; idx += 256) {
+        const int t = idx / B, c = idx % B;
+        s_wd[t][c] = (t < bt && c < bt) ? w[(size_t)t * n + k0 + c] : qnan<T>();
+    }
 
     T d[CPW];
     int32_t nx[CPW];
@@ -167,7 +206,7 @@ __global__ __launch_bounds__(256) void fused_colpanel(const T *rate, const int32
             ccol[t & 1][lane] = d[oq];
             if (HAS_NEXT) ncol[t & 1][lane] = nx[oq];
         }
-        __syncthreads();
+        __syncthreads();                                      // also orders s_wd at t == 0
         T c = ccol[t & 1][lane];
         const int32_t cn = HAS_NEXT ? ncol[t & 1][lane] : 0;
         if (gi == k0 + t) c = qnan<T>();                      // skip i == k
@@ -175,27 +214,27 @@ __global__ __launch_bounds__(256) void fused_colpanel(const T *rate, const int32
             ct[(size_t)t * rows + il] = c;
             if (HAS_NEXT) cnt[(size_t)t * rows + il] = cn;
         }
-        const T *wd = w + (size_t)t * n + k0;                 // Wd[t][.], wave-uniform
 #pragma unroll
         for (int q = 0; q < CPW; ++q) {
             if (q == oq && wave == ow) continue;              // skip j == k
-            const int cq = wave * CPW + q;
-            const T wv = cq < bt ? wd[cq] : qnan<T>();
-            const T cand = c * wv;
-            if (d[q] < cand) {
-                d[q] = cand;
-                if (HAS_NEXT) nx[q] = cn;
-            }
+            const T cand = c * s_wd[t][wave * CPW + q];
+            const bool up = d[q] < cand;
+            d[q] = up ? cand : d[q];
+            if (HAS_NEXT) nx[q] = up ? cn : nx[q];
         }
     }
 }
 
 // ------------------------------------------------------------------------------------------------
-template <typename T, bool HAS_NEXT, bool COUNT>
-__global__ __launch_bounds__(256) void fused_main(T *rate, int32_t *next, int rows, int n,
-                                                  int row0, int k0, int bt, const T *w,
-                                                  const T *ct, const int32_t *cnt,
-                                                  unsigned long long *updates)
+// BS pivots are staged in LDS at a time (the register tile lives across stages), which keeps a
+// workgroup at 32 KiB of LDS and <= 128 VGPRs: 4 workgroups = 16 waves per CU.  The loop is pure
+// VALU (v_pk_mul_f32 + v_cmp + v_cndmask per pair of relaxations) and one wave alone issues at
+// half rate on a SIMD-32, so occupancy, not bytes, is what this kernel needs.
+template <typename T, bool HAS_NEXT, bool COUNT, int BS, int MINW>
+__global__ __launch_bounds__(256, MINW) void fused_main(T *rate, int32_t *next, int rows, int n,
+                                                        int row0, int k0, int bt, const T *w,
+                                                        const T *ct, const int32_t *cnt,
+                                                        unsigned long long *updates)
 {
     using V = typename Vec16<T>::type;
     using IV = typename IVec<Vec16<T>::W>::type;
@@ -204,40 +243,15 @@ __global__ __launch_bounds__(256) void fused_main(T *rate, int32_t *next, int ro
     constexpr int TJ = 16 * 2 * VW;           // 128 (f32) / 64 (f64) columns
     constexpr int HJ = TJ / 2;
 
-    __shared__ __attribute__((aligned(16))) T sW[B][TJ];
-    __shared__ __attribute__((aligned(16))) T sC[B][TI];
-    __shared__ __attribute__((aligned(16))) int32_t sN[HAS_NEXT ? B : 1][HAS_NEXT ? TI : 4];
+    __shared__ __attribute__((aligned(16))) T sW[BS][TJ];
+    __shared__ __attribute__((aligned(16))) T sC[BS][TI];
+    __shared__ __attribute__((aligned(16))) int32_t sN[HAS_NEXT ? BS : 1][HAS_NEXT ? TI : 4];
     __shared__ unsigned int s_cnt;
 
     const int tid = threadIdx.x;
     const int i_base = blockIdx.y * TI;
     const int j_base = blockIdx.x * TJ;
     if (COUNT && tid == 0) s_cnt = 0;
-
-    // ---- stage the W tile (NaN at j == k: skip j==k) and the C tile --------------------------
-    constexpr int WV_PER_ROW = TJ / VW;
-    for (int idx = tid; idx < B * WV_PER_ROW; idx += 256) {
-        const int t = idx / WV_PER_ROW, jv = idx % WV_PER_ROW;
-        const int j = j_base + jv * VW;
-        V v;
-        if (t < bt && j < n) {
-            v = *reinterpret_cast<const V *>(w + (size_t)t * n + j);
-#pragma unroll
-            for (int e = 0; e < VW; ++e)
-                if (j + e == k0 + t) v[e] = qnan<T>();
-        } else {
-#pragma unroll
-            for (int e = 0; e < VW; ++e) v[e] = qnan<T>();
-        }
-        *reinterpret_cast<V *>(&sW[t][jv * VW]) = v;
-    }
-    for (int idx = tid; idx < B * TI; idx += 256) {
-        const int t = idx / TI, il = idx % TI;
-        const int i = i_base + il;
-        const bool ok = t < bt && i < rows;
-        sC[t][il] = ok ? ct[(size_t)t * rows + i] : qnan<T>();
-        if (HAS_NEXT) sN[t][il] = ok ? cnt[(size_t)t * rows + i] : -1;
-    }
 
     // ---- this thread's 8 x (2 vectors) register tile -------------------------------------------
     const int ti = tid >> 4, tj = tid & 15;
@@ -261,47 +275,76 @@ __global__ __launch_bounds__(256) void fused_main(T *rate, int32_t *next, int ro
             if (HAS_NEXT) nx[r][h] = *reinterpret_cast<const IV *>(next + (size_t)i * n + jcol[h]);
         }
     }
-    __syncthreads();
 
     // A diagonal tile holds entries with i == j, which no step may touch (Algorithms.hs:54).
     const int gi_lo = row0 + i_base, gj_lo = j_base;
     const bool diag_tile = gi_lo < gj_lo + TJ && gj_lo < gi_lo + TI;
     unsigned int my_updates = 0;
 
-    // ---- B in-order relaxations per entry, operands from LDS ----------------------------------
-#pragma unroll 2
-    for (int t = 0; t < bt; ++t) {
-        T c[RI];
-        int32_t cn[HAS_NEXT ? RI : 1];
-        V wv[2];
+    for (int s0 = 0; s0 < bt; s0 += BS) {
+        const int bs = min(BS, bt - s0);
+        if (s0) __syncthreads();              // everyone is done reading the previous stage
+        // ---- stage W (NaN at j == k: skip j==k) and C for pivots [s0, s0+bs) -------------------
+        constexpr int WV_PER_ROW = TJ / VW;
+        for (int idx = tid; idx < BS * WV_PER_ROW; idx += 256) {
+            const int tl = idx / WV_PER_ROW, jv = idx % WV_PER_ROW;
+            const int t = s0 + tl;
+            const int j = j_base + jv * VW;
+            V v;
+            if (tl < bs && j < n) {
+                v = *reinterpret_cast<const V *>(w + (size_t)t * n + j);
 #pragma unroll
-        for (int q = 0; q < RI / VW; ++q) {
-            const V cv = *reinterpret_cast<const V *>(&sC[t][ti * RI + q * VW]);
+                for (int e = 0; e < VW; ++e)
+                    if (j + e == k0 + t) v[e] = qnan<T>();
+            } else {
 #pragma unroll
-            for (int e = 0; e < VW; ++e) c[q * VW + e] = cv[e];
-            if (HAS_NEXT) {
-                const IV nv = *reinterpret_cast<const IV *>(&sN[t][ti * RI + q * VW]);
-#pragma unroll
-                for (int e = 0; e < VW; ++e) cn[q * VW + e] = nv[e];
+                for (int e = 0; e < VW; ++e) v[e] = qnan<T>();
             }
+            *reinterpret_cast<V *>(&sW[tl][jv * VW]) = v;
         }
-        wv[0] = *reinterpret_cast<const V *>(&sW[t][tj * VW]);
-        wv[1] = *reinterpret_cast<const V *>(&sW[t][HJ + tj * VW]);
+        for (int idx = tid; idx < BS * TI; idx += 256) {
+            const int tl = idx / TI, il = idx % TI;
+            const int i = i_base + il;
+            const bool ok = tl < bs && i < rows;
+            sC[tl][il] = ok ? ct[(size_t)(s0 + tl) * rows + i] : qnan<T>();
+            if (HAS_NEXT) sN[tl][il] = ok ? cnt[(size_t)(s0 + tl) * rows + i] : -1;
+        }
+        __syncthreads();
+
+        // ---- bs in-order relaxations per entry, operands from LDS ------------------------------
+        for (int tl = 0; tl < bs; ++tl) {
+            T c[RI];
+            int32_t cn[HAS_NEXT ? RI : 1];
+            V wv[2];
 #pragma unroll
-        for (int r = 0; r < RI; ++r)
+            for (int q = 0; q < RI / VW; ++q) {
+                const V cv = *reinterpret_cast<const V *>(&sC[tl][ti * RI + q * VW]);
 #pragma unroll
-            for (int h = 0; h < 2; ++h)
+                for (int e = 0; e < VW; ++e) c[q * VW + e] = cv[e];
+                if (HAS_NEXT) {
+                    const IV nv = *reinterpret_cast<const IV *>(&sN[tl][ti * RI + q * VW]);
 #pragma unroll
-                for (int e = 0; e < VW; ++e) {
-                    const T cand = c[r] * wv[h][e];
-                    const bool up = x[r][h][e] < cand;
-                    if (COUNT) {
-                        const bool is_diag = diag_tile && (row0 + i0 + r == jcol[h] + e);
-                        my_updates += (up && !is_diag && jok[h] && i0 + r < rows) ? 1u : 0u;
-                    }
-                    x[r][h][e] = up ? cand : x[r][h][e];
-                    if (HAS_NEXT) nx[r][h][e] = up ? cn[r] : nx[r][h][e];
+                    for (int e = 0; e < VW; ++e) cn[q * VW + e] = nv[e];
                 }
+            }
+            wv[0] = *reinterpret_cast<const V *>(&sW[tl][tj * VW]);
+            wv[1] = *reinterpret_cast<const V *>(&sW[tl][HJ + tj * VW]);
+#pragma unroll
+            for (int r = 0; r < RI; ++r)
+#pragma unroll
+                for (int h = 0; h < 2; ++h)
+#pragma unroll
+                    for (int e = 0; e < VW; ++e) {
+                        const T cand = c[r] * wv[h][e];
+                        const bool up = x[r][h][e] < cand;
+                        if (COUNT) {
+                            const bool is_diag = diag_tile && (row0 + i0 + r == jcol[h] + e);
+                            my_updates += (up && !is_diag && jok[h] && i0 + r < rows) ? 1u : 0u;
+                        }
+                        x[r][h][e] = up ? cand : x[r][h][e];
+                        if (HAS_NEXT) nx[r][h][e] = up ? cn[r] : nx[r][h][e];
+                    }
+        }
     }
 
     // ---- write back (the diagonal entry, if any, is restored from memory first) ---------------
@@ -337,6 +380,13 @@ __global__ __launch_bounds__(256) void fused_main(T *rate, int32_t *next, int ro
 
 }  // namespace
 
+// Stage size / occupancy target per variant (LDS = BS * (TJ + TI) * sizeof(T) [+ BS*TI*4]).
+template <typename T, bool HAS_NEXT> struct FusedCfg;
+template <> struct FusedCfg<float, false> { static constexpr int BS = 32, MINW = 4; };
+template <> struct FusedCfg<float, true> { static constexpr int BS = 32, MINW = 2; };
+template <> struct FusedCfg<double, false> { static constexpr int BS = 32, MINW = 2; };
+template <> struct FusedCfg<double, true> { static constexpr int BS = 16, MINW = 2; };
+
 template <typename T> hipError_t launch_fused_relax(const FusedArgs<T> &a, hipStream_t s)
 {
     constexpr int VW = Vec16<T>::W;
@@ -356,8 +406,9 @@ template <typename T> hipError_t launch_fused_relax(const FusedArgs<T> &a, hipSt
     if (e != hipSuccess) return e;
     const dim3 grid((unsigned)((a.n + TJ - 1) / TJ), (unsigned)((a.rows + TI - 1) / TI));
 #define FWX_FUSED_LAUNCH(HN, CN)                                                                   \
-    hipLaunchKernelGGL((fused_main<T, HN, CN>), grid, block, 0, s, a.rate, a.next, a.rows, a.n,    \
-                       a.row0, a.k0, a.bt, a.w, a.ct, a.cnt, a.updates)
+    hipLaunchKernelGGL((fused_main<T, HN, CN, FusedCfg<T, HN>::BS, FusedCfg<T, HN>::MINW>), grid,  \
+                       block, 0, s, a.rate, a.next, a.rows, a.n, a.row0, a.k0, a.bt, a.w, a.ct,    \
+                       a.cnt, a.updates)
     if (a.next) {
         if (a.updates) FWX_FUSED_LAUNCH(true, true); else FWX_FUSED_LAUNCH(true, false);
     } else {
