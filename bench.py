@@ -49,6 +49,7 @@ def parse_args():
     ap.add_argument("--block", type=int, default=64, help="pivots per broadcast (N > 1)")
     ap.add_argument("--no-serpentine", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-fused-extra", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--kslice", type=int, default=0,
                     help="DEBUG: run only this many pivots per step (result flagged invalid)")
@@ -142,6 +143,7 @@ def main():
     k_end = args.kslice if args.kslice > 0 else n
     serp = not args.no_serpentine
 
+    dist_backend = fwdist.HipBackend(args.engine) if world > 1 else None
     ev_pairs = []
     fused_ws = None
     if args.engine == "fused" and world == 1:
@@ -177,7 +179,8 @@ def main():
                 evs[-1].record()
                 ev_pairs.append((evs, segs))
         else:
-            fwdist.solve_partitioned(rate, n, rank, world, nxt=nxt, block=args.block)
+            fwdist.solve_partitioned(rate, n, rank, world, nxt=nxt, block=args.block,
+                                     backend=dist_backend)
 
     def fence():
         torch.cuda.synchronize()
@@ -251,6 +254,26 @@ def main():
                            "alg_bytes_per_launch": alg_bytes, "updates_per_solve": updates,
                            "frac_of_measured_copy_peak_6290": achieved / 6290.0,
                            "avg_launch_us_by_k_sixteenth": seg_us}
+    if world == 1 and args.engine == "perk" and not args.kslice and not args.no_fused_extra:
+        # Not part of `value`: the same workload on the fused engine (64 pivots per pass, same
+        # bits), measured after the timed region.  See DESIGN.md section 4.2.
+        ws = engine.FusedWorkspace(n, n, rate.dtype, dev, with_next=args.with_next)
+        def fused_step():
+            rate.copy_(pristine)
+            if nxt is not None:
+                nxt.copy_(pristine_next)
+            engine.dev_solve_fused(rate, n, 0, n, next_t=nxt, ws=ws)
+        fused_step()
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for _ in range(2):
+            fused_step()
+        torch.cuda.synchronize()
+        ft = (time.perf_counter() - t1) / 2
+        out["fused_engine"] = {"value": relax_per_step / ft, "unit": "edge-relaxations/s",
+                               "ms_per_step": 1e3 * ft, "steps": 2,
+                               "note": "same workload, fused engine (64 pivots per pass, bit-identical "
+                                       "results, VALU-bound); not part of `value`"}
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(rate_host, args.cpu_seconds)
     if rank == 0:

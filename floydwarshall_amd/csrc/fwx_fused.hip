@@ -55,6 +55,14 @@ template <> struct IVec<2> { typedef int type __attribute__((ext_vector_type(2))
 
 constexpr int B = FWX_FUSED_B;
 
+// Workgroup barrier that orders LDS traffic only.  __syncthreads() also drains the vector-memory
+// counter (vmcnt(0)), i.e. waits for the snapshot stores each panel step issues to reach memory
+// (~1 us per step, 64 steps per panel); nothing in these kernels reads those stores back.
+__device__ __forceinline__ void lds_barrier()
+{
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
+
 // ------------------------------------------------------------------------------------------------
 // The three panel kernels share one shape: 256 threads = 4 waves, each thread keeps 16 entries
 // in registers (indices are compile-time constants: the t loop is fully unrolled), and the
@@ -99,7 +107,7 @@ __global__ __launch_bounds__(256) void fused_diag(const T *rows, int n, int k0, 
             colbuf[t & 1][r] = d[oq];             // column t at time t
             cdt[t * B + r] = d[oq];               // (entry r == t is the diagonal: never consumed)
         }
-        __syncthreads();
+        lds_barrier();
         T cval = colbuf[t & 1][r];
         if (r == t) cval = qnan<T>();             // skip i == k
 #pragma unroll
@@ -153,7 +161,7 @@ __global__ __launch_bounds__(256) void fused_rowpanel(const T *rows, int n, int 
         T cd[RPW];
 #pragma unroll
         for (int q = 0; q < RPW; ++q) cd[q] = s_cd[t][wave * RPW + q];
-        __syncthreads();
+        lds_barrier();
         T w = wrow[t & 1][lane];
         if (j == k0 + t) w = qnan<T>();                       // skip j == k
 #pragma unroll
@@ -187,6 +195,7 @@ __global__ __launch_bounds__(256) void fused_colpanel(const T *rate, const int32
         const int t = idx / B, c = idx % B;
         s_wd[t][c] = (t < bt && c < bt) ? w[(size_t)t * n + k0 + c] : qnan<T>();
     }
+    __syncthreads();
 
     T d[CPW];
     int32_t nx[CPW];
@@ -206,7 +215,7 @@ __global__ __launch_bounds__(256) void fused_colpanel(const T *rate, const int32
             ccol[t & 1][lane] = d[oq];
             if (HAS_NEXT) ncol[t & 1][lane] = nx[oq];
         }
-        __syncthreads();                                      // also orders s_wd at t == 0
+        lds_barrier();
         T c = ccol[t & 1][lane];
         const int32_t cn = HAS_NEXT ? ncol[t & 1][lane] : 0;
         if (gi == k0 + t) c = qnan<T>();                      // skip i == k

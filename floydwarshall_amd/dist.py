@@ -8,10 +8,10 @@ OF STEP k, which lives on one rank.  That is the only exchange, so the only coll
 broadcast of pivot rows.
 
 Latency, not bandwidth, is the problem (N messages of N*4 bytes): pivots are therefore exchanged
-B at a time.  The owner of pivots [k0, k0+B) runs the PANEL phase -- it evolves just those B rows
-through those B pivots in exact k order and exports the time-k snapshot of each pivot row -- and
-broadcasts the B x N snapshot panel once; every rank then applies the B pivots to its slab using
-the snapshots.  No operand and no order changes, so the result is bit-identical to the
+B at a time.  The owner of pivots [k0, k0+B) runs the PANEL phase -- it evolves a scratch copy of
+just those B rows through those B pivots in exact k order and exports the time-k snapshot of each
+pivot row -- and broadcasts the B x N snapshot panel once; every rank then applies the B pivots to
+ALL its rows (the pivot rows included) using the snapshots.  No operand and no order changes, so the result is bit-identical to the
 single-GPU solve (tests/test_dist_gloo.py, tests/test_gpu_parity.py).
 
 Look-ahead: while a rank relaxes its slab with panel b, the owner of panel b+1 first brings just
@@ -43,13 +43,30 @@ def pivot_blocks(n, world, block):
 
 
 class HipBackend:
-    """The product backend: libfwx kernels on torch-owned device memory, current stream."""
+    """The product backend: libfwx kernels on torch-owned device memory, current stream.
 
-    def panel(self, block_rate, n, k0, w, block_next=None):
-        engine.dev_panel(block_rate, n, k0, w, next_t=block_next)
+    engine "fused": fwx_dev_relax_fused (64 pivots per pass); "perk": fwx_dev_relax (one launch per
+    pivot).  Both consume the same snapshot panel and give the same bits."""
+
+    def __init__(self, engine_name="fused"):
+        assert engine_name in ("fused", "perk")
+        self.engine_name = engine_name
+        self.ws = None
+
+    def prepare(self, n, rows, dtype, device, with_next):
+        self.ws = engine.FusedWorkspace(n, rows, dtype, device, with_next=with_next)
+
+    def panel(self, block_rate, n, k0, w):
+        """Snapshot panel of the pivot rows (the matrix is not modified)."""
+        engine.dev_panel_snap(block_rate, n, k0, w, self.ws.diag)
 
     def relax(self, slab_rate, n, row0, k0, k1, w, slab_next=None):
-        if slab_rate.shape[0] > 0:
+        if slab_rate.shape[0] == 0:
+            return
+        if self.engine_name == "fused":
+            engine.dev_relax_fused(slab_rate, n, row0, k0, k1, w, self.ws.ct, next_t=slab_next,
+                                   cnt_t=self.ws.cnt)
+        else:
             engine.dev_relax(slab_rate, n, row0, k0, k1, pivots_t=w, next_t=slab_next)
 
 
@@ -61,19 +78,23 @@ def solve_partitioned(rate, n, rank, world, *, nxt=None, block=64, backend=None,
     backend and the process group support (HIP + RCCL in production; the tests drive it on
     CPU + gloo with an oracle-backed backend to check the schedule).
 
-    Schedule per panel b (pivots [k0, k0+B), snapshots W_b):
+    Schedule per panel b (pivots [k0, k0+B), snapshots W_b).  A panel is a pure SNAPSHOT of the
+    pivot rows (they are not modified by it), so every rank relaxes ALL its rows with W_b:
         wait for W_b
-        owner of panel b+1: relax ONLY the rows of panel b+1 with W_b, run their panel phase
+        owner of panel b+1: relax ONLY the rows of panel b+1 with W_b, then snapshot them
         everyone:           start the broadcast of W_{b+1} (async, other buffer)
         everyone:           relax the rest of the slab with W_b   <- overlaps the broadcast
     """
     backend = backend or HipBackend()
+    assert 1 <= block <= engine.FWX_FUSED_BLOCK
     bounds = row_bounds(n, world)
     row0, rows = bounds[rank], bounds[rank + 1] - bounds[rank]
     assert tuple(rate.shape) == (rows, n)
     blocks = pivot_blocks(n, world, block)
     if not blocks:
         return
+    if hasattr(backend, "prepare"):
+        backend.prepare(n, rows, rate.dtype, rate.device, nxt is not None)
     bufs = [torch.empty((block, n), dtype=rate.dtype, device=rate.device) for _ in range(2)]
 
     def sub(t, lo, hi):
@@ -84,7 +105,7 @@ def solve_partitioned(rate, n, rank, world, *, nxt=None, block=64, backend=None,
         w = bufs[idx & 1][:b]
         if rank == owner:
             lo = k0 - row0
-            backend.panel(rate[lo:lo + b], n, k0, w, sub(nxt, lo, lo + b))
+            backend.panel(rate[lo:lo + b], n, k0, w)
         work = None
         if world > 1:
             src = owner if group is None else dist.get_global_rank(group, owner)
@@ -103,7 +124,7 @@ def solve_partitioned(rate, n, rank, world, *, nxt=None, block=64, backend=None,
         if work is not None:
             work.wait()
         k1 = k0 + b
-        skips = [(k0 - row0, k0 - row0 + b)] if rank == owner else []
+        skips = []
         nxt_w = nxt_work = None
         if idx + 1 < len(blocks) and lookahead:
             nk0, nb, nowner = blocks[idx + 1]

@@ -46,13 +46,12 @@ class OracleBackend:
         for k in range(k0, k1):
             self._apply(r, nx, n, row0, k, wn[k - k0])
 
-    def panel(self, block_rate, n, k0, w, block_next=None):
-        r = block_rate.numpy()
-        nx = None if block_next is None else block_next.numpy()
+    def panel(self, block_rate, n, k0, w):
+        r = block_rate.numpy().copy()         # snapshot only: the matrix itself is not modified
         wn = w.numpy()
         for t in range(r.shape[0]):
             wn[t] = r[t]                      # time-k snapshot of pivot row k0+t
-            self._apply(r, nx, n, k0, k0 + t, wn[t])
+            self._apply(r, None, n, k0, k0 + t, wn[t])
 
 
 def _worker(rank, world, port, n, block, lookahead, kind, with_next, outdir):

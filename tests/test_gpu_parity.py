@@ -333,3 +333,24 @@ def test_fused_device_api_partition_emulation():
     assert_bits_equal(torch.cat(slabs).cpu().numpy(), er, "partitioned fused rate")
     assert_bits_equal(torch.cat(nslabs).cpu().numpy(), en, "partitioned fused next")
     assert int(upd.sum().item()) == eu
+
+
+@pytest.mark.parametrize("engine_name", ["fused", "perk"])
+@pytest.mark.parametrize("lookahead", [True, False])
+def test_dist_driver_single_rank_on_gpu(engine_name, lookahead):
+    """floydwarshall_amd.dist.solve_partitioned with the HIP backend at world size 1 (no process
+    group needed): the panel / look-ahead schedule drives the real kernels."""
+    import torch
+    from floydwarshall_amd import dist as fwdist
+    n = 448
+    rate, nxt, _ = synth.make("t2", n, np.float32, seed=41)
+    er, en = rate.copy(), nxt.copy()
+    oracle.relax(er, en)
+    dev = torch.device("cuda:0")
+    r = torch.from_numpy(rate).to(dev)
+    nx = torch.from_numpy(nxt).to(dev)
+    fwdist.solve_partitioned(r, n, 0, 1, nxt=nx, block=48, lookahead=lookahead,
+                             backend=fwdist.HipBackend(engine_name))
+    torch.cuda.synchronize()
+    assert_bits_equal(r.cpu().numpy(), er, "rate")
+    assert_bits_equal(nx.cpu().numpy(), en, "next")
