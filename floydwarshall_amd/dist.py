@@ -69,6 +69,17 @@ class HipBackend:
         else:
             engine.dev_relax(slab_rate, n, row0, k0, k1, pivots_t=w, next_t=slab_next)
 
+    def relax_lookahead(self, slab_rate, n, row0, k0, k1, w, slab_next=None):
+        """The few rows the next panel is made of.  They sit on the owner's critical path, so
+        they always take the one-launch fused kernel (bit-identical to 64 per-k launches)."""
+        if slab_rate.shape[0] == 0:
+            return
+        if n % (16 // slab_rate.element_size()) == 0:
+            engine.dev_relax_fused(slab_rate, n, row0, k0, k1, w, self.ws.ct, next_t=slab_next,
+                                   cnt_t=self.ws.cnt)
+        else:
+            self.relax(slab_rate, n, row0, k0, k1, w, slab_next)
+
 
 def solve_partitioned(rate, n, rank, world, *, nxt=None, block=64, backend=None, group=None,
                       lookahead=True):
@@ -130,7 +141,8 @@ def solve_partitioned(rate, n, rank, world, *, nxt=None, block=64, backend=None,
             nk0, nb, nowner = blocks[idx + 1]
             if rank == nowner:
                 nlo = nk0 - row0
-                backend.relax(rate[nlo:nlo + nb], n, nk0, k0, k1, w, sub(nxt, nlo, nlo + nb))
+                getattr(backend, "relax_lookahead", backend.relax)(
+                    rate[nlo:nlo + nb], n, nk0, k0, k1, w, sub(nxt, nlo, nlo + nb))
                 skips.append((nlo, nlo + nb))
             nxt_w, nxt_work = panel_and_broadcast(idx + 1)
             relax_rows_except(skips, k0, k1, w)
