@@ -251,6 +251,40 @@ __global__ void follow_path_kernel(const int32_t *next, int n, int src, int dst,
 template <typename T>
 int matrix_solve_typed(fwx_matrix *m, const Opts &op, unsigned long long *upd, hipStream_t s);
 
+// One thread per (src, dst) pair: batch path reconstruction from the next-hop matrix.
+template <typename T>
+__global__ __launch_bounds__(256) void follow_paths_kernel(const int32_t *next, int n, int count,
+                                                           const int32_t *src, const int32_t *dst,
+                                                           int32_t *len_out, const T *edge,
+                                                           double *prod_out, int32_t *path_out,
+                                                           int cap)
+{
+    const int q = blockIdx.x * 256 + threadIdx.x;
+    if (q >= count) return;
+    const int s = src[q], d = dst[q];
+    int len = 0, cur = s;
+    double prod = 1.0;
+    if (s < 0 || d < 0 || s >= n || d >= n) {
+        len_out[q] = FWX_ERR_INVALID;
+        return;
+    }
+    while (true) {
+        const int nx = next[(size_t)cur * n + d];
+        if (nx < 0) {
+            if (len) len = FWX_ERR_CYCLE;    // a broken walk: only possible on inconsistent input
+            break;
+        }
+        if (nx >= n || len >= n) { len = FWX_ERR_CYCLE; break; }
+        if (edge) prod *= (double)edge[(size_t)cur * n + nx];
+        if (path_out && len < cap) path_out[(size_t)q * cap + len] = nx;
+        ++len;
+        cur = nx;
+        if (cur == d) break;
+    }
+    len_out[q] = len;
+    if (prod_out) prod_out[q] = len > 0 ? prod : 0.0;
+}
+
 int check_slab(const fwx_slab *s)
 {
     if (!s || s->n < 0 || s->rows < 0 || s->row0 < 0 || (int64_t)s->row0 + s->rows > s->n ||
@@ -525,6 +559,29 @@ int fwx_dev_panel(const fwx_slab *block, void *w_rate, int32_t *w_hops,
     if (block->dtype == FWX_F64)
         return panel_impl<double>(block, (double *)w_rate, w_hops, d_updates, s);
     return panel_impl<float>(block, (float *)w_rate, w_hops, d_updates, s);
+}
+
+int fwx_dev_follow_paths(int32_t n, const int32_t *next, int32_t count, const int32_t *src,
+                         const int32_t *dst, int32_t *len_out, const void *edge_rate,
+                         int32_t dtype, double *prod_out, int32_t *path_out, int32_t cap,
+                         void *stream)
+{
+    if (n < 0 || count < 0 || cap < 0 || (dtype != FWX_F32 && dtype != FWX_F64))
+        return FWX_ERR_INVALID;
+    if (count == 0) return FWX_OK;
+    if (!next || !src || !dst || !len_out || (prod_out && !edge_rate) || (path_out && cap == 0))
+        return FWX_ERR_INVALID;
+    if (device_count() <= 0) return FWX_ERR_NO_DEVICE;
+    hipStream_t s = (hipStream_t)stream;
+    const dim3 grid((unsigned)((count + 255) / 256)), block(256);
+    if (dtype == FWX_F64)
+        hipLaunchKernelGGL(follow_paths_kernel<double>, grid, block, 0, s, next, n, count, src,
+                           dst, len_out, (const double *)edge_rate, prod_out, path_out, cap);
+    else
+        hipLaunchKernelGGL(follow_paths_kernel<float>, grid, block, 0, s, next, n, count, src, dst,
+                           len_out, (const float *)edge_rate, prod_out, path_out, cap);
+    FWX_HIP(hipGetLastError());
+    return FWX_OK;
 }
 
 size_t fwx_fused_diag_ws_bytes(int32_t dtype)

@@ -14,7 +14,7 @@ from ._lib import (FWX_ENGINE_AUTO, FWX_ENGINE_FUSED, FWX_ENGINE_PERK, FWX_F32, 
                    FWX_FUSED_BLOCK, FWX_UPDATE_SHARDS, FwxError, FwxOpts, FwxPivots, FwxSlab, check,
                    lib)
 
-__all__ = ["solve", "follow_path", "DeviceMatrix", "dev_relax", "dev_panel", "dev_panel_snap",
+__all__ = ["solve", "follow_path", "dev_follow_paths", "DeviceMatrix", "dev_relax", "dev_panel", "dev_panel_snap",
            "dev_relax_fused", "FusedWorkspace", "FWX_FUSED_BLOCK", "device_count",
            "FwxError", "FWX_ENGINE_AUTO", "FWX_ENGINE_PERK", "FWX_ENGINE_FUSED",
            "FWX_UPDATE_SHARDS"]
@@ -255,3 +255,30 @@ def dev_solve_fused(rate_t, n, k_begin=0, k_end=None, *, next_t=None, ws=None, u
         dev_relax_fused(rate_t, n, 0, k0, k1, w, ws.ct, next_t=next_t, cnt_t=ws.cnt,
                         updates_t=updates_t)
     return ws
+
+
+def dev_follow_paths(next_t, src_t, dst_t, *, edge_rate_t=None, path_cap=0):
+    """Batch path reconstruction on the device (fwx_dev_follow_paths).  next_t: full n x n int32
+    next-hop matrix; src_t/dst_t: int32 vectors.  Returns (len, prod or None, paths or None) as
+    device tensors; asynchronous on the current stream."""
+    import torch
+    n = next_t.shape[0]
+    assert next_t.is_cuda and next_t.is_contiguous() and next_t.dtype == torch.int32
+    assert src_t.dtype == torch.int32 and dst_t.dtype == torch.int32 and src_t.shape == dst_t.shape
+    count = src_t.numel()
+    dev = next_t.device
+    len_t = torch.empty(count, dtype=torch.int32, device=dev)
+    prod_t = torch.empty(count, dtype=torch.float64, device=dev) if edge_rate_t is not None else None
+    path_t = torch.empty((count, path_cap), dtype=torch.int32, device=dev) if path_cap else None
+    code = FWX_F32
+    if edge_rate_t is not None:
+        assert edge_rate_t.is_cuda and edge_rate_t.is_contiguous() and edge_rate_t.shape == next_t.shape
+        code = _tensor_dtype_code(edge_rate_t)
+    vp = ctypes.c_void_p
+    check(lib().fwx_dev_follow_paths(
+        n, vp(next_t.data_ptr()), count, vp(src_t.data_ptr()), vp(dst_t.data_ptr()),
+        vp(len_t.data_ptr()), vp(edge_rate_t.data_ptr()) if edge_rate_t is not None else None, code,
+        vp(prod_t.data_ptr()) if prod_t is not None else None,
+        vp(path_t.data_ptr()) if path_t is not None else None, path_cap, _stream_ptr()),
+        "fwx_dev_follow_paths")
+    return len_t, prod_t, path_t

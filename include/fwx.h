@@ -150,6 +150,18 @@ int fwx_dev_relax(const fwx_slab *slab, const fwx_pivots *piv, int32_t serpentin
 int fwx_dev_panel(const fwx_slab *block, void *w_rate, int32_t *w_hops,
                   unsigned long long *d_updates, void *stream);
 
+/* Batch form of `optimum`'s path reconstruction (Algorithms.hs:74-75) on the device: for each
+ * pair q, walk next-hops from src[q] until dst[q].  All pointers are DEVICE pointers; `next` is
+ * the full n x n matrix.  len_out[q] = path length (0 = no route, FWX_ERR_CYCLE if dst is not
+ * reached within n hops).  Optional outputs (NULL to skip): prod_out[q] = product, accumulated in
+ * double left to right, of edge_rate[u][v] along the path (edge_rate = the UNSOLVED input matrix,
+ * dtype given) -- the solved rate must equal it up to rounding; path_out + q*cap receives up to
+ * cap vertices (longer paths are truncated there but still walked and counted).                */
+int fwx_dev_follow_paths(int32_t n, const int32_t *next, int32_t count, const int32_t *src,
+                         const int32_t *dst, int32_t *len_out, const void *edge_rate,
+                         int32_t dtype, double *prod_out, int32_t *path_out, int32_t cap,
+                         void *stream);
+
 /* ---- fused engine (FWX_FUSED_BLOCK pivots per pass; bit-identical to the per-k engine) --------
  * fwx_dev_panel_snap: snapshot panel of the pivot rows in `block` (rows [row0,row0+rows), rows <=
  *   FWX_FUSED_BLOCK, at time row0): writes the time-k snapshot of each pivot row to w_rate

@@ -354,3 +354,79 @@ def test_dist_driver_single_rank_on_gpu(engine_name, lookahead):
     torch.cuda.synchronize()
     assert_bits_equal(r.cpu().numpy(), er, "rate")
     assert_bits_equal(nx.cpu().numpy(), en, "next")
+
+
+def test_batch_path_follow_matches_host_walk():
+    import torch
+    n = 300
+    rate0, nxt0, hops0 = synth.make("d2", n, np.float64, seed=61)
+    rate, nxt, hops = rate0.copy(), nxt0.copy(), hops0.copy()
+    engine.solve(rate, nxt, hops)
+    dev = torch.device("cuda:0")
+    rnd = np.random.default_rng(3)
+    src = rnd.integers(0, n, 5000).astype(np.int32)
+    dst = rnd.integers(0, n, 5000).astype(np.int32)
+    ln, prod, paths = engine.dev_follow_paths(torch.from_numpy(nxt).to(dev), torch.from_numpy(src).to(dev),
+                                              torch.from_numpy(dst).to(dev),
+                                              edge_rate_t=torch.from_numpy(rate0).to(dev), path_cap=n)
+    ln, prod, paths = ln.cpu().numpy(), prod.cpu().numpy(), paths.cpu().numpy()
+    for q in range(len(src)):
+        exp = oracle.follow_path(nxt, int(src[q]), int(dst[q]))
+        assert ln[q] == len(exp) == hops[src[q], dst[q]]
+        assert list(paths[q, :ln[q]]) == exp
+        if ln[q]:
+            assert abs(prod[q] - rate[src[q], dst[q]]) <= 1e-12 * rate[src[q], dst[q]]
+    # unreachable pairs and cycles
+    sparse_r, sparse_n, _ = synth.make("t2", 64, np.float64, seed=2)
+    engine.solve(sparse_r, sparse_n)
+    s2 = np.arange(64, dtype=np.int32)
+    ln2, _, _ = engine.dev_follow_paths(torch.from_numpy(sparse_n).to(dev), torch.from_numpy(s2).to(dev),
+                                        torch.from_numpy(s2).to(dev))
+    assert (ln2.cpu().numpy() == 0).all()                     # src == dst: empty path
+    loop = np.array([[-1, 1, 1], [0, -1, 0], [0, 0, -1]], dtype=np.int32)
+    ln3, _, _ = engine.dev_follow_paths(torch.from_numpy(loop).to(dev),
+                                        torch.tensor([0], dtype=torch.int32, device=dev),
+                                        torch.tensor([2], dtype=torch.int32, device=dev))
+    assert int(ln3.cpu()[0]) == -5
+
+
+def test_config5_n32768_fp32_with_next_hop_matrix():
+    """BASELINE.json configs[4] size on one GPU: N=32768 fp32 with the predecessor (next-hop)
+    matrix, full solve (fused engine), then full best-rate path reconstruction for 10^6 sampled
+    (src, dst) pairs on the device: every path ends at dst, and the product of the INPUT edge rates
+    along it equals the solved rate to fp32 rounding.  Oracle parity on a mid-solve pivot slice."""
+    import torch
+    n = 32768
+    dev = torch.device("cuda:0")
+    rate_h, next_h = synth.d1_uniform(n, np.float32, synth.BASE_SEED + 4)
+    rate0 = torch.from_numpy(rate_h).to(dev)
+    rate = rate0.clone()
+    nxt = torch.from_numpy(next_h).to(dev)
+    del next_h
+    ws = engine.dev_solve_fused(rate, n, 0, 4096, next_t=nxt)
+    # oracle slice: pivots [4096, 4098) from the GPU state
+    er = rate.cpu().numpy()
+    en = nxt.cpu().numpy()
+    oracle.relax_mt(er, en, 4096, 4098)
+    engine.dev_solve_fused(rate, n, 4096, 4098, next_t=nxt, ws=ws)
+    torch.cuda.synchronize()
+    assert_bits_equal(rate.cpu().numpy(), er, "rate after slice")
+    assert_bits_equal(nxt.cpu().numpy(), en, "next after slice")
+    del er, en
+    engine.dev_solve_fused(rate, n, 4098, n, next_t=nxt, ws=ws)
+    torch.cuda.synchronize()
+    assert bool((rate >= rate0).all())
+    g = torch.Generator(device="cpu").manual_seed(7)
+    src = torch.randint(0, n, (1000000,), generator=g, dtype=torch.int32).to(dev)
+    dst = torch.randint(0, n, (1000000,), generator=g, dtype=torch.int32).to(dev)
+    ln, prod, paths = engine.dev_follow_paths(nxt, src, dst, edge_rate_t=rate0, path_cap=4)
+    torch.cuda.synchronize()
+    same = src == dst
+    assert bool((ln[same] == 0).all()) and bool((ln[~same] >= 1).all())
+    solved = rate[src.long(), dst.long()].double()
+    rel = ((prod - solved).abs() / solved.clamp_min(1e-30))[~same]
+    assert float(rel.max()) < 2e-5, float(rel.max())
+    assert int(ln.max()) < 64
+    short = (ln >= 1) & (ln <= 4)
+    last = paths[short].gather(1, (ln[short].long() - 1).unsqueeze(1)).squeeze(1)
+    assert bool((last == dst[short]).all())
