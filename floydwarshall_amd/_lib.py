@@ -18,6 +18,7 @@ FWX_F32, FWX_F64 = 0, 1
 FWX_ENGINE_AUTO, FWX_ENGINE_PERK, FWX_ENGINE_FUSED = 0, 1, 2
 FWX_UPDATE_SHARDS = 256
 FWX_FUSED_BLOCK = 64
+FWX_FLAG_NONNEG = 1
 
 c_i32 = ctypes.c_int32
 c_vp = ctypes.c_void_p
@@ -73,7 +74,8 @@ SIGNATURES = {
     "fwx_fused_diag_ws_bytes": (ctypes.c_size_t, [c_i32]),
     "fwx_dev_panel_snap": (ctypes.c_int, [ctypes.POINTER(FwxSlab), c_vp, c_vp, c_vp]),
     "fwx_dev_relax_fused": (ctypes.c_int, [ctypes.POINTER(FwxSlab), ctypes.POINTER(FwxPivots), c_vp,
-                                           c_vp, c_vp, c_vp]),
+                                           c_vp, c_vp, c_i32, c_vp]),
+    "fwx_dev_check_nonneg": (ctypes.c_int, [ctypes.POINTER(FwxSlab), c_vp, c_vp]),
 }
 
 _LIB = None

@@ -107,9 +107,10 @@ int relax_range(T *rate, int32_t *next, int32_t *hops, int rows, int n, int row0
 
 template <typename T>
 int fused_block(T *rate, int32_t *next, int rows, int n, int row0, int k0, int bt, const T *w, T *ct,
-                int32_t *cnt, unsigned long long *d_updates, hipStream_t s)
+                int32_t *cnt, unsigned long long *d_updates, bool nonneg, hipStream_t s)
 {
     fwx::FusedArgs<T> a;
+    a.nonneg = nonneg;
     a.rate = rate; a.next = next; a.rows = rows; a.n = n; a.row0 = row0;
     a.k0 = k0; a.bt = bt; a.w = w; a.ct = ct; a.cnt = cnt; a.updates = d_updates;
     hipError_t e = fwx::launch_fused_relax<T>(a, s);
@@ -134,12 +135,23 @@ int fused_range(T *rate, int32_t *next, int n, int k_begin, int k_end, void *ws,
     T *w = (T *)p;                 p += (size_t)FWX_FUSED_B * n * sizeof(T);
     T *ct = (T *)p;                p += (size_t)FWX_FUSED_B * n * sizeof(T);
     int32_t *cnt = (int32_t *)p;   p += (size_t)FWX_FUSED_B * n * sizeof(int32_t);
-    T *diag = (T *)p;
+    T *diag = (T *)p;              p += (size_t)2 * FWX_FUSED_B * FWX_FUSED_B * sizeof(T);
+    bool nonneg = false;
+    if (sizeof(T) == 4 && !next && !d_updates) {
+        // one read of the matrix decides whether the max3 kernel may be used (see fwx.h)
+        int *flag = (int *)(((uintptr_t)p + 15) & ~(uintptr_t)15);
+        int h = 1;
+        FWX_HIP(hipMemcpyAsync(flag, &h, sizeof(int), hipMemcpyHostToDevice, s));
+        FWX_HIP(fwx::launch_nonneg_check((const float *)rate, (size_t)n * n, flag, s));
+        FWX_HIP(hipMemcpyAsync(&h, flag, sizeof(int), hipMemcpyDeviceToHost, s));
+        FWX_HIP(hipStreamSynchronize(s));
+        nonneg = h == 1;
+    }
     for (int k0 = k_begin; k0 < k_end; k0 += FWX_FUSED_B) {
         const int bt = k_end - k0 < FWX_FUSED_B ? k_end - k0 : FWX_FUSED_B;
         FWX_HIP(fwx::launch_fused_panel<T>(rate + (size_t)k0 * n, n, k0, bt, w, diag, s));
         const int rc = fused_block<T>(rate, next, n, n, 0, k0, bt, w, ct, next ? cnt : nullptr,
-                                      d_updates, s);
+                                      d_updates, nonneg, s);
         if (rc) return rc;
     }
     return FWX_OK;
@@ -606,8 +618,25 @@ int fwx_dev_panel_snap(const fwx_slab *block, void *w_rate, void *diag_ws, void 
     return FWX_OK;
 }
 
+int fwx_dev_check_nonneg(const fwx_slab *slab, int32_t *d_flag, void *stream)
+{
+    int rc = check_slab(slab);
+    if (rc) return rc;
+    if (!d_flag) return FWX_ERR_INVALID;
+    if (device_count() <= 0) return FWX_ERR_NO_DEVICE;
+    hipStream_t s = (hipStream_t)stream;
+    if (slab->dtype != FWX_F32) {
+        FWX_HIP(hipMemsetAsync(d_flag, 0, sizeof(int32_t), s));
+        return FWX_OK;
+    }
+    FWX_HIP(fwx::launch_nonneg_check((const float *)slab->rate, (size_t)slab->rows * slab->n,
+                                     (int *)d_flag, s));
+    return FWX_OK;
+}
+
 int fwx_dev_relax_fused(const fwx_slab *slab, const fwx_pivots *piv, void *col_rate,
-                        int32_t *col_next, unsigned long long *d_updates, void *stream)
+                        int32_t *col_next, unsigned long long *d_updates, int32_t flags,
+                        void *stream)
 {
     int rc = check_slab(slab);
     if (rc) return rc;
@@ -623,10 +652,11 @@ int fwx_dev_relax_fused(const fwx_slab *slab, const fwx_pivots *piv, void *col_r
     if (slab->dtype == FWX_F64)
         return fused_block<double>((double *)slab->rate, slab->next, slab->rows, slab->n, slab->row0,
                                    piv->k_begin, piv->k_end - piv->k_begin, (const double *)piv->rate,
-                                   (double *)col_rate, col_next, d_updates, s);
+                                   (double *)col_rate, col_next, d_updates, false, s);
     return fused_block<float>((float *)slab->rate, slab->next, slab->rows, slab->n, slab->row0,
                               piv->k_begin, piv->k_end - piv->k_begin, (const float *)piv->rate,
-                              (float *)col_rate, col_next, d_updates, s);
+                              (float *)col_rate, col_next, d_updates, (flags & FWX_FLAG_NONNEG) != 0,
+                              s);
 }
 
 }  // extern "C"

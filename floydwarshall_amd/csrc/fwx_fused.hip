@@ -387,6 +387,149 @@ __global__ __launch_bounds__(256, MINW) void fused_main(T *rate, int32_t *next, 
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// fused_main_max: rates-only f32 main kernel for matrices whose entries are all >= +0 and not NaN
+// (what the reference's parser guarantees: rates > 0, Parsers.hs:40; unreachable = +0.0).
+//
+// On that domain the strict fold  x <- (x < c) ? c : x  equals  x <- max(x, c)  BIT FOR BIT:
+// every candidate is a product of non-negative operands, hence >= +0, +inf, or NaN (inf * 0);
+// x is never NaN and never -0 (it only ever takes the value of a candidate that won a strict
+// compare), max(x, NaN) = x exactly as `x < NaN` is false, and for x == c both forms leave the
+// same bits.  max is associative, so two pivots fold per instruction:
+//       x <- max3(x, C_t[i]*W_t[j], C_{t+1}[i]*W_{t+1}[j])
+// with both products from ONE v_pk_mul_f32 (operands stored as (t, t+1) pairs in LDS):
+// 1.0 VALU instruction per relaxation instead of 2.5.  The caller must have verified the domain
+// (fwx_dev_check_nonneg); the next-hop variant needs the compare and stays on fused_main.
+// ------------------------------------------------------------------------------------------------
+template <int BS, int MINW>
+__global__ __launch_bounds__(256, MINW) void fused_main_max(float *rate, int rows, int n, int row0,
+                                                            int k0, int bt, const float *w,
+                                                            const float *ct)
+{
+    typedef float V4 __attribute__((ext_vector_type(4)));
+    typedef float V2 __attribute__((ext_vector_type(2)));
+    constexpr int RI = 8, TI = 128, TJ = 128, HJ = 64, HP = BS / 2;
+
+    __shared__ __attribute__((aligned(16))) V2 sW[HP][TJ];   // (W_t[j], W_{t+1}[j])
+    __shared__ __attribute__((aligned(16))) V2 sC[HP][TI];   // (C_t[i], C_{t+1}[i])
+
+    const int tid = threadIdx.x;
+    const int i_base = blockIdx.y * TI;
+    const int j_base = blockIdx.x * TJ;
+    const int ti = tid >> 4, tj = tid & 15;
+    const int i0 = i_base + ti * RI;
+    int jcol[2];
+    bool jok[2];
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        const int j = j_base + h * HJ + tj * 4;
+        jok[h] = j < n;
+        jcol[h] = jok[h] ? j : n - 4;
+    }
+    V4 x[RI][2];
+#pragma unroll
+    for (int r = 0; r < RI; ++r) {
+        const int i = min(i0 + r, rows - 1);
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+            x[r][h] = *reinterpret_cast<const V4 *>(rate + (size_t)i * n + jcol[h]);
+    }
+    const int gi_lo = row0 + i_base, gj_lo = j_base;
+    const bool diag_tile = gi_lo < gj_lo + TJ && gj_lo < gi_lo + TI;
+    const float nanv = qnan<float>();
+
+    for (int s0 = 0; s0 < bt; s0 += BS) {
+        const int bs = min(BS, bt - s0);
+        if (s0) __syncthreads();
+        // stage (t, t+1) pairs; missing pivots and skipped operands are NaN (ignored by max)
+        for (int idx = tid; idx < HP * TJ; idx += 256) {
+            const int tp = idx / TJ, jl = idx % TJ;
+            const int j = j_base + jl;
+            V2 v;
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                const int tl = 2 * tp + u, t = s0 + tl;
+                float val = nanv;
+                if (tl < bs && j < n && j != k0 + t) val = w[(size_t)t * n + j];
+                v[u] = val;
+            }
+            sW[tp][jl] = v;
+        }
+        for (int idx = tid; idx < HP * TI; idx += 256) {
+            const int tp = idx / TI, il = idx % TI;
+            const int i = i_base + il;
+            V2 v;
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                const int tl = 2 * tp + u;
+                v[u] = (tl < bs && i < rows) ? ct[(size_t)(s0 + tl) * rows + i] : nanv;
+            }
+            sC[tp][il] = v;
+        }
+        __syncthreads();
+
+        const int np = (bs + 1) / 2;
+        for (int tp = 0; tp < np; ++tp) {
+            V2 c[RI], wv[2][4];
+#pragma unroll
+            for (int q = 0; q < RI / 2; ++q) {
+                const V4 cv = *reinterpret_cast<const V4 *>(&sC[tp][ti * RI + q * 2]);
+                c[2 * q] = V2{cv[0], cv[1]};
+                c[2 * q + 1] = V2{cv[2], cv[3]};
+            }
+#pragma unroll
+            for (int h = 0; h < 2; ++h)
+#pragma unroll
+                for (int q = 0; q < 2; ++q) {
+                    const V4 wq = *reinterpret_cast<const V4 *>(&sW[tp][h * HJ + tj * 4 + q * 2]);
+                    wv[h][2 * q] = V2{wq[0], wq[1]};
+                    wv[h][2 * q + 1] = V2{wq[2], wq[3]};
+                }
+#pragma unroll
+            for (int r = 0; r < RI; ++r)
+#pragma unroll
+                for (int h = 0; h < 2; ++h)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const V2 cand = c[r] * wv[h][e];                     // v_pk_mul_f32
+                        x[r][h][e] = __builtin_fmaxf(__builtin_fmaxf(x[r][h][e], cand[0]), cand[1]);
+                    }
+        }
+    }
+
+#pragma unroll
+    for (int r = 0; r < RI; ++r) {
+        const int i = i0 + r;
+        if (i >= rows) continue;
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            if (!jok[h]) continue;
+            const size_t off = (size_t)i * n + jcol[h];
+            if (diag_tile) {
+                const int gi = row0 + i;
+                if (gi >= jcol[h] && gi < jcol[h] + 4) x[r][h][gi - jcol[h]] = rate[off + gi - jcol[h]];
+            }
+            *reinterpret_cast<V4 *>(rate + off) = x[r][h];
+        }
+    }
+}
+
+// Domain check for fused_main_max: clears *flag if any entry has its sign bit set or is NaN.
+__global__ __launch_bounds__(256) void nonneg_check_f32(const float *rate, size_t count, int *flag)
+{
+    const size_t stride = (size_t)gridDim.x * 256 * 4;
+    bool bad = false;
+    for (size_t i = ((size_t)blockIdx.x * 256 + threadIdx.x) * 4; i < count; i += stride) {
+        if (i + 4 <= count) {
+            const uint4 v = *reinterpret_cast<const uint4 *>(rate + i);
+            bad |= (v.x > 0x7F800000u) | (v.y > 0x7F800000u) | (v.z > 0x7F800000u) | (v.w > 0x7F800000u);
+        } else {
+            for (size_t e = i; e < count; ++e) bad |= __float_as_uint(rate[e]) > 0x7F800000u;
+        }
+    }
+    if (bad) *flag = 0;
+}
+
 }  // namespace
 
 // Stage size / occupancy target per variant (LDS = BS * (TJ + TI) * sizeof(T) [+ BS*TI*4]).
@@ -395,6 +538,26 @@ template <> struct FusedCfg<float, false> { static constexpr int BS = 32, MINW =
 template <> struct FusedCfg<float, true> { static constexpr int BS = 32, MINW = 2; };
 template <> struct FusedCfg<double, false> { static constexpr int BS = 32, MINW = 2; };
 template <> struct FusedCfg<double, true> { static constexpr int BS = 16, MINW = 2; };
+
+// f32, rates only, no update counting, domain verified by the caller: the max3 kernel.
+static bool launch_max_form(const FusedArgs<float> &a, dim3 grid, dim3 block, hipStream_t s)
+{
+    if (!a.nonneg || a.next || a.updates) return false;
+    hipLaunchKernelGGL((fused_main_max<32, 4>), grid, block, 0, s, a.rate, a.rows, a.n, a.row0,
+                       a.k0, a.bt, a.w, a.ct);
+    return true;
+}
+static bool launch_max_form(const FusedArgs<double> &, dim3, dim3, hipStream_t) { return false; }
+
+hipError_t launch_nonneg_check(const float *rate, size_t count, int *flag, hipStream_t s)
+{
+    if (count == 0) return hipSuccess;
+    size_t blocks = (count / 4 + 255) / 256;
+    if (blocks > 4096) blocks = 4096;
+    if (blocks == 0) blocks = 1;
+    hipLaunchKernelGGL(nonneg_check_f32, dim3((unsigned)blocks), dim3(256), 0, s, rate, count, flag);
+    return hipGetLastError();
+}
 
 template <typename T> hipError_t launch_fused_relax(const FusedArgs<T> &a, hipStream_t s)
 {
@@ -414,6 +577,7 @@ template <typename T> hipError_t launch_fused_relax(const FusedArgs<T> &a, hipSt
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
     const dim3 grid((unsigned)((a.n + TJ - 1) / TJ), (unsigned)((a.rows + TI - 1) / TI));
+    if (launch_max_form(a, grid, block, s)) return hipGetLastError();
 #define FWX_FUSED_LAUNCH(HN, CN)                                                                   \
     hipLaunchKernelGGL((fused_main<T, HN, CN, FusedCfg<T, HN>::BS, FusedCfg<T, HN>::MINW>), grid,  \
                        block, 0, s, a.rate, a.next, a.rows, a.n, a.row0, a.k0, a.bt, a.w, a.ct,    \

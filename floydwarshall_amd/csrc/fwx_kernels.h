@@ -38,7 +38,11 @@ template <typename T> struct FusedArgs {
     T *ct;                 // scratch bt x rows: ct[t*rows + i] = column k0+t at time k0+t (NaN if i==k)
     int32_t *cnt;          // scratch bt x rows (iff next)
     unsigned long long *updates;
+    bool nonneg;           // caller verified: every matrix entry is >= +0 and not NaN (max form)
 };
+
+// Clears *flag (device int, preset to 1) if any of `count` f32 values is negative, -0 or NaN.
+hipError_t launch_nonneg_check(const float *rate, size_t count, int *flag, hipStream_t s);
 
 // colpanel + main: applies the bt pivots to every row of the slab.
 template <typename T> hipError_t launch_fused_relax(const FusedArgs<T> &a, hipStream_t s);

@@ -52,6 +52,14 @@ class HipBackend:
         assert engine_name in ("fused", "perk")
         self.engine_name = engine_name
         self.ws = None
+        self.nonneg = False
+
+    def check_domain(self, slab_rate, n, row0, slab_next):
+        """1 if this slab allows the max-form kernel (f32, rates only, all entries >= +0, no NaN);
+        solve_partitioned combines the answers of all ranks (the domain must hold globally)."""
+        if slab_next is not None or slab_rate.element_size() != 4 or self.engine_name != "fused":
+            return 0
+        return int(engine.dev_check_nonneg(slab_rate, n, row0)) if slab_rate.shape[0] else 1
 
     def prepare(self, n, rows, dtype, device, with_next):
         self.ws = engine.FusedWorkspace(n, rows, dtype, device, with_next=with_next)
@@ -65,7 +73,7 @@ class HipBackend:
             return
         if self.engine_name == "fused":
             engine.dev_relax_fused(slab_rate, n, row0, k0, k1, w, self.ws.ct, next_t=slab_next,
-                                   cnt_t=self.ws.cnt)
+                                   cnt_t=self.ws.cnt, nonneg=self.nonneg)
         else:
             engine.dev_relax(slab_rate, n, row0, k0, k1, pivots_t=w, next_t=slab_next)
 
@@ -76,7 +84,7 @@ class HipBackend:
             return
         if n % (16 // slab_rate.element_size()) == 0:
             engine.dev_relax_fused(slab_rate, n, row0, k0, k1, w, self.ws.ct, next_t=slab_next,
-                                   cnt_t=self.ws.cnt)
+                                   cnt_t=self.ws.cnt, nonneg=self.nonneg)
         else:
             self.relax(slab_rate, n, row0, k0, k1, w, slab_next)
 
@@ -106,6 +114,12 @@ def solve_partitioned(rate, n, rank, world, *, nxt=None, block=64, backend=None,
         return
     if hasattr(backend, "prepare"):
         backend.prepare(n, rows, rate.dtype, rate.device, nxt is not None)
+    if hasattr(backend, "check_domain"):
+        ok = torch.tensor([backend.check_domain(rate, n, row0, nxt)], dtype=torch.int32,
+                          device=rate.device)
+        if world > 1:
+            dist.all_reduce(ok, op=dist.ReduceOp.MIN, group=group)
+        backend.nonneg = bool(ok.item() == 1)
     bufs = [torch.empty((block, n), dtype=rate.dtype, device=rate.device) for _ in range(2)]
 
     def sub(t, lo, hi):

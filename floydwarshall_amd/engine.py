@@ -14,7 +14,7 @@ from ._lib import (FWX_ENGINE_AUTO, FWX_ENGINE_FUSED, FWX_ENGINE_PERK, FWX_F32, 
                    FWX_FUSED_BLOCK, FWX_UPDATE_SHARDS, FwxError, FwxOpts, FwxPivots, FwxSlab, check,
                    lib)
 
-__all__ = ["solve", "follow_path", "dev_follow_paths", "DeviceMatrix", "dev_relax", "dev_panel", "dev_panel_snap",
+__all__ = ["solve", "follow_path", "dev_follow_paths", "dev_check_nonneg", "dev_solve_fused", "DeviceMatrix", "dev_relax", "dev_panel", "dev_panel_snap",
            "dev_relax_fused", "FusedWorkspace", "FWX_FUSED_BLOCK", "device_count",
            "FwxError", "FWX_ENGINE_AUTO", "FWX_ENGINE_PERK", "FWX_ENGINE_FUSED",
            "FWX_UPDATE_SHARDS"]
@@ -222,7 +222,18 @@ def dev_panel_snap(block_rate_t, n, k0, w_rate_t, diag_ws_t):
           "fwx_dev_panel_snap")
 
 
-def dev_relax_fused(rate_t, n, row0, k0, k1, w_t, ct_t, *, next_t=None, cnt_t=None, updates_t=None):
+def dev_check_nonneg(rate_t, n, row0=0):
+    """True iff every rate of the slab is >= +0.0 and not NaN (f32 only; synchronises)."""
+    import torch
+    s = _slab(rate_t, None, None, n, row0)
+    flag = torch.ones(1, dtype=torch.int32, device=rate_t.device)
+    check(lib().fwx_dev_check_nonneg(ctypes.byref(s), ctypes.c_void_p(flag.data_ptr()),
+                                     _stream_ptr()), "fwx_dev_check_nonneg")
+    return bool(flag.item() == 1)
+
+
+def dev_relax_fused(rate_t, n, row0, k0, k1, w_t, ct_t, *, next_t=None, cnt_t=None, updates_t=None,
+                    nonneg=False):
     """Apply pivots [k0,k1) (at most 64) to EVERY row of the slab in one pass, from the snapshot
     panel w_t ((k1-k0) x n).  ct_t / cnt_t: scratch of at least 64*rows elements."""
     s = _slab(rate_t, next_t, None, n, row0)
@@ -238,14 +249,21 @@ def dev_relax_fused(rate_t, n, row0, k0, k1, w_t, ct_t, *, next_t=None, cnt_t=No
         assert cnt_t is not None and cnt_t.numel() >= FWX_FUSED_BLOCK * rate_t.shape[0]
         cn = ctypes.c_void_p(cnt_t.data_ptr())
     check(lib().fwx_dev_relax_fused(ctypes.byref(s), ctypes.byref(p),
-                                    ctypes.c_void_p(ct_t.data_ptr()), cn, upd, _stream_ptr()),
+                                    ctypes.c_void_p(ct_t.data_ptr()), cn, upd,
+                                    _lib.FWX_FLAG_NONNEG if nonneg else 0, _stream_ptr()),
           "fwx_dev_relax_fused")
 
 
-def dev_solve_fused(rate_t, n, k_begin=0, k_end=None, *, next_t=None, ws=None, updates_t=None):
+def dev_solve_fused(rate_t, n, k_begin=0, k_end=None, *, next_t=None, ws=None, updates_t=None,
+                    nonneg=None):
     """Single-GPU solve of pivots [k_begin,k_end) with the fused engine on a torch tensor holding
-    the whole n x n matrix; asynchronous on the current stream."""
+    the whole n x n matrix; asynchronous on the current stream (after one small synchronising
+    domain check when the max-form kernel could apply and `nonneg` is not given)."""
+    import torch
     k_end = n if k_end is None else k_end
+    if nonneg is None:
+        nonneg = (rate_t.dtype == torch.float32 and next_t is None and updates_t is None
+                  and dev_check_nonneg(rate_t, n))
     ws = ws or FusedWorkspace(n, n, rate_t.dtype, rate_t.device, with_next=next_t is not None)
     B = FWX_FUSED_BLOCK
     for k0 in range(k_begin, k_end, B):
@@ -253,7 +271,7 @@ def dev_solve_fused(rate_t, n, k_begin=0, k_end=None, *, next_t=None, ws=None, u
         w = ws.w[0][:k1 - k0]
         dev_panel_snap(rate_t[k0:k1], n, k0, w, ws.diag)
         dev_relax_fused(rate_t, n, 0, k0, k1, w, ws.ct, next_t=next_t, cnt_t=ws.cnt,
-                        updates_t=updates_t)
+                        updates_t=updates_t, nonneg=nonneg)
     return ws
 
 

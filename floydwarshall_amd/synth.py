@@ -10,6 +10,7 @@ off-diagonal rate / next j (or 0.0 / -1 where there is no edge).
   t1_ties        rate = 2^-e, e in {0..3}: exact ties everywhere (earliest k must win)
   t2_sparse_ties t1 at 15 % density, zeros = unreachable
   t3_arbitrage   rates up to 4 with inf and NaN sprinkled in: overflow / NaN semantics
+  t4_overflow    non-negative NaN-free rates up to e^60 at 70 % density: +inf and inf*0 = NaN arise
 """
 import numpy as np
 
@@ -71,8 +72,17 @@ def t3_arbitrage(n, dtype=np.float32, seed=BASE_SEED):
     return _finish(rate, dtype)
 
 
+def t4_overflow(n, dtype=np.float32, seed=BASE_SEED):
+    """Non-negative, NaN-free, but huge: products overflow to +inf and inf * 0 = NaN candidates
+    appear.  Inside the max-form kernel's domain, at its edge."""
+    rng = np.random.Generator(np.random.PCG64(seed))
+    rate = np.exp(rng.uniform(-5.0, 60.0, size=(n, n)))
+    present = rng.random((n, n)) < 0.7
+    return _finish(rate, dtype, present)
+
+
 GENERATORS = {"d1": d1_uniform, "d2": d2_market, "t1": t1_ties, "t2": t2_sparse_ties,
-              "t3": t3_arbitrage}
+              "t3": t3_arbitrage, "t4": t4_overflow}
 
 
 def make(kind, n, dtype=np.float32, seed=BASE_SEED):

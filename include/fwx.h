@@ -173,12 +173,23 @@ int fwx_dev_follow_paths(int32_t n, const int32_t *next, int32_t count, const in
  *   carries next).  Slabs with hops are not supported (FWX_ERR_UNSUPPORTED); n must be a multiple
  *   of 16 bytes worth of elements.
  * The snapshot panel also feeds fwx_dev_relax (per-k engine), so fwx_dev_panel_snap +
- * fwx_dev_relax over all rows is a valid (slower) combination.                                  */
+ * fwx_dev_relax over all rows is a valid (slower) combination.
+ *
+ * flags: FWX_FLAG_NONNEG = the caller has verified (fwx_dev_check_nonneg on EVERY slab of the
+ *   matrix, all ranks) that every entry is >= +0.0 and not NaN -- what the reference's parser
+ *   guarantees (rates > 0, Parsers.hs:40; "no route" = +0.0).  On that domain the strict fold
+ *   equals max() bit for bit, and rates-only f32 slabs take a kernel that folds two pivots per
+ *   instruction (v_pk_mul_f32 + v_max3_f32).  Without the flag nothing is assumed.              */
 #define FWX_FUSED_BLOCK 64
+#define FWX_FLAG_NONNEG 1
 size_t fwx_fused_diag_ws_bytes(int32_t dtype);
 int fwx_dev_panel_snap(const fwx_slab *block, void *w_rate, void *diag_ws, void *stream);
 int fwx_dev_relax_fused(const fwx_slab *slab, const fwx_pivots *piv, void *col_rate,
-                        int32_t *col_next, unsigned long long *d_updates, void *stream);
+                        int32_t *col_next, unsigned long long *d_updates, int32_t flags,
+                        void *stream);
+/* Clears *d_flag (a device int32 the caller has set to 1) if any rate of the slab is negative,
+ * -0.0 or NaN.  f32 slabs only; an f64 slab always clears it (no max-form kernel for f64).      */
+int fwx_dev_check_nonneg(const fwx_slab *slab, int32_t *d_flag, void *stream);
 
 #ifdef __cplusplus
 }

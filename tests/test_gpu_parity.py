@@ -430,3 +430,66 @@ def test_config5_n32768_fp32_with_next_hop_matrix():
     short = (ln >= 1) & (ln <= 4)
     last = paths[short].gather(1, (ln[short].long() - 1).unsqueeze(1)).squeeze(1)
     assert bool((last == dst[short]).all())
+
+
+# ---------------------------------------------------------------------------------------------
+# max-form kernel (v_pk_mul_f32 + v_max3_f32): only taken for f32, rates only, no update counting,
+# after the domain check (all entries >= +0, no NaN).  Must still be bit-identical.
+# ---------------------------------------------------------------------------------------------
+
+def _rates_only_fused(rate):
+    exp = rate.copy()
+    oracle.relax(exp)
+    got = rate.copy()
+    engine.solve(got, engine=engine.FWX_ENGINE_FUSED)          # no next, no counting
+    assert_bits_equal(got, exp, "max-form rate")
+    return got
+
+
+@pytest.mark.parametrize("kind", ["d1", "d2", "t1", "t2", "t4"])
+@pytest.mark.parametrize("n", [64, 132, 516])
+def test_max_form_kernel_inside_its_domain(kind, n):
+    rate, _, _ = synth.make(kind, n, np.float32, seed=300 + n)
+    assert (rate >= 0).all() and not np.isnan(rate).any() and not np.signbit(rate).any()
+    got = _rates_only_fused(rate)
+    if kind == "t4":
+        assert np.isinf(got).any()                              # the overflow edge was exercised
+
+
+@pytest.mark.parametrize("poison", ["nan", "negative", "negzero"])
+def test_max_form_kernel_is_not_taken_outside_its_domain(poison):
+    rate, _, _ = synth.make("d1", 260, np.float32, seed=9)
+    rate[17, 201] = {"nan": np.nan, "negative": -0.75, "negzero": -0.0}[poison]
+    _rates_only_fused(rate)
+    rate, _, _ = synth.make("t3", 260, np.float32, seed=10)
+    _rates_only_fused(rate)
+
+
+def test_domain_check_and_flagged_device_api():
+    import torch
+    dev = torch.device("cuda:0")
+    n = 384
+    rate, _, _ = synth.make("t4", n, np.float32, seed=12)
+    exp = rate.copy()
+    oracle.relax(exp)
+    r = torch.from_numpy(rate).to(dev)
+    assert engine.dev_check_nonneg(r, n)
+    engine.dev_solve_fused(r, n)                               # takes the max-form kernel
+    torch.cuda.synchronize()
+    assert_bits_equal(r.cpu().numpy(), exp, "max-form via device API")
+    bad = torch.from_numpy(rate).to(dev)
+    bad[5, 7] = float("nan")
+    assert not engine.dev_check_nonneg(bad, n)
+    bad[5, 7] = -0.0
+    assert not engine.dev_check_nonneg(bad, n)
+    assert not engine.dev_check_nonneg(torch.from_numpy(rate.astype(np.float64)).to(dev), n)
+
+
+def test_max_form_full_size_n8192_vs_perk():
+    n = 8192
+    rate0, _ = synth.d1_uniform(n, np.float32, synth.BASE_SEED + 2)
+    a = rate0.copy()
+    engine.solve(a, engine=engine.FWX_ENGINE_FUSED)
+    b = rate0.copy()
+    engine.solve(b, engine=engine.FWX_ENGINE_PERK)
+    assert_bits_equal(a, b, "max-form fused vs per-k, N=8192")
