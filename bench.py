@@ -157,8 +157,10 @@ def main():
             if timed:
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 e0.record()
-            engine.dev_solve_fused(rate, n, 0, k_end, next_t=nxt, ws=fused_ws,
-                                   updates_t=upd if count else None)
+            if count:
+                engine.dev_solve_fused(rate, n, 0, k_end, next_t=nxt, ws=fused_ws, updates_t=upd)
+            else:
+                engine.dev_solve(rate, next_t=nxt, engine=engine.FWX_ENGINE_FUSED, k_end=k_end)
             if timed:
                 e1.record()
                 ev_pairs.append(([e0, e1], [0, k_end]))
@@ -262,7 +264,7 @@ def main():
             rate.copy_(pristine)
             if nxt is not None:
                 nxt.copy_(pristine_next)
-            engine.dev_solve_fused(rate, n, 0, n, next_t=nxt, ws=ws)
+            engine.dev_solve(rate, next_t=nxt, engine=engine.FWX_ENGINE_FUSED)
         fused_step()
         torch.cuda.synchronize()
         t1 = time.perf_counter()

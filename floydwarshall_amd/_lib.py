@@ -69,6 +69,7 @@ SIGNATURES = {
     "fwx_dev_relax": (ctypes.c_int, [ctypes.POINTER(FwxSlab), ctypes.POINTER(FwxPivots), c_i32,
                                      c_vp, c_vp]),
     "fwx_dev_panel": (ctypes.c_int, [ctypes.POINTER(FwxSlab), c_vp, c_vp, c_vp, c_vp]),
+    "fwx_dev_solve": (ctypes.c_int, [ctypes.POINTER(FwxSlab), ctypes.POINTER(FwxOpts)]),
     "fwx_dev_follow_paths": (ctypes.c_int, [c_i32, c_vp, c_i32, c_vp, c_vp, c_vp, c_vp, c_i32, c_vp,
                                             c_vp, c_i32, c_vp]),
     "fwx_fused_diag_ws_bytes": (ctypes.c_size_t, [c_i32]),

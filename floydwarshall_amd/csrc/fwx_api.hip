@@ -113,6 +113,7 @@ int fused_block(T *rate, int32_t *next, int rows, int n, int row0, int k0, int b
     a.nonneg = nonneg;
     a.rate = rate; a.next = next; a.rows = rows; a.n = n; a.row0 = row0;
     a.k0 = k0; a.bt = bt; a.w = w; a.ct = ct; a.cnt = cnt; a.updates = d_updates;
+    a.ct_ld = (rows + 3) & ~3;
     hipError_t e = fwx::launch_fused_relax<T>(a, s);
     if (e == hipErrorInvalidValue) return FWX_ERR_INVALID;
     FWX_HIP(e);
@@ -125,16 +126,40 @@ template <typename T> bool fused_ok(int n, const void *rate, const int32_t *hops
     return hops == nullptr && n % (16 / (int)sizeof(T)) == 0 && ((uintptr_t)rate % 16) == 0;
 }
 
-// Single-GPU solve of pivots [k_begin,k_end) with the fused engine: per block of <= 64 pivots,
-// snapshot panel (diag + rowpanel), then colpanel + main over all rows.  ws: see fused_ws_bytes.
+// Single-GPU solve of pivots [k_begin,k_end) with the fused engine.  Per block of <= 64 pivots:
+// snapshot panel W_b, pivot-column snapshots for all rows, main kernel over all rows.
+// Look-ahead: the panel chain of block b+1 only needs the 64 pivot ROWS of b+1 at time k1, so
+// main(b) runs on those rows first, then the snapshot panel of b+1 runs on a side stream while
+// main(b) sweeps the rest of the matrix.  ws: see fused_ws_bytes.
+struct SideStream {
+    hipStream_t s = nullptr;
+    hipEvent_t rows_done = nullptr, panel_done = nullptr;
+    ~SideStream()
+    {
+        if (rows_done) (void)hipEventDestroy(rows_done);
+        if (panel_done) (void)hipEventDestroy(panel_done);
+        if (s) (void)hipStreamDestroy(s);
+    }
+    int init()
+    {
+        FWX_HIP(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
+        FWX_HIP(hipEventCreateWithFlags(&rows_done, hipEventDisableTiming));
+        FWX_HIP(hipEventCreateWithFlags(&panel_done, hipEventDisableTiming));
+        return FWX_OK;
+    }
+};
+
 template <typename T>
 int fused_range(T *rate, int32_t *next, int n, int k_begin, int k_end, void *ws,
                 unsigned long long *d_updates, hipStream_t s)
 {
     char *p = (char *)ws;
-    T *w = (T *)p;                 p += (size_t)FWX_FUSED_B * n * sizeof(T);
-    T *ct = (T *)p;                p += (size_t)FWX_FUSED_B * n * sizeof(T);
-    int32_t *cnt = (int32_t *)p;   p += (size_t)FWX_FUSED_B * n * sizeof(int32_t);
+    const int ld = (n + 3) & ~3;
+    T *wbuf[2];
+    wbuf[0] = (T *)p;              p += (size_t)FWX_FUSED_B * n * sizeof(T);
+    wbuf[1] = (T *)p;              p += (size_t)FWX_FUSED_B * n * sizeof(T);
+    T *ct = (T *)p;                p += (size_t)FWX_FUSED_B * ld * sizeof(T);
+    int32_t *cnt = (int32_t *)p;   p += (size_t)FWX_FUSED_B * ld * sizeof(int32_t);
     T *diag = (T *)p;              p += (size_t)2 * FWX_FUSED_B * FWX_FUSED_B * sizeof(T);
     bool nonneg = false;
     if (sizeof(T) == 4 && !next && !d_updates) {
@@ -147,19 +172,53 @@ int fused_range(T *rate, int32_t *next, int n, int k_begin, int k_end, void *ws,
         FWX_HIP(hipStreamSynchronize(s));
         nonneg = h == 1;
     }
-    for (int k0 = k_begin; k0 < k_end; k0 += FWX_FUSED_B) {
-        const int bt = k_end - k0 < FWX_FUSED_B ? k_end - k0 : FWX_FUSED_B;
-        FWX_HIP(fwx::launch_fused_panel<T>(rate + (size_t)k0 * n, n, k0, bt, w, diag, s));
-        const int rc = fused_block<T>(rate, next, n, n, 0, k0, bt, w, ct, next ? cnt : nullptr,
-                                      d_updates, nonneg, s);
-        if (rc) return rc;
+    if (k_end <= k_begin) return FWX_OK;
+    SideStream side;
+    int rc = side.init();
+    if (rc) return rc;
+
+    fwx::FusedArgs<T> a;
+    a.rate = rate; a.next = next; a.rows = n; a.n = n; a.row0 = 0;
+    a.ct = ct; a.cnt = next ? cnt : nullptr; a.ct_ld = ld; a.updates = d_updates; a.nonneg = nonneg;
+
+    int bi = 0;
+    {
+        const int bt = k_end - k_begin < FWX_FUSED_B ? k_end - k_begin : FWX_FUSED_B;
+        FWX_HIP(fwx::launch_fused_panel<T>(rate + (size_t)k_begin * n, n, k_begin, bt, wbuf[0], diag, s));
     }
+    for (int k0 = k_begin; k0 < k_end; k0 += FWX_FUSED_B, bi ^= 1) {
+        const int bt = k_end - k0 < FWX_FUSED_B ? k_end - k0 : FWX_FUSED_B;
+        const int k1 = k0 + bt;
+        a.k0 = k0; a.bt = bt; a.w = wbuf[bi];
+        FWX_HIP(fwx::launch_fused_colpanel<T>(a, s));
+        if (k1 < k_end) {
+            const int bt1 = k_end - k1 < FWX_FUSED_B ? k_end - k1 : FWX_FUSED_B;
+            // the next panel's rows first ...
+            FWX_HIP(fwx::launch_fused_main<T>(a, k1, k1 + bt1, s));
+            FWX_HIP(hipEventRecord(side.rows_done, s));
+            FWX_HIP(hipStreamWaitEvent(side.s, side.rows_done, 0));
+            // ... their snapshot panel on the side stream ...
+            FWX_HIP(fwx::launch_fused_panel<T>(rate + (size_t)k1 * n, n, k1, bt1, wbuf[bi ^ 1], diag,
+                                               side.s));
+            FWX_HIP(hipEventRecord(side.panel_done, side.s));
+            // ... while the rest of the matrix is relaxed on the main stream
+            FWX_HIP(fwx::launch_fused_main<T>(a, 0, k1, s));
+            FWX_HIP(fwx::launch_fused_main<T>(a, k1 + bt1, n, s));
+            FWX_HIP(hipStreamWaitEvent(s, side.panel_done, 0));
+        } else {
+            FWX_HIP(fwx::launch_fused_main<T>(a, 0, n, s));
+        }
+    }
+    // the side stream's work is ordered before `s` by the last panel_done wait (or it never ran)
+    FWX_HIP(hipStreamSynchronize(s));
     return FWX_OK;
 }
 
 size_t fused_ws_bytes(int n, size_t es)
 {
-    return (size_t)FWX_FUSED_B * n * (2 * es + 4) + (size_t)2 * FWX_FUSED_B * FWX_FUSED_B * es + 256;
+    const size_t ld = ((size_t)n + 3) & ~(size_t)3;
+    return (size_t)FWX_FUSED_B * n * 2 * es + (size_t)FWX_FUSED_B * ld * (es + 4) +
+           (size_t)2 * FWX_FUSED_B * FWX_FUSED_B * es + 256;
 }
 
 // AUTO: the fused engine wherever it applies and the matrix is big enough to fill the chip.
@@ -571,6 +630,34 @@ int fwx_dev_panel(const fwx_slab *block, void *w_rate, int32_t *w_hops,
     if (block->dtype == FWX_F64)
         return panel_impl<double>(block, (double *)w_rate, w_hops, d_updates, s);
     return panel_impl<float>(block, (float *)w_rate, w_hops, d_updates, s);
+}
+
+int fwx_dev_solve(const fwx_slab *full, const fwx_opts *opts)
+{
+    int rc = check_slab(full);
+    if (rc) return rc;
+    if (full->row0 != 0 || full->rows != full->n) return FWX_ERR_INVALID;
+    if (full->n == 0) return FWX_OK;
+    Opts op;
+    if ((rc = read_opts(opts, full->n, op))) return rc;
+    if (device_count() <= 0) return FWX_ERR_NO_DEVICE;
+    fwx_matrix m;
+    memset(&m, 0, sizeof(m));
+    m.n = full->n; m.dtype = full->dtype;
+    m.rate = full->rate; m.next = full->next; m.hops = full->hops;
+    DevBuf upd;
+    if (op.updates_out) {
+        if ((rc = upd.alloc(FWX_UPDATE_SHARDS * 8))) return rc;
+        FWX_HIP(hipMemsetAsync(upd.p, 0, FWX_UPDATE_SHARDS * 8, nullptr));
+    }
+    hipStream_t s = nullptr;
+    rc = full->dtype == FWX_F64
+             ? matrix_solve_typed<double>(&m, op, (unsigned long long *)upd.p, s)
+             : matrix_solve_typed<float>(&m, op, (unsigned long long *)upd.p, s);
+    if (rc) return rc;
+    FWX_HIP(hipStreamSynchronize(s));
+    if (op.updates_out) return sum_updates((unsigned long long *)upd.p, op.updates_out, s);
+    return FWX_OK;
 }
 
 int fwx_dev_follow_paths(int32_t n, const int32_t *next, int32_t count, const int32_t *src,

@@ -64,126 +64,152 @@ __device__ __forceinline__ void lds_barrier()
 }
 
 // ------------------------------------------------------------------------------------------------
-// The three panel kernels share one shape: 256 threads = 4 waves, each thread keeps 16 entries
-// in registers (indices are compile-time constants: the t loop is fully unrolled), and the
-// pivot row / pivot column of step t is exchanged through a double-buffered LDS line with ONE
-// barrier per step.  All per-step operands come from LDS (latency ~100 cycles), never from L2.
+// Panel kernels.  256 threads = 4 waves; the 64 pivots are handled as 4 SUB-BLOCKS of 16.
+// Wave b owns 16 of the 64 panel lines (rows for the row panel, block columns for the column
+// panel), one register per line, lanes across the other dimension.  For sub-block b:
+//   serial phase  -- wave b alone steps through its 16 pivots: the pivot line of each step is its
+//                    OWN register (no LDS, no barrier in the chain); it publishes every time-t
+//                    line to LDS on the way;
+//   apply phase   -- after ONE barrier the other three waves fold those 16 published pivots into
+//                    their own 16 lines, in order.
+// 4 barriers per panel instead of 64, and no memory latency on the serial chain.  All register
+// indices are compile-time constants (loops fully unrolled).
 // ------------------------------------------------------------------------------------------------
+constexpr int SB = 16;            // pivots per sub-block = lines per wave
 
-// Diagonal block: thread (r = tid/4, cg = tid%4) owns blk[r][16cg .. 16cg+15].
-template <typename T>
-__global__ __launch_bounds__(256) void fused_diag(const T *rows, int n, int k0, int bt, T *wd,
-                                                  T *cdt)
+template <typename T> __device__ __forceinline__ T readlane(T v, int lane);
+template <> __device__ __forceinline__ float readlane<float>(float v, int lane)
 {
-    constexpr int Q = B / 4;
-    __shared__ __attribute__((aligned(16))) T rowbuf[2][B];
-    __shared__ T colbuf[2][B];
-    const int tid = threadIdx.x;
-    const int r = tid >> 2, cg = tid & 3;
-
-    T d[Q];
-#pragma unroll
-    for (int q = 0; q < Q; ++q) {
-        const int c = cg * Q + q;
-        d[q] = (r < bt && c < bt) ? rows[(size_t)r * n + k0 + c] : qnan<T>();
-    }
-
-#pragma unroll
-    for (int t = 0; t < B; ++t) {
-        if (t >= bt) continue;                    // uniform
-        const int og = t / Q, oq = t % Q;         // compile-time owner of column t
-        if (r == t) {
-            // publish row t (time-t snapshot); its own column-t entry is the diagonal: NaN there
-            // makes every candidate of column t NaN (skip j == k)
-#pragma unroll
-            for (int q = 0; q < Q; ++q) {
-                const int c = cg * Q + q;
-                rowbuf[t & 1][c] = (c == t) ? qnan<T>() : d[q];
-                if (c != t) wd[t * B + c] = d[q];
-            }
-            if (cg == og) wd[t * B + t] = rows[(size_t)t * n + k0 + t];   // diagonal: never changed
-        }
-        if (cg == og) {
-            colbuf[t & 1][r] = d[oq];             // column t at time t
-            cdt[t * B + r] = d[oq];               // (entry r == t is the diagonal: never consumed)
-        }
-        lds_barrier();
-        T cval = colbuf[t & 1][r];
-        if (r == t) cval = qnan<T>();             // skip i == k
-#pragma unroll
-        for (int q = 0; q < Q; ++q) {
-            const T cand = cval * rowbuf[t & 1][cg * Q + q];
-            d[q] = (d[q] < cand) ? cand : d[q];   // the r == c entry may go stale: never consumed
-        }
-    }
+    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), lane));
+}
+template <> __device__ __forceinline__ double readlane<double>(double v, int lane)
+{
+    const long long b = __builtin_bit_cast(long long, v);
+    const int lo = __builtin_amdgcn_readlane((int)(b & 0xffffffffll), lane);
+    const int hi = __builtin_amdgcn_readlane((int)(b >> 32), lane);
+    return __builtin_bit_cast(double, ((long long)hi << 32) | (unsigned int)lo);
 }
 
-// ------------------------------------------------------------------------------------------------
-// 64 columns per workgroup; wave w keeps pivot rows 16w..16w+15 of its columns in registers.
+// Row panel: snapshot panel W of the pivot rows.  Every workgroup first evolves the 64 x 64
+// diagonal block itself (lanes = block columns) to obtain Cd[r][t] = D_t[k0+r][k0+t] in LDS --
+// redundant across workgroups, but it removes a kernel boundary and a single-workgroup launch from
+// the critical path -- and then its own strip of 64 columns.
 template <typename T>
 __global__ __launch_bounds__(256) void fused_rowpanel(const T *rows, int n, int k0, int bt,
-                                                      const T *cdt, T *w_out)
+                                                      T *w_out)
 {
-    constexpr int RPW = B / 4;
-    __shared__ T wrow[2][64];
-    __shared__ __attribute__((aligned(16))) T s_cd[B][B];     // s_cd[t][r] = D_t[k0+r][k0+t]
+    __shared__ T s_line[B][64];                    // published pivot rows (time-t), per phase
+    __shared__ T s_cd[B][B];                       // s_cd[t][r] = D_t[k0+r][k0+t]
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+
+    T p[SB];
+    // ---------------- phase 0: the diagonal block, lanes = block columns -------------------------
+#pragma unroll
+    for (int q = 0; q < SB; ++q) {
+        const int r = wave * SB + q;
+        p[q] = (r < bt && lane < bt) ? rows[(size_t)r * n + k0 + lane] : qnan<T>();
+    }
+#pragma unroll 1                                   // code size: keep the panel inside the I-cache
+    for (int b = 0; b < B / SB; ++b) {
+        if (b * SB >= bt) continue;                // uniform
+        if (wave == b) {
+#pragma unroll
+            for (int tq = 0; tq < SB; ++tq) {
+                const int t = b * SB + tq;
+                T w = p[tq];
+                if (lane == t) w = qnan<T>();      // skip j == k (also hides the stale diagonal)
+                s_line[t][lane] = w;
+#pragma unroll
+                for (int q = 0; q < SB; ++q) {
+                    if (q == tq) continue;         // skip i == k
+                    const T cval = readlane<T>(p[q], t);
+                    if (lane == 0) s_cd[t][b * SB + q] = cval;
+                    const T cand = cval * w;
+                    p[q] = (p[q] < cand) ? cand : p[q];
+                }
+            }
+        }
+        lds_barrier();
+        if (wave > b) {            // earlier rows are past their own pivots: nothing needs them
+#pragma unroll
+            for (int tq = 0; tq < SB; ++tq) {
+                const int t = b * SB + tq;
+                if (t >= bt) continue;
+                const T w = s_line[t][lane];
+#pragma unroll
+                for (int q = 0; q < SB; ++q) {
+                    const T cval = readlane<T>(p[q], t);
+                    if (lane == 0) s_cd[t][wave * SB + q] = cval;
+                    const T cand = cval * w;
+                    p[q] = (p[q] < cand) ? cand : p[q];
+                }
+            }
+        }
+    }
+    lds_barrier();                                 // s_cd complete; s_line free for reuse
+
+    // ---------------- phase 1: this workgroup's strip of 64 columns ------------------------------
     const int j = blockIdx.x * 64 + lane;
     const bool valid = j < n;
     const int jc = valid ? j : n - 1;
-
-    for (int idx = threadIdx.x; idx < B * B; idx += 256)
-        s_cd[idx / B][idx % B] = (idx / B) < bt ? cdt[idx] : qnan<T>();
-    __syncthreads();
-
-    T p[RPW];
 #pragma unroll
-    for (int q = 0; q < RPW; ++q) {
-        const int r = wave * RPW + q;
+    for (int q = 0; q < SB; ++q) {
+        const int r = wave * SB + q;
         p[q] = r < bt ? rows[(size_t)r * n + jc] : qnan<T>();
     }
-    // a column inside the block carries one diagonal entry, which must be published untouched
+    // a column inside the block carries one diagonal entry: published from memory, untouched
     const bool in_blk = valid && j >= k0 && j < k0 + bt;
     const T dorig = in_blk ? rows[(size_t)(j - k0) * n + j] : T(0);
 
+#pragma unroll 1
+    for (int b = 0; b < B / SB; ++b) {
+        if (b * SB >= bt) continue;
+        if (wave == b) {
 #pragma unroll
-    for (int t = 0; t < B; ++t) {
-        if (t >= bt) continue;   // wave-uniform; `continue` keeps the loop fully unrollable so
-                                 // that every p[..] index below is a compile-time constant
-        const int ow = t / RPW, oq = t % RPW;
-        if (wave == ow) {
-            T v = p[oq];
-            if (j == k0 + t) v = dorig;
-            wrow[t & 1][lane] = v;
-            if (valid) w_out[(size_t)t * n + j] = v;
+            for (int tq = 0; tq < SB; ++tq) {
+                const int t = b * SB + tq;
+                if (t >= bt) continue;
+                T w = p[tq];
+                if (j == k0 + t) w = dorig;
+                if (valid) w_out[(size_t)t * n + j] = w;          // the snapshot
+                if (j == k0 + t) w = qnan<T>();                   // skip j == k
+                s_line[t][lane] = w;
+#pragma unroll
+                for (int q = 0; q < SB; ++q) {
+                    if (q == tq) continue;                        // skip i == k
+                    const T cand = s_cd[t][b * SB + q] * w;
+                    p[q] = (p[q] < cand) ? cand : p[q];
+                }
+            }
         }
-        T cd[RPW];
-#pragma unroll
-        for (int q = 0; q < RPW; ++q) cd[q] = s_cd[t][wave * RPW + q];
         lds_barrier();
-        T w = wrow[t & 1][lane];
-        if (j == k0 + t) w = qnan<T>();                       // skip j == k
+        if (wave > b) {            // rows above the sub-block have all been snapshotted already
 #pragma unroll
-        for (int q = 0; q < RPW; ++q) {
-            if (q == oq && wave == ow) continue;              // skip i == k
-            const T cand = cd[q] * w;
-            p[q] = (p[q] < cand) ? cand : p[q];
+            for (int tq = 0; tq < SB; ++tq) {
+                const int t = b * SB + tq;
+                if (t >= bt) continue;
+                const T w = s_line[t][lane];
+#pragma unroll
+                for (int q = 0; q < SB; ++q) {
+                    const T cand = s_cd[t][wave * SB + q] * w;
+                    p[q] = (p[q] < cand) ? cand : p[q];
+                }
+            }
         }
     }
 }
 
-// ------------------------------------------------------------------------------------------------
-// 64 rows per workgroup; wave w keeps block columns 16w..16w+15 of its rows in registers.
+// Column panel: time-t snapshots of the 64 pivot columns for 64 rows per workgroup (lanes = rows).
+// Needs only the block columns of W (Wd[t][c] = W[t][k0+c]), so it runs on every rank.
 template <typename T, bool HAS_NEXT>
 __global__ __launch_bounds__(256) void fused_colpanel(const T *rate, const int32_t *next, int rows,
                                                       int n, int row0, int k0, int bt, const T *w,
-                                                      T *ct, int32_t *cnt)
+                                                      T *ct, int32_t *cnt, int ct_ld)
 {
-    constexpr int CPW = B / 4;
-    __shared__ T ccol[2][64];
-    __shared__ int32_t ncol[2][64];
-    __shared__ __attribute__((aligned(16))) T s_wd[B][B];     // s_wd[t][c] = D_t[k0+t][k0+c]
+    __shared__ T s_line[B][64];                    // published pivot columns (time-t, NaN at i==k)
+    __shared__ int32_t s_nline[HAS_NEXT ? B : 1][64];
+    __shared__ T s_wd[B][B];                       // s_wd[t][c] = D_t[k0+t][k0+c]
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int il = blockIdx.x * 64 + lane;
@@ -195,41 +221,61 @@ __global__ __launch_bounds__(256) void fused_colpanel(const T *rate, const int32
         const int t = idx / B, c = idx % B;
         s_wd[t][c] = (t < bt && c < bt) ? w[(size_t)t * n + k0 + c] : qnan<T>();
     }
-    __syncthreads();
 
-    T d[CPW];
-    int32_t nx[CPW];
+    T d[SB];
+    int32_t nx[SB];
 #pragma unroll
-    for (int q = 0; q < CPW; ++q) {
-        const int c = wave * CPW + q;
+    for (int q = 0; q < SB; ++q) {
+        const int c = wave * SB + q;
         const size_t off = (size_t)ic * n + k0 + (c < bt ? c : 0);
         d[q] = c < bt ? rate[off] : qnan<T>();
         nx[q] = (HAS_NEXT && c < bt) ? next[off] : -1;
     }
+    __syncthreads();
 
+#pragma unroll 1
+    for (int b = 0; b < B / SB; ++b) {
+        if (b * SB >= bt) continue;
+        if (wave == b) {
 #pragma unroll
-    for (int t = 0; t < B; ++t) {
-        if (t >= bt) continue;   // wave-uniform (see fused_rowpanel)
-        const int ow = t / CPW, oq = t % CPW;
-        if (wave == ow) {
-            ccol[t & 1][lane] = d[oq];
-            if (HAS_NEXT) ncol[t & 1][lane] = nx[oq];
+            for (int tq = 0; tq < SB; ++tq) {
+                const int t = b * SB + tq;
+                if (t >= bt) continue;
+                T c = d[tq];
+                const int32_t cn = nx[tq];
+                if (gi == k0 + t) c = qnan<T>();                  // skip i == k
+                s_line[t][lane] = c;
+                if (HAS_NEXT) s_nline[t][lane] = cn;
+                if (valid) {
+                    ct[(size_t)t * ct_ld + il] = c;
+                    if (HAS_NEXT) cnt[(size_t)t * ct_ld + il] = cn;
+                }
+#pragma unroll
+                for (int q = 0; q < SB; ++q) {
+                    if (q == tq) continue;                        // skip j == k
+                    const T cand = c * s_wd[t][b * SB + q];
+                    const bool up = d[q] < cand;
+                    d[q] = up ? cand : d[q];
+                    if (HAS_NEXT) nx[q] = up ? cn : nx[q];
+                }
+            }
         }
         lds_barrier();
-        T c = ccol[t & 1][lane];
-        const int32_t cn = HAS_NEXT ? ncol[t & 1][lane] : 0;
-        if (gi == k0 + t) c = qnan<T>();                      // skip i == k
-        if (wave == ow && valid) {
-            ct[(size_t)t * rows + il] = c;
-            if (HAS_NEXT) cnt[(size_t)t * rows + il] = cn;
-        }
+        if (wave > b) {            // columns left of the sub-block have been snapshotted already
 #pragma unroll
-        for (int q = 0; q < CPW; ++q) {
-            if (q == oq && wave == ow) continue;              // skip j == k
-            const T cand = c * s_wd[t][wave * CPW + q];
-            const bool up = d[q] < cand;
-            d[q] = up ? cand : d[q];
-            if (HAS_NEXT) nx[q] = up ? cn : nx[q];
+            for (int tq = 0; tq < SB; ++tq) {
+                const int t = b * SB + tq;
+                if (t >= bt) continue;
+                const T c = s_line[t][lane];
+                const int32_t cn = HAS_NEXT ? s_nline[t][lane] : 0;
+#pragma unroll
+                for (int q = 0; q < SB; ++q) {
+                    const T cand = c * s_wd[t][wave * SB + q];
+                    const bool up = d[q] < cand;
+                    d[q] = up ? cand : d[q];
+                    if (HAS_NEXT) nx[q] = up ? cn : nx[q];
+                }
+            }
         }
     }
 }
@@ -242,7 +288,7 @@ __global__ __launch_bounds__(256) void fused_colpanel(const T *rate, const int32
 template <typename T, bool HAS_NEXT, bool COUNT, int BS, int MINW>
 __global__ __launch_bounds__(256, MINW) void fused_main(T *rate, int32_t *next, int rows, int n,
                                                         int row0, int k0, int bt, const T *w,
-                                                        const T *ct, const int32_t *cnt,
+                                                        const T *ct, const int32_t *cnt, int ct_ld,
                                                         unsigned long long *updates)
 {
     using V = typename Vec16<T>::type;
@@ -315,8 +361,8 @@ __global__ __launch_bounds__(256, MINW) void fused_main(T *rate, int32_t *next, 
             const int tl = idx / TI, il = idx % TI;
             const int i = i_base + il;
             const bool ok = tl < bs && i < rows;
-            sC[tl][il] = ok ? ct[(size_t)(s0 + tl) * rows + i] : qnan<T>();
-            if (HAS_NEXT) sN[tl][il] = ok ? cnt[(size_t)(s0 + tl) * rows + i] : -1;
+            sC[tl][il] = ok ? ct[(size_t)(s0 + tl) * ct_ld + i] : qnan<T>();
+            if (HAS_NEXT) sN[tl][il] = ok ? cnt[(size_t)(s0 + tl) * ct_ld + i] : -1;
         }
         __syncthreads();
 
@@ -401,23 +447,61 @@ __global__ __launch_bounds__(256, MINW) void fused_main(T *rate, int32_t *next, 
 // 1.0 VALU instruction per relaxation instead of 2.5.  The caller must have verified the domain
 // (fwx_dev_check_nonneg); the next-hop variant needs the compare and stays on fused_main.
 // ------------------------------------------------------------------------------------------------
-template <int BS, int MINW>
+template <int MINW, int UNR>
 __global__ __launch_bounds__(256, MINW) void fused_main_max(float *rate, int rows, int n, int row0,
                                                             int k0, int bt, const float *w,
-                                                            const float *ct)
+                                                            const float *ct, int ct_ld, int ct_vec)
 {
     typedef float V4 __attribute__((ext_vector_type(4)));
     typedef float V2 __attribute__((ext_vector_type(2)));
-    constexpr int RI = 8, TI = 128, TJ = 128, HJ = 64, HP = BS / 2;
+    // 16 pivots (8 pairs) per LDS stage, two stages resident: while stage s is being folded the
+    // operands of stage s+1 are already in flight from L2 into registers.
+    constexpr int RI = 8, TI = 128, TJ = 128, HJ = 64, BS = 16, HP = BS / 2;
 
-    __shared__ __attribute__((aligned(16))) V2 sW[HP][TJ];   // (W_t[j], W_{t+1}[j])
-    __shared__ __attribute__((aligned(16))) V2 sC[HP][TI];   // (C_t[i], C_{t+1}[i])
+    __shared__ __attribute__((aligned(16))) V2 sW[2][HP][TJ];   // (W_t[j], W_{t+1}[j])
+    __shared__ __attribute__((aligned(16))) V2 sC[2][HP][TI];   // (C_t[i], C_{t+1}[i])
 
     const int tid = threadIdx.x;
     const int i_base = blockIdx.y * TI;
     const int j_base = blockIdx.x * TJ;
     const int ti = tid >> 4, tj = tid & 15;
     const int i0 = i_base + ti * RI;
+    const float nanv = qnan<float>();
+
+    // staging role of this thread: pivot pair sp (0..7), 4 consecutive columns / rows at sv*4
+    const int sp = tid >> 5, sv = tid & 31;
+    const int sj = j_base + sv * 4;              // W columns
+    const int si = i_base + sv * 4;              // C rows
+    const bool sj_ok = sj < n;                   // n % 4 == 0: whole vector in or out
+    V4 pw[2], pc[2];
+    auto prefetch = [&](int s0) {
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int t = s0 + 2 * sp + u;
+            const bool t_ok = t < bt;
+            pw[u] = (t_ok && sj_ok) ? *reinterpret_cast<const V4 *>(w + (size_t)t * n + sj)
+                                    : V4{nanv, nanv, nanv, nanv};
+            if (t_ok && ct_vec && si + 4 <= rows) {
+                pc[u] = *reinterpret_cast<const V4 *>(ct + (size_t)t * ct_ld + si);
+            } else {
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    pc[u][e] = (t_ok && si + e < rows) ? ct[(size_t)t * ct_ld + si + e] : nanv;
+            }
+            // skip j == k: the pivot's own column
+            const int kcol = k0 + t - sj;
+            if (kcol >= 0 && kcol < 4) pw[u][kcol] = nanv;
+        }
+    };
+    auto commit = [&](int buf) {
+        *reinterpret_cast<V4 *>(&sW[buf][sp][sv * 4]) = V4{pw[0][0], pw[1][0], pw[0][1], pw[1][1]};
+        *reinterpret_cast<V4 *>(&sW[buf][sp][sv * 4 + 2]) = V4{pw[0][2], pw[1][2], pw[0][3], pw[1][3]};
+        *reinterpret_cast<V4 *>(&sC[buf][sp][sv * 4]) = V4{pc[0][0], pc[1][0], pc[0][1], pc[1][1]};
+        *reinterpret_cast<V4 *>(&sC[buf][sp][sv * 4 + 2]) = V4{pc[0][2], pc[1][2], pc[0][3], pc[1][3]};
+    };
+
+    prefetch(0);
+
     int jcol[2];
     bool jok[2];
 #pragma unroll
@@ -436,44 +520,21 @@ __global__ __launch_bounds__(256, MINW) void fused_main_max(float *rate, int row
     }
     const int gi_lo = row0 + i_base, gj_lo = j_base;
     const bool diag_tile = gi_lo < gj_lo + TJ && gj_lo < gi_lo + TI;
-    const float nanv = qnan<float>();
 
-    for (int s0 = 0; s0 < bt; s0 += BS) {
-        const int bs = min(BS, bt - s0);
-        if (s0) __syncthreads();
-        // stage (t, t+1) pairs; missing pivots and skipped operands are NaN (ignored by max)
-        for (int idx = tid; idx < HP * TJ; idx += 256) {
-            const int tp = idx / TJ, jl = idx % TJ;
-            const int j = j_base + jl;
-            V2 v;
-#pragma unroll
-            for (int u = 0; u < 2; ++u) {
-                const int tl = 2 * tp + u, t = s0 + tl;
-                float val = nanv;
-                if (tl < bs && j < n && j != k0 + t) val = w[(size_t)t * n + j];
-                v[u] = val;
-            }
-            sW[tp][jl] = v;
-        }
-        for (int idx = tid; idx < HP * TI; idx += 256) {
-            const int tp = idx / TI, il = idx % TI;
-            const int i = i_base + il;
-            V2 v;
-#pragma unroll
-            for (int u = 0; u < 2; ++u) {
-                const int tl = 2 * tp + u;
-                v[u] = (tl < bs && i < rows) ? ct[(size_t)(s0 + tl) * rows + i] : nanv;
-            }
-            sC[tp][il] = v;
-        }
-        __syncthreads();
+    commit(0);
+    __syncthreads();
 
-        const int np = (bs + 1) / 2;
+    int buf = 0;
+    for (int s0 = 0; s0 < bt; s0 += BS, buf ^= 1) {
+        const bool more = s0 + BS < bt;
+        if (more) prefetch(s0 + BS);             // in flight during the fold below
+        const int np = (min(BS, bt - s0) + 1) / 2;
+#pragma unroll UNR
         for (int tp = 0; tp < np; ++tp) {
             V2 c[RI], wv[2][4];
 #pragma unroll
             for (int q = 0; q < RI / 2; ++q) {
-                const V4 cv = *reinterpret_cast<const V4 *>(&sC[tp][ti * RI + q * 2]);
+                const V4 cv = *reinterpret_cast<const V4 *>(&sC[buf][tp][ti * RI + q * 2]);
                 c[2 * q] = V2{cv[0], cv[1]};
                 c[2 * q + 1] = V2{cv[2], cv[3]};
             }
@@ -481,7 +542,7 @@ __global__ __launch_bounds__(256, MINW) void fused_main_max(float *rate, int row
             for (int h = 0; h < 2; ++h)
 #pragma unroll
                 for (int q = 0; q < 2; ++q) {
-                    const V4 wq = *reinterpret_cast<const V4 *>(&sW[tp][h * HJ + tj * 4 + q * 2]);
+                    const V4 wq = *reinterpret_cast<const V4 *>(&sW[buf][tp][h * HJ + tj * 4 + q * 2]);
                     wv[h][2 * q] = V2{wq[0], wq[1]};
                     wv[h][2 * q + 1] = V2{wq[2], wq[3]};
                 }
@@ -494,6 +555,10 @@ __global__ __launch_bounds__(256, MINW) void fused_main_max(float *rate, int row
                         const V2 cand = c[r] * wv[h][e];                     // v_pk_mul_f32
                         x[r][h][e] = __builtin_fmaxf(__builtin_fmaxf(x[r][h][e], cand[0]), cand[1]);
                     }
+        }
+        if (more) {
+            commit(buf ^ 1);                      // the other buffer: nobody reads it now
+            __syncthreads();
         }
     }
 
@@ -543,8 +608,9 @@ template <> struct FusedCfg<double, true> { static constexpr int BS = 16, MINW =
 static bool launch_max_form(const FusedArgs<float> &a, dim3 grid, dim3 block, hipStream_t s)
 {
     if (!a.nonneg || a.next || a.updates) return false;
-    hipLaunchKernelGGL((fused_main_max<32, 4>), grid, block, 0, s, a.rate, a.rows, a.n, a.row0,
-                       a.k0, a.bt, a.w, a.ct);
+    const int ct_vec = ((uintptr_t)a.ct % 16 == 0 && a.ct_ld % 4 == 0) ? 1 : 0;
+    hipLaunchKernelGGL((fused_main_max<3, 1>), grid, block, 0, s, a.rate, a.rows, a.n, a.row0, a.k0,
+                       a.bt, a.w, a.ct, a.ct_ld, ct_vec);
     return true;
 }
 static bool launch_max_form(const FusedArgs<double> &, dim3, dim3, hipStream_t) { return false; }
@@ -559,29 +625,53 @@ hipError_t launch_nonneg_check(const float *rate, size_t count, int *flag, hipSt
     return hipGetLastError();
 }
 
-template <typename T> hipError_t launch_fused_relax(const FusedArgs<T> &a, hipStream_t s)
+template <typename T> static hipError_t check_fused_args(const FusedArgs<T> &a)
 {
     constexpr int VW = Vec16<T>::W;
-    constexpr int TI = 128, TJ = 16 * 2 * VW;
-    if (a.rows <= 0 || a.n <= 0 || a.bt <= 0) return hipSuccess;
     if (a.bt > B || a.n % VW != 0 || ((uintptr_t)a.rate % 16) || ((uintptr_t)a.w % 16) ||
-        (a.next && ((uintptr_t)a.next % 16)))
+        (a.next && ((uintptr_t)a.next % 16)) || a.ct_ld < a.rows)
         return hipErrorInvalidValue;
+    return hipSuccess;
+}
+
+template <typename T> hipError_t launch_fused_colpanel(const FusedArgs<T> &a, hipStream_t s)
+{
+    if (a.rows <= 0 || a.n <= 0 || a.bt <= 0) return hipSuccess;
+    hipError_t e = check_fused_args(a);
+    if (e != hipSuccess) return e;
     const dim3 cgrid((unsigned)((a.rows + 63) / 64)), block(256);
     if (a.next)
         hipLaunchKernelGGL((fused_colpanel<T, true>), cgrid, block, 0, s, a.rate, a.next, a.rows,
-                           a.n, a.row0, a.k0, a.bt, a.w, a.ct, a.cnt);
+                           a.n, a.row0, a.k0, a.bt, a.w, a.ct, a.cnt, a.ct_ld);
     else
         hipLaunchKernelGGL((fused_colpanel<T, false>), cgrid, block, 0, s, a.rate, a.next, a.rows,
-                           a.n, a.row0, a.k0, a.bt, a.w, a.ct, a.cnt);
-    hipError_t e = hipGetLastError();
+                           a.n, a.row0, a.k0, a.bt, a.w, a.ct, a.cnt, a.ct_ld);
+    return hipGetLastError();
+}
+
+// Main kernel on local rows [r_lo, r_hi) of the slab (the colpanel must have run on them).
+template <typename T>
+hipError_t launch_fused_main(const FusedArgs<T> &full, int r_lo, int r_hi, hipStream_t s)
+{
+    constexpr int VW = Vec16<T>::W;
+    constexpr int TI = 128, TJ = 16 * 2 * VW;
+    if (r_hi <= r_lo || full.n <= 0 || full.bt <= 0) return hipSuccess;
+    hipError_t e = check_fused_args(full);
     if (e != hipSuccess) return e;
+    FusedArgs<T> a = full;
+    a.rate = full.rate + (size_t)r_lo * full.n;
+    a.next = full.next ? full.next + (size_t)r_lo * full.n : nullptr;
+    a.rows = r_hi - r_lo;
+    a.row0 = full.row0 + r_lo;
+    a.ct = full.ct + r_lo;
+    a.cnt = full.cnt ? full.cnt + r_lo : nullptr;
+    const dim3 block(256);
     const dim3 grid((unsigned)((a.n + TJ - 1) / TJ), (unsigned)((a.rows + TI - 1) / TI));
     if (launch_max_form(a, grid, block, s)) return hipGetLastError();
 #define FWX_FUSED_LAUNCH(HN, CN)                                                                   \
     hipLaunchKernelGGL((fused_main<T, HN, CN, FusedCfg<T, HN>::BS, FusedCfg<T, HN>::MINW>), grid,  \
                        block, 0, s, a.rate, a.next, a.rows, a.n, a.row0, a.k0, a.bt, a.w, a.ct,    \
-                       a.cnt, a.updates)
+                       a.cnt, a.ct_ld, a.updates)
     if (a.next) {
         if (a.updates) FWX_FUSED_LAUNCH(true, true); else FWX_FUSED_LAUNCH(true, false);
     } else {
@@ -591,23 +681,31 @@ template <typename T> hipError_t launch_fused_relax(const FusedArgs<T> &a, hipSt
     return hipGetLastError();
 }
 
+template <typename T> hipError_t launch_fused_relax(const FusedArgs<T> &a, hipStream_t s)
+{
+    hipError_t e = launch_fused_colpanel<T>(a, s);
+    if (e != hipSuccess) return e;
+    return launch_fused_main<T>(a, 0, a.rows, s);
+}
+
 template <typename T>
 hipError_t launch_fused_panel(const T *rows_base, int n, int k0, int bt, T *w, T *diag_ws,
                               hipStream_t s)
 {
+    (void)diag_ws;   // kept in the ABI: the diagonal block is now evolved inside fused_rowpanel
     if (n <= 0 || bt <= 0) return hipSuccess;
     if (bt > B) return hipErrorInvalidValue;
-    T *wd = diag_ws, *cdt = diag_ws + B * B;
-    hipLaunchKernelGGL((fused_diag<T>), dim3(1), dim3(256), 0, s, rows_base, n, k0, bt, wd, cdt);
-    hipError_t e = hipGetLastError();
-    if (e != hipSuccess) return e;
     hipLaunchKernelGGL((fused_rowpanel<T>), dim3((unsigned)((n + 63) / 64)), dim3(256), 0, s,
-                       rows_base, n, k0, bt, cdt, w);
+                       rows_base, n, k0, bt, w);
     return hipGetLastError();
 }
 
 template hipError_t launch_fused_relax<float>(const FusedArgs<float> &, hipStream_t);
 template hipError_t launch_fused_relax<double>(const FusedArgs<double> &, hipStream_t);
+template hipError_t launch_fused_colpanel<float>(const FusedArgs<float> &, hipStream_t);
+template hipError_t launch_fused_colpanel<double>(const FusedArgs<double> &, hipStream_t);
+template hipError_t launch_fused_main<float>(const FusedArgs<float> &, int, int, hipStream_t);
+template hipError_t launch_fused_main<double>(const FusedArgs<double> &, int, int, hipStream_t);
 template hipError_t launch_fused_panel<float>(const float *, int, int, int, float *, float *,
                                               hipStream_t);
 template hipError_t launch_fused_panel<double>(const double *, int, int, int, double *, double *,

@@ -37,6 +37,8 @@ template <typename T> struct FusedArgs {
     const T *w;            // snapshot panel: w[t*n + j] = row k0+t at time k0+t
     T *ct;                 // scratch bt x rows: ct[t*rows + i] = column k0+t at time k0+t (NaN if i==k)
     int32_t *cnt;          // scratch bt x rows (iff next)
+    int ct_ld;             // leading dimension of ct / cnt (>= rows; a multiple of 4 keeps the
+                           // staging loads 16-byte aligned)
     unsigned long long *updates;
     bool nonneg;           // caller verified: every matrix entry is >= +0 and not NaN (max form)
 };
@@ -46,6 +48,11 @@ hipError_t launch_nonneg_check(const float *rate, size_t count, int *flag, hipSt
 
 // colpanel + main: applies the bt pivots to every row of the slab.
 template <typename T> hipError_t launch_fused_relax(const FusedArgs<T> &a, hipStream_t s);
+// The two halves separately: pivot-column snapshots for all rows of the slab, then the main
+// kernel on local rows [r_lo, r_hi) (used by the look-ahead schedule).
+template <typename T> hipError_t launch_fused_colpanel(const FusedArgs<T> &a, hipStream_t s);
+template <typename T>
+hipError_t launch_fused_main(const FusedArgs<T> &a, int r_lo, int r_hi, hipStream_t s);
 
 // diag + rowpanel: snapshot panel of the pivot rows `rows_base` (bt x n, at time k0); the matrix
 // is not modified.  diag_ws: 2 * FWX_FUSED_B^2 elements of scratch.

@@ -14,7 +14,8 @@ from ._lib import (FWX_ENGINE_AUTO, FWX_ENGINE_FUSED, FWX_ENGINE_PERK, FWX_F32, 
                    FWX_FUSED_BLOCK, FWX_UPDATE_SHARDS, FwxError, FwxOpts, FwxPivots, FwxSlab, check,
                    lib)
 
-__all__ = ["solve", "follow_path", "dev_follow_paths", "dev_check_nonneg", "dev_solve_fused", "DeviceMatrix", "dev_relax", "dev_panel", "dev_panel_snap",
+__all__ = ["solve", "follow_path", "dev_follow_paths", "dev_check_nonneg", "dev_solve_fused",
+           "dev_solve", "DeviceMatrix", "dev_relax", "dev_panel", "dev_panel_snap",
            "dev_relax_fused", "FusedWorkspace", "FWX_FUSED_BLOCK", "device_count",
            "FwxError", "FWX_ENGINE_AUTO", "FWX_ENGINE_PERK", "FWX_ENGINE_FUSED",
            "FWX_UPDATE_SHARDS"]
@@ -205,8 +206,9 @@ class FusedWorkspace:
         import torch
         B = FWX_FUSED_BLOCK
         self.w = [torch.empty((B, n), dtype=dtype, device=device) for _ in range(2)]
-        self.ct = torch.empty((B, max(rows, 1)), dtype=dtype, device=device)
-        self.cnt = torch.empty((B, max(rows, 1)), dtype=torch.int32, device=device) if with_next else None
+        ld = (max(rows, 1) + 3) & ~3
+        self.ct = torch.empty((B, ld), dtype=dtype, device=device)
+        self.cnt = torch.empty((B, ld), dtype=torch.int32, device=device) if with_next else None
         code = FWX_F64 if dtype == torch.float64 else FWX_F32
         self.diag = torch.empty(lib().fwx_fused_diag_ws_bytes(code), dtype=torch.uint8, device=device)
 
@@ -241,12 +243,13 @@ def dev_relax_fused(rate_t, n, row0, k0, k1, w_t, ct_t, *, next_t=None, cnt_t=No
     p.k_begin, p.k_end = k0, k1
     assert w_t.is_cuda and w_t.is_contiguous() and w_t.dtype == rate_t.dtype
     assert tuple(w_t.shape) == (k1 - k0, n)
-    assert ct_t.numel() >= FWX_FUSED_BLOCK * rate_t.shape[0] and ct_t.dtype == rate_t.dtype
+    ld = (rate_t.shape[0] + 3) & ~3
+    assert ct_t.numel() >= FWX_FUSED_BLOCK * ld and ct_t.dtype == rate_t.dtype
     p.rate, p.hops, p.stride = w_t.data_ptr(), None, n
     upd = ctypes.c_void_p(updates_t.data_ptr()) if updates_t is not None else None
     cn = None
     if next_t is not None:
-        assert cnt_t is not None and cnt_t.numel() >= FWX_FUSED_BLOCK * rate_t.shape[0]
+        assert cnt_t is not None and cnt_t.numel() >= FWX_FUSED_BLOCK * ld
         cn = ctypes.c_void_p(cnt_t.data_ptr())
     check(lib().fwx_dev_relax_fused(ctypes.byref(s), ctypes.byref(p),
                                     ctypes.c_void_p(ct_t.data_ptr()), cn, upd,
@@ -300,3 +303,18 @@ def dev_follow_paths(next_t, src_t, dst_t, *, edge_rate_t=None, path_cap=0):
         vp(path_t.data_ptr()) if path_t is not None else None, path_cap, _stream_ptr()),
         "fwx_dev_follow_paths")
     return len_t, prod_t, path_t
+
+
+def dev_solve(rate_t, *, next_t=None, hops_t=None, engine=FWX_ENGINE_AUTO, k_begin=0, k_end=0,
+              serpentine=True, count_updates=False):
+    """fwx_dev_solve: whole solve (or a pivot range) on a torch tensor holding the entire n x n
+    matrix, in place, BLOCKING.  The fused engine runs with look-ahead on an internal side stream.
+    Work queued on torch's current stream must be finished first: this synchronises it."""
+    import torch
+    n = rate_t.shape[0]
+    assert rate_t.shape == (n, n)
+    torch.cuda.current_stream().synchronize()
+    s = _slab(rate_t, next_t, hops_t, n, 0)
+    o, u = _opts(-1, engine, k_begin, k_end, 0, serpentine, count_updates)
+    check(lib().fwx_dev_solve(ctypes.byref(s), ctypes.byref(o)), "fwx_dev_solve")
+    return int(u.value) if count_updates else None

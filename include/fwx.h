@@ -150,6 +150,13 @@ int fwx_dev_relax(const fwx_slab *slab, const fwx_pivots *piv, int32_t serpentin
 int fwx_dev_panel(const fwx_slab *block, void *w_rate, int32_t *w_hops,
                   unsigned long long *d_updates, void *stream);
 
+/* Whole solve on caller-owned DEVICE memory: `full` must hold the entire matrix (row0 = 0,
+ * rows = n).  Same engines and options as fwx_matrix_solve (opts->device is ignored: the memory
+ * decides); scratch is allocated and released internally; BLOCKING (returns after the solve has
+ * completed on the device).  The fused engine overlaps each snapshot panel with the previous
+ * pass on an internal side stream (look-ahead).                                                 */
+int fwx_dev_solve(const fwx_slab *full, const fwx_opts *opts);
+
 /* Batch form of `optimum`'s path reconstruction (Algorithms.hs:74-75) on the device: for each
  * pair q, walk next-hops from src[q] until dst[q].  All pointers are DEVICE pointers; `next` is
  * the full n x n matrix.  len_out[q] = path length (0 = no route, FWX_ERR_CYCLE if dst is not
@@ -169,8 +176,8 @@ int fwx_dev_follow_paths(int32_t n, const int32_t *next, int32_t count, const in
  *   like any other row.  diag_ws: device scratch, fwx_fused_diag_ws_bytes(dtype) bytes.
  * fwx_dev_relax_fused: applies the pivots [piv->k_begin, piv->k_end) (at most FWX_FUSED_BLOCK,
  *   piv->rate = snapshot panel, stride n) to EVERY row of the slab in one pass.  col_rate /
- *   col_next: device scratch of FWX_FUSED_BLOCK * slab->rows elements (col_next only if the slab
- *   carries next).  Slabs with hops are not supported (FWX_ERR_UNSUPPORTED); n must be a multiple
+ *   col_next: device scratch of FWX_FUSED_BLOCK * ((slab->rows + 3) & ~3) elements (col_next only
+ *   if the slab carries next).  Slabs with hops are not supported (FWX_ERR_UNSUPPORTED); n must be a multiple
  *   of 16 bytes worth of elements.
  * The snapshot panel also feeds fwx_dev_relax (per-k engine), so fwx_dev_panel_snap +
  * fwx_dev_relax over all rows is a valid (slower) combination.

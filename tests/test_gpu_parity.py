@@ -493,3 +493,27 @@ def test_max_form_full_size_n8192_vs_perk():
     b = rate0.copy()
     engine.solve(b, engine=engine.FWX_ENGINE_PERK)
     assert_bits_equal(a, b, "max-form fused vs per-k, N=8192")
+
+
+@pytest.mark.parametrize("with_next", [False, True])
+def test_dev_solve_blocking_api_with_lookahead(with_next):
+    """fwx_dev_solve on torch-owned memory: the fused engine's look-ahead schedule (side stream)
+    against the oracle, odd pivot ranges included."""
+    import torch
+    dev = torch.device("cuda:0")
+    n = 708
+    rate, nxt, _ = synth.make("t1", n, np.float32, seed=91)
+    er, en = rate.copy(), nxt.copy()
+    eu = oracle.relax(er, en if with_next else None, None, 33, 650)
+    r = torch.from_numpy(rate).to(dev)
+    nx = torch.from_numpy(nxt).to(dev) if with_next else None
+    u = engine.dev_solve(r, next_t=nx, engine=engine.FWX_ENGINE_FUSED, k_begin=33, k_end=650,
+                         count_updates=True)
+    assert u == eu
+    assert_bits_equal(r.cpu().numpy(), er, "rate")
+    if with_next:
+        assert_bits_equal(nx.cpu().numpy(), en, "next")
+    # the max-form path (no counting) through the same schedule
+    r2 = torch.from_numpy(rate).to(dev)
+    engine.dev_solve(r2, engine=engine.FWX_ENGINE_FUSED, k_begin=33, k_end=650)
+    assert_bits_equal(r2.cpu().numpy(), er, "rate (max form)")
