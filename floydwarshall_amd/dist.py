@@ -121,21 +121,48 @@ def solve_partitioned(rate, n, rank, world, *, nxt=None, block=64, backend=None,
             dist.all_reduce(ok, op=dist.ReduceOp.MIN, group=group)
         backend.nonneg = bool(ok.item() == 1)
     bufs = [torch.empty((block, n), dtype=rate.dtype, device=rate.device) for _ in range(2)]
+    # On a GPU the panel phase and the broadcast run on a SIDE stream, so that on the owner they
+    # overlap the bulk relax of the previous panel instead of queueing behind it.
+    on_gpu = rate.is_cuda
+    main = torch.cuda.current_stream(rate.device) if on_gpu else None
+    side = torch.cuda.Stream(device=rate.device) if on_gpu else None
 
     def sub(t, lo, hi):
         return None if t is None else t[lo:hi]
 
     def panel_and_broadcast(idx):
+        """Snapshot panel idx (owner) + its broadcast; returns (w, wait) where wait() orders the
+        current stream behind both."""
         k0, b, owner = blocks[idx]
         w = bufs[idx & 1][:b]
-        if rank == owner:
-            lo = k0 - row0
-            backend.panel(rate[lo:lo + b], n, k0, w)
         work = None
-        if world > 1:
-            src = owner if group is None else dist.get_global_rank(group, owner)
-            work = dist.broadcast(w, src=src, group=group, async_op=True)
-        return w, work
+        if on_gpu:
+            side.wait_stream(main)                 # everything queued so far precedes the panel
+            with torch.cuda.stream(side):
+                if rank == owner:
+                    lo = k0 - row0
+                    backend.panel(rate[lo:lo + b], n, k0, w)
+                if world > 1:
+                    src = owner if group is None else dist.get_global_rank(group, owner)
+                    work = dist.broadcast(w, src=src, group=group, async_op=True)
+        else:
+            if rank == owner:
+                lo = k0 - row0
+                backend.panel(rate[lo:lo + b], n, k0, w)
+            if world > 1:
+                src = owner if group is None else dist.get_global_rank(group, owner)
+                work = dist.broadcast(w, src=src, group=group, async_op=True)
+
+        def wait():
+            if work is not None:
+                if on_gpu:
+                    with torch.cuda.stream(side):
+                        work.wait()                # side stream behind the collective
+                else:
+                    work.wait()
+            if on_gpu:
+                main.wait_stream(side)
+        return w, wait
 
     def relax_rows_except(skips, k0, k1, w):
         pos = 0
@@ -144,13 +171,12 @@ def solve_partitioned(rate, n, rank, world, *, nxt=None, block=64, backend=None,
                 backend.relax(rate[pos:lo], n, row0 + pos, k0, k1, w, sub(nxt, pos, lo))
             pos = max(pos, hi)
 
-    w, work = panel_and_broadcast(0)
+    w, wait = panel_and_broadcast(0)
     for idx, (k0, b, owner) in enumerate(blocks):
-        if work is not None:
-            work.wait()
+        wait()
         k1 = k0 + b
         skips = []
-        nxt_w = nxt_work = None
+        nxt_w = nxt_wait = None
         if idx + 1 < len(blocks) and lookahead:
             nk0, nb, nowner = blocks[idx + 1]
             if rank == nowner:
@@ -158,10 +184,12 @@ def solve_partitioned(rate, n, rank, world, *, nxt=None, block=64, backend=None,
                 getattr(backend, "relax_lookahead", backend.relax)(
                     rate[nlo:nlo + nb], n, nk0, k0, k1, w, sub(nxt, nlo, nlo + nb))
                 skips.append((nlo, nlo + nb))
-            nxt_w, nxt_work = panel_and_broadcast(idx + 1)
+            nxt_w, nxt_wait = panel_and_broadcast(idx + 1)
             relax_rows_except(skips, k0, k1, w)
         else:
             relax_rows_except(skips, k0, k1, w)
             if idx + 1 < len(blocks):
-                nxt_w, nxt_work = panel_and_broadcast(idx + 1)
-        w, work = nxt_w, nxt_work
+                nxt_w, nxt_wait = panel_and_broadcast(idx + 1)
+        w, wait = nxt_w, nxt_wait
+    if on_gpu:
+        main.wait_stream(side)
