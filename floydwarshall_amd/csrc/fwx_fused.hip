@@ -285,7 +285,7 @@ __global__ __launch_bounds__(256) void fused_colpanel(const T *rate, const int32
 // workgroup at 32 KiB of LDS and <= 128 VGPRs: 4 workgroups = 16 waves per CU.  The loop is pure
 // VALU (v_pk_mul_f32 + v_cmp + v_cndmask per pair of relaxations) and one wave alone issues at
 // half rate on a SIMD-32, so occupancy, not bytes, is what this kernel needs.
-template <typename T, bool HAS_NEXT, bool COUNT, int BS, int MINW>
+template <typename T, bool HAS_NEXT, bool COUNT, int BS, int MINW, int NH>
 __global__ __launch_bounds__(256, MINW) void fused_main(T *rate, int32_t *next, int rows, int n,
                                                         int row0, int k0, int bt, const T *w,
                                                         const T *ct, const int32_t *cnt, int ct_ld,
@@ -295,8 +295,8 @@ __global__ __launch_bounds__(256, MINW) void fused_main(T *rate, int32_t *next, 
     using IV = typename IVec<Vec16<T>::W>::type;
     constexpr int VW = Vec16<T>::W;
     constexpr int RI = 8, TI = 16 * RI;       // 128 rows
-    constexpr int TJ = 16 * 2 * VW;           // 128 (f32) / 64 (f64) columns
-    constexpr int HJ = TJ / 2;
+    constexpr int TJ = 16 * NH * VW;          // NH = 2: 128 (f32) / 64 (f64) columns; NH = 1: half
+    constexpr int HJ = TJ / NH;               // NH 16-byte vectors per thread and row
 
     __shared__ __attribute__((aligned(16))) T sW[BS][TJ];
     __shared__ __attribute__((aligned(16))) T sC[BS][TI];
@@ -311,21 +311,21 @@ __global__ __launch_bounds__(256, MINW) void fused_main(T *rate, int32_t *next, 
     // ---- this thread's 8 x (2 vectors) register tile -------------------------------------------
     const int ti = tid >> 4, tj = tid & 15;
     const int i0 = i_base + ti * RI;
-    int jcol[2];
-    bool jok[2];
+    int jcol[NH];
+    bool jok[NH];
 #pragma unroll
-    for (int h = 0; h < 2; ++h) {
+    for (int h = 0; h < NH; ++h) {
         const int j = j_base + h * HJ + tj * VW;
         jok[h] = j < n;
         jcol[h] = jok[h] ? j : n - VW;
     }
-    V x[RI][2];
-    IV nx[HAS_NEXT ? RI : 1][2];
+    V x[RI][NH];
+    IV nx[HAS_NEXT ? RI : 1][NH];
 #pragma unroll
     for (int r = 0; r < RI; ++r) {
         const int i = min(i0 + r, rows - 1);
 #pragma unroll
-        for (int h = 0; h < 2; ++h) {
+        for (int h = 0; h < NH; ++h) {
             x[r][h] = *reinterpret_cast<const V *>(rate + (size_t)i * n + jcol[h]);
             if (HAS_NEXT) nx[r][h] = *reinterpret_cast<const IV *>(next + (size_t)i * n + jcol[h]);
         }
@@ -370,7 +370,7 @@ __global__ __launch_bounds__(256, MINW) void fused_main(T *rate, int32_t *next, 
         for (int tl = 0; tl < bs; ++tl) {
             T c[RI];
             int32_t cn[HAS_NEXT ? RI : 1];
-            V wv[2];
+            V wv[NH];
 #pragma unroll
             for (int q = 0; q < RI / VW; ++q) {
                 const V cv = *reinterpret_cast<const V *>(&sC[tl][ti * RI + q * VW]);
@@ -382,12 +382,13 @@ __global__ __launch_bounds__(256, MINW) void fused_main(T *rate, int32_t *next, 
                     for (int e = 0; e < VW; ++e) cn[q * VW + e] = nv[e];
                 }
             }
-            wv[0] = *reinterpret_cast<const V *>(&sW[tl][tj * VW]);
-            wv[1] = *reinterpret_cast<const V *>(&sW[tl][HJ + tj * VW]);
+#pragma unroll
+            for (int h = 0; h < NH; ++h)
+                wv[h] = *reinterpret_cast<const V *>(&sW[tl][h * HJ + tj * VW]);
 #pragma unroll
             for (int r = 0; r < RI; ++r)
 #pragma unroll
-                for (int h = 0; h < 2; ++h)
+                for (int h = 0; h < NH; ++h)
 #pragma unroll
                     for (int e = 0; e < VW; ++e) {
                         const T cand = c[r] * wv[h][e];
@@ -408,7 +409,7 @@ __global__ __launch_bounds__(256, MINW) void fused_main(T *rate, int32_t *next, 
         const int i = i0 + r;
         if (i >= rows) continue;
 #pragma unroll
-        for (int h = 0; h < 2; ++h) {
+        for (int h = 0; h < NH; ++h) {
             if (!jok[h]) continue;
             const size_t off = (size_t)i * n + jcol[h];
             if (diag_tile) {
@@ -599,10 +600,12 @@ __global__ __launch_bounds__(256) void nonneg_check_f32(const float *rate, size_
 
 // Stage size / occupancy target per variant (LDS = BS * (TJ + TI) * sizeof(T) [+ BS*TI*4]).
 template <typename T, bool HAS_NEXT> struct FusedCfg;
-template <> struct FusedCfg<float, false> { static constexpr int BS = 32, MINW = 4; };
-template <> struct FusedCfg<float, true> { static constexpr int BS = 32, MINW = 2; };
-template <> struct FusedCfg<double, false> { static constexpr int BS = 32, MINW = 2; };
-template <> struct FusedCfg<double, true> { static constexpr int BS = 16, MINW = 2; };
+// The next-hop variant doubles the register tile (rate + next), so it takes a half-width tile
+// (NH = 1: one 16-byte vector per thread and row) to stay at 4 waves per SIMD.
+template <> struct FusedCfg<float, false> { static constexpr int BS = 32, MINW = 4, NH = 2; };
+template <> struct FusedCfg<float, true> { static constexpr int BS = 16, MINW = 4, NH = 1; };
+template <> struct FusedCfg<double, false> { static constexpr int BS = 32, MINW = 2, NH = 2; };
+template <> struct FusedCfg<double, true> { static constexpr int BS = 16, MINW = 2, NH = 1; };
 
 // f32, rates only, no update counting, domain verified by the caller: the max3 kernel.
 static bool launch_max_form(const FusedArgs<float> &a, dim3 grid, dim3 block, hipStream_t s)
@@ -654,7 +657,7 @@ template <typename T>
 hipError_t launch_fused_main(const FusedArgs<T> &full, int r_lo, int r_hi, hipStream_t s)
 {
     constexpr int VW = Vec16<T>::W;
-    constexpr int TI = 128, TJ = 16 * 2 * VW;
+    constexpr int TI = 128;
     if (r_hi <= r_lo || full.n <= 0 || full.bt <= 0) return hipSuccess;
     hipError_t e = check_fused_args(full);
     if (e != hipSuccess) return e;
@@ -666,12 +669,14 @@ hipError_t launch_fused_main(const FusedArgs<T> &full, int r_lo, int r_hi, hipSt
     a.ct = full.ct + r_lo;
     a.cnt = full.cnt ? full.cnt + r_lo : nullptr;
     const dim3 block(256);
-    const dim3 grid((unsigned)((a.n + TJ - 1) / TJ), (unsigned)((a.rows + TI - 1) / TI));
+    const int tj = 16 * VW * (a.next ? FusedCfg<T, true>::NH : FusedCfg<T, false>::NH);
+    const dim3 grid((unsigned)((a.n + tj - 1) / tj), (unsigned)((a.rows + TI - 1) / TI));
     if (launch_max_form(a, grid, block, s)) return hipGetLastError();
 #define FWX_FUSED_LAUNCH(HN, CN)                                                                   \
-    hipLaunchKernelGGL((fused_main<T, HN, CN, FusedCfg<T, HN>::BS, FusedCfg<T, HN>::MINW>), grid,  \
-                       block, 0, s, a.rate, a.next, a.rows, a.n, a.row0, a.k0, a.bt, a.w, a.ct,    \
-                       a.cnt, a.ct_ld, a.updates)
+    hipLaunchKernelGGL((fused_main<T, HN, CN, FusedCfg<T, HN>::BS, FusedCfg<T, HN>::MINW,          \
+                                   FusedCfg<T, HN>::NH>),                                          \
+                       grid, block, 0, s, a.rate, a.next, a.rows, a.n, a.row0, a.k0, a.bt, a.w,    \
+                       a.ct, a.cnt, a.ct_ld, a.updates)
     if (a.next) {
         if (a.updates) FWX_FUSED_LAUNCH(true, true); else FWX_FUSED_LAUNCH(true, false);
     } else {
