@@ -39,7 +39,7 @@ def parse_args():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=2)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--n", type=int, default=16384)
+    ap.add_argument("--size", dest="n", type=int, default=16384, help="matrix order N")
     ap.add_argument("--dtype", default="f32", choices=["f32", "f64"])
     ap.add_argument("--dist", default="d1", choices=["d1", "d2"])
     ap.add_argument("--with-next", action="store_true", help="carry the next-hop matrix")
@@ -50,6 +50,9 @@ def parse_args():
     ap.add_argument("--no-serpentine", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-fused-extra", action="store_true")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
+                    help="process-group backend for N > 1 (gloo only to rehearse the N > 1 code path "
+                         "with several ranks on one GPU; never a performance number)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--kslice", type=int, default=0,
                     help="DEBUG: run only this many pivots per step (result flagged invalid)")
@@ -116,11 +119,15 @@ def main():
         if world == 1 and args.gpus > 1:
             raise SystemExit("--gpus %d needs torch.distributed.run with %d ranks" % (args.gpus, args.gpus))
         args.gpus = world
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    dev_index = local_rank % torch.cuda.device_count()   # one rank per GPU on a real node
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group("gloo")
 
     n = args.n
     np_dtype = np.float32 if args.dtype == "f32" else np.float64
@@ -218,20 +225,23 @@ def main():
         "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True,
         "scaling": "strong", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
         "config": {"workload": "N=%d dense %s rate matrix (%s), full solve = %d pivot steps per "
-                               "step, per-k engine%s" % (n, args.dtype, args.dist.upper(), k_end,
-                                                         ", with next-hop matrix" if args.with_next else ""),
+                               "step, %s%s" % (n, args.dtype, args.dist.upper(), k_end,
+                                               "per-k engine" if args.engine == "perk"
+                                               else "fused engine (64 pivots per pass)",
+                                               ", with next-hop matrix" if args.with_next else ""),
                    "n": n, "engine": "perk", "serpentine": serp,
                    "partition": "single GPU" if world == 1 else
                    "row-block x%d, %d-pivot snapshot panels broadcast on RCCL" % (world, args.block)},
     }
     if args.kslice > 0:
         out["INVALID_debug_kslice"] = args.kslice
+    if world > 1 and args.backend != "nccl":
+        out["INVALID_rehearsal_backend"] = args.backend
 
     out["config"]["engine"] = args.engine
     if world == 1 and ev_pairs and args.engine == "fused":
         passes = args.steps * ((k_end + 63) // 64)
         kern_ms = sum(evs[0].elapsed_time(evs[-1]) for evs, _ in ev_pairs)
-        out["config"]["workload"] = out["config"]["workload"].replace("per-k engine", "fused engine (64 pivots per pass)")
         out["fused"] = {"passes_per_solve": (k_end + 63) // 64, "avg_pass_us": 1e3 * kern_ms / passes,
                         "effective_GBps_at_4B_per_relaxation": 4.0 * relax_per_step * args.steps / (kern_ms * 1e-3) / 1e9,
                         "note": "VALU-bound kernel (3 lane-ops per relaxation); the GB/s figure is "
