@@ -517,3 +517,43 @@ def test_dev_solve_blocking_api_with_lookahead(with_next):
     r2 = torch.from_numpy(rate).to(dev)
     engine.dev_solve(r2, engine=engine.FWX_ENGINE_FUSED, k_begin=33, k_end=650)
     assert_bits_equal(r2.cpu().numpy(), er, "rate (max form)")
+
+
+def test_config4_n16384_fp32_full_solve_fused_equals_perk():
+    """BASELINE.json's headline size, whole solve: the per-k engine (16384 launches), the fused
+    engine in max form (rates only) and the fused engine in compare form (with the next-hop
+    matrix) must agree bit for bit on all 2^28 rates; next-hops agree with a per-k + next run on a
+    k-prefix.  (~10 s of GPU time.)"""
+    import torch
+    n = 16384
+    dev = torch.device("cuda:0")
+    rate_h, next_h = synth.d1_uniform(n, np.float32, synth.BASE_SEED + 3)
+    r0 = torch.from_numpy(rate_h).to(dev)
+    del rate_h
+    a = r0.clone()
+    engine.dev_solve(a, engine=engine.FWX_ENGINE_PERK)
+    b = r0.clone()
+    engine.dev_solve(b, engine=engine.FWX_ENGINE_FUSED)                 # max form
+    assert torch.equal(a, b)
+    c = r0.clone()
+    nc = torch.from_numpy(next_h).to(dev)
+    engine.dev_solve(c, next_t=nc, engine=engine.FWX_ENGINE_FUSED)      # compare form + next
+    assert torch.equal(a, c)
+    del b, c
+    # next-hops: per-k vs fused on the first 1024 pivots
+    d = r0.clone()
+    nd = torch.from_numpy(next_h).to(dev)
+    engine.dev_solve(d, next_t=nd, engine=engine.FWX_ENGINE_PERK, k_end=1024)
+    e = r0.clone()
+    ne = torch.from_numpy(next_h).to(dev)
+    engine.dev_solve(e, next_t=ne, engine=engine.FWX_ENGINE_FUSED, k_end=1024)
+    assert torch.equal(d, e) and torch.equal(nd, ne)
+    # every path of the full solve ends at its destination, product of input edges == rate
+    g = torch.Generator(device="cpu").manual_seed(11)
+    src = torch.randint(0, n, (200000,), generator=g, dtype=torch.int32).to(dev)
+    dst = torch.randint(0, n, (200000,), generator=g, dtype=torch.int32).to(dev)
+    ln, prod, _ = engine.dev_follow_paths(nc, src, dst, edge_rate_t=r0)
+    ok = src != dst
+    assert bool((ln[ok] >= 1).all())
+    solved = a[src.long(), dst.long()].double()
+    assert float((((prod - solved).abs() / solved.clamp_min(1e-30))[ok]).max()) < 2e-5
