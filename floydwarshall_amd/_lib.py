@@ -3,7 +3,8 @@ import ctypes
 import os
 
 PKG = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(PKG, "libfwx.so")
+# FWX_LIB_PATH: developer override, e.g. an experimental build of the same ABI
+LIB_PATH = os.environ.get("FWX_LIB_PATH") or os.path.join(PKG, "libfwx.so")
 
 FWX_OK = 0
 FWX_ERR_INVALID = -1

@@ -186,7 +186,7 @@ int fwx_dev_follow_paths(int32_t n, const int32_t *next, int32_t count, const in
  *   matrix, all ranks) that every entry is >= +0.0 and not NaN -- what the reference's parser
  *   guarantees (rates > 0, Parsers.hs:40; "no route" = +0.0).  On that domain the strict fold
  *   equals max() bit for bit, and rates-only f32 slabs take a kernel that folds two pivots per
- *   instruction (v_pk_mul_f32 + v_max3_f32).  Without the flag nothing is assumed.              */
+ *   v_max3_f32.  Without the flag nothing is assumed.              */
 #define FWX_FUSED_BLOCK 64
 #define FWX_FLAG_NONNEG 1
 size_t fwx_fused_diag_ws_bytes(int32_t dtype);
