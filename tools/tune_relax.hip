@@ -4,6 +4,7 @@
 //   hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -Iinclude \
 //         -Ifloydwarshall_amd/csrc tools/tune_relax.hip -o gpurun_out/tune_relax && gpurun_out/tune_relax
 #include "../floydwarshall_amd/csrc/fwx_kernels.hip"
+#include "../floydwarshall_amd/csrc/fwx_fused.hip"
 
 #include <stdio.h>
 #include <stdlib.h>
@@ -66,6 +67,33 @@ int main(int argc, char **argv)
         float ms; CK(hipEventElapsedTime(&ms, e0, e1));
         printf("solve n=%d: %.3f ms, %.1f us/launch, %.3e relax/s\n", n, ms, 1e3 * ms / n,
                (double)n * n * n / (ms * 1e-3));
+        return 0;
+    }
+
+    if (argc > 5 && !strcmp(argv[5], "fused")) {
+        // PMC probe mode for the fused engine: `passes` passes of 64 pivots (panel, colpanel, main
+        // in max form), a device sync after every pass so that rocprofv3 --pmc survives.
+        const int passes = argc > 6 ? atoi(argv[6]) : 16;
+        float *w, *ct;
+        CK(hipMalloc(&w, (size_t)64 * n * sizeof(float)));
+        CK(hipMalloc(&ct, (size_t)64 * n * sizeof(float)));
+        fwx::FusedArgs<float> a;
+        a.rate = d; a.next = nullptr; a.rows = n; a.n = n; a.row0 = 0; a.w = w; a.ct = ct;
+        a.cnt = nullptr; a.ct_ld = n; a.updates = nullptr; a.nonneg = true;
+        hipEvent_t e0, e1;
+        CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+        CK(hipEventRecord(e0, 0));
+        for (int p = 0; p < passes; ++p) {
+            a.k0 = p * 64; a.bt = 64;
+            CK(fwx::launch_fused_panel<float>(d + (size_t)a.k0 * n, n, a.k0, 64, w, nullptr, 0));
+            CK(fwx::launch_fused_relax<float>(a, 0));
+            CK(hipDeviceSynchronize());
+        }
+        CK(hipEventRecord(e1, 0));
+        CK(hipEventSynchronize(e1));
+        float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+        printf("fused n=%d: %d passes, %.1f us/pass (synchronised after each pass)\n", n, passes,
+               1e3 * ms / passes);
         return 0;
     }
 
