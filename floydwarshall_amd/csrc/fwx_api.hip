@@ -280,7 +280,10 @@ int solve_host(int32_t n, T *rate, int32_t *next, int32_t *hops, const fwx_opts 
     int32_t *dh = (int32_t *)d_hops.p;
     unsigned long long *upd = op.updates_out ? (unsigned long long *)d_upd.p : nullptr;
     if (op.engine == FWX_ENGINE_FUSED && !fused_ok<T>(n, dr, dh)) return FWX_ERR_UNSUPPORTED;
-    if (pick_fused<T>(op.engine, n, dr, dh)) {
+    if (op.engine == FWX_ENGINE_AUTO && n <= FWX_SMALL_N) {
+        // the reference's own regime: the whole solve in one single-workgroup launch
+        FWX_HIP(fwx::launch_small_solve<T>(dr, (int32_t *)d_next.p, dh, n, op.k_begin, op.k_end, upd, s));
+    } else if (pick_fused<T>(op.engine, n, dr, dh)) {
         DevBuf d_ws;
         if ((rc = d_ws.alloc(fused_ws_bytes(n, sizeof(T))))) return rc;
         rc = fused_range<T>(dr, (int32_t *)d_next.p, n, op.k_begin, op.k_end, d_ws.p, upd, s);
@@ -404,6 +407,10 @@ int matrix_solve_typed(fwx_matrix *m, const Opts &op, unsigned long long *upd, h
     const int n = m->n;
     T *r = (T *)m->rate;
     if (op.engine == FWX_ENGINE_FUSED && !fused_ok<T>(n, r, m->hops)) return FWX_ERR_UNSUPPORTED;
+    if (op.engine == FWX_ENGINE_AUTO && n <= FWX_SMALL_N) {
+        FWX_HIP(fwx::launch_small_solve<T>(r, m->next, m->hops, n, op.k_begin, op.k_end, upd, s));
+        return FWX_OK;
+    }
     if (pick_fused<T>(op.engine, n, r, m->hops)) {
         DevBuf ws;
         int rc = ws.alloc(fused_ws_bytes(n, sizeof(T)));

@@ -193,6 +193,81 @@ __global__ __launch_bounds__(256, MINW) void relax_k(T *rate, int32_t *next, int
     }
 }
 
+// -------------------------------------------------------------------------------------------------
+// small_solve: the whole of runAlgo for n <= 64 in ONE launch of one workgroup -- the reference's
+// own regime (its tests stop at 4 x 4, src/test/AlgorithmsTest.hs:66-77; the README session has 4
+// vertices).  rate / next / hops live in LDS for the entire solve, one barrier per pivot.  Row k
+// and column k are fixed points of step k, so the in-place LDS update reads exactly the step-start
+// operands (Algorithms.hs:58-60).
+// -------------------------------------------------------------------------------------------------
+template <typename T, bool HAS_NEXT, bool HAS_HOPS>
+__global__ __launch_bounds__(256) void small_solve(T *rate, int32_t *next, int32_t *hops, int n,
+                                                   int k_begin, int k_end,
+                                                   unsigned long long *updates)
+{
+    constexpr int M = FWX_SMALL_N;
+    __shared__ T R[M][M + 1];
+    __shared__ int32_t NX[HAS_NEXT ? M : 1][M + 1];
+    __shared__ int32_t HP[HAS_HOPS ? M : 1][M + 1];
+    __shared__ unsigned int s_cnt;
+    const int tid = threadIdx.x;
+    if (tid == 0) s_cnt = 0;
+    for (int idx = tid; idx < n * n; idx += 256) {
+        const int r = idx / n, c = idx % n;
+        R[r][c] = rate[idx];
+        if (HAS_NEXT) NX[r][c] = next[idx];
+        if (HAS_HOPS) HP[r][c] = hops[idx];
+    }
+    __syncthreads();
+    unsigned int mine = 0;
+    for (int k = k_begin; k < k_end; ++k) {
+        for (int idx = tid; idx < n * n; idx += 256) {
+            const int r = idx / n, c = idx % n;
+            if (r == k || c == k || r == c) continue;      // Algorithms.hs:50, :54
+            const T cand = R[r][k] * R[k][c];              // :61
+            if (R[r][c] < cand) {                          // :55
+                R[r][c] = cand;
+                if (HAS_NEXT) NX[r][c] = NX[r][k];
+                if (HAS_HOPS) HP[r][c] = HP[r][k] + HP[k][c];
+                ++mine;
+            }
+        }
+        __syncthreads();
+    }
+    for (int idx = tid; idx < n * n; idx += 256) {
+        const int r = idx / n, c = idx % n;
+        rate[idx] = R[r][c];
+        if (HAS_NEXT) next[idx] = NX[r][c];
+        if (HAS_HOPS) hops[idx] = HP[r][c];
+    }
+    if (updates) {
+        if (mine) atomicAdd(&s_cnt, mine);
+        __syncthreads();
+        if (tid == 0 && s_cnt) atomicAdd(&updates[0], (unsigned long long)s_cnt);
+    }
+}
+
+template <typename T>
+hipError_t launch_small_solve(T *rate, int32_t *next, int32_t *hops, int n, int k_begin, int k_end,
+                              unsigned long long *updates, hipStream_t s)
+{
+    if (n <= 0 || k_end <= k_begin) return hipSuccess;
+    if (n > FWX_SMALL_N || (hops && !next)) return hipErrorInvalidValue;
+#define FWX_SMALL(HN, HH)                                                                          \
+    hipLaunchKernelGGL((small_solve<T, HN, HH>), dim3(1), dim3(256), 0, s, rate, next, hops, n,    \
+                       k_begin, k_end, updates)
+    if (hops) FWX_SMALL(true, true);
+    else if (next) FWX_SMALL(true, false);
+    else FWX_SMALL(false, false);
+#undef FWX_SMALL
+    return hipGetLastError();
+}
+
+template hipError_t launch_small_solve<float>(float *, int32_t *, int32_t *, int, int, int,
+                                              unsigned long long *, hipStream_t);
+template hipError_t launch_small_solve<double>(double *, int32_t *, int32_t *, int, int, int,
+                                               unsigned long long *, hipStream_t);
+
 template <typename T>
 __global__ __launch_bounds__(256) void snapshot_row(T *dst, const T *src, int32_t *hdst,
                                                     const int32_t *hsrc, int n)

@@ -557,3 +557,20 @@ def test_config4_n16384_fp32_full_solve_fused_equals_perk():
     assert bool((ln[ok] >= 1).all())
     solved = a[src.long(), dst.long()].double()
     assert float((((prod - solved).abs() / solved.clamp_min(1e-30))[ok]).max()) < 2e-5
+
+
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+@pytest.mark.parametrize("n", [1, 2, 4, 7, 31, 63, 64])
+def test_small_solve_single_launch(n, dtype):
+    """n <= 64 (the reference's own regime): AUTO solves in one single-workgroup launch; must equal
+    the oracle and the per-k engine bit for bit, all fields, all distributions, k-ranges."""
+    for kind in ("d1", "t1", "t2", "t3"):
+        rate, nxt, hops = synth.make(kind, n, dtype, seed=500 + n)
+        a = _solve_and_compare(rate, nxt, hops)                                  # AUTO -> small
+        b = _solve_and_compare(rate, nxt, hops, engine=engine.FWX_ENGINE_PERK)
+        assert_bits_equal(a[0], b[0])
+        _solve_and_compare(rate, None, None)
+        _solve_and_compare(rate, nxt, None)
+    if n >= 4:
+        rate, nxt, hops = synth.make("d2", n, dtype, seed=9)
+        _solve_and_compare(rate, nxt, hops, k_begin=1, k_end=n - 1)
