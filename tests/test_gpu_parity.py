@@ -574,3 +574,33 @@ def test_small_solve_single_launch(n, dtype):
     if n >= 4:
         rate, nxt, hops = synth.make("d2", n, dtype, seed=9)
         _solve_and_compare(rate, nxt, hops, k_begin=1, k_end=n - 1)
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+def test_subnormal_products_are_not_flushed(dtype):
+    """The reference multiplies IEEE doubles with gradual underflow.  Rates small enough that every
+    multi-hop product is SUBNORMAL (or underflows to +0): the device must neither flush inputs nor
+    outputs to zero, in any engine (per-k, fused compare form, fused max form)."""
+    n = 192
+    rnd = np.random.default_rng(17)
+    tiny = np.finfo(dtype).tiny                      # smallest normal
+    scale = np.sqrt(float(tiny)) * 0.5               # every two-hop product is < tiny/4: subnormal
+    rate = (scale * (0.05 + rnd.random((n, n)))).astype(dtype)
+    rate[rnd.random((n, n)) < 0.3] *= dtype(1e-2)    # some deeper inside the subnormal range
+    np.fill_diagonal(rate, 0)
+    direct = rnd.random((n, n)) < 0.6                # knock out direct edges so that
+    rate[~direct] = 0                                # subnormal two-hop products win
+    np.fill_diagonal(rate, 0)
+    nxt = np.where(rate > 0, np.arange(n, dtype=np.int32)[None, :], -1).astype(np.int32)
+    exp_r, exp_n = rate.copy(), nxt.copy()
+    oracle.relax(exp_r, exp_n)
+    sub = (exp_r > 0) & (exp_r < tiny)
+    assert sub.sum() > n                             # the case really exercises subnormals
+    for eng in (engine.FWX_ENGINE_PERK, engine.FWX_ENGINE_FUSED):
+        r, nx = rate.copy(), nxt.copy()
+        engine.solve(r, nx, engine=eng)
+        assert_bits_equal(r, exp_r, "rate engine %d" % eng)
+        assert_bits_equal(nx, exp_n, "next engine %d" % eng)
+    r = rate.copy()
+    engine.solve(r, engine=engine.FWX_ENGINE_FUSED)  # f32: max form
+    assert_bits_equal(r, exp_r, "rate, rates-only fused")
