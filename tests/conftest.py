@@ -18,6 +18,12 @@ def golden_dir():
 
 
 @pytest.fixture(scope="session", autouse=True)
-def _built_oracle():
+def _built_native():
+    """Build (or refresh) the native pieces before any test: libfwx.so + fwx_cli with hipcc
+    (cross-compiles without a GPU) and the oracle with gcc.  The .so files are git-ignored, so a
+    fresh checkout has none."""
+    from floydwarshall_amd import build as fbuild
+    fbuild.build_lib()
     import oracle
+    oracle.build()
     oracle.lib()
