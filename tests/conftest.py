@@ -10,6 +10,14 @@ if ROOT not in sys.path:
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    # Build (or refresh) the native pieces before collection: libfwx.so + fwx_cli with hipcc
+    # (cross-compiles without a GPU) and the oracle with gcc.  The .so files are git-ignored, so a
+    # fresh checkout has none, and some test modules query the library while being imported.
+    from floydwarshall_amd import build as fbuild
+    fbuild.build_lib()
+    import oracle
+    oracle.build()
+    oracle.lib()
 
 
 @pytest.fixture(scope="session")
@@ -17,13 +25,3 @@ def golden_dir():
     return os.path.join(ROOT, "tests", "golden")
 
 
-@pytest.fixture(scope="session", autouse=True)
-def _built_native():
-    """Build (or refresh) the native pieces before any test: libfwx.so + fwx_cli with hipcc
-    (cross-compiles without a GPU) and the oracle with gcc.  The .so files are git-ignored, so a
-    fresh checkout has none."""
-    from floydwarshall_amd import build as fbuild
-    fbuild.build_lib()
-    import oracle
-    oracle.build()
-    oracle.lib()
