@@ -548,18 +548,24 @@ __global__ __launch_bounds__(256, MINW) void fused_main_max(float *rate, int row
                     wv[h][2 * q + 1] = V2{wq[2], wq[3]};
                 }
 #pragma unroll
-            for (int r = 0; r < RI; ++r)
+            for (int r = 0; r < RI; ++r) {
+                // All 16 products of this row first, then the 8 folds: a v_max3 never issues right
+                // behind the multiplies it depends on.  Two plain v_mul_f32 rather than one
+                // v_pk_mul_f32: same issue cycles per pair, no register-pair shuffles (measured).
+                float p0[2][4], p1[2][4];
 #pragma unroll
                 for (int h = 0; h < 2; ++h)
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
-                        // two plain v_mul_f32 rather than one v_pk_mul_f32: same 4 issue cycles
-                        // per pair, no register-pair shuffles, 3 % faster end to end (measured)
-                        float c0, c1;
-                        asm("v_mul_f32 %0, %1, %2" : "=v"(c0) : "v"(c[r][0]), "v"(wv[h][e][0]));
-                        asm("v_mul_f32 %0, %1, %2" : "=v"(c1) : "v"(c[r][1]), "v"(wv[h][e][1]));
-                        x[r][h][e] = __builtin_fmaxf(__builtin_fmaxf(x[r][h][e], c0), c1);
+                        asm("v_mul_f32 %0, %1, %2" : "=v"(p0[h][e]) : "v"(c[r][0]), "v"(wv[h][e][0]));
+                        asm("v_mul_f32 %0, %1, %2" : "=v"(p1[h][e]) : "v"(c[r][1]), "v"(wv[h][e][1]));
                     }
+#pragma unroll
+                for (int h = 0; h < 2; ++h)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+                        x[r][h][e] = __builtin_fmaxf(__builtin_fmaxf(x[r][h][e], p0[h][e]), p1[h][e]);
+            }
         }
         if (more) {
             commit(buf ^ 1);                      // the other buffer: nobody reads it now
