@@ -202,8 +202,12 @@ int fused_range(T *rate, int32_t *next, int n, int k_begin, int k_end, void *ws,
                                                side.s));
             FWX_HIP(hipEventRecord(side.panel_done, side.s));
             // ... while the rest of the matrix is relaxed on the main stream
-            FWX_HIP(fwx::launch_fused_main<T>(a, 0, k1, s));
-            FWX_HIP(fwx::launch_fused_main<T>(a, k1 + bt1, n, s));
+            if (k1 % 8 == 0 && bt1 % 8 == 0) {
+                FWX_HIP(fwx::launch_fused_main<T>(a, 0, n, s, k1, k1 + bt1));   // one launch, rows skipped
+            } else {
+                FWX_HIP(fwx::launch_fused_main<T>(a, 0, k1, s));
+                FWX_HIP(fwx::launch_fused_main<T>(a, k1 + bt1, n, s));
+            }
             FWX_HIP(hipStreamWaitEvent(s, side.panel_done, 0));
         } else {
             FWX_HIP(fwx::launch_fused_main<T>(a, 0, n, s));

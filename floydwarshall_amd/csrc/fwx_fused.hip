@@ -289,6 +289,7 @@ template <typename T, bool HAS_NEXT, bool COUNT, int BS, int MINW, int NH>
 __global__ __launch_bounds__(256, MINW) void fused_main(T *rate, int32_t *next, int rows, int n,
                                                         int row0, int k0, int bt, const T *w,
                                                         const T *ct, const int32_t *cnt, int ct_ld,
+                                                        int skip_lo, int skip_hi,
                                                         unsigned long long *updates)
 {
     using V = typename Vec16<T>::type;
@@ -311,6 +312,9 @@ __global__ __launch_bounds__(256, MINW) void fused_main(T *rate, int32_t *next, 
     // ---- this thread's 8 x (2 vectors) register tile -------------------------------------------
     const int ti = tid >> 4, tj = tid & 15;
     const int i0 = i_base + ti * RI;
+    // rows [skip_lo, skip_hi) (multiples of 8 = one thread's rows) were relaxed by an earlier
+    // launch of this pass (look-ahead): their threads only help with staging and barriers
+    const bool skip = i0 >= skip_lo && i0 < skip_hi;
     int jcol[NH];
     bool jok[NH];
 #pragma unroll
@@ -367,7 +371,7 @@ __global__ __launch_bounds__(256, MINW) void fused_main(T *rate, int32_t *next, 
         __syncthreads();
 
         // ---- bs in-order relaxations per entry, operands from LDS ------------------------------
-        for (int tl = 0; tl < bs; ++tl) {
+        for (int tl = 0; tl < (skip ? 0 : bs); ++tl) {
             T c[RI];
             int32_t cn[HAS_NEXT ? RI : 1];
             V wv[NH];
@@ -407,7 +411,7 @@ __global__ __launch_bounds__(256, MINW) void fused_main(T *rate, int32_t *next, 
 #pragma unroll
     for (int r = 0; r < RI; ++r) {
         const int i = i0 + r;
-        if (i >= rows) continue;
+        if (i >= rows || skip) continue;
 #pragma unroll
         for (int h = 0; h < NH; ++h) {
             if (!jok[h]) continue;
@@ -451,7 +455,8 @@ __global__ __launch_bounds__(256, MINW) void fused_main(T *rate, int32_t *next, 
 template <int MINW, int UNR>
 __global__ __launch_bounds__(256, MINW) void fused_main_max(float *rate, int rows, int n, int row0,
                                                             int k0, int bt, const float *w,
-                                                            const float *ct, int ct_ld, int ct_vec)
+                                                            const float *ct, int ct_ld, int ct_vec,
+                                                            int skip_lo, int skip_hi)
 {
     typedef float V4 __attribute__((ext_vector_type(4)));
     typedef float V2 __attribute__((ext_vector_type(2)));
@@ -467,6 +472,7 @@ __global__ __launch_bounds__(256, MINW) void fused_main_max(float *rate, int row
     const int j_base = blockIdx.x * TJ;
     const int ti = tid >> 4, tj = tid & 15;
     const int i0 = i_base + ti * RI;
+    const bool skip = i0 >= skip_lo && i0 < skip_hi;   // rows done by the look-ahead launch
     const float nanv = qnan<float>();
 
     // staging role of this thread: pivot pair sp (0..7), 4 consecutive columns / rows at sv*4
@@ -529,7 +535,7 @@ __global__ __launch_bounds__(256, MINW) void fused_main_max(float *rate, int row
     for (int s0 = 0; s0 < bt; s0 += BS, buf ^= 1) {
         const bool more = s0 + BS < bt;
         if (more) prefetch(s0 + BS);             // in flight during the fold below
-        const int np = (min(BS, bt - s0) + 1) / 2;
+        const int np = skip ? 0 : (min(BS, bt - s0) + 1) / 2;
 #pragma unroll UNR
         for (int tp = 0; tp < np; ++tp) {
             V2 c[RI], wv[2][4];
@@ -576,7 +582,7 @@ __global__ __launch_bounds__(256, MINW) void fused_main_max(float *rate, int row
 #pragma unroll
     for (int r = 0; r < RI; ++r) {
         const int i = i0 + r;
-        if (i >= rows) continue;
+        if (i >= rows || skip) continue;
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
             if (!jok[h]) continue;
@@ -618,15 +624,19 @@ template <> struct FusedCfg<double, false> { static constexpr int BS = 32, MINW 
 template <> struct FusedCfg<double, true> { static constexpr int BS = 16, MINW = 2, NH = 1; };
 
 // f32, rates only, no update counting, domain verified by the caller: the max3 kernel.
-static bool launch_max_form(const FusedArgs<float> &a, dim3 grid, dim3 block, hipStream_t s)
+static bool launch_max_form(const FusedArgs<float> &a, dim3 grid, dim3 block, int skip_lo,
+                            int skip_hi, hipStream_t s)
 {
     if (!a.nonneg || a.next || a.updates) return false;
     const int ct_vec = ((uintptr_t)a.ct % 16 == 0 && a.ct_ld % 4 == 0) ? 1 : 0;
     hipLaunchKernelGGL((fused_main_max<3, 1>), grid, block, 0, s, a.rate, a.rows, a.n, a.row0, a.k0,
-                       a.bt, a.w, a.ct, a.ct_ld, ct_vec);
+                       a.bt, a.w, a.ct, a.ct_ld, ct_vec, skip_lo, skip_hi);
     return true;
 }
-static bool launch_max_form(const FusedArgs<double> &, dim3, dim3, hipStream_t) { return false; }
+static bool launch_max_form(const FusedArgs<double> &, dim3, dim3, int, int, hipStream_t)
+{
+    return false;
+}
 
 hipError_t launch_nonneg_check(const float *rate, size_t count, int *flag, hipStream_t s)
 {
@@ -662,15 +672,21 @@ template <typename T> hipError_t launch_fused_colpanel(const FusedArgs<T> &a, hi
     return hipGetLastError();
 }
 
-// Main kernel on local rows [r_lo, r_hi) of the slab (the colpanel must have run on them).
+// Main kernel on local rows [r_lo, r_hi) of the slab (the colpanel must have run on them), except
+// rows [skip_lo, skip_hi) (slab-local, multiples of 8; empty range = nothing skipped).
 template <typename T>
-hipError_t launch_fused_main(const FusedArgs<T> &full, int r_lo, int r_hi, hipStream_t s)
+hipError_t launch_fused_main(const FusedArgs<T> &full, int r_lo, int r_hi, hipStream_t s,
+                             int skip_lo, int skip_hi)
 {
     constexpr int VW = Vec16<T>::W;
     constexpr int TI = 128;
     if (r_hi <= r_lo || full.n <= 0 || full.bt <= 0) return hipSuccess;
     hipError_t e = check_fused_args(full);
     if (e != hipSuccess) return e;
+    if (skip_hi > skip_lo && ((skip_lo - r_lo) % 8 != 0 || (skip_hi - r_lo) % 8 != 0))
+        return hipErrorInvalidValue;
+    skip_lo -= r_lo;                    // kernel sees rows relative to its own slab
+    skip_hi -= r_lo;
     FusedArgs<T> a = full;
     a.rate = full.rate + (size_t)r_lo * full.n;
     a.next = full.next ? full.next + (size_t)r_lo * full.n : nullptr;
@@ -681,12 +697,12 @@ hipError_t launch_fused_main(const FusedArgs<T> &full, int r_lo, int r_hi, hipSt
     const dim3 block(256);
     const int tj = 16 * VW * (a.next ? FusedCfg<T, true>::NH : FusedCfg<T, false>::NH);
     const dim3 grid((unsigned)((a.n + tj - 1) / tj), (unsigned)((a.rows + TI - 1) / TI));
-    if (launch_max_form(a, grid, block, s)) return hipGetLastError();
+    if (launch_max_form(a, grid, block, skip_lo, skip_hi, s)) return hipGetLastError();
 #define FWX_FUSED_LAUNCH(HN, CN)                                                                   \
     hipLaunchKernelGGL((fused_main<T, HN, CN, FusedCfg<T, HN>::BS, FusedCfg<T, HN>::MINW,          \
                                    FusedCfg<T, HN>::NH>),                                          \
                        grid, block, 0, s, a.rate, a.next, a.rows, a.n, a.row0, a.k0, a.bt, a.w,    \
-                       a.ct, a.cnt, a.ct_ld, a.updates)
+                       a.ct, a.cnt, a.ct_ld, skip_lo, skip_hi, a.updates)
     if (a.next) {
         if (a.updates) FWX_FUSED_LAUNCH(true, true); else FWX_FUSED_LAUNCH(true, false);
     } else {
@@ -700,7 +716,7 @@ template <typename T> hipError_t launch_fused_relax(const FusedArgs<T> &a, hipSt
 {
     hipError_t e = launch_fused_colpanel<T>(a, s);
     if (e != hipSuccess) return e;
-    return launch_fused_main<T>(a, 0, a.rows, s);
+    return launch_fused_main<T>(a, 0, a.rows, s, 0, 0);
 }
 
 template <typename T>
@@ -719,8 +735,10 @@ template hipError_t launch_fused_relax<float>(const FusedArgs<float> &, hipStrea
 template hipError_t launch_fused_relax<double>(const FusedArgs<double> &, hipStream_t);
 template hipError_t launch_fused_colpanel<float>(const FusedArgs<float> &, hipStream_t);
 template hipError_t launch_fused_colpanel<double>(const FusedArgs<double> &, hipStream_t);
-template hipError_t launch_fused_main<float>(const FusedArgs<float> &, int, int, hipStream_t);
-template hipError_t launch_fused_main<double>(const FusedArgs<double> &, int, int, hipStream_t);
+template hipError_t launch_fused_main<float>(const FusedArgs<float> &, int, int, hipStream_t, int,
+                                             int);
+template hipError_t launch_fused_main<double>(const FusedArgs<double> &, int, int, hipStream_t, int,
+                                              int);
 template hipError_t launch_fused_panel<float>(const float *, int, int, int, float *, float *,
                                               hipStream_t);
 template hipError_t launch_fused_panel<double>(const double *, int, int, int, double *, double *,

@@ -58,7 +58,8 @@ template <typename T> hipError_t launch_fused_relax(const FusedArgs<T> &a, hipSt
 // kernel on local rows [r_lo, r_hi) (used by the look-ahead schedule).
 template <typename T> hipError_t launch_fused_colpanel(const FusedArgs<T> &a, hipStream_t s);
 template <typename T>
-hipError_t launch_fused_main(const FusedArgs<T> &a, int r_lo, int r_hi, hipStream_t s);
+hipError_t launch_fused_main(const FusedArgs<T> &a, int r_lo, int r_hi, hipStream_t s,
+                             int skip_lo = 0, int skip_hi = 0);
 
 // diag + rowpanel: snapshot panel of the pivot rows `rows_base` (bt x n, at time k0); the matrix
 // is not modified.  diag_ws: 2 * FWX_FUSED_B^2 elements of scratch.
