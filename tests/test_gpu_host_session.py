@@ -117,3 +117,18 @@ def test_session_on_a_larger_market_matches_list_faithful_oracle():
         except host.AlgoError as e:
             assert exp == ("err", str(e))
     assert s.solves == 1
+
+
+def test_fwx_cli_binary_replays_the_readme_session():
+    """The compiled CLI (csrc/cli/fwx_cli.cpp = the reference's Main loop, Main.hs:10-37) fed the
+    README session on stdin prints the README's output on stdout, byte for byte."""
+    import os
+    import subprocess
+    g = load_golden("readme_session.json")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = os.path.join(root, "floydwarshall_amd", "fwx_cli")
+    stdin = "".join(t["in"] + "\n" for t in g["turns"])
+    expected = "".join(line + "\n" for t in g["turns"] for line in t["out"])
+    r = subprocess.run([exe, "--device", "0"], input=stdin, capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stderr
+    assert r.stdout == expected
