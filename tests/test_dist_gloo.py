@@ -86,6 +86,7 @@ def _free_port():
     (2, 96, 16, False, "d1"),
     (2, 70, 8, True, "t1"),      # ties: earliest pivot must win on every rank
     (3, 50, 7, True, "t3"),      # ragged partition, ragged panels, inf/NaN inputs
+    (8, 131, 5, True, "t2"),     # the 8-rank shape of `bench.py --gpus 8`, ragged everything
 ])
 def test_partitioned_solve_equals_single_process_oracle(tmp_path, world, n, block, lookahead, kind):
     import oracle
