@@ -56,7 +56,17 @@ def parse_args():
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--kslice", type=int, default=0,
                     help="DEBUG: run only this many pivots per step (result flagged invalid)")
-    return ap.parse_args()
+    ap.add_argument("--config", type=int, default=0, choices=[0, 2, 3, 4, 5],
+                    help="preset for one of BASELINE.json's configs (2: N=1024 f64 per-k; 3: N=8192 f32 "
+                         "fused; 4: the default headline; 5: N=32768 f32 + next-hop matrix, fused)")
+    args = ap.parse_args()
+    if args.config == 2:
+        args.n, args.dtype, args.engine = 1024, "f64", "perk"
+    elif args.config == 3:
+        args.n, args.dtype, args.engine = 8192, "f32", "fused"
+    elif args.config == 5:
+        args.n, args.dtype, args.engine, args.with_next = 32768, "f32", "fused", True
+    return args
 
 
 def host_cores():
@@ -132,7 +142,7 @@ def main():
     n = args.n
     np_dtype = np.float32 if args.dtype == "f32" else np.float64
     es = np.dtype(np_dtype).itemsize
-    cfg_index = 3  # BASELINE.json configs[3]: N=16384 fp32
+    cfg_index = {0: 3, 2: 1, 3: 2, 4: 3, 5: 4}[args.config]  # seed = BASE_SEED + configs[] index
     rate_host, next_host = synth.GENERATORS[args.dist](n, np_dtype, synth.BASE_SEED + cfg_index)
 
     bounds = fwdist.row_bounds(n, world)
