@@ -459,13 +459,14 @@ __global__ __launch_bounds__(256, MINW) void fused_main_max(float *rate, int row
                                                             int skip_lo, int skip_hi)
 {
     typedef float V4 __attribute__((ext_vector_type(4)));
-    typedef float V2 __attribute__((ext_vector_type(2)));
     // 16 pivots (8 pairs) per LDS stage, two stages resident: while stage s is being folded the
     // operands of stage s+1 are already in flight from L2 into registers.
     constexpr int RI = 8, TI = 128, TJ = 128, HJ = 64, BS = 16, HP = BS / 2;
 
-    __shared__ __attribute__((aligned(16))) V2 sW[2][HP][TJ];   // (W_t[j], W_{t+1}[j])
-    __shared__ __attribute__((aligned(16))) V2 sC[2][HP][TI];   // (C_t[i], C_{t+1}[i])
+    // [buffer][pivot pair][even/odd pivot of the pair][column or row]: a thread's 16-byte reads of
+    // W are 16 bytes apart across the 16 lanes of a read group -> conflict-free
+    __shared__ __attribute__((aligned(16))) float sW[2][HP][2][TJ];
+    __shared__ __attribute__((aligned(16))) float sC[2][HP][2][TI];
 
     const int tid = threadIdx.x;
     const int i_base = blockIdx.y * TI;
@@ -501,10 +502,11 @@ __global__ __launch_bounds__(256, MINW) void fused_main_max(float *rate, int row
         }
     };
     auto commit = [&](int buf) {
-        *reinterpret_cast<V4 *>(&sW[buf][sp][sv * 4]) = V4{pw[0][0], pw[1][0], pw[0][1], pw[1][1]};
-        *reinterpret_cast<V4 *>(&sW[buf][sp][sv * 4 + 2]) = V4{pw[0][2], pw[1][2], pw[0][3], pw[1][3]};
-        *reinterpret_cast<V4 *>(&sC[buf][sp][sv * 4]) = V4{pc[0][0], pc[1][0], pc[0][1], pc[1][1]};
-        *reinterpret_cast<V4 *>(&sC[buf][sp][sv * 4 + 2]) = V4{pc[0][2], pc[1][2], pc[0][3], pc[1][3]};
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            *reinterpret_cast<V4 *>(&sW[buf][sp][u][sv * 4]) = pw[u];
+            *reinterpret_cast<V4 *>(&sC[buf][sp][u][sv * 4]) = pc[u];
+        }
     };
 
     prefetch(0);
@@ -538,21 +540,22 @@ __global__ __launch_bounds__(256, MINW) void fused_main_max(float *rate, int row
         const int np = skip ? 0 : (min(BS, bt - s0) + 1) / 2;
 #pragma unroll UNR
         for (int tp = 0; tp < np; ++tp) {
-            V2 c[RI], wv[2][4];
+            float c[RI][2], wv[2][4][2];          // [..][u]: pivot u of the pair
 #pragma unroll
-            for (int q = 0; q < RI / 2; ++q) {
-                const V4 cv = *reinterpret_cast<const V4 *>(&sC[buf][tp][ti * RI + q * 2]);
-                c[2 * q] = V2{cv[0], cv[1]};
-                c[2 * q + 1] = V2{cv[2], cv[3]};
-            }
+            for (int u = 0; u < 2; ++u) {
 #pragma unroll
-            for (int h = 0; h < 2; ++h)
+                for (int q = 0; q < RI / 4; ++q) {
+                    const V4 cv = *reinterpret_cast<const V4 *>(&sC[buf][tp][u][ti * RI + q * 4]);
 #pragma unroll
-                for (int q = 0; q < 2; ++q) {
-                    const V4 wq = *reinterpret_cast<const V4 *>(&sW[buf][tp][h * HJ + tj * 4 + q * 2]);
-                    wv[h][2 * q] = V2{wq[0], wq[1]};
-                    wv[h][2 * q + 1] = V2{wq[2], wq[3]};
+                    for (int e = 0; e < 4; ++e) c[q * 4 + e][u] = cv[e];
                 }
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    const V4 wq = *reinterpret_cast<const V4 *>(&sW[buf][tp][u][h * HJ + tj * 4]);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) wv[h][e][u] = wq[e];
+                }
+            }
 #pragma unroll
             for (int r = 0; r < RI; ++r) {
                 // All 16 products of this row first, then the 8 folds: a v_max3 never issues right
