@@ -83,3 +83,33 @@ def test_product_never_imports_the_oracle():
                 text = open(os.path.join(dirpath, f)).read()
                 assert not re.search(r"^\s*(from|import)\s+oracle\b", text, flags=re.M), f
                 assert "fworacle" not in text and "fwo_" not in text, f
+
+
+def test_argument_validation_without_touching_a_device():
+    """Bad arguments are rejected with FWX_ERR_INVALID before any device work (the reference's hot
+    path is total: it has no failure modes of its own to mirror, so the ABI defines them)."""
+    L = _lib.lib()
+    one = np.ones((2, 2))
+    assert L.fwx_solve_f64(-1, one.ctypes.data, None, None, None) == _lib.FWX_ERR_INVALID
+    assert L.fwx_solve_f64(0, None, None, None, None) == _lib.FWX_OK            # empty matrix
+    hops = np.ones((2, 2), dtype=np.int32)
+    assert L.fwx_solve_f64(2, one.ctypes.data, None, hops.ctypes.data, None) == _lib.FWX_ERR_INVALID
+    o = _lib.FwxOpts()
+    o.struct_size = 4                                                            # too small
+    assert L.fwx_solve_f64(2, one.ctypes.data, None, None, ctypes.byref(o)) == _lib.FWX_ERR_INVALID
+    o.struct_size = ctypes.sizeof(_lib.FwxOpts)
+    o.k_begin, o.k_end = 3, 2
+    assert L.fwx_solve_f64(2, one.ctypes.data, None, None, ctypes.byref(o)) == _lib.FWX_ERR_INVALID
+    o.k_begin, o.k_end, o.engine = 0, 0, 99
+    assert L.fwx_solve_f64(2, one.ctypes.data, None, None, ctypes.byref(o)) == _lib.FWX_ERR_INVALID
+    s = _lib.FwxSlab()
+    s.n, s.row0, s.rows, s.dtype = 4, 3, 2, _lib.FWX_F32                         # rows past the end
+    p = _lib.FwxPivots()
+    assert L.fwx_dev_relax(ctypes.byref(s), ctypes.byref(p), 1, None, None) == _lib.FWX_ERR_INVALID
+    assert L.fwx_dev_relax(None, None, 1, None, None) == _lib.FWX_ERR_INVALID
+    nxt = np.full((2, 2), -1, dtype=np.int32)
+    assert L.fwx_follow_path(2, nxt.ctypes.data, 0, 5, None, 0) == _lib.FWX_ERR_INVALID
+    assert L.fwx_follow_path(2, nxt.ctypes.data, 0, 1, None, 0) == 0            # no route
+    assert L.fwx_matrix_create(None, 4, 0, 1, 0, -1) == _lib.FWX_ERR_INVALID
+    assert L.fwx_matrix_destroy(None) == _lib.FWX_OK
+    assert b"unknown" in L.fwx_strerror(-999)

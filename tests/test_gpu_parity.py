@@ -604,3 +604,64 @@ def test_subnormal_products_are_not_flushed(dtype):
     r = rate.copy()
     engine.solve(r, engine=engine.FWX_ENGINE_FUSED)  # f32: max form
     assert_bits_equal(r, exp_r, "rate, rates-only fused")
+
+
+def test_concurrent_solves_from_several_host_threads():
+    """The boundary must be callable from any OS thread (GHC `safe` FFI calls migrate between OS
+    threads): three threads solve three different matrices at once, twice each."""
+    import threading
+    results, errors = {}, []
+
+    def work(tid):
+        try:
+            for rep in range(2):
+                kind, n, dt = [("d1", 260, np.float32), ("t1", 200, np.float64), ("d2", 520, np.float32)][tid]
+                rate, nxt, _ = synth.make(kind, n, dt, seed=900 + tid + 10 * rep)
+                er, en = rate.copy(), nxt.copy()
+                oracle.relax(er, en)
+                engine.solve(rate, nxt)
+                results[(tid, rep)] = (np.array_equal(rate.view(np.uint8), er.view(np.uint8))
+                                       and np.array_equal(nxt, en))
+        except Exception as e:  # noqa: BLE001
+            errors.append(repr(e))
+
+    ts = [threading.Thread(target=work, args=(i,)) for i in range(3)]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join()
+    assert not errors, errors
+    assert len(results) == 6 and all(results.values())
+
+
+def test_index_math_beyond_2_to_31_elements():
+    """N = 49152: 2.4e9 entries (9 GiB of f32) -- every offset must be computed in 64 bits.
+    Per-k engine vs the oracle on two pivots; fused engine (both forms) vs per-k on 64 pivots, all
+    compared on the device."""
+    import torch
+    n = 49152
+    dev = torch.device("cuda:0")
+    g = torch.Generator(device=dev).manual_seed(4242)
+    r0 = torch.rand((n, n), generator=g, device=dev, dtype=torch.float32) * 0.95 + 0.05
+    r0.fill_diagonal_(0.0)
+    k0 = n - 70                                        # pivots near the END: the largest offsets
+    host = r0.cpu().numpy()
+    oracle.relax_mt(host, None, k0, k0 + 2)
+    a = r0.clone()
+    engine.dev_solve(a, engine=engine.FWX_ENGINE_PERK, k_begin=k0, k_end=k0 + 2)
+    assert torch.equal(a.cpu(), torch.from_numpy(host))
+    del host
+    engine.dev_solve(a, engine=engine.FWX_ENGINE_PERK, k_begin=k0 + 2, k_end=k0 + 64)
+    b = r0.clone()
+    engine.dev_solve(b, engine=engine.FWX_ENGINE_FUSED, k_begin=k0, k_end=k0 + 64)      # max form
+    assert torch.equal(a, b)
+    b.copy_(r0)
+    nb = torch.arange(n, dtype=torch.int32, device=dev).repeat(n, 1)
+    nb.fill_diagonal_(-1)
+    engine.dev_solve(b, next_t=nb, engine=engine.FWX_ENGINE_FUSED, k_begin=k0, k_end=k0 + 64)
+    assert torch.equal(a, b)
+    # next-hops written at the far end of the matrix are pivots of the slice or the direct edge
+    tail = nb[-8:, :].long()
+    cols = torch.arange(n, device=dev).expand(8, n)
+    ok = (tail == cols) | ((tail >= k0) & (tail < k0 + 64)) | (tail == -1)
+    assert bool(ok.all())
