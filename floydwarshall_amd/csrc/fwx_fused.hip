@@ -76,6 +76,7 @@ __device__ __forceinline__ void lds_barrier()
 // indices are compile-time constants (loops fully unrolled).
 // ------------------------------------------------------------------------------------------------
 constexpr int SB = 16;            // pivots per sub-block = lines per wave
+static_assert(SB == 16, "gather_column is written for 16 lines per wave");
 
 template <typename T> __device__ __forceinline__ T readlane(T v, int lane);
 template <> __device__ __forceinline__ float readlane<float>(float v, int lane)
@@ -88,6 +89,36 @@ template <> __device__ __forceinline__ double readlane<double>(double v, int lan
     const int lo = __builtin_amdgcn_readlane((int)(b & 0xffffffffll), lane);
     const int hi = __builtin_amdgcn_readlane((int)(b >> 32), lane);
     return __builtin_bit_cast(double, ((long long)hi << 32) | (unsigned int)lo);
+}
+
+// dst with lane LANE replaced by the wave-uniform value v (v_writelane_b32; the lane select is an
+// inline constant, so the one constant-bus slot is free for v).
+template <int LANE> __device__ __forceinline__ int writelane_b32(int dst, int v)
+{
+    asm("v_writelane_b32 %0, %1, %2" : "+v"(dst) : "s"(v), "n"(LANE));
+    return dst;
+}
+template <int LANE> __device__ __forceinline__ float writelane(float dst, float v)
+{
+    return __builtin_bit_cast(float, writelane_b32<LANE>(__builtin_bit_cast(int, dst),
+                                                         __builtin_bit_cast(int, v)));
+}
+template <int LANE> __device__ __forceinline__ double writelane(double dst, double v)
+{
+    const long long bv = __builtin_bit_cast(long long, v), bd = __builtin_bit_cast(long long, dst);
+    const int lo = writelane_b32<LANE>((int)(bd & 0xffffffffll), (int)(bv & 0xffffffffll));
+    const int hi = writelane_b32<LANE>((int)(bd >> 32), (int)(bv >> 32));
+    return __builtin_bit_cast(double, ((long long)hi << 32) | (unsigned int)lo);
+}
+// cv[q] = lane `src_lane` of p[q] for q = 0..SB-1, gathered into one register (lane q <- cv[q])
+template <int Q, typename T>
+__device__ __forceinline__ void gather_column(const T (&p)[16], int src_lane, T (&cv)[16], T &cdv)
+{
+    if constexpr (Q < 16) {
+        cv[Q] = readlane<T>(p[Q], src_lane);
+        cdv = writelane<Q>(cdv, cv[Q]);
+        gather_column<Q + 1, T>(p, src_lane, cv, cdv);
+    }
 }
 
 // Row panel: snapshot panel W of the pivot rows.  Every workgroup first evolves the 64 x 64
@@ -120,12 +151,16 @@ __global__ __launch_bounds__(256) void fused_rowpanel(const T *rows, int n, int 
                 T w = p[tq];
                 if (lane == t) w = qnan<T>();      // skip j == k (also hides the stale diagonal)
                 s_line[t][lane] = w;
+                // column t of this wave's rows: 16 independent cross-lane reads first, gathered
+                // into one register (lane q <- row q) and published with ONE LDS store
+                T cv[SB];
+                T cdv = T(0);
+                gather_column<0, T>(p, t, cv, cdv);
+                if (lane < SB) s_cd[t][b * SB + lane] = cdv;
 #pragma unroll
                 for (int q = 0; q < SB; ++q) {
                     if (q == tq) continue;         // skip i == k
-                    const T cval = readlane<T>(p[q], t);
-                    if (lane == 0) s_cd[t][b * SB + q] = cval;
-                    const T cand = cval * w;
+                    const T cand = cv[q] * w;
                     p[q] = (p[q] < cand) ? cand : p[q];
                 }
             }
@@ -137,11 +172,13 @@ __global__ __launch_bounds__(256) void fused_rowpanel(const T *rows, int n, int 
                 const int t = b * SB + tq;
                 if (t >= bt) continue;
                 const T w = s_line[t][lane];
+                T cv[SB];
+                T cdv = T(0);
+                gather_column<0, T>(p, t, cv, cdv);
+                if (lane < SB) s_cd[t][wave * SB + lane] = cdv;
 #pragma unroll
                 for (int q = 0; q < SB; ++q) {
-                    const T cval = readlane<T>(p[q], t);
-                    if (lane == 0) s_cd[t][wave * SB + q] = cval;
-                    const T cand = cval * w;
+                    const T cand = cv[q] * w;
                     p[q] = (p[q] < cand) ? cand : p[q];
                 }
             }
