@@ -64,19 +64,20 @@ __device__ __forceinline__ void lds_barrier()
 }
 
 // ------------------------------------------------------------------------------------------------
-// Panel kernels.  256 threads = 4 waves; the 64 pivots are handled as 4 SUB-BLOCKS of 16.
-// Wave b owns 16 of the 64 panel lines (rows for the row panel, block columns for the column
+// Panel kernels.  512 threads = 8 waves; the 64 pivots are handled as 8 SUB-BLOCKS of 8.
+// Wave b owns 8 of the 64 panel lines (rows for the row panel, block columns for the column
 // panel), one register per line, lanes across the other dimension.  For sub-block b:
-//   serial phase  -- wave b alone steps through its 16 pivots: the pivot line of each step is its
+//   serial phase  -- wave b alone steps through its 8 pivots: the pivot line of each step is its
 //                    OWN register (no LDS, no barrier in the chain); it publishes every time-t
 //                    line to LDS on the way;
-//   apply phase   -- after ONE barrier the other three waves fold those 16 published pivots into
-//                    their own 16 lines, in order.
-// 4 barriers per panel instead of 64, and no memory latency on the serial chain.  All register
+//   apply phase   -- after ONE barrier the later waves fold those 8 published pivots into their
+//                    own 8 lines, in order.
+// The serial chain is 64*SB line-updates long, so short sub-blocks (and more waves) shorten it;
+// 8 barriers per panel instead of 64, and no memory latency on the serial chain.  All register
 // indices are compile-time constants (loops fully unrolled).
 // ------------------------------------------------------------------------------------------------
-constexpr int SB = 16;            // pivots per sub-block = lines per wave
-static_assert(SB == 16, "gather_column is written for 16 lines per wave");
+constexpr int SB = 8;             // pivots per sub-block = lines per wave
+constexpr int PANEL_THREADS = (B / SB) * 64;   // one wave per sub-block: 8 waves
 
 template <typename T> __device__ __forceinline__ T readlane(T v, int lane);
 template <> __device__ __forceinline__ float readlane<float>(float v, int lane)
@@ -112,9 +113,9 @@ template <int LANE> __device__ __forceinline__ double writelane(double dst, doub
 }
 // cv[q] = lane `src_lane` of p[q] for q = 0..SB-1, gathered into one register (lane q <- cv[q])
 template <int Q, typename T>
-__device__ __forceinline__ void gather_column(const T (&p)[16], int src_lane, T (&cv)[16], T &cdv)
+__device__ __forceinline__ void gather_column(const T (&p)[SB], int src_lane, T (&cv)[SB], T &cdv)
 {
-    if constexpr (Q < 16) {
+    if constexpr (Q < SB) {
         cv[Q] = readlane<T>(p[Q], src_lane);
         cdv = writelane<Q>(cdv, cv[Q]);
         gather_column<Q + 1, T>(p, src_lane, cv, cdv);
@@ -126,7 +127,7 @@ __device__ __forceinline__ void gather_column(const T (&p)[16], int src_lane, T 
 // redundant across workgroups, but it removes a kernel boundary and a single-workgroup launch from
 // the critical path -- and then its own strip of 64 columns.
 template <typename T>
-__global__ __launch_bounds__(256) void fused_rowpanel(const T *rows, int n, int k0, int bt,
+__global__ __launch_bounds__(PANEL_THREADS) void fused_rowpanel(const T *rows, int n, int k0, int bt,
                                                       T *w_out)
 {
     __shared__ T s_line[B][64];                    // published pivot rows (time-t), per phase
@@ -240,7 +241,7 @@ __global__ __launch_bounds__(256) void fused_rowpanel(const T *rows, int n, int 
 // Column panel: time-t snapshots of the 64 pivot columns for 64 rows per workgroup (lanes = rows).
 // Needs only the block columns of W (Wd[t][c] = W[t][k0+c]), so it runs on every rank.
 template <typename T, bool HAS_NEXT>
-__global__ __launch_bounds__(256) void fused_colpanel(const T *rate, const int32_t *next, int rows,
+__global__ __launch_bounds__(PANEL_THREADS) void fused_colpanel(const T *rate, const int32_t *next, int rows,
                                                       int n, int row0, int k0, int bt, const T *w,
                                                       T *ct, int32_t *cnt, int ct_ld)
 {
@@ -254,7 +255,7 @@ __global__ __launch_bounds__(256) void fused_colpanel(const T *rate, const int32
     const int ic = valid ? il : rows - 1;
     const int gi = row0 + ic;
 
-    for (int idx = threadIdx.x; idx < B * B; idx += 256) {
+    for (int idx = threadIdx.x; idx < B * B; idx += PANEL_THREADS) {
         const int t = idx / B, c = idx % B;
         s_wd[t][c] = (t < bt && c < bt) ? w[(size_t)t * n + k0 + c] : qnan<T>();
     }
@@ -702,7 +703,7 @@ template <typename T> hipError_t launch_fused_colpanel(const FusedArgs<T> &a, hi
     if (a.rows <= 0 || a.n <= 0 || a.bt <= 0) return hipSuccess;
     hipError_t e = check_fused_args(a);
     if (e != hipSuccess) return e;
-    const dim3 cgrid((unsigned)((a.rows + 63) / 64)), block(256);
+    const dim3 cgrid((unsigned)((a.rows + 63) / 64)), block(PANEL_THREADS);
     if (a.next)
         hipLaunchKernelGGL((fused_colpanel<T, true>), cgrid, block, 0, s, a.rate, a.next, a.rows,
                            a.n, a.row0, a.k0, a.bt, a.w, a.ct, a.cnt, a.ct_ld);
@@ -766,7 +767,7 @@ hipError_t launch_fused_panel(const T *rows_base, int n, int k0, int bt, T *w, T
     (void)diag_ws;   // kept in the ABI: the diagonal block is now evolved inside fused_rowpanel
     if (n <= 0 || bt <= 0) return hipSuccess;
     if (bt > B) return hipErrorInvalidValue;
-    hipLaunchKernelGGL((fused_rowpanel<T>), dim3((unsigned)((n + 63) / 64)), dim3(256), 0, s,
+    hipLaunchKernelGGL((fused_rowpanel<T>), dim3((unsigned)((n + 63) / 64)), dim3(PANEL_THREADS), 0, s,
                        rows_base, n, k0, bt, w);
     return hipGetLastError();
 }
