@@ -64,20 +64,21 @@ __device__ __forceinline__ void lds_barrier()
 }
 
 // ------------------------------------------------------------------------------------------------
-// Panel kernels.  512 threads = 8 waves; the 64 pivots are handled as 8 SUB-BLOCKS of 8.
-// Wave b owns 8 of the 64 panel lines (rows for the row panel, block columns for the column
+// Panel kernels.  One wave per SUB-BLOCK of SB = 4 pivots: 16 waves = 1024 threads per workgroup.
+// Wave b owns SB of the 64 panel lines (rows for the row panel, block columns for the column
 // panel), one register per line, lanes across the other dimension.  For sub-block b:
-//   serial phase  -- wave b alone steps through its 8 pivots: the pivot line of each step is its
+//   serial phase  -- wave b alone steps through its SB pivots: the pivot line of each step is its
 //                    OWN register (no LDS, no barrier in the chain); it publishes every time-t
 //                    line to LDS on the way;
-//   apply phase   -- after ONE barrier the later waves fold those 8 published pivots into their
-//                    own 8 lines, in order.
+//   apply phase   -- after ONE barrier the later waves fold those SB published pivots into their
+//                    own SB lines, in order.
 // The serial chain is 64*SB line-updates long, so short sub-blocks (and more waves) shorten it;
-// 8 barriers per panel instead of 64, and no memory latency on the serial chain.  All register
+// measured at N = 1024 f32: SB = 16 / 8 / 4 -> 2.70 / 2.16 / 2.02 ms per solve.  B/SB barriers per
+// panel instead of 64, and no memory latency on the serial chain.  All register
 // indices are compile-time constants (loops fully unrolled).
 // ------------------------------------------------------------------------------------------------
-constexpr int SB = 8;             // pivots per sub-block = lines per wave
-constexpr int PANEL_THREADS = (B / SB) * 64;   // one wave per sub-block: 8 waves
+constexpr int SB = 4;             // pivots per sub-block = lines per wave
+constexpr int PANEL_THREADS = (B / SB) * 64;   // one wave per sub-block
 
 template <typename T> __device__ __forceinline__ T readlane(T v, int lane);
 template <> __device__ __forceinline__ float readlane<float>(float v, int lane)
