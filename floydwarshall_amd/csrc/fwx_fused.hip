@@ -324,7 +324,7 @@ __global__ __launch_bounds__(PANEL_THREADS) void fused_colpanel(const T *rate, c
 // workgroup at 32 KiB of LDS and <= 128 VGPRs: 4 workgroups = 16 waves per CU.  The loop is pure
 // VALU (v_pk_mul_f32 + v_cmp + v_cndmask per pair of relaxations) and one wave alone issues at
 // half rate on a SIMD-32, so occupancy, not bytes, is what this kernel needs.
-template <typename T, bool HAS_NEXT, bool COUNT, int BS, int MINW, int NH>
+template <typename T, bool HAS_NEXT, bool COUNT, int BS, int MINW, int NH, int RI>
 __global__ __launch_bounds__(256, MINW) void fused_main(T *rate, int32_t *next, int rows, int n,
                                                         int row0, int k0, int bt, const T *w,
                                                         const T *ct, const int32_t *cnt, int ct_ld,
@@ -334,7 +334,7 @@ __global__ __launch_bounds__(256, MINW) void fused_main(T *rate, int32_t *next, 
     using V = typename Vec16<T>::type;
     using IV = typename IVec<Vec16<T>::W>::type;
     constexpr int VW = Vec16<T>::W;
-    constexpr int RI = 8, TI = 16 * RI;       // 128 rows
+    constexpr int TI = 16 * RI;               // RI = 8: 128 rows; RI = 4: 64 (small matrices)
     constexpr int TJ = 16 * NH * VW;          // NH = 2: 128 (f32) / 64 (f64) columns; NH = 1: half
     constexpr int HJ = TJ / NH;               // NH 16-byte vectors per thread and row
 
@@ -491,7 +491,7 @@ __global__ __launch_bounds__(256, MINW) void fused_main(T *rate, int32_t *next, 
 // (two v_mul_f32 + one v_max3_f32) instead of 16 for the compare form.  The caller must have verified the domain
 // (fwx_dev_check_nonneg); the next-hop variant needs the compare and stays on fused_main.
 // ------------------------------------------------------------------------------------------------
-template <int MINW, int UNR>
+template <int MINW, int UNR, int RI, int NH>
 __global__ __launch_bounds__(256, MINW) void fused_main_max(float *rate, int rows, int n, int row0,
                                                             int k0, int bt, const float *w,
                                                             const float *ct, int ct_ld, int ct_vec,
@@ -500,7 +500,7 @@ __global__ __launch_bounds__(256, MINW) void fused_main_max(float *rate, int row
     typedef float V4 __attribute__((ext_vector_type(4)));
     // 16 pivots (8 pairs) per LDS stage, two stages resident: while stage s is being folded the
     // operands of stage s+1 are already in flight from L2 into registers.
-    constexpr int RI = 8, TI = 128, TJ = 128, HJ = 64, BS = 16, HP = BS / 2;
+    constexpr int TI = 16 * RI, TJ = 64 * NH, HJ = 64, BS = 16, HP = BS / 2;
 
     // [buffer][pivot pair][even/odd pivot of the pair][column or row]: a thread's 16-byte reads of
     // W are 16 bytes apart across the 16 lanes of a read group -> conflict-free
@@ -519,7 +519,9 @@ __global__ __launch_bounds__(256, MINW) void fused_main_max(float *rate, int row
     const int sp = tid >> 5, sv = tid & 31;
     const int sj = j_base + sv * 4;              // W columns
     const int si = i_base + sv * 4;              // C rows
-    const bool sj_ok = sj < n;                   // n % 4 == 0: whole vector in or out
+    const bool sw_role = sv * 4 < TJ;            // small tiles: only some threads stage
+    const bool sc_role = sv * 4 < TI;
+    const bool sj_ok = sj < n && sw_role;        // n % 4 == 0: whole vector in or out
     V4 pw[2], pc[2];
     auto prefetch = [&](int s0) {
 #pragma unroll
@@ -528,7 +530,9 @@ __global__ __launch_bounds__(256, MINW) void fused_main_max(float *rate, int row
             const bool t_ok = t < bt;
             pw[u] = (t_ok && sj_ok) ? *reinterpret_cast<const V4 *>(w + (size_t)t * n + sj)
                                     : V4{nanv, nanv, nanv, nanv};
-            if (t_ok && ct_vec && si + 4 <= rows) {
+            if (!sc_role) {
+                pc[u] = V4{nanv, nanv, nanv, nanv};
+            } else if (t_ok && ct_vec && si + 4 <= rows) {
                 pc[u] = *reinterpret_cast<const V4 *>(ct + (size_t)t * ct_ld + si);
             } else {
 #pragma unroll
@@ -543,27 +547,27 @@ __global__ __launch_bounds__(256, MINW) void fused_main_max(float *rate, int row
     auto commit = [&](int buf) {
 #pragma unroll
         for (int u = 0; u < 2; ++u) {
-            *reinterpret_cast<V4 *>(&sW[buf][sp][u][sv * 4]) = pw[u];
-            *reinterpret_cast<V4 *>(&sC[buf][sp][u][sv * 4]) = pc[u];
+            if (sw_role) *reinterpret_cast<V4 *>(&sW[buf][sp][u][sv * 4]) = pw[u];
+            if (sc_role) *reinterpret_cast<V4 *>(&sC[buf][sp][u][sv * 4]) = pc[u];
         }
     };
 
     prefetch(0);
 
-    int jcol[2];
-    bool jok[2];
+    int jcol[NH];
+    bool jok[NH];
 #pragma unroll
-    for (int h = 0; h < 2; ++h) {
+    for (int h = 0; h < NH; ++h) {
         const int j = j_base + h * HJ + tj * 4;
         jok[h] = j < n;
         jcol[h] = jok[h] ? j : n - 4;
     }
-    V4 x[RI][2];
+    V4 x[RI][NH];
 #pragma unroll
     for (int r = 0; r < RI; ++r) {
         const int i = min(i0 + r, rows - 1);
 #pragma unroll
-        for (int h = 0; h < 2; ++h)
+        for (int h = 0; h < NH; ++h)
             x[r][h] = *reinterpret_cast<const V4 *>(rate + (size_t)i * n + jcol[h]);
     }
     const int gi_lo = row0 + i_base, gj_lo = j_base;
@@ -579,7 +583,7 @@ __global__ __launch_bounds__(256, MINW) void fused_main_max(float *rate, int row
         const int np = skip ? 0 : (min(BS, bt - s0) + 1) / 2;
 #pragma unroll UNR
         for (int tp = 0; tp < np; ++tp) {
-            float c[RI][2], wv[2][4][2];          // [..][u]: pivot u of the pair
+            float c[RI][2], wv[NH][4][2];          // [..][u]: pivot u of the pair
 #pragma unroll
             for (int u = 0; u < 2; ++u) {
 #pragma unroll
@@ -589,7 +593,7 @@ __global__ __launch_bounds__(256, MINW) void fused_main_max(float *rate, int row
                     for (int e = 0; e < 4; ++e) c[q * 4 + e][u] = cv[e];
                 }
 #pragma unroll
-                for (int h = 0; h < 2; ++h) {
+                for (int h = 0; h < NH; ++h) {
                     const V4 wq = *reinterpret_cast<const V4 *>(&sW[buf][tp][u][h * HJ + tj * 4]);
 #pragma unroll
                     for (int e = 0; e < 4; ++e) wv[h][e][u] = wq[e];
@@ -600,16 +604,16 @@ __global__ __launch_bounds__(256, MINW) void fused_main_max(float *rate, int row
                 // All 16 products of this row first, then the 8 folds: a v_max3 never issues right
                 // behind the multiplies it depends on.  Two plain v_mul_f32 rather than one
                 // v_pk_mul_f32: same issue cycles per pair, no register-pair shuffles (measured).
-                float p0[2][4], p1[2][4];
+                float p0[NH][4], p1[NH][4];
 #pragma unroll
-                for (int h = 0; h < 2; ++h)
+                for (int h = 0; h < NH; ++h)
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
                         asm("v_mul_f32 %0, %1, %2" : "=v"(p0[h][e]) : "v"(c[r][0]), "v"(wv[h][e][0]));
                         asm("v_mul_f32 %0, %1, %2" : "=v"(p1[h][e]) : "v"(c[r][1]), "v"(wv[h][e][1]));
                     }
 #pragma unroll
-                for (int h = 0; h < 2; ++h)
+                for (int h = 0; h < NH; ++h)
 #pragma unroll
                     for (int e = 0; e < 4; ++e)
                         x[r][h][e] = __builtin_fmaxf(__builtin_fmaxf(x[r][h][e], p0[h][e]), p1[h][e]);
@@ -626,7 +630,7 @@ __global__ __launch_bounds__(256, MINW) void fused_main_max(float *rate, int row
         const int i = i0 + r;
         if (i >= rows || skip) continue;
 #pragma unroll
-        for (int h = 0; h < 2; ++h) {
+        for (int h = 0; h < NH; ++h) {
             if (!jok[h]) continue;
             const size_t off = (size_t)i * n + jcol[h];
             if (diag_tile) {
@@ -665,14 +669,27 @@ template <> struct FusedCfg<float, true> { static constexpr int BS = 16, MINW = 
 template <> struct FusedCfg<double, false> { static constexpr int BS = 32, MINW = 2, NH = 2; };
 template <> struct FusedCfg<double, true> { static constexpr int BS = 16, MINW = 2, NH = 1; };
 
+// Below ~512 full-size tiles the launch is bound by the latency of ONE tile (64 pivots folded into
+// 64 entries per thread); 64 x 64 tiles give 4x the workgroups and a quarter of the serial work.
+static bool small_tiles(int n, int rows)
+{
+    return (long long)((n + 127) / 128) * ((rows + 127) / 128) < 512;
+}
+
 // f32, rates only, no update counting, domain verified by the caller: the max3 kernel.
 static bool launch_max_form(const FusedArgs<float> &a, dim3 grid, dim3 block, int skip_lo,
                             int skip_hi, hipStream_t s)
 {
     if (!a.nonneg || a.next || a.updates) return false;
     const int ct_vec = ((uintptr_t)a.ct % 16 == 0 && a.ct_ld % 4 == 0) ? 1 : 0;
-    hipLaunchKernelGGL((fused_main_max<3, 1>), grid, block, 0, s, a.rate, a.rows, a.n, a.row0, a.k0,
-                       a.bt, a.w, a.ct, a.ct_ld, ct_vec, skip_lo, skip_hi);
+    if (small_tiles(a.n, a.rows)) {
+        const dim3 g((unsigned)((a.n + 63) / 64), (unsigned)((a.rows + 63) / 64));
+        hipLaunchKernelGGL((fused_main_max<4, 1, 4, 1>), g, block, 0, s, a.rate, a.rows, a.n, a.row0,
+                           a.k0, a.bt, a.w, a.ct, a.ct_ld, ct_vec, skip_lo, skip_hi);
+    } else {
+        hipLaunchKernelGGL((fused_main_max<3, 1, 8, 2>), grid, block, 0, s, a.rate, a.rows, a.n,
+                           a.row0, a.k0, a.bt, a.w, a.ct, a.ct_ld, ct_vec, skip_lo, skip_hi);
+    }
     return true;
 }
 static bool launch_max_form(const FusedArgs<double> &, dim3, dim3, int, int, hipStream_t)
@@ -737,14 +754,23 @@ hipError_t launch_fused_main(const FusedArgs<T> &full, int r_lo, int r_hi, hipSt
     a.ct = full.ct + r_lo;
     a.cnt = full.cnt ? full.cnt + r_lo : nullptr;
     const dim3 block(256);
-    const int tj = 16 * VW * (a.next ? FusedCfg<T, true>::NH : FusedCfg<T, false>::NH);
-    const dim3 grid((unsigned)((a.n + tj - 1) / tj), (unsigned)((a.rows + TI - 1) / TI));
+    const bool small = small_tiles(a.n, a.rows);
+    const int tj = 16 * VW * (small ? 1 : (a.next ? FusedCfg<T, true>::NH : FusedCfg<T, false>::NH));
+    const int ti = small ? 64 : TI;
+    const dim3 grid((unsigned)((a.n + tj - 1) / tj), (unsigned)((a.rows + ti - 1) / ti));
     if (launch_max_form(a, grid, block, skip_lo, skip_hi, s)) return hipGetLastError();
 #define FWX_FUSED_LAUNCH(HN, CN)                                                                   \
-    hipLaunchKernelGGL((fused_main<T, HN, CN, FusedCfg<T, HN>::BS, FusedCfg<T, HN>::MINW,          \
-                                   FusedCfg<T, HN>::NH>),                                          \
-                       grid, block, 0, s, a.rate, a.next, a.rows, a.n, a.row0, a.k0, a.bt, a.w,    \
-                       a.ct, a.cnt, a.ct_ld, skip_lo, skip_hi, a.updates)
+    do {                                                                                           \
+        if (small)                                                                                 \
+            hipLaunchKernelGGL((fused_main<T, HN, CN, 16, 2, 1, 4>), grid, block, 0, s, a.rate,    \
+                               a.next, a.rows, a.n, a.row0, a.k0, a.bt, a.w, a.ct, a.cnt, a.ct_ld, \
+                               skip_lo, skip_hi, a.updates);                                       \
+        else                                                                                       \
+            hipLaunchKernelGGL((fused_main<T, HN, CN, FusedCfg<T, HN>::BS, FusedCfg<T, HN>::MINW,  \
+                                           FusedCfg<T, HN>::NH, 8>),                               \
+                               grid, block, 0, s, a.rate, a.next, a.rows, a.n, a.row0, a.k0, a.bt, \
+                               a.w, a.ct, a.cnt, a.ct_ld, skip_lo, skip_hi, a.updates);            \
+    } while (0)
     if (a.next) {
         if (a.updates) FWX_FUSED_LAUNCH(true, true); else FWX_FUSED_LAUNCH(true, false);
     } else {
