@@ -230,7 +230,7 @@ template <typename T> bool pick_fused(int engine, int n, const void *rate, const
 {
     if (engine == FWX_ENGINE_PERK) return false;
     if (!fused_ok<T>(n, rate, hops)) return false;
-    return engine == FWX_ENGINE_FUSED || n >= 512;
+    return engine == FWX_ENGINE_FUSED || n >= 256;   // tools/measure_small.py: fused wins from 256
 }
 
 int sum_updates(unsigned long long *d_updates, uint64_t *out, hipStream_t s)

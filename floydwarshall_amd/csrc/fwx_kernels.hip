@@ -205,40 +205,59 @@ __global__ __launch_bounds__(256) void small_solve(T *rate, int32_t *next, int32
                                                    int k_begin, int k_end,
                                                    unsigned long long *updates)
 {
-    constexpr int M = FWX_SMALL_N;
-    __shared__ T R[M][M + 1];
+    constexpr int M = FWX_SMALL_N;            // the matrix is padded to 64 x 64 with NaN
+    constexpr int E = M * M / 256;            // 16 entries per thread: column c = tid % 64 fixed,
+    __shared__ T R[M][M + 1];                 // rows r = tid / 64 + 4 m  (no divisions anywhere)
     __shared__ int32_t NX[HAS_NEXT ? M : 1][M + 1];
     __shared__ int32_t HP[HAS_HOPS ? M : 1][M + 1];
     __shared__ unsigned int s_cnt;
     const int tid = threadIdx.x;
+    const int c = tid & 63, r0 = tid >> 6;
     if (tid == 0) s_cnt = 0;
-    for (int idx = tid; idx < n * n; idx += 256) {
-        const int r = idx / n, c = idx % n;
-        R[r][c] = rate[idx];
-        if (HAS_NEXT) NX[r][c] = next[idx];
-        if (HAS_HOPS) HP[r][c] = hops[idx];
+
+    T x[E];
+    int32_t nx[HAS_NEXT ? E : 1], hp[HAS_HOPS ? E : 1];
+#pragma unroll
+    for (int m = 0; m < E; ++m) {
+        const int r = r0 + 4 * m;
+        const bool in = r < n && c < n;
+        x[m] = in ? rate[(size_t)r * n + c] : quiet_nan<T>();
+        R[r][c] = x[m];
+        if (HAS_NEXT) { nx[m] = in ? next[(size_t)r * n + c] : -1; NX[r][c] = nx[m]; }
+        if (HAS_HOPS) { hp[m] = in ? hops[(size_t)r * n + c] : 0; HP[r][c] = hp[m]; }
     }
     __syncthreads();
+
     unsigned int mine = 0;
     for (int k = k_begin; k < k_end; ++k) {
-        for (int idx = tid; idx < n * n; idx += 256) {
-            const int r = idx / n, c = idx % n;
-            if (r == k || c == k || r == c) continue;      // Algorithms.hs:50, :54
-            const T cand = R[r][k] * R[k][c];              // :61
-            if (R[r][c] < cand) {                          // :55
+        // row k and column k are fixed points of step k: every operand below is a step-start value
+        T rkc = R[k][c];
+        const int32_t hkc = HAS_HOPS ? HP[k][c] : 0;
+        if (c == k) rkc = quiet_nan<T>();                     // skip j == k
+#pragma unroll
+        for (int m = 0; m < E; ++m) {
+            const int r = r0 + 4 * m;
+            T rik = R[r][k];                                  // wave-uniform: LDS broadcast
+            if (r == k || r == c) rik = quiet_nan<T>();       // skip i == k and j == i
+            const T cand = rik * rkc;                         // Algorithms.hs:61
+            if (x[m] < cand) {                                // :55
+                x[m] = cand;
                 R[r][c] = cand;
-                if (HAS_NEXT) NX[r][c] = NX[r][k];
-                if (HAS_HOPS) HP[r][c] = HP[r][k] + HP[k][c];
+                if (HAS_NEXT) { nx[m] = NX[r][k]; NX[r][c] = nx[m]; }
+                if (HAS_HOPS) { hp[m] = HP[r][k] + hkc; HP[r][c] = hp[m]; }
                 ++mine;
             }
         }
         __syncthreads();
     }
-    for (int idx = tid; idx < n * n; idx += 256) {
-        const int r = idx / n, c = idx % n;
-        rate[idx] = R[r][c];
-        if (HAS_NEXT) next[idx] = NX[r][c];
-        if (HAS_HOPS) hops[idx] = HP[r][c];
+#pragma unroll
+    for (int m = 0; m < E; ++m) {
+        const int r = r0 + 4 * m;
+        if (r < n && c < n) {
+            rate[(size_t)r * n + c] = x[m];
+            if (HAS_NEXT) next[(size_t)r * n + c] = nx[m];
+            if (HAS_HOPS) hops[(size_t)r * n + c] = hp[m];
+        }
     }
     if (updates) {
         if (mine) atomicAdd(&s_cnt, mine);
