@@ -90,11 +90,11 @@ int read_opts(const fwx_opts *o, int n, Opts &out)
 template <typename T>
 int relax_range(T *rate, int32_t *next, int32_t *hops, int rows, int n, int row0, const T *prow0,
                 const int32_t *phops0, int64_t stride, int k_begin, int k_end, int serpentine,
-                unsigned long long *d_updates, hipStream_t s)
+                unsigned long long *d_updates, hipStream_t s, fwx::PathLog plog = fwx::PathLog())
 {
     fwx::RelaxArgs<T> a;
     a.rate = rate; a.next = next; a.hops = hops;
-    a.rows = rows; a.n = n; a.row0 = row0; a.updates = d_updates;
+    a.rows = rows; a.n = n; a.row0 = row0; a.updates = d_updates; a.plog = plog;
     for (int k = k_begin; k < k_end; ++k) {
         a.prow = prow0 + (int64_t)(k - k_begin) * stride;
         a.phops = phops0 ? phops0 + (int64_t)(k - k_begin) * stride : nullptr;
@@ -286,7 +286,8 @@ int solve_host(int32_t n, T *rate, int32_t *next, int32_t *hops, const fwx_opts 
     if (op.engine == FWX_ENGINE_FUSED && !fused_ok<T>(n, dr, dh)) return FWX_ERR_UNSUPPORTED;
     if (op.engine == FWX_ENGINE_AUTO && n <= FWX_SMALL_N) {
         // the reference's own regime: the whole solve in one single-workgroup launch
-        FWX_HIP(fwx::launch_small_solve<T>(dr, (int32_t *)d_next.p, dh, n, op.k_begin, op.k_end, upd, s));
+        FWX_HIP(fwx::launch_small_solve<T>(dr, (int32_t *)d_next.p, dh, n, op.k_begin, op.k_end, upd,
+                                           fwx::PathLog(), s));
     } else if (pick_fused<T>(op.engine, n, dr, dh)) {
         DevBuf d_ws;
         if ((rc = d_ws.alloc(fused_ws_bytes(n, sizeof(T))))) return rc;
@@ -380,7 +381,7 @@ int panel_impl(const fwx_slab *b, T *w, int32_t *w_hops, unsigned long long *d_u
     T *rows = (T *)b->rate;
     fwx::RelaxArgs<T> a;
     a.rate = rows; a.next = b->next; a.hops = b->hops;
-    a.rows = B; a.n = n; a.row0 = k0; a.updates = d_updates; a.flip = 0;
+    a.rows = B; a.n = n; a.row0 = k0; a.updates = d_updates; a.flip = 0; a.plog = fwx::PathLog();
     for (int t = 0; t < B; ++t) {
         // Time-k snapshot of pivot row k = k0+t: every pivot < k has been applied, pivot k
         // leaves row k unchanged (Algorithms.hs:50), later pivots will change it.
@@ -402,6 +403,9 @@ struct fwx_matrix {
     void *rate;
     int32_t *next, *hops, *scratch;
     unsigned long long *upd;
+    fwx::PathLog plog;     // update log for exact `_path` lists (head == nullptr: disabled)
+    int32_t *next0;        // the uploaded (time-0) next-hop matrix, kept while logging
+    int32_t *walk;         // scratch of the exact-path walk (stack + output)
 };
 
 namespace {
@@ -410,12 +414,15 @@ int matrix_solve_typed(fwx_matrix *m, const Opts &op, unsigned long long *upd, h
 {
     const int n = m->n;
     T *r = (T *)m->rate;
-    if (op.engine == FWX_ENGINE_FUSED && !fused_ok<T>(n, r, m->hops)) return FWX_ERR_UNSUPPORTED;
+    const bool logging = m->plog.head != nullptr;
+    if (op.engine == FWX_ENGINE_FUSED && (logging || !fused_ok<T>(n, r, m->hops)))
+        return FWX_ERR_UNSUPPORTED;                 // the update log rides on per-k / small_solve
     if (op.engine == FWX_ENGINE_AUTO && n <= FWX_SMALL_N) {
-        FWX_HIP(fwx::launch_small_solve<T>(r, m->next, m->hops, n, op.k_begin, op.k_end, upd, s));
+        FWX_HIP(fwx::launch_small_solve<T>(r, m->next, m->hops, n, op.k_begin, op.k_end, upd,
+                                           m->plog, s));
         return FWX_OK;
     }
-    if (pick_fused<T>(op.engine, n, r, m->hops)) {
+    if (!logging && pick_fused<T>(op.engine, n, r, m->hops)) {
         DevBuf ws;
         int rc = ws.alloc(fused_ws_bytes(n, sizeof(T)));
         if (rc) return rc;
@@ -426,7 +433,38 @@ int matrix_solve_typed(fwx_matrix *m, const Opts &op, unsigned long long *upd, h
     }
     return relax_range<T>(r, m->next, m->hops, n, n, 0, r + (size_t)op.k_begin * n,
                           m->hops ? m->hops + (size_t)op.k_begin * n : nullptr, n, op.k_begin,
-                          op.k_end, op.serpentine, upd, s);
+                          op.k_end, op.serpentine, upd, s, m->plog);
+}
+
+// The reference's `_path` list of entry (src,dst), rebuilt from the update log exactly as
+// Algorithms.hs:55 built it: the newest update of (a,b) made by a pivot k < T splits the path into
+// path_k(a,k) ++ path_k(k,b); an entry with no update before T still has its buildMatrix path
+// ([b] if next0[a][b] >= 0, else []).  Iterative, one thread; stack and output live in `walk`.
+__global__ void exact_path_kernel(fwx::PathLog plog, const int32_t *next0, int n, int src, int dst,
+                                  int32_t *walk, int cap, int32_t *len_out)
+{
+    int32_t *out = walk;                 // cap entries
+    int32_t *stack = walk + cap;         // 3 * cap entries: (a, b, T) triples
+    int sp = 0, len = 0;
+    stack[0] = src; stack[1] = dst; stack[2] = n; sp = 1;
+    while (sp > 0) {
+        --sp;
+        const int a = stack[3 * sp], b = stack[3 * sp + 1], T = stack[3 * sp + 2];
+        int rec = plog.head[(size_t)a * n + b];
+        while (rec >= 0 && plog.rec_k[rec] >= T) rec = plog.rec_prev[rec];
+        if (rec < 0) {
+            if (next0[(size_t)a * n + b] >= 0) {
+                if (len >= cap) { *len_out = FWX_ERR_CAPACITY; return; }
+                out[len++] = b;
+            }
+        } else {
+            const int k = plog.rec_k[rec];
+            if (sp + 2 > cap) { *len_out = FWX_ERR_CAPACITY; return; }
+            stack[3 * sp] = k; stack[3 * sp + 1] = b; stack[3 * sp + 2] = k; ++sp;   // second half
+            stack[3 * sp] = a; stack[3 * sp + 1] = k; stack[3 * sp + 2] = k; ++sp;   // first half
+        }
+    }
+    *len_out = len;
 }
 }  // namespace
 
@@ -524,6 +562,12 @@ int fwx_matrix_destroy(fwx_matrix *m)
     if (m->hops) (void)hipFree(m->hops);
     if (m->scratch) (void)hipFree(m->scratch);
     if (m->upd) (void)hipFree(m->upd);
+    if (m->plog.head) (void)hipFree(m->plog.head);
+    if (m->plog.rec_k) (void)hipFree(m->plog.rec_k);
+    if (m->plog.rec_prev) (void)hipFree(m->plog.rec_prev);
+    if (m->plog.count) (void)hipFree(m->plog.count);
+    if (m->next0) (void)hipFree(m->next0);
+    if (m->walk) (void)hipFree(m->walk);
     delete m;
     return FWX_OK;
 }
@@ -540,7 +584,81 @@ int fwx_matrix_upload(fwx_matrix *m, const void *rate, const int32_t *next, cons
     FWX_HIP(hipMemcpy(m->rate, rate, nn * es, hipMemcpyHostToDevice));
     if (m->next) FWX_HIP(hipMemcpy(m->next, next, nn * 4, hipMemcpyHostToDevice));
     if (m->hops) FWX_HIP(hipMemcpy(m->hops, hops, nn * 4, hipMemcpyHostToDevice));
+    if (m->plog.head) {   // a fresh matrix starts a fresh log
+        FWX_HIP(hipMemcpy(m->next0, next, nn * 4, hipMemcpyHostToDevice));
+        FWX_HIP(hipMemset(m->plog.head, 0xFF, nn * 4));
+        FWX_HIP(hipMemset(m->plog.count, 0, sizeof(unsigned long long)));
+    }
     return FWX_OK;
+}
+
+int fwx_matrix_enable_path_log(fwx_matrix *m, uint64_t capacity_records)
+{
+    if (!m || !m->next || m->plog.head || capacity_records > 0x7fffffffull) return FWX_ERR_INVALID;
+    if (m->n == 0) return FWX_OK;
+    DeviceGuard g;
+    int rc = g.enter(m->device);
+    if (rc) return rc;
+    const size_t nn = (size_t)m->n * (size_t)m->n;
+    const size_t cap = capacity_records ? capacity_records : 1;
+    FWX_HIP(hipMalloc((void **)&m->plog.head, nn * 4));
+    FWX_HIP(hipMalloc((void **)&m->plog.rec_k, cap * 4));
+    FWX_HIP(hipMalloc((void **)&m->plog.rec_prev, cap * 4));
+    FWX_HIP(hipMalloc((void **)&m->plog.count, sizeof(unsigned long long)));
+    FWX_HIP(hipMalloc((void **)&m->next0, nn * 4));
+    m->plog.capacity = capacity_records;
+    FWX_HIP(hipMemset(m->plog.head, 0xFF, nn * 4));
+    FWX_HIP(hipMemset(m->plog.count, 0, sizeof(unsigned long long)));
+    FWX_HIP(hipMemcpy(m->next0, m->next, nn * 4, hipMemcpyDeviceToDevice));
+    return FWX_OK;
+}
+
+int fwx_matrix_path_log_count(fwx_matrix *m, uint64_t *count_out)
+{
+    if (!m || !count_out) return FWX_ERR_INVALID;
+    *count_out = 0;
+    if (!m->plog.head) return FWX_OK;
+    DeviceGuard g;
+    int rc = g.enter(m->device);
+    if (rc) return rc;
+    unsigned long long c = 0;
+    FWX_HIP(hipMemcpy(&c, m->plog.count, sizeof(c), hipMemcpyDeviceToHost));
+    *count_out = c;
+    return FWX_OK;
+}
+
+int fwx_matrix_query_exact(fwx_matrix *m, int32_t src, int32_t dst, double *rate_out,
+                           int32_t *path_out, int32_t cap)
+{
+    if (!m || src < 0 || dst < 0 || src >= m->n || dst >= m->n || cap <= 0 || !path_out)
+        return FWX_ERR_INVALID;
+    if (!m->plog.head) return FWX_ERR_INVALID;
+    DeviceGuard g;
+    int rc = g.enter(m->device);
+    if (rc) return rc;
+    unsigned long long c = 0;
+    FWX_HIP(hipMemcpy(&c, m->plog.count, sizeof(c), hipMemcpyDeviceToHost));
+    if (c > m->plog.capacity) return FWX_ERR_CAPACITY;     // the log overflowed during the solve
+    const size_t idx = (size_t)src * m->n + dst;
+    if (rate_out) {
+        if (m->dtype == FWX_F64) {
+            FWX_HIP(hipMemcpy(rate_out, (double *)m->rate + idx, 8, hipMemcpyDeviceToHost));
+        } else {
+            float f = 0;
+            FWX_HIP(hipMemcpy(&f, (float *)m->rate + idx, 4, hipMemcpyDeviceToHost));
+            *rate_out = (double)f;
+        }
+    }
+    if (m->walk) { (void)hipFree(m->walk); m->walk = nullptr; }
+    FWX_HIP(hipMalloc((void **)&m->walk, ((size_t)4 * cap + 1) * 4));
+    int32_t *len_dev = m->walk + (size_t)4 * cap;
+    hipLaunchKernelGGL(exact_path_kernel, dim3(1), dim3(1), 0, nullptr, m->plog, m->next0, m->n, src,
+                       dst, m->walk, cap, len_dev);
+    FWX_HIP(hipGetLastError());
+    int32_t len = 0;
+    FWX_HIP(hipMemcpy(&len, len_dev, 4, hipMemcpyDeviceToHost));
+    if (len > 0) FWX_HIP(hipMemcpy(path_out, m->walk, (size_t)len * 4, hipMemcpyDeviceToHost));
+    return len;
 }
 
 int fwx_matrix_download(fwx_matrix *m, void *rate, int32_t *next, int32_t *hops)

@@ -10,6 +10,17 @@
 
 namespace fwx {
 
+// Update log for exact `_path` reconstruction (Algorithms.hs:55 concatenates the time-k paths of
+// (i,k) and (k,j)): every successful relaxation appends one record {k, previous record of the same
+// entry}; head[i*n+j] is the entry's newest record.  All device pointers; head == nullptr = off.
+struct PathLog {
+    int32_t *head;                 // n*n, -1 = never updated
+    int32_t *rec_k;                // capacity records: pivot of the update
+    int32_t *rec_prev;             // capacity records: older record of the same entry or -1
+    unsigned long long *count;     // records appended (may exceed capacity: overflow)
+    unsigned long long capacity;
+};
+
 template <typename T> struct RelaxArgs {
     T *rate;                       // slab: rows x n
     int32_t *next;                 // or nullptr
@@ -18,6 +29,8 @@ template <typename T> struct RelaxArgs {
     const int32_t *phops;          // its hops row (iff hops)
     int rows, n, row0, k, flip;
     unsigned long long *updates;   // FWX_UPDATE_SHARDS_K counters or nullptr
+    PathLog plog;                  // plog.head == nullptr: no logging (slab must be the whole matrix
+                                   // when logging: head is indexed by global row)
 };
 
 template <typename T> hipError_t launch_relax(const RelaxArgs<T> &a, hipStream_t s);
@@ -26,7 +39,7 @@ template <typename T> hipError_t launch_relax(const RelaxArgs<T> &a, hipStream_t
 #define FWX_SMALL_N 64
 template <typename T>
 hipError_t launch_small_solve(T *rate, int32_t *next, int32_t *hops, int n, int k_begin, int k_end,
-                              unsigned long long *updates, hipStream_t s);
+                              unsigned long long *updates, PathLog plog, hipStream_t s);
 
 template <typename T>
 hipError_t launch_snapshot_row(T *dst, const T *src, int32_t *hdst, const int32_t *hsrc, int n,

@@ -25,6 +25,17 @@
 
 namespace fwx {
 
+// Append one update record for entry `off` (= i*n+j, global) made by pivot k.
+__device__ __forceinline__ void log_update(const PathLog &plog, size_t off, int k)
+{
+    const unsigned long long idx = atomicAdd(plog.count, 1ull);
+    if (idx < plog.capacity) {
+        plog.rec_k[idx] = k;
+        plog.rec_prev[idx] = plog.head[off];
+        plog.head[off] = (int32_t)idx;
+    }
+}
+
 template <typename T, int W> struct VecOf;
 template <> struct VecOf<float, 4> { typedef float type __attribute__((ext_vector_type(4))); };
 template <> struct VecOf<double, 2> { typedef double type __attribute__((ext_vector_type(2))); };
@@ -76,7 +87,7 @@ template <typename T, int W, int NV, int RPB, int UNROLL, bool HAS_NEXT, bool HA
 __global__ __launch_bounds__(256, MINW) void relax_k(T *rate, int32_t *next, int32_t *hops,
                                                const T *prow, const int32_t *phops, int rows,
                                                int n, int row0, int k, int nstrips, int flip,
-                                               unsigned long long *updates)
+                                               unsigned long long *updates, PathLog plog)
 {
     using L = Lanes<T, W>;
     using V = typename L::V;
@@ -152,6 +163,7 @@ __global__ __launch_bounds__(256, MINW) void relax_k(T *rate, int32_t *next, int
                     changed = true;
                     if (HAS_NEXT) next[off + c] = s_ncol[r];
                     if (HAS_HOPS) hops[off + c] = s_hcol[r] + phops[cv + c];
+                    if (HAS_NEXT && plog.head) log_update(plog, (size_t)i * n + cv + c, k);
                     if (COUNT) ++my_updates;
                 }
             }
@@ -203,7 +215,7 @@ __global__ __launch_bounds__(256, MINW) void relax_k(T *rate, int32_t *next, int
 template <typename T, bool HAS_NEXT, bool HAS_HOPS>
 __global__ __launch_bounds__(256) void small_solve(T *rate, int32_t *next, int32_t *hops, int n,
                                                    int k_begin, int k_end,
-                                                   unsigned long long *updates)
+                                                   unsigned long long *updates, PathLog plog)
 {
     constexpr int M = FWX_SMALL_N;            // the matrix is padded to 64 x 64 with NaN
     constexpr int E = M * M / 256;            // 16 entries per thread: column c = tid % 64 fixed,
@@ -245,6 +257,7 @@ __global__ __launch_bounds__(256) void small_solve(T *rate, int32_t *next, int32
                 R[r][c] = cand;
                 if (HAS_NEXT) { nx[m] = NX[r][k]; NX[r][c] = nx[m]; }
                 if (HAS_HOPS) { hp[m] = HP[r][k] + hkc; HP[r][c] = hp[m]; }
+                if (HAS_NEXT && plog.head) log_update(plog, (size_t)r * n + c, k);
                 ++mine;
             }
         }
@@ -268,13 +281,13 @@ __global__ __launch_bounds__(256) void small_solve(T *rate, int32_t *next, int32
 
 template <typename T>
 hipError_t launch_small_solve(T *rate, int32_t *next, int32_t *hops, int n, int k_begin, int k_end,
-                              unsigned long long *updates, hipStream_t s)
+                              unsigned long long *updates, PathLog plog, hipStream_t s)
 {
     if (n <= 0 || k_end <= k_begin) return hipSuccess;
     if (n > FWX_SMALL_N || (hops && !next)) return hipErrorInvalidValue;
 #define FWX_SMALL(HN, HH)                                                                          \
     hipLaunchKernelGGL((small_solve<T, HN, HH>), dim3(1), dim3(256), 0, s, rate, next, hops, n,    \
-                       k_begin, k_end, updates)
+                       k_begin, k_end, updates, plog)
     if (hops) FWX_SMALL(true, true);
     else if (next) FWX_SMALL(true, false);
     else FWX_SMALL(false, false);
@@ -283,9 +296,9 @@ hipError_t launch_small_solve(T *rate, int32_t *next, int32_t *hops, int n, int 
 }
 
 template hipError_t launch_small_solve<float>(float *, int32_t *, int32_t *, int, int, int,
-                                              unsigned long long *, hipStream_t);
+                                              unsigned long long *, PathLog, hipStream_t);
 template hipError_t launch_small_solve<double>(double *, int32_t *, int32_t *, int, int, int,
-                                               unsigned long long *, hipStream_t);
+                                               unsigned long long *, PathLog, hipStream_t);
 
 template <typename T>
 __global__ __launch_bounds__(256) void snapshot_row(T *dst, const T *src, int32_t *hdst,
@@ -312,7 +325,7 @@ static hipError_t launch_relax_cfg(const RelaxArgs<T> &a, hipStream_t s)
 #define FWX_LAUNCH(HN, HH, CN)                                                                     \
     hipLaunchKernelGGL((relax_k<T, W, NV, RPB, UNROLL, HN, HH, CN, MINW, NT>), grid, block, 0, s, a.rate,    \
                        a.next, a.hops, a.prow, a.phops, a.rows, a.n, a.row0, a.k, nstrips,         \
-                       a.flip, a.updates)
+                       a.flip, a.updates, a.plog)
     const bool hn = a.next != nullptr, hh = a.hops != nullptr, cn = a.updates != nullptr;
     if (hh) {
         if (cn) FWX_LAUNCH(true, true, true); else FWX_LAUNCH(true, true, false);

@@ -50,10 +50,29 @@ int Session::ensure_solved()
     drop_device();
     vertices_ = m.vertices;
     if (m.n() > 0) {
+        // Two solves per rate change: the first counts U (successful relaxations), the second
+        // repeats the solve with an update log of exactly that capacity, from which
+        // fwx_matrix_query_exact rebuilds the reference's `_path` lists -- under exact ties (the
+        // 1.0 edges of Algorithms.hs:35 make them common) the list the reference stored can be a
+        // longer route than the one the next-hops describe.  Logged solves run on the per-k
+        // engine (single launch for n <= 64), which also carries `hops`.
+        uint64_t u = 0;
+        fwx_opts o;
+        memset(&o, 0, sizeof(o));
+        o.struct_size = sizeof(o);
+        o.device = -1;
+        o.updates_out = &u;
         int rc = fwx_matrix_create(&dev_, m.n(), FWX_F64, 1, 1, device_);
         if (rc) return rc;
         if ((rc = fwx_matrix_upload(dev_, m.rate.data(), m.next.data(), m.hops.data()))) return rc;
-        if ((rc = fwx_matrix_solve(dev_, nullptr))) return rc;      // runAlgo 0, on the GPU
+        o.engine = m.n() <= 64 ? FWX_ENGINE_AUTO : FWX_ENGINE_PERK;
+        if ((rc = fwx_matrix_solve(dev_, &o))) return rc;            // runAlgo 0, counting
+        drop_device();
+        if ((rc = fwx_matrix_create(&dev_, m.n(), FWX_F64, 1, 1, device_))) return rc;
+        if ((rc = fwx_matrix_enable_path_log(dev_, u))) return rc;
+        if ((rc = fwx_matrix_upload(dev_, m.rate.data(), m.next.data(), m.hops.data()))) return rc;
+        o.updates_out = nullptr;
+        if ((rc = fwx_matrix_solve(dev_, &o))) return rc;            // runAlgo 0, logged
     }
     solved_version_ = version_;
     ++solves_;
@@ -83,9 +102,14 @@ OptimumResult Session::find_best_rate(const Vertex &src, const Vertex &dest)
     const int32_t d = s < 0 ? -1 : idx(dest);
     if (s >= 0 && d < 0) { res.error = dest.show() + " is not entered before"; }
     if (s >= 0 && d >= 0) {
-        std::vector<int32_t> path((size_t)n);
+        // the reference's `_path`, exactly (update log); the buffer grows for arbitrage blow-ups
+        std::vector<int32_t> path((size_t)(4 * n > 64 ? 4 * n : 64));
         double rate = 0.0;
-        const int len = fwx_matrix_query(dev_, s, d, &rate, path.data(), n);
+        int len = fwx_matrix_query_exact(dev_, s, d, &rate, path.data(), (int32_t)path.size());
+        while (len == FWX_ERR_CAPACITY && path.size() < ((size_t)1 << 24)) {
+            path.resize(path.size() * 8);
+            len = fwx_matrix_query_exact(dev_, s, d, &rate, path.data(), (int32_t)path.size());
+        }
         if (len < 0) {
             res.status = len;
             res.error = std::string("engine: ") + fwx_strerror(len);

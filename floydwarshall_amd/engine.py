@@ -118,6 +118,26 @@ class DeviceMatrix:
                                           _np_ptr(out), self.n), "fwx_matrix_query")
         return float(r.value), [int(x) for x in out[:ln]]
 
+    def enable_path_log(self, capacity_records):
+        """Record every successful relaxation so that query_exact can rebuild the reference's
+        `_path` lists exactly (see fwx.h); call before upload()."""
+        check(lib().fwx_matrix_enable_path_log(self._h, int(capacity_records)),
+              "fwx_matrix_enable_path_log")
+
+    def path_log_count(self):
+        c = ctypes.c_uint64(0)
+        check(lib().fwx_matrix_path_log_count(self._h, ctypes.byref(c)), "fwx_matrix_path_log_count")
+        return int(c.value)
+
+    def query_exact(self, src, dst, cap=None):
+        """(rate, the reference's `_path` as vertex indices) -- exact under ties."""
+        cap = cap or max(4 * self.n, 64)
+        r = ctypes.c_double(0.0)
+        out = np.empty(cap, dtype=np.int32)
+        ln = check(lib().fwx_matrix_query_exact(self._h, int(src), int(dst), ctypes.byref(r),
+                                                _np_ptr(out), cap), "fwx_matrix_query_exact")
+        return float(r.value), [int(x) for x in out[:ln]]
+
     def close(self):
         if self._h:
             lib().fwx_matrix_destroy(self._h)

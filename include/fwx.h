@@ -108,6 +108,21 @@ int fwx_matrix_query(fwx_matrix *m, int32_t src, int32_t dst, double *rate_out, 
                      int32_t cap);
 int fwx_matrix_destroy(fwx_matrix *m);
 
+/* Exact `_path` lists.  Following next-hops (fwx_matrix_query) yields A best path; the reference
+ * keeps, per entry, the list it concatenated when the entry was last improved
+ * (`_path = ikPath ++ kjPath`, Algorithms.hs:55), and under exact ties (its built-in 1.0 edges
+ * between the same currency on two exchanges make them common) that list can be a different,
+ * longer route of equal rate.  With the update log enabled every successful relaxation appends
+ * one 8-byte record on the device, and fwx_matrix_query_exact rebuilds the reference's list
+ * exactly.  Enable after create / before upload; needs the next-hop matrix; the logged solve runs
+ * on the per-k engine (or small_solve); capacity_records must cover U (fwx_opts.updates_out of a
+ * counting solve of the same input gives it); an overflowed log makes query_exact return
+ * FWX_ERR_CAPACITY.  path_out receives the vertices after src up to dst; returns the length.   */
+int fwx_matrix_enable_path_log(fwx_matrix *m, uint64_t capacity_records);
+int fwx_matrix_path_log_count(fwx_matrix *m, uint64_t *count_out);
+int fwx_matrix_query_exact(fwx_matrix *m, int32_t src, int32_t dst, double *rate_out,
+                           int32_t *path_out, int32_t cap);
+
 /* ---- device-pointer step API (caller-owned DEVICE memory, caller's stream) --------------------
  * Used by the benchmark and by the row-partitioned multi-GPU driver, which own their buffers
  * through torch / torch.distributed.  All launches are asynchronous on `stream` (a hipStream_t,

@@ -132,3 +132,48 @@ def test_fwx_cli_binary_replays_the_readme_session():
     r = subprocess.run([exe, "--device", "0"], input=stdin, capture_output=True, text=True, timeout=120)
     assert r.returncode == 0, r.stderr
     assert r.stdout == expected
+
+
+def test_session_returns_the_references_exact_path_lists_under_ties():
+    """A market with many exact ties (the reference's 1.0 edges between exchanges): for EVERY
+    (src, dst) the session's answer -- rate and the whole path -- equals the list-faithful
+    restatement of floydWarshall + optimum, including the entries where the stored list is a
+    longer equal-rate route than the next-hop walk."""
+    rnd = np.random.default_rng(23)
+    ccys = ["C%02d" % i for i in range(8)]
+    price = dict(zip(ccys, 0.5 + 1.5 * rnd.random(len(ccys))))
+    s = host.Session(device=0)
+    rates = {}
+    for e in range(10):
+        exch = "X" + "ABCDEFGHIJ"[e]
+        for i in range(len(ccys)):
+            for j in range(i + 1, len(ccys)):
+                if rnd.random() < 0.5:
+                    a, b = ccys[i], ccys[j]
+                    fwd = price[b] / price[a] * (0.97 + 0.03 * rnd.random())
+                    bkd = price[a] / price[b] * (0.97 + 0.03 * rnd.random())
+                    s.update_rates(1000 + e, exch, a, b, fwd, bkd)
+                    rates[((exch, a), (exch, b))] = fwd
+                    rates[((exch, b), (exch, a))] = bkd
+    m = lf.floyd_warshall(rates)
+    vertices = [row[0][1] for row in m]
+    assert len(vertices) > 64
+    walk_differs = 0
+    _, _, gnext = None, None, s.solved_matrix()[1]
+    for i, a in enumerate(vertices):
+        for j, b in enumerate(vertices):
+            exp = lf.optimum(a, b, m)
+            try:
+                r, start, path = s.find_best_rate(a, b)
+                assert exp[0] == "ok" and r == exp[1][0] and tuple(path) == exp[1][2]
+                walk = [vertices[v] for v in engine_follow(gnext, i, j)]
+                walk_differs += walk != list(path)
+            except host.AlgoError as e:
+                assert exp == ("err", str(e))
+    assert walk_differs > 0
+    assert s.solves == 1
+
+
+def engine_follow(nxt, i, j):
+    from floydwarshall_amd import engine
+    return engine.follow_path(nxt, i, j)

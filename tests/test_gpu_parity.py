@@ -665,3 +665,85 @@ def test_index_math_beyond_2_to_31_elements():
     cols = torch.arange(n, device=dev).expand(8, n)
     ok = (tail == cols) | ((tail >= k0) & (tail < k0 + 64)) | (tail == -1)
     assert bool(ok.all())
+
+
+# ---------------------------------------------------------------------------------------------
+# Exact `_path` lists: update log + fwx_matrix_query_exact
+# ---------------------------------------------------------------------------------------------
+
+def _market_rates(n_exch, n_ccy, seed, density=0.5):
+    """The reference's own kind of graph: per-exchange quotes plus its built-in rate-1.0 edges
+    between the same currency on two exchanges (Algorithms.hs:35) -- exact ties everywhere."""
+    rnd = np.random.default_rng(seed)
+    ccys = ["C%02d" % i for i in range(n_ccy)]
+    price = dict(zip(ccys, 0.5 + 1.5 * rnd.random(n_ccy)))
+    rates = {}
+    for e in range(n_exch):
+        exch = "X%02d" % e
+        for i in range(n_ccy):
+            for j in range(i + 1, n_ccy):
+                if rnd.random() < density:
+                    a, b = ccys[i], ccys[j]
+                    rates[((exch, a), (exch, b))] = price[b] / price[a] * (0.97 + 0.03 * rnd.random())
+                    rates[((exch, b), (exch, a))] = price[a] / price[b] * (0.97 + 0.03 * rnd.random())
+    return rates
+
+
+def _exact_paths_case(m0, dtype=np.float64):
+    """m0: list-form initial matrix.  Solve with the list-faithful reference and with the logged
+    GPU solve; every entry's `_path` must be identical."""
+    ref = lf.run_algo(m0, dtype)
+    ref_paths = lf.path_indices(ref)
+    _, rate, nxt, hops = lf.to_dense(m0, dtype)
+    n = rate.shape[0]
+    _, erate, enext, ehops = lf.to_dense(ref, dtype)
+    # pass 1: count U; pass 2: logged solve with exactly that capacity
+    u = engine.solve(rate.copy(), nxt.copy(), hops.copy(), count_updates=True,
+                     engine=engine.FWX_ENGINE_PERK if n > 64 else engine.FWX_ENGINE_AUTO)
+    dm = engine.DeviceMatrix(n, dtype, with_next=True, with_hops=True)
+    dm.enable_path_log(u)
+    dm.upload(rate, nxt, hops)
+    dm.solve()
+    assert dm.path_log_count() == u
+    r, nx, hp = dm.download()
+    assert_bits_equal(r, erate, "rate")
+    assert np.array_equal(nx, enext) and np.array_equal(hp, ehops)
+    differs_from_walk = 0
+    for i in range(n):
+        for j in range(n):
+            if ehops[i, j] > 4 * n:
+                continue                                    # arbitrage blow-up: beyond the buffer
+            q_rate, q_path = dm.query_exact(i, j)
+            assert tuple(q_path) == ref_paths[i][j], (i, j)
+            assert q_rate == erate[i, j] or (np.isnan(q_rate) and np.isnan(erate[i, j]))
+            try:
+                walk = engine.follow_path(nx, i, j)
+            except engine.FwxError:
+                walk = None
+            differs_from_walk += walk != q_path
+    dm.close()
+    return differs_from_walk
+
+
+def test_exact_path_lists_on_a_tie_heavy_market():
+    """Market-like input: the reference's stored lists differ from the next-hop walk for some
+    entries (equal-rate detours through its 1.0 edges); query_exact reproduces them all."""
+    m0 = lf.build_matrix(_market_rates(8, 6, seed=23))
+    assert 32 < len(m0) <= 64
+    differs = _exact_paths_case(m0)
+    assert differs > 0          # the case really exercises what the plain walk cannot give
+
+
+@pytest.mark.parametrize("kind", ["d1", "t1", "t2", "t3"])
+def test_exact_path_lists_dense_kinds(kind):
+    n = 20
+    rate, nxt, _ = synth.make(kind, n, np.float64, seed=77)
+    vertices = [("X", "C%03d" % i) for i in range(n)]
+    _exact_paths_case(lf.from_dense(vertices, rate, nxt))
+
+
+def test_exact_path_lists_above_the_single_launch_size():
+    """n = 80 > 64: the log is written by the per-k kernel (relax_k) instead of small_solve."""
+    m0 = lf.build_matrix(_market_rates(10, 8, seed=23))
+    assert 64 < len(m0) <= 80
+    assert _exact_paths_case(m0) > 0
