@@ -134,10 +134,13 @@ def main():
     dev = torch.device("cuda", dev_index)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        import datetime
+        # a rank that dies must fail the job quickly, not leave the others waiting in a collective
+        tmo = datetime.timedelta(seconds=240)
         if args.backend == "nccl":
-            dist.init_process_group("nccl", device_id=dev)
+            dist.init_process_group("nccl", device_id=dev, timeout=tmo)
         else:
-            dist.init_process_group("gloo")
+            dist.init_process_group("gloo", timeout=tmo)
 
     n = args.n
     np_dtype = np.float32 if args.dtype == "f32" else np.float64
