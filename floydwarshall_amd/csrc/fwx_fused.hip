@@ -370,7 +370,11 @@ __global__ __launch_bounds__(256, MINW) void fused_main(T *rate, int32_t *next, 
 #pragma unroll
         for (int h = 0; h < NH; ++h) {
             x[r][h] = *reinterpret_cast<const V *>(rate + (size_t)i * n + jcol[h]);
-            if (HAS_NEXT) nx[r][h] = *reinterpret_cast<const IV *>(next + (size_t)i * n + jcol[h]);
+            // the next-hop tile is NOT read: -2 marks "unchanged" (real values are >= -1) and
+            // only vectors with a changed component are read-modified-written at the end
+            if (HAS_NEXT)
+#pragma unroll
+                for (int e = 0; e < VW; ++e) nx[r][h][e] = -2;
         }
     }
 
@@ -460,11 +464,22 @@ __global__ __launch_bounds__(256, MINW) void fused_main(T *rate, int32_t *next, 
                 if (gi >= jcol[h] && gi < jcol[h] + VW) {
                     const int e = gi - jcol[h];
                     x[r][h][e] = rate[off + e];
-                    if (HAS_NEXT) nx[r][h][e] = next[off + e];
+                    if (HAS_NEXT) nx[r][h][e] = -2;
                 }
             }
             *reinterpret_cast<V *>(rate + off) = x[r][h];
-            if (HAS_NEXT) *reinterpret_cast<IV *>(next + off) = nx[r][h];
+            if (HAS_NEXT) {
+                bool any = false;
+#pragma unroll
+                for (int e = 0; e < VW; ++e) any |= nx[r][h][e] != -2;
+                if (any) {
+                    const IV old = *reinterpret_cast<const IV *>(next + off);
+#pragma unroll
+                    for (int e = 0; e < VW; ++e)
+                        if (nx[r][h][e] == -2) nx[r][h][e] = old[e];
+                    *reinterpret_cast<IV *>(next + off) = nx[r][h];
+                }
+            }
         }
     }
 
