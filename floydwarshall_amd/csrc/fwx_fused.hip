@@ -467,8 +467,8 @@ __global__ __launch_bounds__(256, MINW) void fused_main(T *rate, int32_t *next, 
                     if (HAS_NEXT) nx[r][h][e] = -2;
                 }
             }
-            *reinterpret_cast<V *>(rate + off) = x[r][h];
             if (HAS_NEXT) {
+                // a rate changed <=> its next-hop was set: unchanged vectors are not written at all
                 bool any = false;
 #pragma unroll
                 for (int e = 0; e < VW; ++e) any |= nx[r][h][e] != -2;
@@ -478,7 +478,10 @@ __global__ __launch_bounds__(256, MINW) void fused_main(T *rate, int32_t *next, 
                     for (int e = 0; e < VW; ++e)
                         if (nx[r][h][e] == -2) nx[r][h][e] = old[e];
                     *reinterpret_cast<IV *>(next + off) = nx[r][h];
+                    *reinterpret_cast<V *>(rate + off) = x[r][h];
                 }
+            } else {
+                *reinterpret_cast<V *>(rate + off) = x[r][h];
             }
         }
     }
