@@ -55,7 +55,9 @@ typedef enum fwx_status {
 
 typedef enum fwx_dtype { FWX_F32 = 0, FWX_F64 = 1 } fwx_dtype;
 
-/* Which relaxation engine runs the pivots.  Both are bit-exact with the reference loop. */
+/* Which relaxation engine runs the pivots.  All are bit-exact with the reference loop.
+ * AUTO: n <= 64 -> the whole solve in one single-workgroup launch; n >= 256, rows a multiple of 16
+ * bytes and no hops -> FUSED; otherwise PERK.  A matrix with an update log always takes PERK.    */
 typedef enum fwx_engine {
     FWX_ENGINE_AUTO = 0,
     FWX_ENGINE_PERK = 1,  /* one N x N launch per pivot k (HBM-bound streaming kernel)            */
@@ -69,7 +71,7 @@ typedef struct fwx_opts {
     int32_t engine;        /* fwx_engine                                                           */
     int32_t k_begin;       /* first pivot (default 0): a solve over [k_begin,k_end) is resumable   */
     int32_t k_end;         /* one past the last pivot; <= 0 means n                                */
-    int32_t block;         /* pivots per launch for FWX_ENGINE_FUSED (0 = default)                 */
+    int32_t block;         /* reserved, must be 0 (the fused engine works in FWX_FUSED_BLOCK pivots)*/
     int32_t serpentine;    /* 0 = default (on): alternate sweep direction per pivot so the tail of */
                            /* one launch is re-read from the Infinity Cache; 1 = off               */
     uint64_t *updates_out; /* host pointer, optional: receives U = number of successful updates    */
@@ -188,7 +190,8 @@ int fwx_dev_follow_paths(int32_t n, const int32_t *next, int32_t count, const in
  * fwx_dev_panel_snap: snapshot panel of the pivot rows in `block` (rows [row0,row0+rows), rows <=
  *   FWX_FUSED_BLOCK, at time row0): writes the time-k snapshot of each pivot row to w_rate
  *   (rows x n).  UNLIKE fwx_dev_panel THE MATRIX IS NOT MODIFIED: the pivot rows are then relaxed
- *   like any other row.  diag_ws: device scratch, fwx_fused_diag_ws_bytes(dtype) bytes.
+ *   like any other row.  diag_ws: device scratch, fwx_fused_diag_ws_bytes(dtype) bytes (reserved:
+ *   the current kernels evolve the diagonal block in LDS and do not touch it).
  * fwx_dev_relax_fused: applies the pivots [piv->k_begin, piv->k_end) (at most FWX_FUSED_BLOCK,
  *   piv->rate = snapshot panel, stride n) to EVERY row of the slab in one pass.  col_rate /
  *   col_next: device scratch of FWX_FUSED_BLOCK * ((slab->rows + 3) & ~3) elements (col_next only
