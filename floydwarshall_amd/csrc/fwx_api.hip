@@ -406,6 +406,7 @@ struct fwx_matrix {
     fwx::PathLog plog;     // update log for exact `_path` lists (head == nullptr: disabled)
     int32_t *next0;        // the uploaded (time-0) next-hop matrix, kept while logging
     int32_t *walk;         // scratch of the exact-path walk (stack + output)
+    int32_t walk_cap;      // capacity (path entries) `walk` was sized for
 };
 
 namespace {
@@ -649,8 +650,11 @@ int fwx_matrix_query_exact(fwx_matrix *m, int32_t src, int32_t dst, double *rate
             *rate_out = (double)f;
         }
     }
-    if (m->walk) { (void)hipFree(m->walk); m->walk = nullptr; }
-    FWX_HIP(hipMalloc((void **)&m->walk, ((size_t)4 * cap + 1) * 4));
+    if (!m->walk || m->walk_cap < cap) {      // grow-only scratch, reused across queries
+        if (m->walk) { (void)hipFree(m->walk); m->walk = nullptr; }
+        FWX_HIP(hipMalloc((void **)&m->walk, ((size_t)4 * cap + 1) * 4));
+        m->walk_cap = cap;
+    }
     int32_t *len_dev = m->walk + (size_t)4 * cap;
     hipLaunchKernelGGL(exact_path_kernel, dim3(1), dim3(1), 0, nullptr, m->plog, m->next0, m->n, src,
                        dst, m->walk, cap, len_dev);
