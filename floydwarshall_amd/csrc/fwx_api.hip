@@ -162,12 +162,12 @@ int fused_range(T *rate, int32_t *next, int n, int k_begin, int k_end, void *ws,
     int32_t *cnt = (int32_t *)p;   p += (size_t)FWX_FUSED_B * ld * sizeof(int32_t);
     T *diag = (T *)p;              p += (size_t)2 * FWX_FUSED_B * FWX_FUSED_B * sizeof(T);
     bool nonneg = false;
-    if (sizeof(T) == 4 && !next && !d_updates) {
-        // one read of the matrix decides whether the max3 kernel may be used (see fwx.h)
+    if (!next && !d_updates) {
+        // one read of the matrix decides whether the max-form kernel may be used (see fwx.h)
         int *flag = (int *)(((uintptr_t)p + 15) & ~(uintptr_t)15);
         int h = 1;
         FWX_HIP(hipMemcpyAsync(flag, &h, sizeof(int), hipMemcpyHostToDevice, s));
-        FWX_HIP(fwx::launch_nonneg_check((const float *)rate, (size_t)n * n, flag, s));
+        FWX_HIP(fwx::launch_nonneg_check(rate, (size_t)n * n, flag, s));
         FWX_HIP(hipMemcpyAsync(&h, flag, sizeof(int), hipMemcpyDeviceToHost, s));
         FWX_HIP(hipStreamSynchronize(s));
         nonneg = h == 1;
@@ -845,12 +845,12 @@ int fwx_dev_check_nonneg(const fwx_slab *slab, int32_t *d_flag, void *stream)
     if (!d_flag) return FWX_ERR_INVALID;
     if (device_count() <= 0) return FWX_ERR_NO_DEVICE;
     hipStream_t s = (hipStream_t)stream;
-    if (slab->dtype != FWX_F32) {
-        FWX_HIP(hipMemsetAsync(d_flag, 0, sizeof(int32_t), s));
-        return FWX_OK;
-    }
-    FWX_HIP(fwx::launch_nonneg_check((const float *)slab->rate, (size_t)slab->rows * slab->n,
-                                     (int *)d_flag, s));
+    if (slab->dtype == FWX_F64)
+        FWX_HIP(fwx::launch_nonneg_check((const double *)slab->rate, (size_t)slab->rows * slab->n,
+                                         (int *)d_flag, s));
+    else
+        FWX_HIP(fwx::launch_nonneg_check((const float *)slab->rate, (size_t)slab->rows * slab->n,
+                                         (int *)d_flag, s));
     return FWX_OK;
 }
 
@@ -872,7 +872,8 @@ int fwx_dev_relax_fused(const fwx_slab *slab, const fwx_pivots *piv, void *col_r
     if (slab->dtype == FWX_F64)
         return fused_block<double>((double *)slab->rate, slab->next, slab->rows, slab->n, slab->row0,
                                    piv->k_begin, piv->k_end - piv->k_begin, (const double *)piv->rate,
-                                   (double *)col_rate, col_next, d_updates, false, s);
+                                   (double *)col_rate, col_next, d_updates,
+                                   (flags & FWX_FLAG_NONNEG) != 0, s);
     return fused_block<float>((float *)slab->rate, slab->next, slab->rows, slab->n, slab->row0,
                               piv->k_begin, piv->k_end - piv->k_begin, (const float *)piv->rate,
                               (float *)col_rate, col_next, d_updates, (flags & FWX_FLAG_NONNEG) != 0,

@@ -40,6 +40,9 @@ template <typename T> __device__ __forceinline__ T qnan();
 template <> __device__ __forceinline__ float qnan<float>() { return __builtin_nanf(""); }
 template <> __device__ __forceinline__ double qnan<double>() { return __builtin_nan(""); }
 
+__device__ __forceinline__ float fmax_t(float a, float b) { return __builtin_fmaxf(a, b); }
+__device__ __forceinline__ double fmax_t(double a, double b) { return __builtin_fmax(a, b); }
+
 template <typename T> struct Vec16;
 template <> struct Vec16<float> {
     typedef float type __attribute__((ext_vector_type(4)));
@@ -324,7 +327,7 @@ __global__ __launch_bounds__(PANEL_THREADS) void fused_colpanel(const T *rate, c
 // workgroup at 32 KiB of LDS and <= 128 VGPRs: 4 workgroups = 16 waves per CU.  The loop is pure
 // VALU (v_pk_mul_f32 + v_cmp + v_cndmask per pair of relaxations) and one wave alone issues at
 // half rate on a SIMD-32, so occupancy, not bytes, is what this kernel needs.
-template <typename T, bool HAS_NEXT, bool COUNT, int BS, int MINW, int NH, int RI>
+template <typename T, bool HAS_NEXT, bool COUNT, int BS, int MINW, int NH, int RI, bool MAXF = false>
 __global__ __launch_bounds__(256, MINW) void fused_main(T *rate, int32_t *next, int rows, int n,
                                                         int row0, int k0, int bt, const T *w,
                                                         const T *ct, const int32_t *cnt, int ct_ld,
@@ -439,6 +442,10 @@ __global__ __launch_bounds__(256, MINW) void fused_main(T *rate, int32_t *next, 
 #pragma unroll
                     for (int e = 0; e < VW; ++e) {
                         const T cand = c[r] * wv[h][e];
+                        if (MAXF) {   // max-form domain (see fused_main_max): strict fold == max
+                            x[r][h][e] = fmax_t(x[r][h][e], cand);
+                            continue;
+                        }
                         const bool up = x[r][h][e] < cand;
                         if (COUNT) {
                             const bool is_diag = diag_tile && (row0 + i0 + r == jcol[h] + e);
@@ -694,6 +701,24 @@ static bool small_tiles(int n, int rows)
     return (long long)((n + 127) / 128) * ((rows + 127) / 128) < 512;
 }
 
+__global__ __launch_bounds__(256) void nonneg_check_f64(const double *rate, size_t count, int *flag)
+{
+    const size_t stride = (size_t)gridDim.x * 256;
+    bool bad = false;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < count; i += stride)
+        bad |= (unsigned long long)__double_as_longlong(rate[i]) > 0x7FF0000000000000ull;
+    if (bad) *flag = 0;
+}
+
+hipError_t launch_nonneg_check(const double *rate, size_t count, int *flag, hipStream_t s)
+{
+    if (count == 0) return hipSuccess;
+    size_t blocks = (count + 255) / 256;
+    if (blocks > 8192) blocks = 8192;
+    hipLaunchKernelGGL(nonneg_check_f64, dim3((unsigned)blocks), dim3(256), 0, s, rate, count, flag);
+    return hipGetLastError();
+}
+
 // f32, rates only, no update counting, domain verified by the caller: the max3 kernel.
 static bool launch_max_form(const FusedArgs<float> &a, dim3 grid, dim3 block, int skip_lo,
                             int skip_hi, hipStream_t s)
@@ -710,9 +735,23 @@ static bool launch_max_form(const FusedArgs<float> &a, dim3 grid, dim3 block, in
     }
     return true;
 }
-static bool launch_max_form(const FusedArgs<double> &, dim3, dim3, int, int, hipStream_t)
+// f64 has no packed / three-operand forms: the max form is the generic kernel with
+// v_mul_f64 + v_max_f64 (2 instructions per relaxation instead of 4).
+static bool launch_max_form(const FusedArgs<double> &a, dim3 grid, dim3 block, int skip_lo,
+                            int skip_hi, hipStream_t s)
 {
-    return false;
+    if (!a.nonneg || a.next || a.updates) return false;
+    if (small_tiles(a.n, a.rows))
+        hipLaunchKernelGGL((fused_main<double, false, false, 16, 2, 1, 4, true>), grid, block, 0, s,
+                           a.rate, a.next, a.rows, a.n, a.row0, a.k0, a.bt, a.w, a.ct, a.cnt,
+                           a.ct_ld, skip_lo, skip_hi, a.updates);
+    else
+        hipLaunchKernelGGL((fused_main<double, false, false, FusedCfg<double, false>::BS,
+                                       FusedCfg<double, false>::MINW, FusedCfg<double, false>::NH, 8,
+                                       true>),
+                           grid, block, 0, s, a.rate, a.next, a.rows, a.n, a.row0, a.k0, a.bt, a.w,
+                           a.ct, a.cnt, a.ct_ld, skip_lo, skip_hi, a.updates);
+    return true;
 }
 
 hipError_t launch_nonneg_check(const float *rate, size_t count, int *flag, hipStream_t s)

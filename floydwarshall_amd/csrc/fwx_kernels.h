@@ -64,6 +64,7 @@ template <typename T> struct FusedArgs {
 
 // Clears *flag (device int, preset to 1) if any of `count` f32 values is negative, -0 or NaN.
 hipError_t launch_nonneg_check(const float *rate, size_t count, int *flag, hipStream_t s);
+hipError_t launch_nonneg_check(const double *rate, size_t count, int *flag, hipStream_t s);
 
 // colpanel + main: applies the bt pivots to every row of the slab.
 template <typename T> hipError_t launch_fused_relax(const FusedArgs<T> &a, hipStream_t s);

@@ -55,9 +55,9 @@ class HipBackend:
         self.nonneg = False
 
     def check_domain(self, slab_rate, n, row0, slab_next):
-        """1 if this slab allows the max-form kernel (f32, rates only, all entries >= +0, no NaN);
+        """1 if this slab allows the max-form kernel (rates only, all entries >= +0, no NaN);
         solve_partitioned combines the answers of all ranks (the domain must hold globally)."""
-        if slab_next is not None or slab_rate.element_size() != 4 or self.engine_name != "fused":
+        if slab_next is not None or self.engine_name != "fused":
             return 0
         return int(engine.dev_check_nonneg(slab_rate, n, row0)) if slab_rate.shape[0] else 1
 

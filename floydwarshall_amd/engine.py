@@ -245,7 +245,7 @@ def dev_panel_snap(block_rate_t, n, k0, w_rate_t, diag_ws_t):
 
 
 def dev_check_nonneg(rate_t, n, row0=0):
-    """True iff every rate of the slab is >= +0.0 and not NaN (f32 only; synchronises)."""
+    """True iff every rate of the slab is >= +0.0 and not NaN (synchronises)."""
     import torch
     s = _slab(rate_t, None, None, n, row0)
     flag = torch.ones(1, dtype=torch.int32, device=rate_t.device)
@@ -285,8 +285,7 @@ def dev_solve_fused(rate_t, n, k_begin=0, k_end=None, *, next_t=None, ws=None, u
     import torch
     k_end = n if k_end is None else k_end
     if nonneg is None:
-        nonneg = (rate_t.dtype == torch.float32 and next_t is None and updates_t is None
-                  and dev_check_nonneg(rate_t, n))
+        nonneg = next_t is None and updates_t is None and dev_check_nonneg(rate_t, n)
     ws = ws or FusedWorkspace(n, n, rate_t.dtype, rate_t.device, with_next=next_t is not None)
     B = FWX_FUSED_BLOCK
     for k0 in range(k_begin, k_end, B):

@@ -213,7 +213,7 @@ int fwx_dev_relax_fused(const fwx_slab *slab, const fwx_pivots *piv, void *col_r
                         int32_t *col_next, unsigned long long *d_updates, int32_t flags,
                         void *stream);
 /* Clears *d_flag (a device int32 the caller has set to 1) if any rate of the slab is negative,
- * -0.0 or NaN.  f32 slabs only; an f64 slab always clears it (no max-form kernel for f64).      */
+ * -0.0 or NaN.                                                                                  */
 int fwx_dev_check_nonneg(const fwx_slab *slab, int32_t *d_flag, void *stream);
 
 #ifdef __cplusplus

@@ -446,22 +446,24 @@ def _rates_only_fused(rate):
     return got
 
 
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
 @pytest.mark.parametrize("kind", ["d1", "d2", "t1", "t2", "t4"])
 @pytest.mark.parametrize("n", [64, 132, 516])
-def test_max_form_kernel_inside_its_domain(kind, n):
-    rate, _, _ = synth.make(kind, n, np.float32, seed=300 + n)
+def test_max_form_kernel_inside_its_domain(kind, n, dtype):
+    rate, _, _ = synth.make(kind, n, dtype, seed=300 + n)
     assert (rate >= 0).all() and not np.isnan(rate).any() and not np.signbit(rate).any()
     got = _rates_only_fused(rate)
     if kind == "t4":
         assert np.isinf(got).any()                              # the overflow edge was exercised
 
 
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
 @pytest.mark.parametrize("poison", ["nan", "negative", "negzero"])
-def test_max_form_kernel_is_not_taken_outside_its_domain(poison):
-    rate, _, _ = synth.make("d1", 260, np.float32, seed=9)
+def test_max_form_kernel_is_not_taken_outside_its_domain(poison, dtype):
+    rate, _, _ = synth.make("d1", 260, dtype, seed=9)
     rate[17, 201] = {"nan": np.nan, "negative": -0.75, "negzero": -0.0}[poison]
     _rates_only_fused(rate)
-    rate, _, _ = synth.make("t3", 260, np.float32, seed=10)
+    rate, _, _ = synth.make("t3", 260, dtype, seed=10)
     _rates_only_fused(rate)
 
 
@@ -482,7 +484,10 @@ def test_domain_check_and_flagged_device_api():
     assert not engine.dev_check_nonneg(bad, n)
     bad[5, 7] = -0.0
     assert not engine.dev_check_nonneg(bad, n)
-    assert not engine.dev_check_nonneg(torch.from_numpy(rate.astype(np.float64)).to(dev), n)
+    r64 = torch.from_numpy(rate.astype(np.float64)).to(dev)
+    assert engine.dev_check_nonneg(r64, n)                      # f64 has a max form too
+    r64[9, 1] = -1.0
+    assert not engine.dev_check_nonneg(r64, n)
 
 
 def test_max_form_full_size_n8192_vs_perk():
