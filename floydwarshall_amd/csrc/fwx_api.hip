@@ -404,9 +404,13 @@ struct fwx_matrix {
     int32_t *next, *hops, *scratch;
     unsigned long long *upd;
     fwx::PathLog plog;     // update log for exact `_path` lists (head == nullptr: disabled)
-    int32_t *next0;        // the uploaded (time-0) next-hop matrix, kept while logging
+    unsigned long long log_total;   // records allocated = U of the uploaded input
+    void *rate0;           // pristine copies of the uploaded input, kept while logging (the logged
+    int32_t *next0;        //   solve is a counting solve + a replay from these); next0 is also what
+    int32_t *hops0;        //   the exact-path walk reads for entries never updated
     int32_t *walk;         // scratch of the exact-path walk (stack + output)
     int32_t walk_cap;      // capacity (path entries) `walk` was sized for
+    int32_t rec_ready;     // a logged solve has completed
 };
 
 namespace {
@@ -435,6 +439,51 @@ int matrix_solve_typed(fwx_matrix *m, const Opts &op, unsigned long long *upd, h
     return relax_range<T>(r, m->next, m->hops, n, n, 0, r + (size_t)op.k_begin * n,
                           m->hops ? m->hops + (size_t)op.k_begin * n : nullptr, n, op.k_begin,
                           op.k_end, op.serpentine, upd, s, m->plog);
+}
+
+// Solve with the update log: (1) a counting solve gives the number of records each shard will
+// append; (2) the record arrays are allocated to exactly that size and the shard offsets set;
+// (3) the working matrix is restored from the pristine copy and the solve is replayed, logging.
+int logged_solve(fwx_matrix *m, const Opts &op_in, hipStream_t s)
+{
+    if (op_in.k_begin != 0 || op_in.k_end != m->n || op_in.engine == FWX_ENGINE_FUSED)
+        return FWX_ERR_UNSUPPORTED;
+    Opts op = op_in;                             // both passes must take the same launches
+    if (m->n > FWX_SMALL_N) op.engine = FWX_ENGINE_PERK;
+    const size_t nn = (size_t)m->n * (size_t)m->n, es = m->dtype == FWX_F64 ? 8 : 4;
+    fwx::PathLog saved = m->plog;
+    m->plog = fwx::PathLog();                    // pass 1 must not log
+    FWX_HIP(hipMemsetAsync(m->upd, 0, FWX_UPDATE_SHARDS * 8, s));
+    int rc = m->dtype == FWX_F64 ? matrix_solve_typed<double>(m, op, m->upd, s)
+                                 : matrix_solve_typed<float>(m, op, m->upd, s);
+    m->plog = saved;
+    if (rc) return rc;
+    unsigned long long cnt[FWX_UPDATE_SHARDS], base[FWX_UPDATE_SHARDS + 1];
+    FWX_HIP(hipMemcpyAsync(cnt, m->upd, sizeof(cnt), hipMemcpyDeviceToHost, s));
+    FWX_HIP(hipStreamSynchronize(s));
+    base[0] = 0;
+    for (int i = 0; i < FWX_UPDATE_SHARDS; ++i) base[i + 1] = base[i] + cnt[i];
+    const unsigned long long total = base[FWX_UPDATE_SHARDS];
+    if (total > 0x7fffffffull) return FWX_ERR_UNSUPPORTED;   // record indices are int32
+    if (m->plog.rec_k) { (void)hipFree(m->plog.rec_k); m->plog.rec_k = nullptr; }
+    if (m->plog.rec_prev) { (void)hipFree(m->plog.rec_prev); m->plog.rec_prev = nullptr; }
+    FWX_HIP(hipMalloc((void **)&m->plog.rec_k, (total ? total : 1) * 4));
+    FWX_HIP(hipMalloc((void **)&m->plog.rec_prev, (total ? total : 1) * 4));
+    m->log_total = total;
+    FWX_HIP(hipMemcpyAsync((void *)m->plog.base, base, sizeof(base), hipMemcpyHostToDevice, s));
+    FWX_HIP(hipMemsetAsync(m->plog.count, 0, FWX_UPDATE_SHARDS * 8, s));
+    FWX_HIP(hipMemsetAsync(m->plog.head, 0xFF, nn * 4, s));
+    FWX_HIP(hipMemcpyAsync(m->rate, m->rate0, nn * es, hipMemcpyDeviceToDevice, s));
+    FWX_HIP(hipMemcpyAsync(m->next, m->next0, nn * 4, hipMemcpyDeviceToDevice, s));
+    if (m->hops) FWX_HIP(hipMemcpyAsync(m->hops, m->hops0, nn * 4, hipMemcpyDeviceToDevice, s));
+    FWX_HIP(hipStreamSynchronize(s));            // `base` (host array) must outlive the copy
+    rc = m->dtype == FWX_F64 ? matrix_solve_typed<double>(m, op, nullptr, s)
+                             : matrix_solve_typed<float>(m, op, nullptr, s);
+    if (rc) return rc;
+    FWX_HIP(hipStreamSynchronize(s));
+    m->rec_ready = 1;
+    if (op.updates_out) *op.updates_out = total;
+    return FWX_OK;
 }
 
 // The reference's `_path` list of entry (src,dst), rebuilt from the update log exactly as
@@ -567,6 +616,9 @@ int fwx_matrix_destroy(fwx_matrix *m)
     if (m->plog.rec_k) (void)hipFree(m->plog.rec_k);
     if (m->plog.rec_prev) (void)hipFree(m->plog.rec_prev);
     if (m->plog.count) (void)hipFree(m->plog.count);
+    if (m->plog.base) (void)hipFree((void *)m->plog.base);
+    if (m->rate0) (void)hipFree(m->rate0);
+    if (m->hops0) (void)hipFree(m->hops0);
     if (m->next0) (void)hipFree(m->next0);
     if (m->walk) (void)hipFree(m->walk);
     delete m;
@@ -585,32 +637,37 @@ int fwx_matrix_upload(fwx_matrix *m, const void *rate, const int32_t *next, cons
     FWX_HIP(hipMemcpy(m->rate, rate, nn * es, hipMemcpyHostToDevice));
     if (m->next) FWX_HIP(hipMemcpy(m->next, next, nn * 4, hipMemcpyHostToDevice));
     if (m->hops) FWX_HIP(hipMemcpy(m->hops, hops, nn * 4, hipMemcpyHostToDevice));
-    if (m->plog.head) {   // a fresh matrix starts a fresh log
+    if (m->plog.head) {   // keep the pristine input: the logged solve replays from it
+        FWX_HIP(hipMemcpy(m->rate0, rate, nn * es, hipMemcpyHostToDevice));
         FWX_HIP(hipMemcpy(m->next0, next, nn * 4, hipMemcpyHostToDevice));
+        if (m->hops) FWX_HIP(hipMemcpy(m->hops0, hops, nn * 4, hipMemcpyHostToDevice));
         FWX_HIP(hipMemset(m->plog.head, 0xFF, nn * 4));
-        FWX_HIP(hipMemset(m->plog.count, 0, sizeof(unsigned long long)));
+        FWX_HIP(hipMemset(m->plog.count, 0, FWX_UPDATE_SHARDS * sizeof(unsigned long long)));
+        m->log_total = 0;
     }
     return FWX_OK;
 }
 
-int fwx_matrix_enable_path_log(fwx_matrix *m, uint64_t capacity_records)
+int fwx_matrix_enable_path_log(fwx_matrix *m)
 {
-    if (!m || !m->next || m->plog.head || capacity_records > 0x7fffffffull) return FWX_ERR_INVALID;
+    if (!m || !m->next || m->plog.head) return FWX_ERR_INVALID;
     if (m->n == 0) return FWX_OK;
     DeviceGuard g;
     int rc = g.enter(m->device);
     if (rc) return rc;
-    const size_t nn = (size_t)m->n * (size_t)m->n;
-    const size_t cap = capacity_records ? capacity_records : 1;
+    const size_t nn = (size_t)m->n * (size_t)m->n, es = m->dtype == FWX_F64 ? 8 : 4;
     FWX_HIP(hipMalloc((void **)&m->plog.head, nn * 4));
-    FWX_HIP(hipMalloc((void **)&m->plog.rec_k, cap * 4));
-    FWX_HIP(hipMalloc((void **)&m->plog.rec_prev, cap * 4));
-    FWX_HIP(hipMalloc((void **)&m->plog.count, sizeof(unsigned long long)));
+    FWX_HIP(hipMalloc((void **)&m->plog.count, FWX_UPDATE_SHARDS * sizeof(unsigned long long)));
+    FWX_HIP(hipMalloc((void **)&m->plog.base, (FWX_UPDATE_SHARDS + 1) * sizeof(unsigned long long)));
+    FWX_HIP(hipMalloc(&m->rate0, nn * es));
     FWX_HIP(hipMalloc((void **)&m->next0, nn * 4));
-    m->plog.capacity = capacity_records;
+    if (m->hops) FWX_HIP(hipMalloc((void **)&m->hops0, nn * 4));
     FWX_HIP(hipMemset(m->plog.head, 0xFF, nn * 4));
-    FWX_HIP(hipMemset(m->plog.count, 0, sizeof(unsigned long long)));
+    FWX_HIP(hipMemset(m->plog.count, 0, FWX_UPDATE_SHARDS * sizeof(unsigned long long)));
+    FWX_HIP(hipMemset((void *)m->plog.base, 0, (FWX_UPDATE_SHARDS + 1) * sizeof(unsigned long long)));
+    FWX_HIP(hipMemcpy(m->rate0, m->rate, nn * es, hipMemcpyDeviceToDevice));
     FWX_HIP(hipMemcpy(m->next0, m->next, nn * 4, hipMemcpyDeviceToDevice));
+    if (m->hops) FWX_HIP(hipMemcpy(m->hops0, m->hops, nn * 4, hipMemcpyDeviceToDevice));
     return FWX_OK;
 }
 
@@ -622,9 +679,9 @@ int fwx_matrix_path_log_count(fwx_matrix *m, uint64_t *count_out)
     DeviceGuard g;
     int rc = g.enter(m->device);
     if (rc) return rc;
-    unsigned long long c = 0;
-    FWX_HIP(hipMemcpy(&c, m->plog.count, sizeof(c), hipMemcpyDeviceToHost));
-    *count_out = c;
+    unsigned long long c[FWX_UPDATE_SHARDS];
+    FWX_HIP(hipMemcpy(c, m->plog.count, sizeof(c), hipMemcpyDeviceToHost));
+    for (int i = 0; i < FWX_UPDATE_SHARDS; ++i) *count_out += c[i];
     return FWX_OK;
 }
 
@@ -637,9 +694,7 @@ int fwx_matrix_query_exact(fwx_matrix *m, int32_t src, int32_t dst, double *rate
     DeviceGuard g;
     int rc = g.enter(m->device);
     if (rc) return rc;
-    unsigned long long c = 0;
-    FWX_HIP(hipMemcpy(&c, m->plog.count, sizeof(c), hipMemcpyDeviceToHost));
-    if (c > m->plog.capacity) return FWX_ERR_CAPACITY;     // the log overflowed during the solve
+    if (!m->rec_ready) return FWX_ERR_INVALID;             // no logged solve yet
     const size_t idx = (size_t)src * m->n + dst;
     if (rate_out) {
         if (m->dtype == FWX_F64) {
@@ -690,6 +745,7 @@ int fwx_matrix_solve(fwx_matrix *m, const fwx_opts *opts)
     DeviceGuard g;
     if ((rc = g.enter(m->device))) return rc;
     hipStream_t s = nullptr;
+    if (m->plog.head) return logged_solve(m, op, s);
     unsigned long long *upd = op.updates_out ? m->upd : nullptr;
     if (upd) FWX_HIP(hipMemsetAsync(upd, 0, FWX_UPDATE_SHARDS * 8, s));
     if (m->dtype == FWX_F64)

@@ -15,10 +15,14 @@ namespace fwx {
 // entry}; head[i*n+j] is the entry's newest record.  All device pointers; head == nullptr = off.
 struct PathLog {
     int32_t *head;                 // n*n, -1 = never updated
-    int32_t *rec_k;                // capacity records: pivot of the update
-    int32_t *rec_prev;             // capacity records: older record of the same entry or -1
-    unsigned long long *count;     // records appended (may exceed capacity: overflow)
-    unsigned long long capacity;
+    int32_t *rec_k;                // records: pivot of the update
+    int32_t *rec_prev;             // records: older record of the same entry or -1
+    // The log is SHARDED like the update counters (shard = workgroup id & 255) so that appends
+    // do not contend on one address: shard s owns records [base[s], base[s+1]), sized exactly
+    // from the per-shard counts of a counting solve of the same input (same launch geometry,
+    // hence the same updates per workgroup).
+    unsigned long long *count;     // FWX_UPDATE_SHARDS_K counters: records appended per shard
+    const unsigned long long *base;  // FWX_UPDATE_SHARDS_K + 1 prefix offsets
 };
 
 template <typename T> struct RelaxArgs {

@@ -25,11 +25,11 @@
 
 namespace fwx {
 
-// Append one update record for entry `off` (= i*n+j, global) made by pivot k.
-__device__ __forceinline__ void log_update(const PathLog &plog, size_t off, int k)
+// Append one update record for entry `off` (= i*n+j, global) made by pivot k, in shard `shard`.
+__device__ __forceinline__ void log_update(const PathLog &plog, size_t off, int k, int shard)
 {
-    const unsigned long long idx = atomicAdd(plog.count, 1ull);
-    if (idx < plog.capacity) {
+    const unsigned long long idx = plog.base[shard] + atomicAdd(&plog.count[shard], 1ull);
+    if (idx < plog.base[shard + 1]) {
         plog.rec_k[idx] = k;
         plog.rec_prev[idx] = plog.head[off];
         plog.head[off] = (int32_t)idx;
@@ -163,7 +163,8 @@ __global__ __launch_bounds__(256, MINW) void relax_k(T *rate, int32_t *next, int
                     changed = true;
                     if (HAS_NEXT) next[off + c] = s_ncol[r];
                     if (HAS_HOPS) hops[off + c] = s_hcol[r] + phops[cv + c];
-                    if (HAS_NEXT && plog.head) log_update(plog, (size_t)i * n + cv + c, k);
+                    if (HAS_NEXT && plog.head)
+                        log_update(plog, (size_t)i * n + cv + c, k, bid & (FWX_UPDATE_SHARDS_K - 1));
                     if (COUNT) ++my_updates;
                 }
             }
@@ -257,7 +258,7 @@ __global__ __launch_bounds__(256) void small_solve(T *rate, int32_t *next, int32
                 R[r][c] = cand;
                 if (HAS_NEXT) { nx[m] = NX[r][k]; NX[r][c] = nx[m]; }
                 if (HAS_HOPS) { hp[m] = HP[r][k] + hkc; HP[r][c] = hp[m]; }
-                if (HAS_NEXT && plog.head) log_update(plog, (size_t)r * n + c, k);
+                if (HAS_NEXT && plog.head) log_update(plog, (size_t)r * n + c, k, 0);
                 ++mine;
             }
         }

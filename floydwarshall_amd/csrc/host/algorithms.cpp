@@ -5,7 +5,10 @@
 // (floydWarshall = runAlgo 0 . buildMatrix, :19-20, is Session::ensure_solved in session.cpp:
 //  buildMatrix here, runAlgo on the GPU through fwx_matrix_solve.)
 #include <algorithm>
+#include <map>
 #include <set>
+#include <string>
+#include <vector>
 
 #include "host_types.hpp"
 
@@ -25,23 +28,28 @@ DenseMatrix build_matrix(const ExchRateTimes &rates)
     m.rate.assign(n * n, 0.0);       // isolatedEntry: rate 0.0, path [] (Utils.hs:13-14)
     m.next.assign(n * n, -1);
     m.hops.assign(n * n, 0);
-    for (size_t i = 0; i < n; ++i) {
-        for (size_t j = 0; j < n; ++j) {
-            if (i == j) continue;                                         // :34
-            const Vertex &vi = m.vertices[i], &vj = m.vertices[j];
-            double r;
-            if (vi.ccy == vj.ccy) {                                       // :35 before the lookup
-                r = 1.0;
-            } else {
-                auto it = rates.find(VertexPair(vi, vj));                 // :36
-                if (it == rates.end()) continue;                          // :38
-                r = it->second.first;                                     // :37
-            }
-            m.rate[i * n + j] = r;
-            m.next[i * n + j] = (int32_t)j;                               // path = [vtxJ]
-            m.hops[i * n + j] = 1;
-        }
+    // The reference evaluates, per entry, :34 (i == j) then :35 (same currency) then :36-38 (map
+    // lookup): N^2 lookups.  Same result in O(E log V + sum of group^2): scatter the map entries
+    // first, then let the same-currency rule overwrite (it is tested BEFORE the lookup, so it wins).
+    std::map<Vertex, size_t> index;
+    for (size_t i = 0; i < n; ++i) index[m.vertices[i]] = i;
+    for (const auto &kv : rates) {                                        // :36-37
+        const size_t i = index[kv.first.first], j = index[kv.first.second];
+        if (i == j) continue;                                             // :34
+        m.rate[i * n + j] = kv.second.first;
+        m.next[i * n + j] = (int32_t)j;                                   // path = [vtxJ]
+        m.hops[i * n + j] = 1;
     }
+    std::map<std::string, std::vector<size_t>> by_ccy;
+    for (size_t i = 0; i < n; ++i) by_ccy[m.vertices[i].ccy].push_back(i);
+    for (const auto &g : by_ccy)                                          // :35
+        for (size_t i : g.second)
+            for (size_t j : g.second) {
+                if (i == j) continue;
+                m.rate[i * n + j] = 1.0;
+                m.next[i * n + j] = (int32_t)j;
+                m.hops[i * n + j] = 1;
+            }
     return m;
 }
 

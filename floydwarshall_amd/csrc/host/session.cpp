@@ -50,29 +50,16 @@ int Session::ensure_solved()
     drop_device();
     vertices_ = m.vertices;
     if (m.n() > 0) {
-        // Two solves per rate change: the first counts U (successful relaxations), the second
-        // repeats the solve with an update log of exactly that capacity, from which
-        // fwx_matrix_query_exact rebuilds the reference's `_path` lists -- under exact ties (the
-        // 1.0 edges of Algorithms.hs:35 make them common) the list the reference stored can be a
-        // longer route than the one the next-hops describe.  Logged solves run on the per-k
-        // engine (single launch for n <= 64), which also carries `hops`.
-        uint64_t u = 0;
-        fwx_opts o;
-        memset(&o, 0, sizeof(o));
-        o.struct_size = sizeof(o);
-        o.device = -1;
-        o.updates_out = &u;
+        // The solve keeps an update log (fwx_matrix_enable_path_log: a counting pass, then a
+        // logged replay), from which fwx_matrix_query_exact rebuilds the reference's `_path`
+        // lists -- under exact ties (the 1.0 edges of Algorithms.hs:35 make them common) the list
+        // the reference stored can be a longer route than the one the next-hops describe.  Logged
+        // solves run on the per-k engine (one launch for n <= 64), which also carries `hops`.
         int rc = fwx_matrix_create(&dev_, m.n(), FWX_F64, 1, 1, device_);
         if (rc) return rc;
+        if ((rc = fwx_matrix_enable_path_log(dev_))) return rc;
         if ((rc = fwx_matrix_upload(dev_, m.rate.data(), m.next.data(), m.hops.data()))) return rc;
-        o.engine = m.n() <= 64 ? FWX_ENGINE_AUTO : FWX_ENGINE_PERK;
-        if ((rc = fwx_matrix_solve(dev_, &o))) return rc;            // runAlgo 0, counting
-        drop_device();
-        if ((rc = fwx_matrix_create(&dev_, m.n(), FWX_F64, 1, 1, device_))) return rc;
-        if ((rc = fwx_matrix_enable_path_log(dev_, u))) return rc;
-        if ((rc = fwx_matrix_upload(dev_, m.rate.data(), m.next.data(), m.hops.data()))) return rc;
-        o.updates_out = nullptr;
-        if ((rc = fwx_matrix_solve(dev_, &o))) return rc;            // runAlgo 0, logged
+        if ((rc = fwx_matrix_solve(dev_, nullptr))) return rc;       // runAlgo 0, on the GPU
     }
     solved_version_ = version_;
     ++solves_;

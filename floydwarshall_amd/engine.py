@@ -118,11 +118,10 @@ class DeviceMatrix:
                                           _np_ptr(out), self.n), "fwx_matrix_query")
         return float(r.value), [int(x) for x in out[:ln]]
 
-    def enable_path_log(self, capacity_records):
+    def enable_path_log(self):
         """Record every successful relaxation so that query_exact can rebuild the reference's
-        `_path` lists exactly (see fwx.h); call before upload()."""
-        check(lib().fwx_matrix_enable_path_log(self._h, int(capacity_records)),
-              "fwx_matrix_enable_path_log")
+        `_path` lists exactly (see fwx.h); solve() then runs a counting pass and a logged pass."""
+        check(lib().fwx_matrix_enable_path_log(self._h), "fwx_matrix_enable_path_log")
 
     def path_log_count(self):
         c = ctypes.c_uint64(0)

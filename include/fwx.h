@@ -116,11 +116,12 @@ int fwx_matrix_destroy(fwx_matrix *m);
  * between the same currency on two exchanges make them common) that list can be a different,
  * longer route of equal rate.  With the update log enabled every successful relaxation appends
  * one 8-byte record on the device, and fwx_matrix_query_exact rebuilds the reference's list
- * exactly.  Enable after create / before upload; needs the next-hop matrix; the logged solve runs
- * on the per-k engine (or small_solve); capacity_records must cover U (fwx_opts.updates_out of a
- * counting solve of the same input gives it); an overflowed log makes query_exact return
- * FWX_ERR_CAPACITY.  path_out receives the vertices after src up to dst; returns the length.   */
-int fwx_matrix_enable_path_log(fwx_matrix *m, uint64_t capacity_records);
+ * exactly.  Enable after create; needs the next-hop matrix.  fwx_matrix_solve then (1) runs a
+ * counting solve, (2) sizes the log exactly (sharded by workgroup so appends do not contend),
+ * (3) restores the input from a pristine device copy and replays the solve with logging -- on the
+ * per-k engine (or small_solve), whole pivot range only.  Costs twice the solve time and twice the
+ * memory.  path_out receives the vertices after src up to dst; returns the length.              */
+int fwx_matrix_enable_path_log(fwx_matrix *m);
 int fwx_matrix_path_log_count(fwx_matrix *m, uint64_t *count_out);
 int fwx_matrix_query_exact(fwx_matrix *m, int32_t src, int32_t dst, double *rate_out,
                            int32_t *path_out, int32_t cap);

@@ -702,13 +702,12 @@ def _exact_paths_case(m0, dtype=np.float64):
     _, rate, nxt, hops = lf.to_dense(m0, dtype)
     n = rate.shape[0]
     _, erate, enext, ehops = lf.to_dense(ref, dtype)
-    # pass 1: count U; pass 2: logged solve with exactly that capacity
     u = engine.solve(rate.copy(), nxt.copy(), hops.copy(), count_updates=True,
                      engine=engine.FWX_ENGINE_PERK if n > 64 else engine.FWX_ENGINE_AUTO)
     dm = engine.DeviceMatrix(n, dtype, with_next=True, with_hops=True)
-    dm.enable_path_log(u)
+    dm.enable_path_log()
     dm.upload(rate, nxt, hops)
-    dm.solve()
+    assert dm.solve(count_updates=True) == u           # counting pass + logged replay
     assert dm.path_log_count() == u
     r, nx, hp = dm.download()
     assert_bits_equal(r, erate, "rate")
