@@ -411,6 +411,7 @@ struct fwx_matrix {
     int32_t *walk;         // scratch of the exact-path walk (stack + output)
     int32_t walk_cap;      // capacity (path entries) `walk` was sized for
     int32_t rec_ready;     // a logged solve has completed
+    int32_t clean;         // the working arrays still equal the pristine copy (fresh upload)
 };
 
 namespace {
@@ -451,6 +452,14 @@ int logged_solve(fwx_matrix *m, const Opts &op_in, hipStream_t s)
     Opts op = op_in;                             // both passes must take the same launches
     if (m->n > FWX_SMALL_N) op.engine = FWX_ENGINE_PERK;
     const size_t nn = (size_t)m->n * (size_t)m->n, es = m->dtype == FWX_F64 ? 8 : 4;
+    auto restore = [&]() -> int {
+        FWX_HIP(hipMemcpyAsync(m->rate, m->rate0, nn * es, hipMemcpyDeviceToDevice, s));
+        FWX_HIP(hipMemcpyAsync(m->next, m->next0, nn * 4, hipMemcpyDeviceToDevice, s));
+        if (m->hops) FWX_HIP(hipMemcpyAsync(m->hops, m->hops0, nn * 4, hipMemcpyDeviceToDevice, s));
+        return FWX_OK;
+    };
+    if (!m->clean && restore()) return FWX_ERR_HIP;   // both passes start from the uploaded input
+    m->clean = 0;
     fwx::PathLog saved = m->plog;
     m->plog = fwx::PathLog();                    // pass 1 must not log
     FWX_HIP(hipMemsetAsync(m->upd, 0, FWX_UPDATE_SHARDS * 8, s));
@@ -473,9 +482,7 @@ int logged_solve(fwx_matrix *m, const Opts &op_in, hipStream_t s)
     FWX_HIP(hipMemcpyAsync((void *)m->plog.base, base, sizeof(base), hipMemcpyHostToDevice, s));
     FWX_HIP(hipMemsetAsync(m->plog.count, 0, FWX_UPDATE_SHARDS * 8, s));
     FWX_HIP(hipMemsetAsync(m->plog.head, 0xFF, nn * 4, s));
-    FWX_HIP(hipMemcpyAsync(m->rate, m->rate0, nn * es, hipMemcpyDeviceToDevice, s));
-    FWX_HIP(hipMemcpyAsync(m->next, m->next0, nn * 4, hipMemcpyDeviceToDevice, s));
-    if (m->hops) FWX_HIP(hipMemcpyAsync(m->hops, m->hops0, nn * 4, hipMemcpyDeviceToDevice, s));
+    if (restore()) return FWX_ERR_HIP;
     FWX_HIP(hipStreamSynchronize(s));            // `base` (host array) must outlive the copy
     rc = m->dtype == FWX_F64 ? matrix_solve_typed<double>(m, op, nullptr, s)
                              : matrix_solve_typed<float>(m, op, nullptr, s);
@@ -644,6 +651,8 @@ int fwx_matrix_upload(fwx_matrix *m, const void *rate, const int32_t *next, cons
         FWX_HIP(hipMemset(m->plog.head, 0xFF, nn * 4));
         FWX_HIP(hipMemset(m->plog.count, 0, FWX_UPDATE_SHARDS * sizeof(unsigned long long)));
         m->log_total = 0;
+        m->rec_ready = 0;      // the log of an earlier input is stale
+        m->clean = 1;
     }
     return FWX_OK;
 }
@@ -668,6 +677,7 @@ int fwx_matrix_enable_path_log(fwx_matrix *m)
     FWX_HIP(hipMemcpy(m->rate0, m->rate, nn * es, hipMemcpyDeviceToDevice));
     FWX_HIP(hipMemcpy(m->next0, m->next, nn * 4, hipMemcpyDeviceToDevice));
     if (m->hops) FWX_HIP(hipMemcpy(m->hops0, m->hops, nn * 4, hipMemcpyDeviceToDevice));
+    m->clean = 1;
     return FWX_OK;
 }
 
@@ -681,6 +691,7 @@ int fwx_matrix_path_log_count(fwx_matrix *m, uint64_t *count_out)
     if (rc) return rc;
     unsigned long long c[FWX_UPDATE_SHARDS];
     FWX_HIP(hipMemcpy(c, m->plog.count, sizeof(c), hipMemcpyDeviceToHost));
+    *count_out = 0;
     for (int i = 0; i < FWX_UPDATE_SHARDS; ++i) *count_out += c[i];
     return FWX_OK;
 }

@@ -90,7 +90,7 @@ class HipBackend:
 
 
 def solve_partitioned(rate, n, rank, world, *, nxt=None, block=64, backend=None, group=None,
-                      lookahead=True):
+                      lookahead=True, force_collectives=False):
     """In-place solve of this rank's slab `rate` (rows row_bounds(n, world)[rank]...).
 
     All ranks must call this with the same n / world / block / lookahead.  Works on any device the
@@ -105,6 +105,7 @@ def solve_partitioned(rate, n, rank, world, *, nxt=None, block=64, backend=None,
         everyone:           relax the rest of the slab with W_b   <- overlaps the broadcast
     """
     backend = backend or HipBackend()
+    collectives = world > 1 or force_collectives   # force: rehearse the RCCL calls on one rank
     assert 1 <= block <= engine.FWX_FUSED_BLOCK
     bounds = row_bounds(n, world)
     row0, rows = bounds[rank], bounds[rank + 1] - bounds[rank]
@@ -117,7 +118,7 @@ def solve_partitioned(rate, n, rank, world, *, nxt=None, block=64, backend=None,
     if hasattr(backend, "check_domain"):
         ok = torch.tensor([backend.check_domain(rate, n, row0, nxt)], dtype=torch.int32,
                           device=rate.device)
-        if world > 1:
+        if collectives:
             dist.all_reduce(ok, op=dist.ReduceOp.MIN, group=group)
         backend.nonneg = bool(ok.item() == 1)
     bufs = [torch.empty((block, n), dtype=rate.dtype, device=rate.device) for _ in range(2)]
@@ -142,14 +143,14 @@ def solve_partitioned(rate, n, rank, world, *, nxt=None, block=64, backend=None,
                 if rank == owner:
                     lo = k0 - row0
                     backend.panel(rate[lo:lo + b], n, k0, w)
-                if world > 1:
+                if collectives:
                     src = owner if group is None else dist.get_global_rank(group, owner)
                     work = dist.broadcast(w, src=src, group=group, async_op=True)
         else:
             if rank == owner:
                 lo = k0 - row0
                 backend.panel(rate[lo:lo + b], n, k0, w)
-            if world > 1:
+            if collectives:
                 src = owner if group is None else dist.get_global_rank(group, owner)
                 work = dist.broadcast(w, src=src, group=group, async_op=True)
 

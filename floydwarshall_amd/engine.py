@@ -142,6 +142,13 @@ class DeviceMatrix:
             lib().fwx_matrix_destroy(self._h)
             self._h = None
 
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+        return False
+
     def __del__(self):
         try:
             self.close()

@@ -120,7 +120,9 @@ int fwx_matrix_destroy(fwx_matrix *m);
  * counting solve, (2) sizes the log exactly (sharded by workgroup so appends do not contend),
  * (3) restores the input from a pristine device copy and replays the solve with logging -- on the
  * per-k engine (or small_solve), whole pivot range only.  Costs twice the solve time and twice the
- * memory.  path_out receives the vertices after src up to dst; returns the length.              */
+ * memory; a logged solve always starts from the uploaded input (solving twice gives the same
+ * matrix).  query_exact before a completed logged solve of the current upload: FWX_ERR_INVALID.
+ * path_out receives the vertices after src up to dst; returns the length.                       */
 int fwx_matrix_enable_path_log(fwx_matrix *m);
 int fwx_matrix_path_log_count(fwx_matrix *m, uint64_t *count_out);
 int fwx_matrix_query_exact(fwx_matrix *m, int32_t src, int32_t dst, double *rate_out,

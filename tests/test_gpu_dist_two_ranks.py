@@ -76,3 +76,50 @@ def test_two_ranks_one_gpu(tmp_path, world, n, block, engine_name, kind, with_ne
     assert len(votes) == 1                                       # the domain vote is global
     if engine_name == "fused" and not with_next:
         assert votes == ({"1"} if kind == "d1" else {"0"})
+
+
+def _rccl_worker(rank, port, n, engine_name, with_next, outdir):
+    import datetime
+    import torch
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    torch.cuda.set_device(0)
+    dev = torch.device("cuda:0")
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev,
+                            timeout=datetime.timedelta(seconds=120))
+    from floydwarshall_amd import dist as fwdist
+    from floydwarshall_amd import synth
+    rate, nxt, _ = synth.make("d2", n, np.float32, seed=778)
+    slab = torch.from_numpy(rate).to(dev)
+    nslab = torch.from_numpy(nxt).to(dev) if with_next else None
+    fwdist.solve_partitioned(slab, n, 0, 1, nxt=nslab, backend=fwdist.HipBackend(engine_name),
+                             force_collectives=True)
+    dist.barrier()
+    torch.cuda.synchronize()
+    t = torch.tensor([1.5], dtype=torch.float64, device=dev)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)          # what bench.py does with the step time
+    assert float(t.item()) == 1.5
+    np.save(os.path.join(outdir, "rate.npy"), slab.cpu().numpy())
+    if with_next:
+        np.save(os.path.join(outdir, "next.npy"), nslab.cpu().numpy())
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("engine_name,with_next", [("fused", False), ("perk", True)])
+def test_rccl_calls_on_a_single_rank(tmp_path, engine_name, with_next):
+    """RCCL itself (backend "nccl"), one rank: the MIN all-reduce of the domain vote and the async
+    panel broadcasts on the side stream are issued exactly as with N ranks (force_collectives),
+    so stream ordering against RCCL's internal stream is exercised on the real library."""
+    import torch.multiprocessing as mp
+    import oracle
+    from floydwarshall_amd import synth
+    from helpers import assert_bits_equal
+    n = 640
+    mp.spawn(_rccl_worker, args=(_free_port(), n, engine_name, with_next, str(tmp_path)),
+             nprocs=1, join=True)
+    rate, nxt, _ = synth.make("d2", n, np.float32, seed=778)
+    oracle.relax(rate, nxt if with_next else None)
+    assert_bits_equal(np.load(tmp_path / "rate.npy"), rate, "rate over RCCL")
+    if with_next:
+        assert_bits_equal(np.load(tmp_path / "next.npy"), nxt, "next over RCCL")

@@ -746,6 +746,36 @@ def test_exact_path_lists_dense_kinds(kind):
     _exact_paths_case(lf.from_dense(vertices, rate, nxt))
 
 
+def test_path_log_lifecycle():
+    """query_exact needs a completed logged solve of the CURRENT upload; a logged solve always
+    replays from the uploaded input, so solving twice gives the same matrix; k-ranges and the
+    fused engine are refused for logged matrices."""
+    n = 96
+    rate, nxt, _ = synth.make("t1", n, np.float32, seed=5)
+    want_r, want_n = rate.copy(), nxt.copy()
+    oracle.relax(want_r, want_n)
+    with engine.DeviceMatrix(n, np.float32, with_next=True) as dm:
+        dm.enable_path_log()
+        dm.upload(rate, nxt)
+        with pytest.raises(engine.FwxError):
+            dm.query_exact(0, 1)
+        with pytest.raises(engine.FwxError):
+            dm.solve(k_begin=0, k_end=n // 2)
+        with pytest.raises(engine.FwxError):
+            dm.solve(engine=engine.FWX_ENGINE_FUSED)
+        u1 = dm.solve(count_updates=True)
+        u2 = dm.solve(count_updates=True)
+        assert u1 == u2 == dm.path_log_count()
+        r, nx = dm.download()[:2]
+        assert_bits_equal(r, want_r, "rate")
+        assert np.array_equal(nx, want_n)
+        q_rate, q_path = dm.query_exact(3, 7)
+        assert q_rate == want_r[3, 7] and q_path[-1] == 7
+        dm.upload(rate, nxt)                              # new input: the old log is stale
+        with pytest.raises(engine.FwxError):
+            dm.query_exact(3, 7)
+
+
 def test_exact_path_lists_above_the_single_launch_size():
     """n = 80 > 64: the log is written by the per-k kernel (relax_k) instead of small_solve."""
     m0 = lf.build_matrix(_market_rates(10, 8, seed=23))
