@@ -40,7 +40,7 @@ template <typename T> struct RelaxArgs {
 template <typename T> hipError_t launch_relax(const RelaxArgs<T> &a, hipStream_t s);
 
 // Whole solve (pivots [k_begin,k_end)) of an n <= FWX_SMALL_N matrix in one single-workgroup launch.
-#define FWX_SMALL_N 64
+#define FWX_SMALL_N 128
 template <typename T>
 hipError_t launch_small_solve(T *rate, int32_t *next, int32_t *hops, int n, int k_begin, int k_end,
                               unsigned long long *updates, PathLog plog, hipStream_t s);

@@ -207,74 +207,153 @@ __global__ __launch_bounds__(256, MINW) void relax_k(T *rate, int32_t *next, int
 }
 
 // -------------------------------------------------------------------------------------------------
-// small_solve: the whole of runAlgo for n <= 64 in ONE launch of one workgroup -- the reference's
+// small_solve: the whole of runAlgo for n <= 128 in ONE launch of one workgroup -- the reference's
 // own regime (its tests stop at 4 x 4, src/test/AlgorithmsTest.hs:66-77; the README session has 4
-// vertices).  rate / next / hops live in LDS for the entire solve, one barrier per pivot.  Row k
-// and column k are fixed points of step k, so the in-place LDS update reads exactly the step-start
-// operands (Algorithms.hs:58-60).
+// vertices; a market of 10 exchanges x 12 currencies has 120).  The matrix is padded with NaN to
+// M x M (M = 64 or 128) and lives in REGISTERS for the entire solve (1024 threads; the 128-wide
+// tile keeps its index matrices in LDS): thread (r0, c) holds column c of the rows r0, r0+RG, ...  Only pivot row k and pivot column k pass through LDS, double
+// buffered: during step k the threads that own entries of row k+1 / column k+1 publish their
+// post-step values (= the time-(k+1) operands) into the other buffer, so one barrier per pivot is
+// enough.  Row k and column k are fixed points of step k, so what step k reads are exactly the
+// step-start operands (Algorithms.hs:58-60).
 // -------------------------------------------------------------------------------------------------
-template <typename T, bool HAS_NEXT, bool HAS_HOPS>
-__global__ __launch_bounds__(256) void small_solve(T *rate, int32_t *next, int32_t *hops, int n,
-                                                   int k_begin, int k_end,
-                                                   unsigned long long *updates, PathLog plog)
+template <typename T, int M, int RG, bool HAS_NEXT, bool HAS_HOPS, bool LOG>
+__global__ __launch_bounds__(M * RG) void small_solve(T *rate, int32_t *next, int32_t *hops, int n,
+                                                      int k_begin, int k_end,
+                                                      unsigned long long *updates, PathLog plog)
 {
-    constexpr int M = FWX_SMALL_N;            // the matrix is padded to 64 x 64 with NaN
-    constexpr int E = M * M / 256;            // 16 entries per thread: column c = tid % 64 fixed,
-    __shared__ T R[M][M + 1];                 // rows r = tid / 64 + 4 m  (no divisions anywhere)
-    __shared__ int32_t NX[HAS_NEXT ? M : 1][M + 1];
-    __shared__ int32_t HP[HAS_HOPS ? M : 1][M + 1];
-    __shared__ unsigned int s_cnt;
+    constexpr int E = M / RG;                 // entries per thread; rows r = r0 + RG*m
+    constexpr int G = 4;                      // entries per branch-free group
+    constexpr int LOG_M = M == 64 ? 6 : 7;
+    // Where next / hops live.  64-wide tile: in registers like the rates (4 entries per thread).
+    // 128-wide tile: 16 entries per thread and 128 registers each, so the two index matrices
+    // stay in LDS (2 x 66 KB of the CU's 160 KB) and only the rates are in registers; row k and
+    // column k of an LDS-resident matrix are read in place (they are not written during step k).
+    constexpr bool IDXL = M == 128;
+    constexpr bool NXL = IDXL && HAS_NEXT, HPL = IDXL && HAS_HOPS;
+    static_assert(M == 64 || M == 128, "M");
+    static_assert(E % G == 0, "E");
+    __shared__ T rowR[2][M], colR[2][M];      // pivot row k / pivot column k at time k
+    __shared__ int32_t rowH[2][HAS_HOPS && !IDXL ? M : 1], colH[2][HAS_HOPS && !IDXL ? M : 1];
+    __shared__ int32_t colN[2][HAS_NEXT && !IDXL ? M : 1];
+    __shared__ int32_t NX[NXL ? M : 1][NXL ? M + 1 : 1], HP[HPL ? M : 1][HPL ? M + 1 : 1];
+    __shared__ unsigned int s_cnt, s_log;
     const int tid = threadIdx.x;
-    const int c = tid & 63, r0 = tid >> 6;
-    if (tid == 0) s_cnt = 0;
+    // a wave never straddles two rows: r0 is wave-uniform, say so (scalar row tests, fewer VGPRs)
+    const int c = tid & (M - 1), r0 = __builtin_amdgcn_readfirstlane(tid >> LOG_M);
+    if (tid == 0) { s_cnt = 0; s_log = 0; }
+    const int off0 = r0 * n + c, off_step = RG * n;   // entry (r0 + RG*m, c) is at off0 + m*off_step
+    // Update log of this launch (one workgroup = shard 0): records are numbered by an LDS counter
+    // and each thread keeps the newest record of its own entries in a register, so appending is
+    // two fire-and-forget stores; heads and the record count go to memory once, at the end.
+    const unsigned int log_base = LOG ? (unsigned int)plog.base[0] : 0u;
+    const unsigned int log_cap = LOG ? (unsigned int)(plog.base[1] - plog.base[0]) : 0u;
 
     T x[E];
-    int32_t nx[HAS_NEXT ? E : 1], hp[HAS_HOPS ? E : 1];
+    int32_t nx[HAS_NEXT && !IDXL ? E : 1], hp[HAS_HOPS && !IDXL ? E : 1], hd[LOG ? E : 1];
+    auto publish = [&](int k, int b) {        // my entries of row k / column k -> buffer b
+#pragma unroll
+        for (int m = 0; m < E; ++m) {
+            if (r0 + RG * m == k) {           // scalar
+                rowR[b][c] = x[m];
+                if constexpr (HAS_HOPS && !IDXL) rowH[b][c] = hp[m];
+            }
+        }
+        if (c == k) {                         // one lane of the wave that holds column k
+#pragma unroll
+            for (int m = 0; m < E; ++m) {
+                const int r = r0 + RG * m;
+                colR[b][r] = r == k ? quiet_nan<T>() : x[m];   // skip i == k: NaN at the source
+                if constexpr (HAS_NEXT && !IDXL) colN[b][r] = nx[m];
+                if constexpr (HAS_HOPS && !IDXL) colH[b][r] = hp[m];
+            }
+        }
+    };
 #pragma unroll
     for (int m = 0; m < E; ++m) {
-        const int r = r0 + 4 * m;
+        const int r = r0 + RG * m;
         const bool in = r < n && c < n;
-        x[m] = in ? rate[(size_t)r * n + c] : quiet_nan<T>();
-        R[r][c] = x[m];
-        if (HAS_NEXT) { nx[m] = in ? next[(size_t)r * n + c] : -1; NX[r][c] = nx[m]; }
-        if (HAS_HOPS) { hp[m] = in ? hops[(size_t)r * n + c] : 0; HP[r][c] = hp[m]; }
+        x[m] = in ? rate[off0 + m * off_step] : quiet_nan<T>();
+        // skip j == i: a diagonal entry is never an operand (it could only be one in the steps
+        // that skip it) and never a target, so its register holds +inf -- no candidate compares
+        // greater -- and the value in memory is left as it is
+        if (r == c) x[m] = (T)__builtin_huge_val();
+        if constexpr (HAS_NEXT) {
+            const int32_t v = in ? next[off0 + m * off_step] : -1;
+            if constexpr (IDXL) NX[r][c] = v; else nx[m] = v;
+        }
+        if constexpr (HAS_HOPS) {
+            const int32_t v = in ? hops[off0 + m * off_step] : 0;
+            if constexpr (IDXL) HP[r][c] = v; else hp[m] = v;
+        }
+        if constexpr (LOG) hd[m] = -1;
     }
+    publish(k_begin, k_begin & 1);
     __syncthreads();
 
     unsigned int mine = 0;
     for (int k = k_begin; k < k_end; ++k) {
-        // row k and column k are fixed points of step k: every operand below is a step-start value
-        T rkc = R[k][c];
-        const int32_t hkc = HAS_HOPS ? HP[k][c] : 0;
+        const int b = k & 1;
+        T rkc = rowR[b][c];
+        int32_t hkc = 0;
+        if constexpr (HPL) hkc = HP[k][c];
+        else if constexpr (HAS_HOPS) hkc = rowH[b][c];
         if (c == k) rkc = quiet_nan<T>();                     // skip j == k
 #pragma unroll
-        for (int m = 0; m < E; ++m) {
-            const int r = r0 + 4 * m;
-            T rik = R[r][k];                                  // wave-uniform: LDS broadcast
-            if (r == k || r == c) rik = quiet_nan<T>();       // skip i == k and j == i
-            const T cand = rik * rkc;                         // Algorithms.hs:61
-            if (x[m] < cand) {                                // :55
-                x[m] = cand;
-                R[r][c] = cand;
-                if (HAS_NEXT) { nx[m] = NX[r][k]; NX[r][c] = nx[m]; }
-                if (HAS_HOPS) { hp[m] = HP[r][k] + hkc; HP[r][c] = hp[m]; }
-                if (HAS_NEXT && plog.head) log_update(plog, (size_t)r * n + c, k, 0);
-                ++mine;
+        for (int g = 0; g < E; g += G) {
+            if (r0 + RG * g >= n) break;                      // scalar: nothing but padding rows left
+            // G entries: the pivot-column operands are read unconditionally (so the LDS reads of
+            // the group overlap) and the update is a select / predicated store, exactly
+            //   if (x < cand) { x = cand; next = next[i][k]; hops = hops[i][k] + hops[k][j]; }
+#pragma unroll
+            for (int m = g; m < g + G; ++m) {
+                const int r = r0 + RG * m;
+                const T raw = colR[b][r];                     // wave-uniform address: LDS broadcast
+                int32_t cn = 0, ch = 0;
+                if constexpr (NXL) cn = NX[r][k]; else if constexpr (HAS_NEXT) cn = colN[b][r];
+                if constexpr (HPL) ch = HP[r][k]; else if constexpr (HAS_HOPS) ch = colH[b][r];
+                const T cand = raw * rkc;                     // Algorithms.hs:61
+                const bool p = x[m] < cand;                   // :55 (false on NaN)
+                x[m] = p ? cand : x[m];
+                if constexpr (!IDXL) {
+                    if constexpr (HAS_NEXT) nx[m] = p ? cn : nx[m];
+                    if constexpr (HAS_HOPS) hp[m] = p ? ch + hkc : hp[m];
+                } else if (p) {
+                    if constexpr (HAS_NEXT) NX[r][c] = cn;
+                    if constexpr (HAS_HOPS) HP[r][c] = ch + hkc;
+                }
+                mine += (unsigned int)__builtin_popcountll(__ballot(p));   // scalar; wave total
+                if (LOG && p) {
+                    const unsigned int idx = atomicAdd(&s_log, 1u);
+                    if (idx < log_cap) {
+                        plog.rec_k[log_base + idx] = k;
+                        plog.rec_prev[log_base + idx] = hd[m];
+                        hd[m] = (int32_t)(log_base + idx);
+                    }
+                }
             }
         }
+        if (k + 1 < k_end) publish(k + 1, b ^ 1);
         __syncthreads();
     }
 #pragma unroll
     for (int m = 0; m < E; ++m) {
-        const int r = r0 + 4 * m;
+        const int r = r0 + RG * m;
         if (r < n && c < n) {
-            rate[(size_t)r * n + c] = x[m];
-            if (HAS_NEXT) next[(size_t)r * n + c] = nx[m];
-            if (HAS_HOPS) hops[(size_t)r * n + c] = hp[m];
+            if (r != c) rate[off0 + m * off_step] = x[m];
+            if constexpr (NXL) next[off0 + m * off_step] = NX[r][c];
+            else if constexpr (HAS_NEXT) next[off0 + m * off_step] = nx[m];
+            if constexpr (HPL) hops[off0 + m * off_step] = HP[r][c];
+            else if constexpr (HAS_HOPS) hops[off0 + m * off_step] = hp[m];
+            if constexpr (LOG) plog.head[off0 + m * off_step] = hd[m];
         }
     }
+    if (LOG) {
+        __syncthreads();
+        if (tid == 0) plog.count[0] = s_log;     // may exceed the capacity: overflow is visible
+    }
     if (updates) {
-        if (mine) atomicAdd(&s_cnt, mine);
+        if (mine && (tid & 63) == 0) atomicAdd(&s_cnt, mine);   // `mine` is a wave total
         __syncthreads();
         if (tid == 0 && s_cnt) atomicAdd(&updates[0], (unsigned long long)s_cnt);
     }
@@ -285,13 +364,20 @@ hipError_t launch_small_solve(T *rate, int32_t *next, int32_t *hops, int n, int 
                               unsigned long long *updates, PathLog plog, hipStream_t s)
 {
     if (n <= 0 || k_end <= k_begin) return hipSuccess;
-    if (n > FWX_SMALL_N || (hops && !next)) return hipErrorInvalidValue;
-#define FWX_SMALL(HN, HH)                                                                          \
-    hipLaunchKernelGGL((small_solve<T, HN, HH>), dim3(1), dim3(256), 0, s, rate, next, hops, n,    \
-                       k_begin, k_end, updates, plog)
-    if (hops) FWX_SMALL(true, true);
-    else if (next) FWX_SMALL(true, false);
-    else FWX_SMALL(false, false);
+    if (n > FWX_SMALL_N || (hops && !next) || k_begin < 0 || k_end > n) return hipErrorInvalidValue;
+#define FWX_SMALL(M, RG, HN, HH, LG)                                                               \
+    hipLaunchKernelGGL((small_solve<T, M, RG, HN, HH, LG>), dim3(1), dim3(M * RG), 0, s, rate,     \
+                       next, hops, n, k_begin, k_end, updates, plog)
+#define FWX_SMALL_M(M, RG)                                                                         \
+    do {                                                                                           \
+        const bool lg = next && plog.head;                                                         \
+        if (hops) { if (lg) FWX_SMALL(M, RG, true, true, true); else FWX_SMALL(M, RG, true, true, false); }    \
+        else if (next) { if (lg) FWX_SMALL(M, RG, true, false, true); else FWX_SMALL(M, RG, true, false, false); } \
+        else FWX_SMALL(M, RG, false, false, false);                                                \
+    } while (0)
+    if (n <= 64) FWX_SMALL_M(64, 16);         // 1024 threads x 4 entries: 4 waves per SIMD hide
+    else FWX_SMALL_M(128, 8);                 //   the LDS latency; 1024 threads x 16 entries
+#undef FWX_SMALL_M
 #undef FWX_SMALL
     return hipGetLastError();
 }

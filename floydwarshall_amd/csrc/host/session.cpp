@@ -54,7 +54,7 @@ int Session::ensure_solved()
         // logged replay), from which fwx_matrix_query_exact rebuilds the reference's `_path`
         // lists -- under exact ties (the 1.0 edges of Algorithms.hs:35 make them common) the list
         // the reference stored can be a longer route than the one the next-hops describe.  Logged
-        // solves run on the per-k engine (one launch for n <= 64), which also carries `hops`.
+        // solves run on the per-k engine (one launch for n <= 128), which also carries `hops`.
         int rc = fwx_matrix_create(&dev_, m.n(), FWX_F64, 1, 1, device_);
         if (rc) return rc;
         if ((rc = fwx_matrix_enable_path_log(dev_))) return rc;

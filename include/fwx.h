@@ -56,8 +56,9 @@ typedef enum fwx_status {
 typedef enum fwx_dtype { FWX_F32 = 0, FWX_F64 = 1 } fwx_dtype;
 
 /* Which relaxation engine runs the pivots.  All are bit-exact with the reference loop.
- * AUTO: n <= 64 -> the whole solve in one single-workgroup launch; n >= 256, rows a multiple of 16
- * bytes and no hops -> FUSED; otherwise PERK.  A matrix with an update log always takes PERK.    */
+ * AUTO: n <= 128 -> the whole solve in one single-workgroup launch; n >= 256, rows a multiple of 16
+ * bytes and no hops -> FUSED; otherwise PERK.  A matrix with an update log takes the single launch
+ * (n <= 128) or PERK.                                                                            */
 typedef enum fwx_engine {
     FWX_ENGINE_AUTO = 0,
     FWX_ENGINE_PERK = 1,  /* one N x N launch per pivot k (HBM-bound streaming kernel)            */

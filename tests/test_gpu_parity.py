@@ -565,10 +565,11 @@ def test_config4_n16384_fp32_full_solve_fused_equals_perk():
 
 
 @pytest.mark.parametrize("dtype", [np.float64, np.float32])
-@pytest.mark.parametrize("n", [1, 2, 4, 7, 31, 63, 64])
+@pytest.mark.parametrize("n", [1, 2, 4, 7, 31, 63, 64, 65, 72, 100, 120, 127, 128])
 def test_small_solve_single_launch(n, dtype):
-    """n <= 64 (the reference's own regime): AUTO solves in one single-workgroup launch; must equal
-    the oracle and the per-k engine bit for bit, all fields, all distributions, k-ranges."""
+    """n <= 128 (the reference's own regime): AUTO solves in one single-workgroup launch (a 64- or
+    a 128-wide register tile); must equal the oracle and the per-k engine bit for bit, all fields,
+    all distributions, k-ranges."""
     for kind in ("d1", "t1", "t2", "t3"):
         rate, nxt, hops = synth.make(kind, n, dtype, seed=500 + n)
         a = _solve_and_compare(rate, nxt, hops)                                  # AUTO -> small
@@ -694,7 +695,7 @@ def _market_rates(n_exch, n_ccy, seed, density=0.5):
     return rates
 
 
-def _exact_paths_case(m0, dtype=np.float64):
+def _exact_paths_case(m0, dtype=np.float64, solve_engine=engine.FWX_ENGINE_AUTO):
     """m0: list-form initial matrix.  Solve with the list-faithful reference and with the logged
     GPU solve; every entry's `_path` must be identical."""
     ref = lf.run_algo(m0, dtype)
@@ -703,11 +704,11 @@ def _exact_paths_case(m0, dtype=np.float64):
     n = rate.shape[0]
     _, erate, enext, ehops = lf.to_dense(ref, dtype)
     u = engine.solve(rate.copy(), nxt.copy(), hops.copy(), count_updates=True,
-                     engine=engine.FWX_ENGINE_PERK if n > 64 else engine.FWX_ENGINE_AUTO)
+                     engine=engine.FWX_ENGINE_PERK)
     dm = engine.DeviceMatrix(n, dtype, with_next=True, with_hops=True)
     dm.enable_path_log()
     dm.upload(rate, nxt, hops)
-    assert dm.solve(count_updates=True) == u           # counting pass + logged replay
+    assert dm.solve(count_updates=True, engine=solve_engine) == u   # counting pass + logged replay
     assert dm.path_log_count() == u
     r, nx, hp = dm.download()
     assert_bits_equal(r, erate, "rate")
@@ -776,8 +777,10 @@ def test_path_log_lifecycle():
             dm.query_exact(3, 7)
 
 
-def test_exact_path_lists_above_the_single_launch_size():
-    """n = 80 > 64: the log is written by the per-k kernel (relax_k) instead of small_solve."""
+@pytest.mark.parametrize("solve_engine", [engine.FWX_ENGINE_AUTO, engine.FWX_ENGINE_PERK])
+def test_exact_path_lists_80_vertices(solve_engine):
+    """n = 80: AUTO writes the log from the 128-wide single launch, PERK from relax_k (the kernel
+    that logs for n > 128); both must rebuild every list of the reference."""
     m0 = lf.build_matrix(_market_rates(10, 8, seed=23))
     assert 64 < len(m0) <= 80
-    assert _exact_paths_case(m0) > 0
+    assert _exact_paths_case(m0, solve_engine=solve_engine) > 0
