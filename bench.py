@@ -95,8 +95,17 @@ def cpu_baseline(rate_host, cpu_seconds):
         t_total += time.perf_counter() - t0
         done = k1
     relax = float(done) * n * n
+    # the same loop on ONE thread (SURVEY.md section 8d asks for both), a few pivots further on
+    st_done, st_total = done, 0.0
+    while st_total < cpu_seconds / 4 and st_done < n:
+        t0 = time.perf_counter()
+        oracle.relax(work, None, None, st_done, st_done + 1)
+        st_total += time.perf_counter() - t0
+        st_done += 1
+    single = {"value": float(st_done - done) * n * n / st_total if st_total > 0 else None,
+              "cores": 1, "sample": "pivots [%d,%d) (%.1f s)" % (done, st_done, st_total)}
     return {"value": relax / t_total, "unit": "edge-relaxations/s", "cores": cores,
-            "kind": "port",
+            "single_thread": single, "kind": "port",
             "sample": "pivots [0,%d) of the same N=%d %s matrix (%.1f s); oracle/fw_oracle.c "
                       "fwo_relax_mt, a C restatement of Algorithms.hs:42-61 -- the Haskell "
                       "reference cannot be built in this image" % (done, n, rate_host.dtype, t_total)}
