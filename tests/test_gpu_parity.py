@@ -784,3 +784,46 @@ def test_exact_path_lists_80_vertices(solve_engine):
     m0 = lf.build_matrix(_market_rates(10, 8, seed=23))
     assert 64 < len(m0) <= 80
     assert _exact_paths_case(m0, solve_engine=solve_engine) > 0
+
+
+def _hostile_matrix(rnd, n, dtype):
+    """Entries drawn from a pool of awkward values: zeros of both signs, ties, subnormals, values
+    that overflow when multiplied, infinities, NaN, negatives.  The diagonal is arbitrary too
+    (the reference never reads or writes it, Algorithms.hs:54)."""
+    fi = np.finfo(dtype)
+    pool = np.array([0.0, -0.0, 1.0, 1.0, 0.5, 0.5, 2.0, 0.25, 3.0, 1e-3, 7.0, fi.tiny, fi.tiny / 4,
+                     fi.max / 2, fi.max, np.inf, -np.inf, np.nan, -1.0, -0.5, 1.5, 0.999], dtype=dtype)
+    heavy = rnd.random() < 0.5          # half of the cases: mostly ordinary rates, a few oddities
+    p = np.ones(len(pool))
+    if heavy:
+        p[2:11] = 12.0
+    rate = rnd.choice(pool, size=(n, n), p=p / p.sum()).astype(dtype)
+    nxt = np.where(rnd.random((n, n)) < 0.8, np.arange(n, dtype=np.int32)[None, :], -1).astype(np.int32)
+    hops = (nxt >= 0).astype(np.int32)
+    return np.ascontiguousarray(rate), np.ascontiguousarray(nxt), np.ascontiguousarray(hops)
+
+
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+def test_fuzz_hostile_values_every_engine(dtype):
+    """A few hundred small matrices of hostile values through every engine that accepts them
+    (single launch 64- and 128-wide, per-k, fused compare form; rates only / + next / + hops)."""
+    rnd = np.random.default_rng(4242 if dtype == np.float64 else 4343)
+    sizes = [1, 2, 3, 4, 5, 8, 13, 16, 31, 32, 33, 48, 63, 64, 65, 66, 80, 100, 127, 128, 129, 132, 160]
+    with np.errstate(all="ignore"):
+        for rep in range(18):
+            for n in sizes:
+                rate, nxt, hops = _hostile_matrix(rnd, n, dtype)
+                _solve_and_compare(rate, nxt, hops)                              # AUTO
+                _solve_and_compare(rate, nxt, hops, engine=engine.FWX_ENGINE_PERK)
+                variant = rep % 3
+                if variant == 0:
+                    _solve_and_compare(rate, None, None)
+                elif variant == 1:
+                    _solve_and_compare(rate, nxt, None)
+                if n % (16 // np.dtype(dtype).itemsize) == 0:
+                    _solve_and_compare(rate, nxt if variant else None, None,
+                                       engine=engine.FWX_ENGINE_FUSED)
+                if n >= 3:
+                    k0 = int(rnd.integers(0, n - 1))
+                    k1 = int(rnd.integers(k0 + 1, n + 1))
+                    _solve_and_compare(rate, nxt, hops, k_begin=k0, k_end=k1)
