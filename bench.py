@@ -266,7 +266,7 @@ def main():
         kern_ms = sum(evs[0].elapsed_time(evs[-1]) for evs, _ in ev_pairs)
         out["fused"] = {"passes_per_solve": (k_end + 63) // 64, "avg_pass_us": 1e3 * kern_ms / passes,
                         "effective_GBps_at_4B_per_relaxation": 4.0 * relax_per_step * args.steps / (kern_ms * 1e-3) / 1e9,
-                        "note": "VALU-bound kernel (3 lane-ops per relaxation); the GB/s figure is "
+                        "note": "VALU-issue-bound kernel (8.0 cycles per pair of relaxations, DESIGN 4.2); the GB/s figure is "
                                 "'effective' (algorithmic bytes of the per-k form), not an HBM roofline "
                                 "fraction", "updates_per_solve": updates}
     elif world == 1 and ev_pairs:

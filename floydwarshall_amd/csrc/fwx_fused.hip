@@ -512,8 +512,9 @@ __global__ __launch_bounds__(256, MINW) void fused_main(T *rate, int32_t *next, 
 // compare), max(x, NaN) = x exactly as `x < NaN` is false, and for x == c both forms leave the
 // same bits.  max is associative, so two pivots fold per instruction:
 //       x <- max3(x, C_t[i]*W_t[j], C_{t+1}[i]*W_{t+1}[j])
-// with the operands stored as (t, t+1) pairs in LDS: 6 issue cycles per pair of relaxations
-// (two v_mul_f32 + one v_max3_f32) instead of 16 for the compare form.  The caller must have verified the domain
+// with the operands stored as (t, t+1) pairs in LDS: 8.0 issue cycles per pair of relaxations
+// (two 2-cycle v_mul_f32 + one 4-cycle v_max3_f32; tools/valu_rate.hip) instead of 24 for the
+// compare form.  The caller must have verified the domain
 // (fwx_dev_check_nonneg); the next-hop variant needs the compare and stays on fused_main.
 // ------------------------------------------------------------------------------------------------
 template <int MINW, int UNR, int RI, int NH>

@@ -1,0 +1,125 @@
+// valu_rate.hip -- issue cost of the VALU instructions the fused kernels are made of, measured on
+// the device: long unrolled streams per wave, 1..4 waves per SIMD, cycles from s_memtime.
+// Build: hipcc --offload-arch=gfx950 -O3 tools/valu_rate.hip -o build/valu_rate
+#include <hip/hip_runtime.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <vector>
+
+#define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s line %d\n", hipGetErrorString(e_), __LINE__); exit(1); } } while (0)
+
+constexpr int REG = 16;      // independent accumulators per lane
+constexpr int INNER = 64;    // repetitions of the REG-instruction group per loop trip
+constexpr int TRIPS = 512;
+
+template <int KIND>
+__global__ __launch_bounds__(256) void stream(float *out, unsigned long long *cycles, float seed)
+{
+    float a[REG], b[REG], c[REG];
+#pragma unroll
+    for (int i = 0; i < REG; ++i) { a[i] = seed + i + threadIdx.x; b[i] = 1.0f + 0.001f * i; c[i] = 0.5f + i; }
+    const float s0 = seed;                       // kernel argument: lives in an SGPR
+    const unsigned long long w0 = wall_clock64();
+    const unsigned long long t0 = __builtin_readcyclecounter();
+#pragma unroll 1
+    for (int t = 0; t < TRIPS; ++t) {
+#pragma unroll
+        for (int r = 0; r < INNER; ++r) {
+#pragma unroll
+            for (int i = 0; i < REG; ++i) {
+                if (KIND == 0) asm volatile("v_mul_f32 %0, %0, %1" : "+v"(a[i]) : "v"(b[i]));
+                if (KIND == 1) asm volatile("v_max3_f32 %0, %0, %1, %2" : "+v"(a[i]) : "v"(b[i]), "v"(c[i]));
+                if (KIND == 2) asm volatile("v_max_f32 %0, %0, %1" : "+v"(a[i]) : "v"(b[i]));
+                if (KIND == 3) asm volatile("v_mul_f32 %0, %1, %0" : "+v"(a[i]) : "s"(s0));
+                if (KIND == 4) {   // the max-form triple: two products, one fold (REG/2 entries... 3 instr)
+                    float p, q;
+                    asm volatile("v_mul_f32 %0, %1, %2" : "=v"(p) : "v"(b[i]), "v"(c[i]));
+                    asm volatile("v_mul_f32 %0, %1, %2" : "=v"(q) : "v"(c[i]), "v"(b[(i + 1) % REG]));
+                    asm volatile("v_max3_f32 %0, %0, %1, %2" : "+v"(a[i]) : "v"(p), "v"(q));
+                }
+                if (KIND == 5) {   // compare-form quadruple: product, compare, two selects
+                    float p;
+                    asm volatile("v_mul_f32 %0, %1, %2" : "=v"(p) : "v"(b[i]), "v"(c[i]));
+                    asm volatile("v_cmp_lt_f32 vcc, %0, %1\n\tv_cndmask_b32 %0, %0, %1, vcc\n\tv_cndmask_b32 %2, %2, %3, vcc"
+                                 : "+v"(a[i]), "+v"(p), "+v"(c[i]) : "v"(b[i]) : "vcc");
+                }
+                if (KIND == 6) asm volatile("v_mul_f64 %0, %0, %1" : "+v"(*(double *)&a[i & ~1]) : "v"(*(double *)&b[i & ~1]));
+                if (KIND == 7) asm volatile("v_max_f64 %0, %0, %1" : "+v"(*(double *)&a[i & ~1]) : "v"(*(double *)&b[i & ~1]));
+                if (KIND == 8) asm volatile("v_pk_mul_f32 %0, %0, %1" : "+v"(*(double *)&a[i & ~1]) : "v"(*(double *)&b[i & ~1]));
+                if (KIND == 9) asm volatile("v_max_u32 %0, %0, %1" : "+v"(a[i]) : "v"(b[i]));
+                if (KIND == 10) asm volatile("v_max3_u32 %0, %0, %1, %2" : "+v"(a[i]) : "v"(b[i]), "v"(c[i]));
+                if (KIND == 11) asm volatile("v_add_f32 %0, %0, %1" : "+v"(a[i]) : "v"(b[i]));
+                if (KIND == 12) asm volatile("v_fma_f32 %0, %0, %1, %2" : "+v"(a[i]) : "v"(b[i]), "v"(c[i]));
+                if (KIND == 13) asm volatile("v_min_f32 %0, %0, %1" : "+v"(a[i]) : "v"(b[i]));
+                if (KIND == 14) asm volatile("v_cndmask_b32 %0, %0, %1, vcc" : "+v"(a[i]) : "v"(b[i]) : "vcc");
+                if (KIND == 15) asm volatile("v_cmp_lt_f32 vcc, %0, %1" : : "v"(a[i]), "v"(b[i]) : "vcc");
+                if (KIND == 16) asm volatile("v_mul_f32 %0, %1, %2" : "=v"(a[i]) : "v"(b[i]), "v"(c[(i + 1) % REG]));
+                if (KIND == 17) asm volatile("v_max_f32 %0, %1, %2" : "=v"(a[i]) : "v"(b[i]), "v"(c[(i + 1) % REG]));
+                if (KIND == 18) asm volatile("v_and_b32 %0, %0, %1" : "+v"(a[i]) : "v"(b[i]));
+                if (KIND == 19) asm volatile("v_max_i32 %0, %0, %1" : "+v"(a[i]) : "v"(b[i]));
+            }
+        }
+    }
+    const unsigned long long t1 = __builtin_readcyclecounter();
+    const unsigned long long w1 = wall_clock64();
+    float acc = 0;
+#pragma unroll
+    for (int i = 0; i < REG; ++i) acc += a[i] + c[i];
+    out[blockIdx.x * blockDim.x + threadIdx.x] = acc;
+    if (threadIdx.x == 0) { cycles[2 * blockIdx.x] = t1 - t0; cycles[2 * blockIdx.x + 1] = w1 - w0; }
+}
+
+template <int KIND> static void run(const char *name, int per_group, float *out, unsigned long long *cyc)
+{
+    for (int wg_per_cu = 1; wg_per_cu <= 4; wg_per_cu *= 2) {   // 256 threads = 1 wave per SIMD
+        const int blocks = 256 * wg_per_cu;
+        hipEvent_t e0, e1;
+        CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+        hipLaunchKernelGGL(stream<KIND>, dim3(blocks), dim3(256), 0, 0, out, cyc, 1.5f);
+        CK(hipDeviceSynchronize());
+        CK(hipEventRecord(e0, 0));
+        hipLaunchKernelGGL(stream<KIND>, dim3(blocks), dim3(256), 0, 0, out, cyc, 1.5f);
+        CK(hipEventRecord(e1, 0));
+        CK(hipEventSynchronize(e1));
+        float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+        std::vector<unsigned long long> h(2 * blocks);
+        CK(hipMemcpy(h.data(), cyc, 2 * blocks * 8, hipMemcpyDeviceToHost));
+        double avg = 0, wall = 0;
+        for (int i = 0; i < blocks; ++i) { avg += (double)h[2 * i]; wall += (double)h[2 * i + 1]; }
+        avg /= blocks; wall /= blocks;
+        const double instr = (double)TRIPS * INNER * REG * per_group;     // per wave
+        // s_memrealtime ticks at 100 MHz: shader clock = ticks(s_memtime) / ticks(realtime) * 100 MHz
+        const double ghz = avg / wall * 0.1;
+        const double ns = ms * 1e6 / (instr * wg_per_cu);
+        printf("%-30s %d wave/SIMD: %.2f ns per instruction per SIMD = %.2f cycles at the measured %.2f GHz (%.2f ms)\n",
+               name, wg_per_cu, ns, ns * ghz, ghz, ms);
+    }
+}
+
+int main()
+{
+    float *out; unsigned long long *cyc;
+    CK(hipMalloc(&out, 1024 * 256 * 4)); CK(hipMalloc(&cyc, 2 * 1024 * 8));
+    run<0>("v_mul_f32 (v,v)", 1, out, cyc);
+    run<3>("v_mul_f32 (s,v)", 1, out, cyc);
+    run<2>("v_max_f32", 1, out, cyc);
+    run<1>("v_max3_f32", 1, out, cyc);
+    run<4>("2 x v_mul_f32 + v_max3_f32", 3, out, cyc);
+    run<5>("v_mul + v_cmp + 2 x v_cndmask", 4, out, cyc);
+    run<8>("v_pk_mul_f32", 1, out, cyc);
+    run<6>("v_mul_f64", 1, out, cyc);
+    run<7>("v_max_f64", 1, out, cyc);
+    run<9>("v_max_u32", 1, out, cyc);
+    run<19>("v_max_i32", 1, out, cyc);
+    run<10>("v_max3_u32", 1, out, cyc);
+    run<11>("v_add_f32", 1, out, cyc);
+    run<12>("v_fma_f32", 1, out, cyc);
+    run<13>("v_min_f32", 1, out, cyc);
+    run<18>("v_and_b32", 1, out, cyc);
+    run<14>("v_cndmask_b32", 1, out, cyc);
+    run<15>("v_cmp_lt_f32", 1, out, cyc);
+    run<16>("v_mul_f32 d,b,c (3 regs)", 1, out, cyc);
+    run<17>("v_max_f32 d,b,c (3 regs)", 1, out, cyc);
+    run<0>("v_mul_f32 (v,v) again", 1, out, cyc);
+    return 0;
+}
