@@ -110,6 +110,37 @@ def test_build_matrix_same_currency_wins_over_map_entry():
     assert vertices == ev and np.array_equal(rate, er) and np.array_equal(nxt, en)
 
 
+def test_build_matrix_random_markets_equal_the_list_faithful_restatement():
+    """The C++ buildMatrix scatters the map entries instead of looking every (i, j) up; it must
+    still give what Algorithms.hs:26-40 gives: vertex order (Ord on exch, then ccy; names of
+    different lengths and cases), later updates replacing earlier ones, stale timestamps ignored,
+    the same-currency 1.0 rule across exchanges."""
+    rnd = np.random.default_rng(99)
+    exchs = ["KRAKEN", "GDAX", "B", "Bb", "a", "ZED", "AA", "A"]
+    ccys = ["BTC", "USD", "ETH", "EUR", "X", "usd", "JPY"]
+    for case in range(25):
+        s = host.Session()
+        rates, stamp = {}, {}
+        for _ in range(int(rnd.integers(1, 40))):
+            e = exchs[int(rnd.integers(0, 1 + case % len(exchs)))]
+            a, b = (ccys[int(i)] for i in rnd.choice(len(ccys), size=2, replace=False))
+            t = int(rnd.integers(1000, 1010))
+            fwd, bkd = float(rnd.random() * 3 + 0.01), float(rnd.random() * 3 + 0.01)
+            applied = s.update_rates(t, e, a, b, fwd, bkd)
+            # updateRates (ProcessRequests.hs:89-102): only a strictly newer timestamp replaces
+            key = ((e, a), (e, b))
+            newer = key not in stamp or t > stamp[key]
+            assert applied == newer
+            if newer:
+                stamp[key] = stamp[((e, b), (e, a))] = t
+                rates[key] = fwd
+                rates[((e, b), (e, a))] = bkd
+        vertices, rate, nxt = s.build_matrix()
+        ev, er, en, _ = lf.to_dense(lf.build_matrix(rates))
+        assert vertices == ev
+        assert np.array_equal(rate, er) and np.array_equal(nxt, en)
+
+
 def test_optimum_dense_golden_cases():
     g = load_golden("algorithms_4x4.json")
     c = load_golden("optimum_cases.json")
