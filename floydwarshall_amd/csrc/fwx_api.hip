@@ -267,7 +267,16 @@ int solve_host(int32_t n, T *rate, int32_t *next, int32_t *hops, const fwx_opts 
     DeviceGuard g;
     if ((rc = g.enter(op.device))) return rc;
 
-    const size_t nn = (size_t)n * (size_t)n;
+    // Device order of the matrix.  The fused engine needs rows that are a multiple of 16 bytes; an
+    // odd-sized matrix headed for it is PADDED on the device with +0.0 rows and columns.  Padding
+    // never reaches a real entry -- step k reads r[i][k] and r[k][j] of real pivots k only, and a
+    // padding entry is never a pivot row or column -- and a +0.0 target is never improved
+    // (0 < +-0 and 0 < NaN are false), so U is unchanged too.  The caller's arrays stay n x n.
+    constexpr int VW = 16 / (int)sizeof(T);
+    const bool to_fused = !hops && (op.engine == FWX_ENGINE_FUSED ||
+                                    (op.engine == FWX_ENGINE_AUTO && n >= 256));
+    const int nd = (to_fused && n % VW) ? (n + VW - 1) / VW * VW : n;
+    const size_t nn = (size_t)nd * (size_t)nd;
     DevBuf d_rate, d_next, d_hops, d_upd;
     if ((rc = d_rate.alloc(nn * sizeof(T)))) return rc;
     if (next && (rc = d_next.alloc(nn * sizeof(int32_t)))) return rc;
@@ -275,23 +284,35 @@ int solve_host(int32_t n, T *rate, int32_t *next, int32_t *hops, const fwx_opts 
     if ((rc = d_upd.alloc(FWX_UPDATE_SHARDS * sizeof(unsigned long long)))) return rc;
 
     hipStream_t s = nullptr;
-    FWX_HIP(hipMemcpyAsync(d_rate.p, rate, nn * sizeof(T), hipMemcpyHostToDevice, s));
-    if (next) FWX_HIP(hipMemcpyAsync(d_next.p, next, nn * sizeof(int32_t), hipMemcpyHostToDevice, s));
-    if (hops) FWX_HIP(hipMemcpyAsync(d_hops.p, hops, nn * sizeof(int32_t), hipMemcpyHostToDevice, s));
+    auto copy2d = [&](void *dst, size_t dpitch, const void *src, size_t spitch, size_t es,
+                      hipMemcpyKind kind) -> int {
+        if (dpitch == spitch)
+            FWX_HIP(hipMemcpyAsync(dst, src, (size_t)n * (size_t)n * es, kind, s));
+        else
+            FWX_HIP(hipMemcpy2DAsync(dst, dpitch * es, src, spitch * es, (size_t)n * es, (size_t)n, kind, s));
+        return FWX_OK;
+    };
+    if (nd != n) {
+        FWX_HIP(hipMemsetAsync(d_rate.p, 0, nn * sizeof(T), s));                  // +0.0
+        if (next) FWX_HIP(hipMemsetAsync(d_next.p, 0xFF, nn * sizeof(int32_t), s));   // -1
+    }
+    if ((rc = copy2d(d_rate.p, nd, rate, n, sizeof(T), hipMemcpyHostToDevice))) return rc;
+    if (next && (rc = copy2d(d_next.p, nd, next, n, sizeof(int32_t), hipMemcpyHostToDevice))) return rc;
+    if (hops && (rc = copy2d(d_hops.p, nd, hops, n, sizeof(int32_t), hipMemcpyHostToDevice))) return rc;
     FWX_HIP(hipMemsetAsync(d_upd.p, 0, FWX_UPDATE_SHARDS * sizeof(unsigned long long), s));
 
     T *dr = (T *)d_rate.p;
     int32_t *dh = (int32_t *)d_hops.p;
     unsigned long long *upd = op.updates_out ? (unsigned long long *)d_upd.p : nullptr;
-    if (op.engine == FWX_ENGINE_FUSED && !fused_ok<T>(n, dr, dh)) return FWX_ERR_UNSUPPORTED;
+    if (op.engine == FWX_ENGINE_FUSED && !fused_ok<T>(nd, dr, dh)) return FWX_ERR_UNSUPPORTED;
     if (op.engine == FWX_ENGINE_AUTO && n <= FWX_SMALL_N) {
         // the reference's own regime: the whole solve in one single-workgroup launch
         FWX_HIP(fwx::launch_small_solve<T>(dr, (int32_t *)d_next.p, dh, n, op.k_begin, op.k_end, upd,
                                            fwx::PathLog(), s));
-    } else if (pick_fused<T>(op.engine, n, dr, dh)) {
+    } else if (pick_fused<T>(op.engine, nd, dr, dh)) {
         DevBuf d_ws;
-        if ((rc = d_ws.alloc(fused_ws_bytes(n, sizeof(T))))) return rc;
-        rc = fused_range<T>(dr, (int32_t *)d_next.p, n, op.k_begin, op.k_end, d_ws.p, upd, s);
+        if ((rc = d_ws.alloc(fused_ws_bytes(nd, sizeof(T))))) return rc;
+        rc = fused_range<T>(dr, (int32_t *)d_next.p, nd, op.k_begin, op.k_end, d_ws.p, upd, s);
         if (rc) return rc;
         FWX_HIP(hipStreamSynchronize(s));   // d_ws is released at scope exit
     } else {
@@ -301,9 +322,9 @@ int solve_host(int32_t n, T *rate, int32_t *next, int32_t *hops, const fwx_opts 
         if (rc) return rc;
     }
 
-    FWX_HIP(hipMemcpyAsync(rate, d_rate.p, nn * sizeof(T), hipMemcpyDeviceToHost, s));
-    if (next) FWX_HIP(hipMemcpyAsync(next, d_next.p, nn * sizeof(int32_t), hipMemcpyDeviceToHost, s));
-    if (hops) FWX_HIP(hipMemcpyAsync(hops, d_hops.p, nn * sizeof(int32_t), hipMemcpyDeviceToHost, s));
+    if ((rc = copy2d(rate, n, d_rate.p, nd, sizeof(T), hipMemcpyDeviceToHost))) return rc;
+    if (next && (rc = copy2d(next, n, d_next.p, nd, sizeof(int32_t), hipMemcpyDeviceToHost))) return rc;
+    if (hops && (rc = copy2d(hops, n, d_hops.p, nd, sizeof(int32_t), hipMemcpyDeviceToHost))) return rc;
     FWX_HIP(hipStreamSynchronize(s));
     if (op.updates_out) {
         if ((rc = sum_updates((unsigned long long *)d_upd.p, op.updates_out, s))) return rc;

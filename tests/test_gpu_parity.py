@@ -277,10 +277,30 @@ def test_fused_engine_k_range_and_unsupported():
     with pytest.raises(engine.FwxError) as e:           # hops ride on the per-k engine only
         engine.solve(rate.copy(), nxt.copy(), hops.copy(), engine=engine.FWX_ENGINE_FUSED)
     assert e.value.status == -7
-    odd, _, _ = synth.make("d1", 63, np.float32, seed=1)  # n not a multiple of the vector width
+    # n not a multiple of the 16-byte vector width: the device-pointer API refuses the fused engine
+    # (it cannot pad memory it does not own) ...
+    import torch
+    odd, _, _ = synth.make("d1", 63, np.float32, seed=1)
     with pytest.raises(engine.FwxError):
-        engine.solve(odd, engine=engine.FWX_ENGINE_FUSED)
-    engine.solve(odd)                                     # AUTO falls back to the per-k engine
+        engine.dev_solve(torch.from_numpy(odd).cuda(), engine=engine.FWX_ENGINE_FUSED)
+    with pytest.raises(engine.FwxError):
+        with engine.DeviceMatrix(63, np.float32, with_next=False) as dm:
+            dm.upload(odd)
+            dm.solve(engine=engine.FWX_ENGINE_FUSED)
+
+
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+@pytest.mark.parametrize("n", [3, 63, 257, 301, 511, 1001])
+def test_host_api_pads_odd_sizes_for_the_fused_engine(n, dtype):
+    """... while fwx_solve_* pads an odd-sized matrix on the device with +0.0 rows / columns
+    (inert: never a pivot, never improved), so AUTO keeps the fused engine for any n >= 256 and an
+    explicit FUSED request works for every n.  Same bits, same U, all input kinds."""
+    for kind in ("d2", "t1", "t3"):
+        rate, nxt, _ = synth.make(kind, n, dtype, seed=3000 + n)
+        _solve_and_compare(rate, nxt, None, engine=engine.FWX_ENGINE_FUSED)
+        _solve_and_compare(rate, None, None, engine=engine.FWX_ENGINE_FUSED)
+        _solve_and_compare(rate, nxt, None)                                     # AUTO
+        _solve_and_compare(rate, None, None, k_begin=n // 3, k_end=n - 1)       # AUTO, pivot range
 
 
 def test_config3_n8192_fp32_fused_vs_perk_and_oracle_slices():
