@@ -692,8 +692,10 @@ template <typename T, bool HAS_NEXT> struct FusedCfg;
 // (NH = 1: one 16-byte vector per thread and row) to stay at 4 waves per SIMD.
 template <> struct FusedCfg<float, false> { static constexpr int BS = 32, MINW = 4, NH = 2; };
 template <> struct FusedCfg<float, true> { static constexpr int BS = 16, MINW = 4, NH = 1; };
-template <> struct FusedCfg<double, false> { static constexpr int BS = 32, MINW = 2, NH = 2; };
-template <> struct FusedCfg<double, true> { static constexpr int BS = 16, MINW = 2, NH = 1; };
+// f64: 16 pivots per stage and 3+ waves per SIMD (tools/measure_f64.py: N=16384 rates only 500 ms
+// against 595 ms with 32-pivot stages at 2 waves; the compare form with next-hops 767 against 779)
+template <> struct FusedCfg<double, false> { static constexpr int BS = 16, MINW = 3, NH = 2; };
+template <> struct FusedCfg<double, true> { static constexpr int BS = 16, MINW = 3, NH = 1; };
 
 // Below ~512 full-size tiles the launch is bound by the latency of ONE tile (64 pivots folded into
 // 64 entries per thread); 64 x 64 tiles give 4x the workgroups and a quarter of the serial work.
