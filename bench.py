@@ -29,6 +29,8 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+# the host driver of this pool only supports dmabuf IPC; RCCL needs it before HIP initialises
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 
 SEGMENTS = 16
 HBM_PEAK_GBPS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
