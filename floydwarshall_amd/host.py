@@ -174,10 +174,15 @@ class Session:
         """findBestRate (ProcessRequests.hs:70-85) -> (rate, start, [path]); AlgoError on Left."""
         r = ctypes.c_double()
         n = max(self.rate_count * 2, 4)
-        pbuf = ctypes.create_string_buffer(64 * (n + 2) + 1024)
+        cap = 64 * (n + 2) + 1024
         ebuf = ctypes.create_string_buffer(1024)
-        rc = hlib().fwxh_find_best_rate(self._h, _b(src[0]), _b(src[1]), _b(dest[0]), _b(dest[1]),
-                                        ctypes.byref(r), pbuf, len(pbuf), ebuf, len(ebuf))
+        while True:
+            pbuf = ctypes.create_string_buffer(cap)
+            rc = hlib().fwxh_find_best_rate(self._h, _b(src[0]), _b(src[1]), _b(dest[0]),
+                                            _b(dest[1]), ctypes.byref(r), pbuf, cap, ebuf, len(ebuf))
+            if rc != _lib.FWX_ERR_CAPACITY or cap >= 1 << 30:
+                break
+            cap *= 8       # arbitrage inputs: the reference's `_path` lists revisit vertices
         if rc == FWXH_ERR_ALGO:
             raise AlgoError(ebuf.value.decode())
         if rc < 0:

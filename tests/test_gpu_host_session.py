@@ -177,3 +177,70 @@ def test_session_returns_the_references_exact_path_lists_under_ties():
 def engine_follow(nxt, i, j):
     from floydwarshall_amd import engine
     return engine.follow_path(nxt, i, j)
+
+
+def test_no_device_memory_leak_over_many_sessions_and_logged_solves():
+    """Handles own device memory (solved matrix, pristine copies, update log, walk buffers): a few
+    hundred create / solve / query / destroy cycles must leave the free HBM where it was."""
+    import torch
+    from floydwarshall_amd import engine, synth
+    price = [1.0, 1.7, 0.6, 2.3, 0.9, 1.2, 3.1]                     # a potential: no arbitrage anywhere
+    rows = [(1000 + i, "X%d" % (i % 5), "C%d" % (i % 7), "C%d" % ((i * 3 + 1) % 7),
+             0.98 * price[(i * 3 + 1) % 7] / price[i % 7], 0.97 * price[i % 7] / price[(i * 3 + 1) % 7])
+            for i in range(40) if i % 7 != (i * 3 + 1) % 7]
+
+    def cycle():
+        s = _session_with(rows)
+        vertices, _, _ = s.build_matrix()
+        try:
+            s.find_best_rate(vertices[0], vertices[-1])
+        except host.AlgoError:
+            pass
+        s.update_rates(99999, "X0", "C0", "C1", 0.97 * price[1] / price[0], 0.96 * price[0] / price[1])
+        try:
+            s.find_best_rate(vertices[1], vertices[-2])
+        except host.AlgoError:
+            pass
+        s.close()
+        rate, nxt, hops = synth.make("t1", 150, np.float64, seed=1)
+        with engine.DeviceMatrix(150, np.float64, with_next=True, with_hops=True) as dm:
+            dm.enable_path_log()
+            dm.upload(rate, nxt, hops)
+            dm.solve()
+            dm.query_exact(3, 77)
+        engine.solve(rate.copy(), nxt.copy(), engine=engine.FWX_ENGINE_FUSED)
+
+    for _ in range(5):
+        cycle()                                   # warm allocator pools and lazy runtime state
+    torch.cuda.synchronize()
+    free0, _ = torch.cuda.mem_get_info()
+    for _ in range(100):
+        cycle()
+    torch.cuda.synchronize()
+    free1, _ = torch.cuda.mem_get_info()
+    assert free0 - free1 < 32 << 20, "device memory shrank by %d bytes" % (free0 - free1)
+
+
+def test_arbitrage_market_long_path_lists_grow_the_buffers():
+    """Rates whose round trips multiply to more than 1: the reference's `_path` lists revisit
+    vertices and get long.  The session must hand them over whole (buffers grow), and they must
+    equal the list-faithful restatement."""
+    rows = [(1, "K", "A", "B", 1.2, 0.9), (2, "K", "B", "C", 1.1, 0.95), (3, "K", "C", "A", 1.05, 0.99),
+            (4, "G", "A", "B", 1.15, 0.9), (5, "G", "B", "C", 1.2, 0.9)]
+    s = _session_with(rows)
+    rates = {}
+    for _, e, a, b, f, bk in rows:
+        rates[((e, a), (e, b))] = f
+        rates[((e, b), (e, a))] = bk
+    ref = lf.floyd_warshall(rates)
+    vertices = [row[0][1] for row in ref]
+    longest = 0
+    for i, src in enumerate(vertices):
+        for j, dst in enumerate(vertices):
+            want_rate, _, want_path = ref[i][j]
+            if not want_path:
+                continue
+            rate, start, path = s.find_best_rate(src, dst)
+            assert rate == want_rate and start == src and tuple(path) == tuple(want_path)
+            longest = max(longest, len(path))
+    assert longest > len(vertices)            # the case really has lists that revisit vertices
