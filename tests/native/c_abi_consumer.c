@@ -1,0 +1,70 @@
+/* c_abi_consumer.c -- a plain C99 program that uses libfwx the way a foreign host would: only
+ * include/fwx.h and include/fwx_host.h, plain pointers and sizes.  Built and run by
+ * tests/test_gpu_c_consumer.py on the GPU box; also compiled (syntax only) on CPU to keep the
+ * headers valid C.
+ *
+ * 1. the reference's 4-vertex graph (src/test/MockData.hs:47-57) through fwx_solve_f64 and the
+ *    expectations of src/test/AlgorithmsTest.hs:72-75;
+ * 2. the same rates through the host mirror (updateRates -> findBestRate), README.md:188-246. */
+#include <math.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include "fwx.h"
+#include "fwx_host.h"
+
+#define CHECK(cond)                                                                                \
+    do {                                                                                           \
+        if (!(cond)) {                                                                             \
+            fprintf(stderr, "FAILED %s (line %d)\n", #cond, __LINE__);                             \
+            return 1;                                                                              \
+        }                                                                                          \
+    } while (0)
+
+int main(void)
+{
+    /* vertices in matrix order: (GDAX,BTC) (GDAX,USD) (KRAKEN,BTC) (KRAKEN,USD) */
+    double rate[16] = {0.0, 1001.0, 1.0, 0.0,   0.0008, 0.0, 0.0, 1.0,
+                       1.0, 0.0, 0.0, 1000.0,   0.0, 1.0, 0.0009, 0.0};
+    int32_t next[16] = {-1, 1, 2, -1,   0, -1, -1, 3,   0, -1, -1, 3,   -1, 1, 2, -1};
+    int32_t hops[16] = {0, 1, 1, 0,   1, 0, 0, 1,   1, 0, 0, 1,   0, 1, 1, 0};
+    int32_t path[8];
+    uint64_t updates = 0;
+    fwx_opts opts;
+    int rc, len;
+
+    if (fwx_device_count() < 1) {
+        fprintf(stderr, "no HIP device\n");
+        return 2;
+    }
+    memset(&opts, 0, sizeof(opts));
+    opts.struct_size = (uint32_t)sizeof(opts);
+    opts.device = -1;
+    opts.updates_out = &updates;
+    rc = fwx_solve_f64(4, rate, next, hops, &opts);
+    if (rc) fprintf(stderr, "fwx_solve_f64: %s\n", fwx_strerror(rc));
+    CHECK(rc == FWX_OK);
+    /* AlgorithmsTest.hs:72-75: [1][0] = (0.0009, [3,2,0]); [2][3] = (1001, [0,1,3]) */
+    CHECK(rate[1 * 4 + 0] == 0.0009 && next[1 * 4 + 0] == 3 && hops[1 * 4 + 0] == 3);
+    CHECK(rate[2 * 4 + 3] == 1001.0 && next[2 * 4 + 3] == 0 && hops[2 * 4 + 3] == 3);
+    len = fwx_follow_path(4, next, 2, 3, path, 8);
+    CHECK(len == 3 && path[0] == 0 && path[1] == 1 && path[2] == 3);
+    CHECK(updates > 0);
+
+    {
+        fwxh_session *s = NULL;
+        char out[2048];
+        CHECK(fwxh_session_create(&s, -1) == 0 && s != NULL);
+        CHECK(fwxh_serve_line(s, "2017-11-01T09:42:23+00:00 KRAKEN BTC USD 1000.0 0.0009", out, sizeof(out)) >= 0);
+        CHECK(fwxh_serve_line(s, "2017-11-01T09:43:23+00:00 GDAX BTC USD 1001.0 0.0008", out, sizeof(out)) >= 0);
+        CHECK(fwxh_session_state(s) == FWXH_STATE_OUTSYNC);
+        CHECK(fwxh_serve_line(s, "KRAKEN BTC GDAX USD", out, sizeof(out)) >= 0);
+        CHECK(strstr(out, "BEST_RATES_BEGIN KRAKEN BTC GDAX USD 1001.0") == out);
+        CHECK(strstr(out, "(KRAKEN, BTC)\n(GDAX, BTC)\n(GDAX, USD)\nBEST_RATES_END") != NULL);
+        CHECK(fwxh_session_state(s) == FWXH_STATE_INSYNC);
+        CHECK(fwxh_session_destroy(s) == 0);
+    }
+    printf("c_abi_consumer: OK (U = %llu)\n", (unsigned long long)updates);
+    return 0;
+}
