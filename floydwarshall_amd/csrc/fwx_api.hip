@@ -425,7 +425,7 @@ struct fwx_matrix {
     int32_t *next, *hops, *scratch;
     unsigned long long *upd;
     fwx::PathLog plog;     // update log for exact `_path` lists (head == nullptr: disabled)
-    unsigned long long log_total;   // records allocated = U of the uploaded input
+    unsigned long long log_total;   // records the rec_k / rec_prev arrays are allocated for
     void *rate0;           // pristine copies of the uploaded input, kept while logging (the logged
     int32_t *next0;        //   solve is a counting solve + a replay from these); next0 is also what
     int32_t *hops0;        //   the exact-path walk reads for entries never updated
@@ -481,6 +481,34 @@ int logged_solve(fwx_matrix *m, const Opts &op_in, hipStream_t s)
     };
     if (!m->clean && restore()) return FWX_ERR_HIP;   // both passes start from the uploaded input
     m->clean = 0;
+    if (m->n <= FWX_SMALL_N && op.engine == FWX_ENGINE_AUTO) {
+        // Single-launch regime: U <= n (n-1) (n-2) -- each (k, i, j) improves at most once -- is at
+        // most 2 M records here, so the log is simply sized for that bound (once per handle) and
+        // the counting pass is skipped: one launch per solve.
+        const unsigned long long bound = (unsigned long long)m->n * m->n * m->n;
+        if (m->log_total < bound) {
+            if (m->plog.rec_k) { (void)hipFree(m->plog.rec_k); m->plog.rec_k = nullptr; }
+            if (m->plog.rec_prev) { (void)hipFree(m->plog.rec_prev); m->plog.rec_prev = nullptr; }
+            FWX_HIP(hipMalloc((void **)&m->plog.rec_k, bound * 4));
+            FWX_HIP(hipMalloc((void **)&m->plog.rec_prev, bound * 4));
+            m->log_total = bound;
+        }
+        unsigned long long base[FWX_UPDATE_SHARDS + 1];
+        base[0] = 0;
+        for (int i = 1; i <= FWX_UPDATE_SHARDS; ++i) base[i] = bound;   // one workgroup = shard 0
+        FWX_HIP(hipMemcpyAsync((void *)m->plog.base, base, sizeof(base), hipMemcpyHostToDevice, s));
+        FWX_HIP(hipMemsetAsync(m->plog.count, 0, FWX_UPDATE_SHARDS * 8, s));
+        FWX_HIP(hipStreamSynchronize(s));        // `base` (host array) must outlive the copy
+        int rc1 = m->dtype == FWX_F64 ? matrix_solve_typed<double>(m, op, nullptr, s)
+                                      : matrix_solve_typed<float>(m, op, nullptr, s);
+        if (rc1) return rc1;
+        unsigned long long u = 0;
+        FWX_HIP(hipMemcpyAsync(&u, m->plog.count, sizeof(u), hipMemcpyDeviceToHost, s));
+        FWX_HIP(hipStreamSynchronize(s));
+        m->rec_ready = 1;
+        if (op.updates_out) *op.updates_out = u;
+        return FWX_OK;
+    }
     fwx::PathLog saved = m->plog;
     m->plog = fwx::PathLog();                    // pass 1 must not log
     FWX_HIP(hipMemsetAsync(m->upd, 0, FWX_UPDATE_SHARDS * 8, s));
@@ -671,8 +699,7 @@ int fwx_matrix_upload(fwx_matrix *m, const void *rate, const int32_t *next, cons
         if (m->hops) FWX_HIP(hipMemcpy(m->hops0, hops, nn * 4, hipMemcpyHostToDevice));
         FWX_HIP(hipMemset(m->plog.head, 0xFF, nn * 4));
         FWX_HIP(hipMemset(m->plog.count, 0, FWX_UPDATE_SHARDS * sizeof(unsigned long long)));
-        m->log_total = 0;
-        m->rec_ready = 0;      // the log of an earlier input is stale
+        m->rec_ready = 0;      // the log of an earlier input is stale (its arrays are reused)
         m->clean = 1;
     }
     return FWX_OK;

@@ -104,6 +104,7 @@ private:
     uint64_t solved_version_ = ~0ull;
     std::vector<Vertex> vertices_;   // of the cached solve
     fwx_matrix *dev_ = nullptr;      // solved matrix, resident in HBM
+    int32_t dev_n_ = 0;              // order of the matrix dev_ was created for
     int64_t solves_ = 0;
 };
 

@@ -47,19 +47,29 @@ int Session::ensure_solved()
 {
     if (solved_version_ == version_) return FWX_OK;
     DenseMatrix m = build_matrix(rates_);
-    drop_device();
+    // The device handle (matrix, pristine copies, log arrays) is kept while the vertex count stays
+    // the same -- a rate update between known vertices, the common case -- and only re-uploaded.
+    if (dev_ && dev_n_ != m.n()) drop_device();
     vertices_ = m.vertices;
     if (m.n() > 0) {
-        // The solve keeps an update log (fwx_matrix_enable_path_log: a counting pass, then a
-        // logged replay), from which fwx_matrix_query_exact rebuilds the reference's `_path`
-        // lists -- under exact ties (the 1.0 edges of Algorithms.hs:35 make them common) the list
-        // the reference stored can be a longer route than the one the next-hops describe.  Logged
-        // solves run on the per-k engine (one launch for n <= 128), which also carries `hops`.
-        int rc = fwx_matrix_create(&dev_, m.n(), FWX_F64, 1, 1, device_);
-        if (rc) return rc;
-        if ((rc = fwx_matrix_enable_path_log(dev_))) return rc;
-        if ((rc = fwx_matrix_upload(dev_, m.rate.data(), m.next.data(), m.hops.data()))) return rc;
-        if ((rc = fwx_matrix_solve(dev_, nullptr))) return rc;       // runAlgo 0, on the GPU
+        // The solve keeps an update log (fwx_matrix_enable_path_log), from which
+        // fwx_matrix_query_exact rebuilds the reference's `_path` lists -- under exact ties (the
+        // 1.0 edges of Algorithms.hs:35 make them common) the list the reference stored can be a
+        // longer route than the one the next-hops describe.  Logged solves run as one launch for
+        // n <= 128 and on the per-k engine above; both carry `hops`.
+        int rc = FWX_OK;
+        if (!dev_) {
+            if ((rc = fwx_matrix_create(&dev_, m.n(), FWX_F64, 1, 1, device_))) return rc;
+            dev_n_ = m.n();
+            if ((rc = fwx_matrix_enable_path_log(dev_))) { drop_device(); return rc; }
+        }
+        if ((rc = fwx_matrix_upload(dev_, m.rate.data(), m.next.data(), m.hops.data())) ||
+            (rc = fwx_matrix_solve(dev_, nullptr))) {               // runAlgo 0, on the GPU
+            drop_device();
+            return rc;
+        }
+    } else {
+        drop_device();
     }
     solved_version_ = version_;
     ++solves_;

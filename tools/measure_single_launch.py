@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Latency of the single-launch solve (small_solve, n <= 128) against the per-k engine on the same
 matrices: device-resident f64 + next + hops (what the host mirror solves), restore-from-pristine
-cost subtracted; and of a logged solve (counting pass + logged replay) through fwx_matrix_solve."""
+cost subtracted; and of a logged solve through fwx_matrix_solve (one launch for n <= 128)."""
 import sys
 import time
 
@@ -46,6 +46,6 @@ for n in (4, 16, 48, 64, 65, 96, 120, 128):
     with engine.DeviceMatrix(n, np.float64, with_next=True, with_hops=True) as dm:
         dm.enable_path_log()
         dm.upload(rate, nxt, hops)
-        line += "  logged solve (2 passes) %.1f us" % (1e6 * timed(dm.solve))
+        line += "  logged solve %.1f us" % (1e6 * timed(dm.solve))
         line += "  [per-k logged %.1f us]" % (1e6 * timed(lambda: dm.solve(engine=engine.FWX_ENGINE_PERK)))
     print(line, flush=True)
