@@ -433,6 +433,8 @@ struct fwx_matrix {
     int32_t walk_cap;      // capacity (path entries) `walk` was sized for
     int32_t rec_ready;     // a logged solve has completed
     int32_t clean;         // the working arrays still equal the pristine copy (fresh upload)
+    int32_t have_hint;     // hint[] holds the per-shard record counts of the previous logged solve
+    unsigned long long hint[FWX_UPDATE_SHARDS];
 };
 
 namespace {
@@ -479,9 +481,10 @@ int logged_solve(fwx_matrix *m, const Opts &op_in, hipStream_t s)
         if (m->hops) FWX_HIP(hipMemcpyAsync(m->hops, m->hops0, nn * 4, hipMemcpyDeviceToDevice, s));
         return FWX_OK;
     };
-    if (!m->clean && restore()) return FWX_ERR_HIP;   // both passes start from the uploaded input
-    m->clean = 0;
+    if (!m->clean && restore()) return FWX_ERR_HIP;   // every pass starts from the uploaded input
+    m->clean = 1;
     if (m->n <= FWX_SMALL_N && op.engine == FWX_ENGINE_AUTO) {
+        m->clean = 0;
         // Single-launch regime: U <= n (n-1) (n-2) -- each (k, i, j) improves at most once -- is at
         // most 2 M records here, so the log is simply sized for that bound (once per handle) and
         // the counting pass is skipped: one launch per solve.
@@ -509,37 +512,75 @@ int logged_solve(fwx_matrix *m, const Opts &op_in, hipStream_t s)
         if (op.updates_out) *op.updates_out = u;
         return FWX_OK;
     }
-    fwx::PathLog saved = m->plog;
-    m->plog = fwx::PathLog();                    // pass 1 must not log
-    FWX_HIP(hipMemsetAsync(m->upd, 0, FWX_UPDATE_SHARDS * 8, s));
-    int rc = m->dtype == FWX_F64 ? matrix_solve_typed<double>(m, op, m->upd, s)
+    // Sizes the sharded log for `cap` records per shard, replays the solve with logging on, and
+    // reads back how many records each shard really appended (the counters run past the capacity).
+    unsigned long long cnt[FWX_UPDATE_SHARDS];
+    auto logged_pass = [&](const unsigned long long *cap, bool &overflow) -> int {
+        unsigned long long base[FWX_UPDATE_SHARDS + 1];
+        base[0] = 0;
+        for (int i = 0; i < FWX_UPDATE_SHARDS; ++i) base[i + 1] = base[i] + cap[i];
+        const unsigned long long total = base[FWX_UPDATE_SHARDS];
+        if (total > 0x7fffffffull) return FWX_ERR_UNSUPPORTED;   // record indices are int32
+        if (m->log_total < total || !m->plog.rec_k) {
+            if (m->plog.rec_k) { (void)hipFree(m->plog.rec_k); m->plog.rec_k = nullptr; }
+            if (m->plog.rec_prev) { (void)hipFree(m->plog.rec_prev); m->plog.rec_prev = nullptr; }
+            m->log_total = 0;
+            FWX_HIP(hipMalloc((void **)&m->plog.rec_k, (total ? total : 1) * 4));
+            FWX_HIP(hipMalloc((void **)&m->plog.rec_prev, (total ? total : 1) * 4));
+            m->log_total = total;
+        }
+        FWX_HIP(hipMemcpyAsync((void *)m->plog.base, base, sizeof(base), hipMemcpyHostToDevice, s));
+        FWX_HIP(hipMemsetAsync(m->plog.count, 0, FWX_UPDATE_SHARDS * 8, s));
+        FWX_HIP(hipMemsetAsync(m->plog.head, 0xFF, nn * 4, s));
+        if (!m->clean && restore()) return FWX_ERR_HIP;
+        m->clean = 0;
+        FWX_HIP(hipStreamSynchronize(s));            // `base` (host array) must outlive the copy
+        const int rc2 = m->dtype == FWX_F64 ? matrix_solve_typed<double>(m, op, nullptr, s)
+                                            : matrix_solve_typed<float>(m, op, nullptr, s);
+        if (rc2) return rc2;
+        FWX_HIP(hipMemcpyAsync(cnt, m->plog.count, sizeof(cnt), hipMemcpyDeviceToHost, s));
+        FWX_HIP(hipStreamSynchronize(s));
+        overflow = false;
+        for (int i = 0; i < FWX_UPDATE_SHARDS; ++i) overflow |= cnt[i] > cap[i];
+        return FWX_OK;
+    };
+    auto finish = [&]() {
+        unsigned long long u = 0;
+        for (int i = 0; i < FWX_UPDATE_SHARDS; ++i) { m->hint[i] = cnt[i]; u += cnt[i]; }
+        m->have_hint = 1;
+        m->rec_ready = 1;
+        if (op.updates_out) *op.updates_out = u;
+        return FWX_OK;
+    };
+
+    // A handle that has solved a matrix of this order before (a host that re-solves after every
+    // rate update keeps its handle) sizes the log from the previous solve's per-shard counts plus
+    // a quarter: one pass.  Only if some shard outgrows that is the solve replayed, with the
+    // exact counts the overflowed pass has just produced.
+    int rc = FWX_OK;
+    bool overflow = false;
+    if (m->have_hint) {
+        unsigned long long cap[FWX_UPDATE_SHARDS];
+        for (int i = 0; i < FWX_UPDATE_SHARDS; ++i) cap[i] = m->hint[i] + m->hint[i] / 4 + 256;
+        if ((rc = logged_pass(cap, overflow))) return rc;
+        if (!overflow) return finish();
+    } else {
+        fwx::PathLog saved = m->plog;
+        m->plog = fwx::PathLog();                    // the counting pass must not log
+        m->clean = 0;
+        FWX_HIP(hipMemsetAsync(m->upd, 0, FWX_UPDATE_SHARDS * 8, s));
+        rc = m->dtype == FWX_F64 ? matrix_solve_typed<double>(m, op, m->upd, s)
                                  : matrix_solve_typed<float>(m, op, m->upd, s);
-    m->plog = saved;
-    if (rc) return rc;
-    unsigned long long cnt[FWX_UPDATE_SHARDS], base[FWX_UPDATE_SHARDS + 1];
-    FWX_HIP(hipMemcpyAsync(cnt, m->upd, sizeof(cnt), hipMemcpyDeviceToHost, s));
-    FWX_HIP(hipStreamSynchronize(s));
-    base[0] = 0;
-    for (int i = 0; i < FWX_UPDATE_SHARDS; ++i) base[i + 1] = base[i] + cnt[i];
-    const unsigned long long total = base[FWX_UPDATE_SHARDS];
-    if (total > 0x7fffffffull) return FWX_ERR_UNSUPPORTED;   // record indices are int32
-    if (m->plog.rec_k) { (void)hipFree(m->plog.rec_k); m->plog.rec_k = nullptr; }
-    if (m->plog.rec_prev) { (void)hipFree(m->plog.rec_prev); m->plog.rec_prev = nullptr; }
-    FWX_HIP(hipMalloc((void **)&m->plog.rec_k, (total ? total : 1) * 4));
-    FWX_HIP(hipMalloc((void **)&m->plog.rec_prev, (total ? total : 1) * 4));
-    m->log_total = total;
-    FWX_HIP(hipMemcpyAsync((void *)m->plog.base, base, sizeof(base), hipMemcpyHostToDevice, s));
-    FWX_HIP(hipMemsetAsync(m->plog.count, 0, FWX_UPDATE_SHARDS * 8, s));
-    FWX_HIP(hipMemsetAsync(m->plog.head, 0xFF, nn * 4, s));
-    if (restore()) return FWX_ERR_HIP;
-    FWX_HIP(hipStreamSynchronize(s));            // `base` (host array) must outlive the copy
-    rc = m->dtype == FWX_F64 ? matrix_solve_typed<double>(m, op, nullptr, s)
-                             : matrix_solve_typed<float>(m, op, nullptr, s);
-    if (rc) return rc;
-    FWX_HIP(hipStreamSynchronize(s));
-    m->rec_ready = 1;
-    if (op.updates_out) *op.updates_out = total;
-    return FWX_OK;
+        m->plog = saved;
+        if (rc) return rc;
+        FWX_HIP(hipMemcpyAsync(cnt, m->upd, sizeof(cnt), hipMemcpyDeviceToHost, s));
+        FWX_HIP(hipStreamSynchronize(s));
+    }
+    unsigned long long exact[FWX_UPDATE_SHARDS];
+    for (int i = 0; i < FWX_UPDATE_SHARDS; ++i) exact[i] = cnt[i];
+    if ((rc = logged_pass(exact, overflow))) return rc;
+    if (overflow) return FWX_ERR_HIP;                // cannot happen: same input, same launches
+    return finish();
 }
 
 // The reference's `_path` list of entry (src,dst), rebuilt from the update log exactly as

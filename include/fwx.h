@@ -123,8 +123,10 @@ int fwx_matrix_destroy(fwx_matrix *m);
  * exactly.  Enable after create; needs the next-hop matrix.  fwx_matrix_solve then (1) runs a
  * counting solve, (2) sizes the log exactly (sharded by workgroup so appends do not contend),
  * (3) restores the input from a pristine device copy and replays the solve with logging -- on the
- * per-k engine, whole pivot range only.  Costs twice the solve time and twice the memory.  For
- * n <= 128 the log is sized for the bound U <= n^3 instead and the solve is a single launch.
+ * per-k engine, whole pivot range only.  Costs twice the solve time and twice the memory.  A handle
+ * that has solved before sizes the log from the previous solve's counts (+25 %) and needs one pass
+ * (replayed only if a shard outgrows that); for n <= 128 the log is sized for the bound U <= n^3
+ * and the solve is a single launch.
  * A logged solve always starts from the uploaded input (solving twice gives the same
  * matrix).  query_exact before a completed logged solve of the current upload: FWX_ERR_INVALID.
  * path_out receives the vertices after src up to dst; returns the length.                       */

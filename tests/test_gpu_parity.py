@@ -767,6 +767,40 @@ def test_exact_path_lists_dense_kinds(kind):
     _exact_paths_case(lf.from_dense(vertices, rate, nxt))
 
 
+def test_path_log_hinted_single_pass_and_overflow_replay():
+    """A handle that has solved before sizes its log from the previous per-shard counts (+25 %):
+    a similar matrix is then logged in ONE pass; a matrix with many more updates overflows that
+    guess and is replayed with exact sizes.  Either way every list equals the reference's."""
+    n = 136                                              # > 128: the per-k engine writes the log
+    vertices = [("X", "C%03d" % i) for i in range(n)]
+    refs = {}
+
+    def check(dm, name, rate, nxt, hops):
+        dm.upload(rate, nxt, hops)
+        u = dm.solve(count_updates=True)
+        er, en, eh = rate.copy(), nxt.copy(), hops.copy()
+        assert u == oracle.relax(er, en, eh) == dm.path_log_count()
+        r, nx, hp = dm.download()
+        assert_bits_equal(r, er, "rate")
+        assert np.array_equal(nx, en) and np.array_equal(hp, eh)
+        if name not in refs:
+            refs[name] = lf.path_indices(lf.run_algo(lf.from_dense(vertices, rate, nxt), np.float64))
+        rnd = np.random.default_rng(u % 1000)
+        for _ in range(300):
+            i, j = (int(x) for x in rnd.integers(0, n, size=2))
+            assert tuple(dm.query_exact(i, j)[1]) == refs[name][i][j]
+
+    sparse = synth.make("t2", n, np.float64, seed=5)     # few updates
+    dense = synth.make("t1", n, np.float64, seed=6)      # many more: overflows the sparse hint
+    with engine.DeviceMatrix(n, np.float64, with_next=True, with_hops=True) as dm:
+        dm.enable_path_log()
+        check(dm, "sparse", *sparse)                     # counting pass + logged pass
+        check(dm, "sparse", *sparse)                     # hinted: one pass
+        check(dm, "dense", *dense)                       # hint too small: replay with exact sizes
+        check(dm, "dense", *dense)                       # hinted again
+        check(dm, "sparse", *sparse)                     # generous hint: one pass
+
+
 def test_path_log_lifecycle():
     """query_exact needs a completed logged solve of the CURRENT upload; a logged solve always
     replays from the uploaded input, so solving twice gives the same matrix; k-ranges and the
