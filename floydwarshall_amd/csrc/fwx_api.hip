@@ -731,18 +731,24 @@ int fwx_matrix_upload(fwx_matrix *m, const void *rate, const int32_t *next, cons
     int rc = g.enter(m->device);
     if (rc) return rc;
     const size_t nn = (size_t)m->n * (size_t)m->n, es = m->dtype == FWX_F64 ? 8 : 4;
-    FWX_HIP(hipMemcpy(m->rate, rate, nn * es, hipMemcpyHostToDevice));
-    if (m->next) FWX_HIP(hipMemcpy(m->next, next, nn * 4, hipMemcpyHostToDevice));
-    if (m->hops) FWX_HIP(hipMemcpy(m->hops, hops, nn * 4, hipMemcpyHostToDevice));
-    if (m->plog.head) {   // keep the pristine input: the logged solve replays from it
+    if (m->plog.head) {
+        // logged matrix: the input crosses PCIe once, into the pristine copy the logged solve
+        // replays from; the working arrays are filled from there on the device
         FWX_HIP(hipMemcpy(m->rate0, rate, nn * es, hipMemcpyHostToDevice));
         FWX_HIP(hipMemcpy(m->next0, next, nn * 4, hipMemcpyHostToDevice));
         if (m->hops) FWX_HIP(hipMemcpy(m->hops0, hops, nn * 4, hipMemcpyHostToDevice));
-        FWX_HIP(hipMemset(m->plog.head, 0xFF, nn * 4));
-        FWX_HIP(hipMemset(m->plog.count, 0, FWX_UPDATE_SHARDS * sizeof(unsigned long long)));
+        FWX_HIP(hipMemcpyAsync(m->rate, m->rate0, nn * es, hipMemcpyDeviceToDevice, nullptr));
+        FWX_HIP(hipMemcpyAsync(m->next, m->next0, nn * 4, hipMemcpyDeviceToDevice, nullptr));
+        if (m->hops)
+            FWX_HIP(hipMemcpyAsync(m->hops, m->hops0, nn * 4, hipMemcpyDeviceToDevice, nullptr));
+        FWX_HIP(hipMemsetAsync(m->plog.count, 0, FWX_UPDATE_SHARDS * sizeof(unsigned long long), nullptr));
         m->rec_ready = 0;      // the log of an earlier input is stale (its arrays are reused)
         m->clean = 1;
+        return FWX_OK;
     }
+    FWX_HIP(hipMemcpy(m->rate, rate, nn * es, hipMemcpyHostToDevice));
+    if (m->next) FWX_HIP(hipMemcpy(m->next, next, nn * 4, hipMemcpyHostToDevice));
+    if (m->hops) FWX_HIP(hipMemcpy(m->hops, hops, nn * 4, hipMemcpyHostToDevice));
     return FWX_OK;
 }
 

@@ -17,6 +17,14 @@ namespace fwxh {
 DenseMatrix build_matrix(const ExchRateTimes &rates)
 {
     DenseMatrix m;
+    build_matrix_into(rates, m);
+    return m;
+}
+
+// Same, into a caller-kept DenseMatrix: a host that rebuilds after every rate update reuses the
+// three n x n host arrays instead of faulting in fresh pages each time.
+void build_matrix_into(const ExchRateTimes &rates, DenseMatrix &m)
+{
     // :29  vertices = sort . nub $ keys >>= \(k1,k2) -> [k1,k2]
     std::set<Vertex> vs;
     for (const auto &kv : rates) {
@@ -50,7 +58,6 @@ DenseMatrix build_matrix(const ExchRateTimes &rates)
                 m.next[i * n + j] = (int32_t)j;
                 m.hops[i * n + j] = 1;
             }
-    return m;
 }
 
 OptimumResult optimum_dense(const std::vector<Vertex> &vertices, int32_t n_cols, const double *rate,

@@ -53,6 +53,7 @@ struct OptimumResult {
 
 // Algorithms.hs:26-40
 DenseMatrix build_matrix(const ExchRateTimes &rates);
+void build_matrix_into(const ExchRateTimes &rates, DenseMatrix &out);   // reuses out's storage
 
 // Algorithms.hs:65-78 on host arrays; n_cols == 0 with rows models "matrix with empty rows".
 OptimumResult optimum_dense(const std::vector<Vertex> &vertices, int32_t n_cols, const double *rate,
@@ -105,6 +106,7 @@ private:
     std::vector<Vertex> vertices_;   // of the cached solve
     fwx_matrix *dev_ = nullptr;      // solved matrix, resident in HBM
     int32_t dev_n_ = 0;              // order of the matrix dev_ was created for
+    DenseMatrix initial_;            // buildMatrix output, storage kept across re-solves
     int64_t solves_ = 0;
 };
 

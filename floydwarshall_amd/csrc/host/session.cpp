@@ -46,7 +46,8 @@ bool Session::update_rates(int64_t time, const Vertex &src, const Vertex &dest, 
 int Session::ensure_solved()
 {
     if (solved_version_ == version_) return FWX_OK;
-    DenseMatrix m = build_matrix(rates_);
+    DenseMatrix &m = initial_;
+    build_matrix_into(rates_, m);
     // The device handle (matrix, pristine copies, log arrays) is kept while the vertex count stays
     // the same -- a rate update between known vertices, the common case -- and only re-uploaded.
     if (dev_ && dev_n_ != m.n()) drop_device();
