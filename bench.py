@@ -306,8 +306,17 @@ def main():
             fused_step()
         torch.cuda.synchronize()
         ft = (time.perf_counter() - t1) / 2
+        # VALU-issue bound of the max-form kernel (rates only, f32): 8.0 cycles per pair of
+        # relaxations per wave (tools/valu_rate.hip, profiles/r01_valu_issue_rates.txt), 1024 SIMDs,
+        # at the 1.92 GHz the chip holds under this load
+        valu = None
+        if es == 4 and not args.with_next:
+            bound_s = relax_per_step / 2.0 * 8.0 / 64.0 / 1024.0 / 1.92e9
+            valu = {"bound": "valu-issue", "cycles_per_pair_of_relaxations": 8.0, "clock_GHz": 1.92,
+                    "bound_ms_per_step": 1e3 * bound_s, "frac": bound_s / ft,
+                    "source": "profiles/r01_valu_issue_rates.txt"}
         out["fused_engine"] = {"value": relax_per_step / ft, "unit": "edge-relaxations/s",
-                               "ms_per_step": 1e3 * ft, "steps": 2,
+                               "ms_per_step": 1e3 * ft, "steps": 2, "valu_roofline": valu,
                                "note": "same workload, fused engine (64 pivots per pass, bit-identical "
                                        "results, VALU-bound); not part of `value`"}
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
