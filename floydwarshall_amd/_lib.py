@@ -73,6 +73,8 @@ SIGNATURES = {
                                               c_vp, c_i32]),
     "fwx_dev_relax": (ctypes.c_int, [ctypes.POINTER(FwxSlab), ctypes.POINTER(FwxPivots), c_i32,
                                      c_vp, c_vp]),
+    "fwx_dev_relax_skip": (ctypes.c_int, [ctypes.POINTER(FwxSlab), ctypes.POINTER(FwxPivots), c_i32,
+                                          c_vp, c_i32, c_i32, c_vp]),
     "fwx_dev_panel": (ctypes.c_int, [ctypes.POINTER(FwxSlab), c_vp, c_vp, c_vp, c_vp]),
     "fwx_dev_solve": (ctypes.c_int, [ctypes.POINTER(FwxSlab), ctypes.POINTER(FwxOpts)]),
     "fwx_dev_follow_paths": (ctypes.c_int, [c_i32, c_vp, c_i32, c_vp, c_vp, c_vp, c_vp, c_i32, c_vp,

@@ -90,17 +90,21 @@ int read_opts(const fwx_opts *o, int n, Opts &out)
 template <typename T>
 int relax_range(T *rate, int32_t *next, int32_t *hops, int rows, int n, int row0, const T *prow0,
                 const int32_t *phops0, int64_t stride, int k_begin, int k_end, int serpentine,
-                unsigned long long *d_updates, hipStream_t s, fwx::PathLog plog = fwx::PathLog())
+                unsigned long long *d_updates, hipStream_t s, fwx::PathLog plog = fwx::PathLog(),
+                int skip_lo = 0, int skip_hi = 0)
 {
     fwx::RelaxArgs<T> a;
     a.rate = rate; a.next = next; a.hops = hops;
     a.rows = rows; a.n = n; a.row0 = row0; a.updates = d_updates; a.plog = plog;
+    a.skip_lo = skip_lo; a.skip_hi = skip_hi;
     for (int k = k_begin; k < k_end; ++k) {
         a.prow = prow0 + (int64_t)(k - k_begin) * stride;
         a.phops = phops0 ? phops0 + (int64_t)(k - k_begin) * stride : nullptr;
         a.k = k;
         a.flip = serpentine ? (k & 1) : 0;
-        FWX_HIP(fwx::launch_relax<T>(a, s));
+        const hipError_t e = fwx::launch_relax<T>(a, s);
+        if (e == hipErrorInvalidValue) return FWX_ERR_INVALID;   // misaligned skip range
+        FWX_HIP(e);
     }
     return FWX_OK;
 }
@@ -896,6 +900,12 @@ int fwx_matrix_query(fwx_matrix *m, int32_t src, int32_t dst, double *rate_out, 
 int fwx_dev_relax(const fwx_slab *slab, const fwx_pivots *piv, int32_t serpentine,
                   unsigned long long *d_updates, void *stream)
 {
+    return fwx_dev_relax_skip(slab, piv, serpentine, d_updates, 0, 0, stream);
+}
+
+int fwx_dev_relax_skip(const fwx_slab *slab, const fwx_pivots *piv, int32_t serpentine,
+                       unsigned long long *d_updates, int32_t skip_lo, int32_t skip_hi, void *stream)
+{
     int rc = check_slab(slab);
     if (rc) return rc;
     if (!piv || piv->k_begin < 0 || piv->k_end < piv->k_begin || piv->k_end > slab->n)
@@ -904,13 +914,18 @@ int fwx_dev_relax(const fwx_slab *slab, const fwx_pivots *piv, int32_t serpentin
     if (!piv->rate || (slab->hops && !piv->hops)) return FWX_ERR_INVALID;
     if (device_count() <= 0) return FWX_ERR_NO_DEVICE;
     hipStream_t s = (hipStream_t)stream;
+    if (skip_lo < 0 || skip_hi < skip_lo || skip_hi > slab->rows ||
+        (skip_hi > skip_lo && (skip_lo % 4 || skip_hi % 4)))
+        return FWX_ERR_INVALID;
     if (slab->dtype == FWX_F64)
         return relax_range<double>((double *)slab->rate, slab->next, slab->hops, slab->rows,
                                    slab->n, slab->row0, (const double *)piv->rate, piv->hops,
-                                   piv->stride, piv->k_begin, piv->k_end, serpentine, d_updates, s);
+                                   piv->stride, piv->k_begin, piv->k_end, serpentine, d_updates, s,
+                                   fwx::PathLog(), skip_lo, skip_hi);
     return relax_range<float>((float *)slab->rate, slab->next, slab->hops, slab->rows, slab->n,
                               slab->row0, (const float *)piv->rate, piv->hops, piv->stride,
-                              piv->k_begin, piv->k_end, serpentine, d_updates, s);
+                              piv->k_begin, piv->k_end, serpentine, d_updates, s, fwx::PathLog(),
+                              skip_lo, skip_hi);
 }
 
 int fwx_dev_panel(const fwx_slab *block, void *w_rate, int32_t *w_hops,

@@ -32,6 +32,8 @@ template <typename T> struct RelaxArgs {
     const T *prow;                 // pivot row k at the start of step k (n elements)
     const int32_t *phops;          // its hops row (iff hops)
     int rows, n, row0, k, flip;
+    int skip_lo = 0, skip_hi = 0;  // slab rows [skip_lo, skip_hi) are left alone (multiples of 4):
+                                   //   a look-ahead launch has already relaxed them
     unsigned long long *updates;   // FWX_UPDATE_SHARDS_K counters or nullptr
     PathLog plog;                  // plog.head == nullptr: no logging (slab must be the whole matrix
                                    // when logging: head is indexed by global row)

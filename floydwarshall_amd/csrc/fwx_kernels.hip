@@ -87,7 +87,8 @@ template <typename T, int W, int NV, int RPB, int UNROLL, bool HAS_NEXT, bool HA
 __global__ __launch_bounds__(256, MINW) void relax_k(T *rate, int32_t *next, int32_t *hops,
                                                const T *prow, const int32_t *phops, int rows,
                                                int n, int row0, int k, int nstrips, int flip,
-                                               unsigned long long *updates, PathLog plog)
+                                               unsigned long long *updates, PathLog plog,
+                                               int skip_lo, int skip_hi)
 {
     using L = Lanes<T, W>;
     using V = typename L::V;
@@ -104,6 +105,7 @@ __global__ __launch_bounds__(256, MINW) void relax_k(T *rate, int32_t *next, int
     const int chunk = bid / nstrips;
     const int r_begin = chunk * RPB;
     const int r_cnt = min(RPB, rows - r_begin);
+    if (r_begin >= skip_lo && r_begin < skip_hi) return;   // whole workgroup: rows already relaxed
 
     // Pivot column -> LDS (one strided gather per chunk).  Row k itself gets NaN: skip i == k.
     if (t < r_cnt) {
@@ -409,10 +411,11 @@ static hipError_t launch_relax_cfg(const RelaxArgs<T> &a, hipStream_t s)
     const int nchunks = (a.rows + RPB - 1) / RPB;
     const dim3 grid((unsigned)(nstrips * nchunks)), block(256);
     if (grid.x == 0) return hipSuccess;
+    if (a.skip_hi > a.skip_lo && (a.skip_lo % RPB || a.skip_hi % RPB)) return hipErrorInvalidValue;
 #define FWX_LAUNCH(HN, HH, CN)                                                                     \
     hipLaunchKernelGGL((relax_k<T, W, NV, RPB, UNROLL, HN, HH, CN, MINW, NT>), grid, block, 0, s, a.rate,    \
                        a.next, a.hops, a.prow, a.phops, a.rows, a.n, a.row0, a.k, nstrips,         \
-                       a.flip, a.updates, a.plog)
+                       a.flip, a.updates, a.plog, a.skip_lo, a.skip_hi)
     const bool hn = a.next != nullptr, hh = a.hops != nullptr, cn = a.updates != nullptr;
     if (hh) {
         if (cn) FWX_LAUNCH(true, true, true); else FWX_LAUNCH(true, true, false);

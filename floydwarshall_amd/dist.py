@@ -77,6 +77,15 @@ class HipBackend:
         else:
             engine.dev_relax(slab_rate, n, row0, k0, k1, pivots_t=w, next_t=slab_next)
 
+    def relax_skipping(self, slab_rate, n, row0, k0, k1, w, slab_next, skip):
+        """The whole slab except the rows skip = (lo, hi) in ONE launch per pivot; False if this
+        backend / alignment cannot do it (the caller then relaxes above and below separately)."""
+        lo, hi = skip
+        if self.engine_name != "perk" or lo % 4 or hi % 4:
+            return False
+        engine.dev_relax(slab_rate, n, row0, k0, k1, pivots_t=w, next_t=slab_next, skip=skip)
+        return True
+
     def relax_lookahead(self, slab_rate, n, row0, k0, k1, w, slab_next=None):
         """The few rows the next panel is made of.  They sit on the owner's critical path, so
         they always take the one-launch fused kernel (bit-identical to 64 per-k launches)."""
@@ -90,7 +99,7 @@ class HipBackend:
 
 
 def solve_partitioned(rate, n, rank, world, *, nxt=None, block=64, backend=None, group=None,
-                      lookahead=True, force_collectives=False):
+                      lookahead=True, force_collectives=False, skip_launch=True):
     """In-place solve of this rank's slab `rate` (rows row_bounds(n, world)[rank]...).
 
     All ranks must call this with the same n / world / block / lookahead.  Works on any device the
@@ -103,6 +112,8 @@ def solve_partitioned(rate, n, rank, world, *, nxt=None, block=64, backend=None,
         owner of panel b+1: relax ONLY the rows of panel b+1 with W_b, then snapshot them
         everyone:           start the broadcast of W_{b+1} (async, other buffer)
         everyone:           relax the rest of the slab with W_b   <- overlaps the broadcast
+    skip_launch: the owner relaxes "the rest" in one launch per pivot that leaves the look-ahead
+    rows alone (backend.relax_skipping) instead of one launch above and one below them.
     """
     backend = backend or HipBackend()
     collectives = world > 1 or force_collectives   # force: rehearse the RCCL calls on one rank
@@ -166,6 +177,9 @@ def solve_partitioned(rate, n, rank, world, *, nxt=None, block=64, backend=None,
         return w, wait
 
     def relax_rows_except(skips, k0, k1, w):
+        if skip_launch and len(skips) == 1 and hasattr(backend, "relax_skipping") and \
+                backend.relax_skipping(rate, n, row0, k0, k1, w, nxt, skips[0]):
+            return
         pos = 0
         for lo, hi in sorted(skips) + [(rows, rows)]:
             if lo > pos:

@@ -187,9 +187,10 @@ def _stream_ptr():
 
 
 def dev_relax(rate_t, n, row0, k_begin, k_end, *, pivots_t=None, pivot_hops_t=None, next_t=None,
-              hops_t=None, serpentine=True, updates_t=None):
+              hops_t=None, serpentine=True, updates_t=None, skip=None):
     """Apply pivots [k_begin,k_end) to the slab `rate_t` (rows [row0,row0+rows) of the n x n
-    matrix) on torch's current stream, asynchronously.
+    matrix) on torch's current stream, asynchronously.  skip = (lo, hi): slab rows [lo, hi)
+    (multiples of 4) are left alone -- a look-ahead step has relaxed them already.
 
     pivots_t None: the slab holds the pivot rows itself (single-GPU solve).  Otherwise pivots_t is
     the (k_end-k_begin) x n panel of time-k snapshots from dev_panel."""
@@ -209,8 +210,9 @@ def dev_relax(rate_t, n, row0, k_begin, k_end, *, pivots_t=None, pivot_hops_t=No
         p.hops = pivot_hops_t.data_ptr() if pivot_hops_t is not None else None
         p.stride = n
     upd = ctypes.c_void_p(updates_t.data_ptr()) if updates_t is not None else None
-    check(lib().fwx_dev_relax(ctypes.byref(s), ctypes.byref(p), int(bool(serpentine)), upd,
-                              _stream_ptr()), "fwx_dev_relax")
+    lo, hi = skip if skip else (0, 0)
+    check(lib().fwx_dev_relax_skip(ctypes.byref(s), ctypes.byref(p), int(bool(serpentine)), upd,
+                                   int(lo), int(hi), _stream_ptr()), "fwx_dev_relax_skip")
 
 
 def dev_panel(block_rate_t, n, k0, w_rate_t, *, next_t=None, hops_t=None, w_hops_t=None,

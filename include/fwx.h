@@ -168,6 +168,11 @@ typedef struct fwx_pivots {
 #define FWX_UPDATE_SHARDS 256
 int fwx_dev_relax(const fwx_slab *slab, const fwx_pivots *piv, int32_t serpentine,
                   unsigned long long *d_updates, void *stream);
+/* Same, leaving the slab rows [skip_lo, skip_hi) (relative to the slab, multiples of 4) alone: the
+ * rows of the NEXT pivot panel, which a look-ahead step has already relaxed -- one launch per
+ * pivot instead of one above and one below those rows.                                          */
+int fwx_dev_relax_skip(const fwx_slab *slab, const fwx_pivots *piv, int32_t serpentine,
+                       unsigned long long *d_updates, int32_t skip_lo, int32_t skip_hi, void *stream);
 
 /* Owner-side panel phase for a partitioned solve.  `block` holds the pivot rows
  * [block->row0, block->row0 + block->rows) at time k = block->row0.  Evolves them in place through

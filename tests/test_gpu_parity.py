@@ -881,3 +881,29 @@ def test_fuzz_hostile_values_every_engine(dtype):
                     k0 = int(rnd.integers(0, n - 1))
                     k1 = int(rnd.integers(k0 + 1, n + 1))
                     _solve_and_compare(rate, nxt, hops, k_begin=k0, k_end=k1)
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+def test_per_k_relax_with_a_skipped_row_range(dtype):
+    """fwx_dev_relax_skip: one launch per pivot over a slab, leaving a row range alone (the rows a
+    look-ahead step has already relaxed).  Rows outside the range must equal the oracle's, rows
+    inside must be untouched; a misaligned range is refused."""
+    import torch
+    n, lo, hi, k0, k1 = 520, 128, 192, 200, 264
+    rate, nxt, _ = synth.make("d2", n, dtype, seed=31)
+    want_r, want_n = rate.copy(), nxt.copy()
+    oracle.relax(want_r, want_n, None, k0, k1)
+    r_t, n_t = torch.from_numpy(rate.copy()).cuda(), torch.from_numpy(nxt.copy()).cuda()
+    w = torch.empty((k1 - k0, n), dtype=r_t.dtype, device="cuda")     # time-k snapshots of the pivots
+    engine.dev_panel_snap(r_t[k0:k1], n, k0, w, engine.FusedWorkspace(n, n, r_t.dtype, r_t.device).diag)
+    engine.dev_relax(r_t, n, 0, k0, k1, pivots_t=w, next_t=n_t, skip=(lo, hi))
+    torch.cuda.synchronize()
+    got_r, got_n = r_t.cpu().numpy(), n_t.cpu().numpy()
+    keep = np.ones(n, dtype=bool)
+    keep[lo:hi] = False
+    assert_bits_equal(got_r[keep], want_r[keep], "rows outside the skipped range")
+    assert np.array_equal(got_n[keep], want_n[keep])
+    assert_bits_equal(got_r[lo:hi], rate[lo:hi], "skipped rows")
+    assert np.array_equal(got_n[lo:hi], nxt[lo:hi])
+    with pytest.raises(engine.FwxError):
+        engine.dev_relax(r_t, n, 0, k0, k1, pivots_t=w, next_t=n_t, skip=(lo + 2, hi))
