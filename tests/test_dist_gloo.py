@@ -46,6 +46,17 @@ class OracleBackend:
         for k in range(k0, k1):
             self._apply(r, nx, n, row0, k, wn[k - k0])
 
+    def relax_skipping(self, slab_rate, n, row0, k0, k1, w, slab_next, skip):
+        """One call for the whole slab minus the rows skip = (lo, hi) -- what the HIP backend does
+        in a single launch per pivot; here simply the two parts.  Multiples of 4 only (as HIP)."""
+        lo, hi = skip
+        if lo % 4 or hi % 4:
+            return False
+        self.skip_calls = getattr(self, "skip_calls", 0) + 1
+        self.relax(slab_rate[:lo], n, row0, k0, k1, w, None if slab_next is None else slab_next[:lo])
+        self.relax(slab_rate[hi:], n, row0 + hi, k0, k1, w, None if slab_next is None else slab_next[hi:])
+        return True
+
     def panel(self, block_rate, n, k0, w):
         r = block_rate.numpy().copy()         # snapshot only: the matrix itself is not modified
         wn = w.numpy()
@@ -87,6 +98,7 @@ def _free_port():
     (2, 70, 8, True, "t1"),      # ties: earliest pivot must win on every rank
     (3, 50, 7, True, "t3"),      # ragged partition, ragged panels, inf/NaN inputs
     (8, 131, 5, True, "t2"),     # the 8-rank shape of `bench.py --gpus 8`, ragged everything
+    (2, 128, 16, True, "d2"),    # aligned panels: the owner takes the single skip-launch path
 ])
 def test_partitioned_solve_equals_single_process_oracle(tmp_path, world, n, block, lookahead, kind):
     import oracle
