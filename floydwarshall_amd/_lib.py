@@ -83,6 +83,8 @@ SIGNATURES = {
     "fwx_dev_panel_snap": (ctypes.c_int, [ctypes.POINTER(FwxSlab), c_vp, c_vp, c_vp]),
     "fwx_dev_relax_fused": (ctypes.c_int, [ctypes.POINTER(FwxSlab), ctypes.POINTER(FwxPivots), c_vp,
                                            c_vp, c_vp, c_i32, c_vp]),
+    "fwx_dev_relax_fused_skip": (ctypes.c_int, [ctypes.POINTER(FwxSlab), ctypes.POINTER(FwxPivots),
+                                                c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_vp]),
     "fwx_dev_check_nonneg": (ctypes.c_int, [ctypes.POINTER(FwxSlab), c_vp, c_vp]),
 }
 

@@ -111,14 +111,15 @@ int relax_range(T *rate, int32_t *next, int32_t *hops, int rows, int n, int row0
 
 template <typename T>
 int fused_block(T *rate, int32_t *next, int rows, int n, int row0, int k0, int bt, const T *w, T *ct,
-                int32_t *cnt, unsigned long long *d_updates, bool nonneg, hipStream_t s)
+                int32_t *cnt, unsigned long long *d_updates, bool nonneg, hipStream_t s,
+                int skip_lo = 0, int skip_hi = 0)
 {
     fwx::FusedArgs<T> a;
     a.nonneg = nonneg;
     a.rate = rate; a.next = next; a.rows = rows; a.n = n; a.row0 = row0;
     a.k0 = k0; a.bt = bt; a.w = w; a.ct = ct; a.cnt = cnt; a.updates = d_updates;
     a.ct_ld = (rows + 3) & ~3;
-    hipError_t e = fwx::launch_fused_relax<T>(a, s);
+    hipError_t e = fwx::launch_fused_relax<T>(a, s, skip_lo, skip_hi);
     if (e == hipErrorInvalidValue) return FWX_ERR_INVALID;
     FWX_HIP(e);
     return FWX_OK;
@@ -1035,6 +1036,13 @@ int fwx_dev_relax_fused(const fwx_slab *slab, const fwx_pivots *piv, void *col_r
                         int32_t *col_next, unsigned long long *d_updates, int32_t flags,
                         void *stream)
 {
+    return fwx_dev_relax_fused_skip(slab, piv, col_rate, col_next, d_updates, flags, 0, 0, stream);
+}
+
+int fwx_dev_relax_fused_skip(const fwx_slab *slab, const fwx_pivots *piv, void *col_rate,
+                             int32_t *col_next, unsigned long long *d_updates, int32_t flags,
+                             int32_t skip_lo, int32_t skip_hi, void *stream)
+{
     int rc = check_slab(slab);
     if (rc) return rc;
     if (!piv || piv->k_begin < 0 || piv->k_end < piv->k_begin || piv->k_end > slab->n ||
@@ -1044,17 +1052,20 @@ int fwx_dev_relax_fused(const fwx_slab *slab, const fwx_pivots *piv, void *col_r
     if (slab->hops) return FWX_ERR_UNSUPPORTED;
     if (!piv->rate || piv->stride != slab->n || !col_rate || (slab->next && !col_next))
         return FWX_ERR_INVALID;
+    if (skip_lo < 0 || skip_hi < skip_lo || skip_hi > slab->rows ||
+        (skip_hi > skip_lo && (skip_lo % 8 || skip_hi % 8)))
+        return FWX_ERR_INVALID;
     if (device_count() <= 0) return FWX_ERR_NO_DEVICE;
     hipStream_t s = (hipStream_t)stream;
     if (slab->dtype == FWX_F64)
         return fused_block<double>((double *)slab->rate, slab->next, slab->rows, slab->n, slab->row0,
                                    piv->k_begin, piv->k_end - piv->k_begin, (const double *)piv->rate,
                                    (double *)col_rate, col_next, d_updates,
-                                   (flags & FWX_FLAG_NONNEG) != 0, s);
+                                   (flags & FWX_FLAG_NONNEG) != 0, s, skip_lo, skip_hi);
     return fused_block<float>((float *)slab->rate, slab->next, slab->rows, slab->n, slab->row0,
                               piv->k_begin, piv->k_end - piv->k_begin, (const float *)piv->rate,
                               (float *)col_rate, col_next, d_updates, (flags & FWX_FLAG_NONNEG) != 0,
-                              s);
+                              s, skip_lo, skip_hi);
 }
 
 }  // extern "C"

@@ -840,11 +840,12 @@ hipError_t launch_fused_main(const FusedArgs<T> &full, int r_lo, int r_hi, hipSt
     return hipGetLastError();
 }
 
-template <typename T> hipError_t launch_fused_relax(const FusedArgs<T> &a, hipStream_t s)
+template <typename T>
+hipError_t launch_fused_relax(const FusedArgs<T> &a, hipStream_t s, int skip_lo, int skip_hi)
 {
-    hipError_t e = launch_fused_colpanel<T>(a, s);
+    hipError_t e = launch_fused_colpanel<T>(a, s);   // skipped rows get snapshots nobody reads
     if (e != hipSuccess) return e;
-    return launch_fused_main<T>(a, 0, a.rows, s, 0, 0);
+    return launch_fused_main<T>(a, 0, a.rows, s, skip_lo, skip_hi);
 }
 
 template <typename T>
@@ -859,8 +860,8 @@ hipError_t launch_fused_panel(const T *rows_base, int n, int k0, int bt, T *w, T
     return hipGetLastError();
 }
 
-template hipError_t launch_fused_relax<float>(const FusedArgs<float> &, hipStream_t);
-template hipError_t launch_fused_relax<double>(const FusedArgs<double> &, hipStream_t);
+template hipError_t launch_fused_relax<float>(const FusedArgs<float> &, hipStream_t, int, int);
+template hipError_t launch_fused_relax<double>(const FusedArgs<double> &, hipStream_t, int, int);
 template hipError_t launch_fused_colpanel<float>(const FusedArgs<float> &, hipStream_t);
 template hipError_t launch_fused_colpanel<double>(const FusedArgs<double> &, hipStream_t);
 template hipError_t launch_fused_main<float>(const FusedArgs<float> &, int, int, hipStream_t, int,

@@ -73,7 +73,8 @@ hipError_t launch_nonneg_check(const float *rate, size_t count, int *flag, hipSt
 hipError_t launch_nonneg_check(const double *rate, size_t count, int *flag, hipStream_t s);
 
 // colpanel + main: applies the bt pivots to every row of the slab.
-template <typename T> hipError_t launch_fused_relax(const FusedArgs<T> &a, hipStream_t s);
+template <typename T>
+hipError_t launch_fused_relax(const FusedArgs<T> &a, hipStream_t s, int skip_lo = 0, int skip_hi = 0);
 // The two halves separately: pivot-column snapshots for all rows of the slab, then the main
 // kernel on local rows [r_lo, r_hi) (used by the look-ahead schedule).
 template <typename T> hipError_t launch_fused_colpanel(const FusedArgs<T> &a, hipStream_t s);

@@ -81,7 +81,13 @@ class HipBackend:
         """The whole slab except the rows skip = (lo, hi) in ONE launch per pivot; False if this
         backend / alignment cannot do it (the caller then relaxes above and below separately)."""
         lo, hi = skip
-        if self.engine_name != "perk" or lo % 4 or hi % 4:
+        if self.engine_name == "fused":
+            if lo % 8 or hi % 8:
+                return False
+            engine.dev_relax_fused(slab_rate, n, row0, k0, k1, w, self.ws.ct, next_t=slab_next,
+                                   cnt_t=self.ws.cnt, nonneg=self.nonneg, skip=skip)
+            return True
+        if lo % 4 or hi % 4:
             return False
         engine.dev_relax(slab_rate, n, row0, k0, k1, pivots_t=w, next_t=slab_next, skip=skip)
         return True

@@ -263,9 +263,10 @@ def dev_check_nonneg(rate_t, n, row0=0):
 
 
 def dev_relax_fused(rate_t, n, row0, k0, k1, w_t, ct_t, *, next_t=None, cnt_t=None, updates_t=None,
-                    nonneg=False):
+                    nonneg=False, skip=None):
     """Apply pivots [k0,k1) (at most 64) to EVERY row of the slab in one pass, from the snapshot
-    panel w_t ((k1-k0) x n).  ct_t / cnt_t: scratch of at least 64*rows elements."""
+    panel w_t ((k1-k0) x n).  ct_t / cnt_t: scratch of at least 64*rows elements.  skip = (lo, hi):
+    slab rows [lo, hi) (multiples of 8) are left to an earlier look-ahead step."""
     s = _slab(rate_t, next_t, None, n, row0)
     p = FwxPivots()
     p.k_begin, p.k_end = k0, k1
@@ -279,10 +280,12 @@ def dev_relax_fused(rate_t, n, row0, k0, k1, w_t, ct_t, *, next_t=None, cnt_t=No
     if next_t is not None:
         assert cnt_t is not None and cnt_t.numel() >= FWX_FUSED_BLOCK * ld
         cn = ctypes.c_void_p(cnt_t.data_ptr())
-    check(lib().fwx_dev_relax_fused(ctypes.byref(s), ctypes.byref(p),
-                                    ctypes.c_void_p(ct_t.data_ptr()), cn, upd,
-                                    _lib.FWX_FLAG_NONNEG if nonneg else 0, _stream_ptr()),
-          "fwx_dev_relax_fused")
+    lo, hi = skip if skip else (0, 0)
+    check(lib().fwx_dev_relax_fused_skip(ctypes.byref(s), ctypes.byref(p),
+                                         ctypes.c_void_p(ct_t.data_ptr()), cn, upd,
+                                         _lib.FWX_FLAG_NONNEG if nonneg else 0, int(lo), int(hi),
+                                         _stream_ptr()),
+          "fwx_dev_relax_fused_skip")
 
 
 def dev_solve_fused(rate_t, n, k_begin=0, k_end=None, *, next_t=None, ws=None, updates_t=None,

@@ -227,6 +227,10 @@ int fwx_dev_panel_snap(const fwx_slab *block, void *w_rate, void *diag_ws, void 
 int fwx_dev_relax_fused(const fwx_slab *slab, const fwx_pivots *piv, void *col_rate,
                         int32_t *col_next, unsigned long long *d_updates, int32_t flags,
                         void *stream);
+/* Same, leaving the slab rows [skip_lo, skip_hi) (multiples of 8) to an earlier look-ahead step. */
+int fwx_dev_relax_fused_skip(const fwx_slab *slab, const fwx_pivots *piv, void *col_rate,
+                             int32_t *col_next, unsigned long long *d_updates, int32_t flags,
+                             int32_t skip_lo, int32_t skip_hi, void *stream);
 /* Clears *d_flag (a device int32 the caller has set to 1) if any rate of the slab is negative,
  * -0.0 or NaN.                                                                                  */
 int fwx_dev_check_nonneg(const fwx_slab *slab, int32_t *d_flag, void *stream);
