@@ -429,17 +429,13 @@ struct fwx_matrix {
     void *rate;
     int32_t *next, *hops, *scratch;
     unsigned long long *upd;
-    fwx::PathLog plog;     // update log for exact `_path` lists (head == nullptr: disabled)
-    unsigned long long log_total;   // records the rec_k / rec_prev arrays are allocated for
-    void *rate0;           // pristine copies of the uploaded input, kept while logging (the logged
-    int32_t *next0;        //   solve is a counting solve + a replay from these); next0 is also what
-    int32_t *hops0;        //   the exact-path walk reads for entries never updated
+    fwx::PathLog plog;     // path trace for exact `_path` lists (last == nullptr: disabled)
+    int32_t *next0;        // the uploaded next-hop matrix: the path of an entry never improved
     int32_t *walk;         // scratch of the exact-path walk (stack + output)
     int32_t walk_cap;      // capacity (path entries) `walk` was sized for
-    int32_t rec_ready;     // a logged solve has completed
-    int32_t clean;         // the working arrays still equal the pristine copy (fresh upload)
-    int32_t have_hint;     // hint[] holds the per-shard record counts of the previous logged solve
-    unsigned long long hint[FWX_UPDATE_SHARDS];
+    int32_t rec_ready;     // a traced solve of the current upload has completed
+    int32_t fresh;         // the arrays hold an uploaded input that has not been solved yet
+    unsigned long long last_u;   // U of the last traced solve
 };
 
 namespace {
@@ -448,9 +444,9 @@ int matrix_solve_typed(fwx_matrix *m, const Opts &op, unsigned long long *upd, h
 {
     const int n = m->n;
     T *r = (T *)m->rate;
-    const bool logging = m->plog.head != nullptr;
+    const bool logging = m->plog.last != nullptr;
     if (op.engine == FWX_ENGINE_FUSED && (logging || !fused_ok<T>(n, r, m->hops)))
-        return FWX_ERR_UNSUPPORTED;                 // the update log rides on per-k / small_solve
+        return FWX_ERR_UNSUPPORTED;                 // the path trace rides on per-k / small_solve
     if (op.engine == FWX_ENGINE_AUTO && n <= FWX_SMALL_N) {
         FWX_HIP(fwx::launch_small_solve<T>(r, m->next, m->hops, n, op.k_begin, op.k_end, upd,
                                            m->plog, s));
@@ -470,150 +466,61 @@ int matrix_solve_typed(fwx_matrix *m, const Opts &op, unsigned long long *upd, h
                           op.k_end, op.serpentine, upd, s, m->plog);
 }
 
-// Solve with the update log: (1) a counting solve gives the number of records each shard will
-// append; (2) the record arrays are allocated to exactly that size and the shard offsets set;
-// (3) the working matrix is restored from the pristine copy and the solve is replayed, logging.
+// Solve with the path trace (PathLog): one pass.  `last` starts at -1 everywhere; the kernels set
+// it on every successful relaxation and copy its column k / row k into at_col / at_row at step k.
 int logged_solve(fwx_matrix *m, const Opts &op_in, hipStream_t s)
 {
     if (op_in.k_begin != 0 || op_in.k_end != m->n || op_in.engine == FWX_ENGINE_FUSED)
-        return FWX_ERR_UNSUPPORTED;
-    Opts op = op_in;                             // both passes must take the same launches
+        return FWX_ERR_UNSUPPORTED;              // the trace covers whole solves of the per-k kind
+    if (!m->fresh) return FWX_ERR_INVALID;       // a traced solve starts from an uploaded input
+    Opts op = op_in;
     if (m->n > FWX_SMALL_N) op.engine = FWX_ENGINE_PERK;
-    const size_t nn = (size_t)m->n * (size_t)m->n, es = m->dtype == FWX_F64 ? 8 : 4;
-    auto restore = [&]() -> int {
-        FWX_HIP(hipMemcpyAsync(m->rate, m->rate0, nn * es, hipMemcpyDeviceToDevice, s));
-        FWX_HIP(hipMemcpyAsync(m->next, m->next0, nn * 4, hipMemcpyDeviceToDevice, s));
-        if (m->hops) FWX_HIP(hipMemcpyAsync(m->hops, m->hops0, nn * 4, hipMemcpyDeviceToDevice, s));
-        return FWX_OK;
-    };
-    if (!m->clean && restore()) return FWX_ERR_HIP;   // every pass starts from the uploaded input
-    m->clean = 1;
-    if (m->n <= FWX_SMALL_N && op.engine == FWX_ENGINE_AUTO) {
-        m->clean = 0;
-        // Single-launch regime: U <= n (n-1) (n-2) -- each (k, i, j) improves at most once -- is at
-        // most 2 M records here, so the log is simply sized for that bound (once per handle) and
-        // the counting pass is skipped: one launch per solve.
-        const unsigned long long bound = (unsigned long long)m->n * m->n * m->n;
-        if (m->log_total < bound) {
-            if (m->plog.rec_k) { (void)hipFree(m->plog.rec_k); m->plog.rec_k = nullptr; }
-            if (m->plog.rec_prev) { (void)hipFree(m->plog.rec_prev); m->plog.rec_prev = nullptr; }
-            FWX_HIP(hipMalloc((void **)&m->plog.rec_k, bound * 4));
-            FWX_HIP(hipMalloc((void **)&m->plog.rec_prev, bound * 4));
-            m->log_total = bound;
-        }
-        unsigned long long base[FWX_UPDATE_SHARDS + 1];
-        base[0] = 0;
-        for (int i = 1; i <= FWX_UPDATE_SHARDS; ++i) base[i] = bound;   // one workgroup = shard 0
-        FWX_HIP(hipMemcpyAsync((void *)m->plog.base, base, sizeof(base), hipMemcpyHostToDevice, s));
-        FWX_HIP(hipMemsetAsync(m->plog.count, 0, FWX_UPDATE_SHARDS * 8, s));
-        FWX_HIP(hipStreamSynchronize(s));        // `base` (host array) must outlive the copy
-        int rc1 = m->dtype == FWX_F64 ? matrix_solve_typed<double>(m, op, nullptr, s)
-                                      : matrix_solve_typed<float>(m, op, nullptr, s);
-        if (rc1) return rc1;
-        unsigned long long u = 0;
-        FWX_HIP(hipMemcpyAsync(&u, m->plog.count, sizeof(u), hipMemcpyDeviceToHost, s));
-        FWX_HIP(hipStreamSynchronize(s));
-        m->rec_ready = 1;
-        if (op.updates_out) *op.updates_out = u;
-        return FWX_OK;
-    }
-    // Sizes the sharded log for `cap` records per shard, replays the solve with logging on, and
-    // reads back how many records each shard really appended (the counters run past the capacity).
-    unsigned long long cnt[FWX_UPDATE_SHARDS];
-    auto logged_pass = [&](const unsigned long long *cap, bool &overflow) -> int {
-        unsigned long long base[FWX_UPDATE_SHARDS + 1];
-        base[0] = 0;
-        for (int i = 0; i < FWX_UPDATE_SHARDS; ++i) base[i + 1] = base[i] + cap[i];
-        const unsigned long long total = base[FWX_UPDATE_SHARDS];
-        if (total > 0x7fffffffull) return FWX_ERR_UNSUPPORTED;   // record indices are int32
-        if (m->log_total < total || !m->plog.rec_k) {
-            if (m->plog.rec_k) { (void)hipFree(m->plog.rec_k); m->plog.rec_k = nullptr; }
-            if (m->plog.rec_prev) { (void)hipFree(m->plog.rec_prev); m->plog.rec_prev = nullptr; }
-            m->log_total = 0;
-            FWX_HIP(hipMalloc((void **)&m->plog.rec_k, (total ? total : 1) * 4));
-            FWX_HIP(hipMalloc((void **)&m->plog.rec_prev, (total ? total : 1) * 4));
-            m->log_total = total;
-        }
-        FWX_HIP(hipMemcpyAsync((void *)m->plog.base, base, sizeof(base), hipMemcpyHostToDevice, s));
-        FWX_HIP(hipMemsetAsync(m->plog.count, 0, FWX_UPDATE_SHARDS * 8, s));
-        FWX_HIP(hipMemsetAsync(m->plog.head, 0xFF, nn * 4, s));
-        if (!m->clean && restore()) return FWX_ERR_HIP;
-        m->clean = 0;
-        FWX_HIP(hipStreamSynchronize(s));            // `base` (host array) must outlive the copy
-        const int rc2 = m->dtype == FWX_F64 ? matrix_solve_typed<double>(m, op, nullptr, s)
-                                            : matrix_solve_typed<float>(m, op, nullptr, s);
-        if (rc2) return rc2;
-        FWX_HIP(hipMemcpyAsync(cnt, m->plog.count, sizeof(cnt), hipMemcpyDeviceToHost, s));
-        FWX_HIP(hipStreamSynchronize(s));
-        overflow = false;
-        for (int i = 0; i < FWX_UPDATE_SHARDS; ++i) overflow |= cnt[i] > cap[i];
-        return FWX_OK;
-    };
-    auto finish = [&]() {
-        unsigned long long u = 0;
-        for (int i = 0; i < FWX_UPDATE_SHARDS; ++i) { m->hint[i] = cnt[i]; u += cnt[i]; }
-        m->have_hint = 1;
-        m->rec_ready = 1;
-        if (op.updates_out) *op.updates_out = u;
-        return FWX_OK;
-    };
-
-    // A handle that has solved a matrix of this order before (a host that re-solves after every
-    // rate update keeps its handle) sizes the log from the previous solve's per-shard counts plus
-    // a quarter: one pass.  Only if some shard outgrows that is the solve replayed, with the
-    // exact counts the overflowed pass has just produced.
-    int rc = FWX_OK;
-    bool overflow = false;
-    if (m->have_hint) {
-        unsigned long long cap[FWX_UPDATE_SHARDS];
-        for (int i = 0; i < FWX_UPDATE_SHARDS; ++i) cap[i] = m->hint[i] + m->hint[i] / 4 + 256;
-        if ((rc = logged_pass(cap, overflow))) return rc;
-        if (!overflow) return finish();
-    } else {
-        fwx::PathLog saved = m->plog;
-        m->plog = fwx::PathLog();                    // the counting pass must not log
-        m->clean = 0;
-        FWX_HIP(hipMemsetAsync(m->upd, 0, FWX_UPDATE_SHARDS * 8, s));
-        rc = m->dtype == FWX_F64 ? matrix_solve_typed<double>(m, op, m->upd, s)
-                                 : matrix_solve_typed<float>(m, op, m->upd, s);
-        m->plog = saved;
-        if (rc) return rc;
-        FWX_HIP(hipMemcpyAsync(cnt, m->upd, sizeof(cnt), hipMemcpyDeviceToHost, s));
-        FWX_HIP(hipStreamSynchronize(s));
-    }
-    unsigned long long exact[FWX_UPDATE_SHARDS];
-    for (int i = 0; i < FWX_UPDATE_SHARDS; ++i) exact[i] = cnt[i];
-    if ((rc = logged_pass(exact, overflow))) return rc;
-    if (overflow) return FWX_ERR_HIP;                // cannot happen: same input, same launches
-    return finish();
+    const size_t nn = (size_t)m->n * (size_t)m->n;
+    FWX_HIP(hipMemsetAsync(m->plog.last, 0xFF, nn * 4, s));
+    FWX_HIP(hipMemsetAsync(m->plog.at_col, 0xFF, nn * 4, s));
+    FWX_HIP(hipMemsetAsync(m->plog.at_row, 0xFF, nn * 4, s));
+    FWX_HIP(hipMemsetAsync(m->upd, 0, FWX_UPDATE_SHARDS * 8, s));
+    m->fresh = 0;
+    const int rc = m->dtype == FWX_F64 ? matrix_solve_typed<double>(m, op, m->upd, s)
+                                       : matrix_solve_typed<float>(m, op, m->upd, s);
+    if (rc) return rc;
+    uint64_t u = 0;
+    const int rc2 = sum_updates(m->upd, &u, s);  // synchronises
+    if (rc2) return rc2;
+    m->last_u = u;
+    m->rec_ready = 1;
+    if (op.updates_out) *op.updates_out = u;
+    return FWX_OK;
 }
 
-// The reference's `_path` list of entry (src,dst), rebuilt from the update log exactly as
-// Algorithms.hs:55 built it: the newest update of (a,b) made by a pivot k < T splits the path into
-// path_k(a,k) ++ path_k(k,b); an entry with no update before T still has its buildMatrix path
-// ([b] if next0[a][b] >= 0, else []).  Iterative, one thread; stack and output live in `walk`.
+// The reference's `_path` list of entry (src,dst), rebuilt from the path trace exactly as
+// Algorithms.hs:55 built it: the newest update of (a,b) before time T, by pivot q, splits the path
+// into path_q(a,q) ++ path_q(q,b); an entry with no update before T still has its buildMatrix path
+// ([b] if next0[a][b] >= 0, else []).  T is the end of the solve for the query itself (`last`), and
+// for every sub-entry it is the step named by one of its own indices: (a,q) at time q is read from
+// at_col, (q,b) at time q from at_row.  Iterative, one thread; stack and output live in `walk`.
 __global__ void exact_path_kernel(fwx::PathLog plog, const int32_t *next0, int n, int src, int dst,
                                   int32_t *walk, int cap, int32_t *len_out)
 {
+    enum { FINAL = 0, AS_COLUMN = 1, AS_ROW = 2 };
     int32_t *out = walk;                 // cap entries
-    int32_t *stack = walk + cap;         // 3 * cap entries: (a, b, T) triples
+    int32_t *stack = walk + cap;         // 3 * cap entries: (a, b, kind) triples
     int sp = 0, len = 0;
-    stack[0] = src; stack[1] = dst; stack[2] = n; sp = 1;
+    stack[0] = src; stack[1] = dst; stack[2] = FINAL; sp = 1;
     while (sp > 0) {
         --sp;
-        const int a = stack[3 * sp], b = stack[3 * sp + 1], T = stack[3 * sp + 2];
-        int rec = plog.head[(size_t)a * n + b];
-        while (rec >= 0 && plog.rec_k[rec] >= T) rec = plog.rec_prev[rec];
-        if (rec < 0) {
-            if (next0[(size_t)a * n + b] >= 0) {
+        const int a = stack[3 * sp], b = stack[3 * sp + 1], kind = stack[3 * sp + 2];
+        const size_t off = (size_t)a * n + b;
+        const int q = kind == FINAL ? plog.last[off] : kind == AS_COLUMN ? plog.at_col[off] : plog.at_row[off];
+        if (q < 0) {
+            if (next0[off] >= 0) {
                 if (len >= cap) { *len_out = FWX_ERR_CAPACITY; return; }
                 out[len++] = b;
             }
         } else {
-            const int k = plog.rec_k[rec];
             if (sp + 2 > cap) { *len_out = FWX_ERR_CAPACITY; return; }
-            stack[3 * sp] = k; stack[3 * sp + 1] = b; stack[3 * sp + 2] = k; ++sp;   // second half
-            stack[3 * sp] = a; stack[3 * sp + 1] = k; stack[3 * sp + 2] = k; ++sp;   // first half
+            stack[3 * sp] = q; stack[3 * sp + 1] = b; stack[3 * sp + 2] = AS_ROW; ++sp;      // second half
+            stack[3 * sp] = a; stack[3 * sp + 1] = q; stack[3 * sp + 2] = AS_COLUMN; ++sp;   // first half
         }
     }
     *len_out = len;
@@ -714,13 +621,9 @@ int fwx_matrix_destroy(fwx_matrix *m)
     if (m->hops) (void)hipFree(m->hops);
     if (m->scratch) (void)hipFree(m->scratch);
     if (m->upd) (void)hipFree(m->upd);
-    if (m->plog.head) (void)hipFree(m->plog.head);
-    if (m->plog.rec_k) (void)hipFree(m->plog.rec_k);
-    if (m->plog.rec_prev) (void)hipFree(m->plog.rec_prev);
-    if (m->plog.count) (void)hipFree(m->plog.count);
-    if (m->plog.base) (void)hipFree((void *)m->plog.base);
-    if (m->rate0) (void)hipFree(m->rate0);
-    if (m->hops0) (void)hipFree(m->hops0);
+    if (m->plog.last) (void)hipFree(m->plog.last);
+    if (m->plog.at_col) (void)hipFree(m->plog.at_col);
+    if (m->plog.at_row) (void)hipFree(m->plog.at_row);
     if (m->next0) (void)hipFree(m->next0);
     if (m->walk) (void)hipFree(m->walk);
     delete m;
@@ -736,63 +639,37 @@ int fwx_matrix_upload(fwx_matrix *m, const void *rate, const int32_t *next, cons
     int rc = g.enter(m->device);
     if (rc) return rc;
     const size_t nn = (size_t)m->n * (size_t)m->n, es = m->dtype == FWX_F64 ? 8 : 4;
-    if (m->plog.head) {
-        // logged matrix: the input crosses PCIe once, into the pristine copy the logged solve
-        // replays from; the working arrays are filled from there on the device
-        FWX_HIP(hipMemcpy(m->rate0, rate, nn * es, hipMemcpyHostToDevice));
-        FWX_HIP(hipMemcpy(m->next0, next, nn * 4, hipMemcpyHostToDevice));
-        if (m->hops) FWX_HIP(hipMemcpy(m->hops0, hops, nn * 4, hipMemcpyHostToDevice));
-        FWX_HIP(hipMemcpyAsync(m->rate, m->rate0, nn * es, hipMemcpyDeviceToDevice, nullptr));
-        FWX_HIP(hipMemcpyAsync(m->next, m->next0, nn * 4, hipMemcpyDeviceToDevice, nullptr));
-        if (m->hops)
-            FWX_HIP(hipMemcpyAsync(m->hops, m->hops0, nn * 4, hipMemcpyDeviceToDevice, nullptr));
-        FWX_HIP(hipMemsetAsync(m->plog.count, 0, FWX_UPDATE_SHARDS * sizeof(unsigned long long), nullptr));
-        m->rec_ready = 0;      // the log of an earlier input is stale (its arrays are reused)
-        m->clean = 1;
-        return FWX_OK;
-    }
     FWX_HIP(hipMemcpy(m->rate, rate, nn * es, hipMemcpyHostToDevice));
     if (m->next) FWX_HIP(hipMemcpy(m->next, next, nn * 4, hipMemcpyHostToDevice));
     if (m->hops) FWX_HIP(hipMemcpy(m->hops, hops, nn * 4, hipMemcpyHostToDevice));
+    if (m->plog.last) {     // traced matrix: keep the uploaded next-hops (paths of entries never improved)
+        FWX_HIP(hipMemcpyAsync(m->next0, m->next, nn * 4, hipMemcpyDeviceToDevice, nullptr));
+        m->rec_ready = 0;   // the trace of an earlier input is stale
+    }
+    m->fresh = 1;
     return FWX_OK;
 }
 
 int fwx_matrix_enable_path_log(fwx_matrix *m)
 {
-    if (!m || !m->next || m->plog.head) return FWX_ERR_INVALID;
+    if (!m || !m->next || m->plog.last) return FWX_ERR_INVALID;
     if (m->n == 0) return FWX_OK;
     DeviceGuard g;
     int rc = g.enter(m->device);
     if (rc) return rc;
-    const size_t nn = (size_t)m->n * (size_t)m->n, es = m->dtype == FWX_F64 ? 8 : 4;
-    FWX_HIP(hipMalloc((void **)&m->plog.head, nn * 4));
-    FWX_HIP(hipMalloc((void **)&m->plog.count, FWX_UPDATE_SHARDS * sizeof(unsigned long long)));
-    FWX_HIP(hipMalloc((void **)&m->plog.base, (FWX_UPDATE_SHARDS + 1) * sizeof(unsigned long long)));
-    FWX_HIP(hipMalloc(&m->rate0, nn * es));
+    const size_t nn = (size_t)m->n * (size_t)m->n;
+    FWX_HIP(hipMalloc((void **)&m->plog.at_col, nn * 4));
+    FWX_HIP(hipMalloc((void **)&m->plog.at_row, nn * 4));
     FWX_HIP(hipMalloc((void **)&m->next0, nn * 4));
-    if (m->hops) FWX_HIP(hipMalloc((void **)&m->hops0, nn * 4));
-    FWX_HIP(hipMemset(m->plog.head, 0xFF, nn * 4));
-    FWX_HIP(hipMemset(m->plog.count, 0, FWX_UPDATE_SHARDS * sizeof(unsigned long long)));
-    FWX_HIP(hipMemset((void *)m->plog.base, 0, (FWX_UPDATE_SHARDS + 1) * sizeof(unsigned long long)));
-    FWX_HIP(hipMemcpy(m->rate0, m->rate, nn * es, hipMemcpyDeviceToDevice));
+    FWX_HIP(hipMalloc((void **)&m->plog.last, nn * 4));      // last: `last != nullptr` = enabled
     FWX_HIP(hipMemcpy(m->next0, m->next, nn * 4, hipMemcpyDeviceToDevice));
-    if (m->hops) FWX_HIP(hipMemcpy(m->hops0, m->hops, nn * 4, hipMemcpyDeviceToDevice));
-    m->clean = 1;
     return FWX_OK;
 }
 
 int fwx_matrix_path_log_count(fwx_matrix *m, uint64_t *count_out)
 {
     if (!m || !count_out) return FWX_ERR_INVALID;
-    *count_out = 0;
-    if (!m->plog.head) return FWX_OK;
-    DeviceGuard g;
-    int rc = g.enter(m->device);
-    if (rc) return rc;
-    unsigned long long c[FWX_UPDATE_SHARDS];
-    FWX_HIP(hipMemcpy(c, m->plog.count, sizeof(c), hipMemcpyDeviceToHost));
-    *count_out = 0;
-    for (int i = 0; i < FWX_UPDATE_SHARDS; ++i) *count_out += c[i];
+    *count_out = (m->plog.last && m->rec_ready) ? m->last_u : 0;
     return FWX_OK;
 }
 
@@ -801,11 +678,11 @@ int fwx_matrix_query_exact(fwx_matrix *m, int32_t src, int32_t dst, double *rate
 {
     if (!m || src < 0 || dst < 0 || src >= m->n || dst >= m->n || cap <= 0 || !path_out)
         return FWX_ERR_INVALID;
-    if (!m->plog.head) return FWX_ERR_INVALID;
+    if (!m->plog.last) return FWX_ERR_INVALID;
     DeviceGuard g;
     int rc = g.enter(m->device);
     if (rc) return rc;
-    if (!m->rec_ready) return FWX_ERR_INVALID;             // no logged solve yet
+    if (!m->rec_ready) return FWX_ERR_INVALID;             // no traced solve of this upload yet
     const size_t idx = (size_t)src * m->n + dst;
     if (rate_out) {
         if (m->dtype == FWX_F64) {
@@ -856,7 +733,7 @@ int fwx_matrix_solve(fwx_matrix *m, const fwx_opts *opts)
     DeviceGuard g;
     if ((rc = g.enter(m->device))) return rc;
     hipStream_t s = nullptr;
-    if (m->plog.head) return logged_solve(m, op, s);
+    if (m->plog.last) return logged_solve(m, op, s);
     unsigned long long *upd = op.updates_out ? m->upd : nullptr;
     if (upd) FWX_HIP(hipMemsetAsync(upd, 0, FWX_UPDATE_SHARDS * 8, s));
     if (m->dtype == FWX_F64)

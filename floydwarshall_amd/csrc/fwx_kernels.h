@@ -14,15 +14,18 @@ namespace fwx {
 // (i,k) and (k,j)): every successful relaxation appends one record {k, previous record of the same
 // entry}; head[i*n+j] is the entry's newest record.  All device pointers; head == nullptr = off.
 struct PathLog {
-    int32_t *head;                 // n*n, -1 = never updated
-    int32_t *rec_k;                // records: pivot of the update
-    int32_t *rec_prev;             // records: older record of the same entry or -1
-    // The log is SHARDED like the update counters (shard = workgroup id & 255) so that appends
-    // do not contend on one address: shard s owns records [base[s], base[s+1]), sized exactly
-    // from the per-shard counts of a counting solve of the same input (same launch geometry,
-    // hence the same updates per workgroup).
-    unsigned long long *count;     // FWX_UPDATE_SHARDS_K counters: records appended per shard
-    const unsigned long long *base;  // FWX_UPDATE_SHARDS_K + 1 prefix offsets
+    // What the reference's `_path` lists (Algorithms.hs:55) need, without storing a single list or
+    // update record: three n x n int32 matrices.
+    //   last[i][j]    pivot of the newest successful relaxation of (i,j) in the whole solve, -1 = never
+    //   at_col[i][j]  the same, but as it stood at the START of step j  (entry (i,j) as pivot-COLUMN operand)
+    //   at_row[i][j]  ...                 at the START of step i        (entry (i,j) as pivot-ROW operand)
+    // path(i,j) = path_q(i,q) ++ path_q(q,j) with q = last[i][j]; path_q(i,q) needs the newest update of
+    // (i,q) before step q = at_col[i][q], path_q(q,j) needs at_row[q][j]; the recursion only ever asks
+    // for an entry "as of the step named by one of its own indices", so these three suffice.
+    // Column k and row k of `last` are not modified during step k: the snapshots are plain copies.
+    int32_t *last;
+    int32_t *at_col;
+    int32_t *at_row;
 };
 
 template <typename T> struct RelaxArgs {
@@ -35,8 +38,8 @@ template <typename T> struct RelaxArgs {
     int skip_lo = 0, skip_hi = 0;  // slab rows [skip_lo, skip_hi) are left alone (multiples of 4):
                                    //   a look-ahead launch has already relaxed them
     unsigned long long *updates;   // FWX_UPDATE_SHARDS_K counters or nullptr
-    PathLog plog;                  // plog.head == nullptr: no logging (slab must be the whole matrix
-                                   // when logging: head is indexed by global row)
+    PathLog plog;                  // plog.last == nullptr: no tracing (slab must be the whole matrix
+                                   // when tracing: the three matrices are indexed by global row)
 };
 
 template <typename T> hipError_t launch_relax(const RelaxArgs<T> &a, hipStream_t s);

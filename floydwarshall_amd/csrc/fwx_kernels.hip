@@ -25,17 +25,6 @@
 
 namespace fwx {
 
-// Append one update record for entry `off` (= i*n+j, global) made by pivot k, in shard `shard`.
-__device__ __forceinline__ void log_update(const PathLog &plog, size_t off, int k, int shard)
-{
-    const unsigned long long idx = plog.base[shard] + atomicAdd(&plog.count[shard], 1ull);
-    if (idx < plog.base[shard + 1]) {
-        plog.rec_k[idx] = k;
-        plog.rec_prev[idx] = plog.head[off];
-        plog.head[off] = (int32_t)idx;
-    }
-}
-
 template <typename T, int W> struct VecOf;
 template <> struct VecOf<float, 4> { typedef float type __attribute__((ext_vector_type(4))); };
 template <> struct VecOf<double, 2> { typedef double type __attribute__((ext_vector_type(2))); };
@@ -117,6 +106,23 @@ __global__ __launch_bounds__(256, MINW) void relax_k(T *rate, int32_t *next, int
         if (HAS_HOPS) s_hcol[t] = hops[off];
     }
     if (COUNT && t == 0) s_cnt = 0;
+    if (HAS_NEXT && plog.last) {
+        // snapshots of `last` for step k (see PathLog): column k by the first strip's workgroups,
+        // row k by the first chunk's -- neither is modified during this launch
+        if (strip == 0 && t < r_cnt) {
+            const size_t off = (size_t)(row0 + r_begin + t) * n + k;
+            plog.at_col[off] = plog.last[off];
+        }
+        if (chunk == 0) {
+#pragma unroll
+            for (int v = 0; v < NV; ++v) {
+                const int c0 = strip * SW + (v * 256 + t) * W;
+#pragma unroll
+                for (int c = 0; c < W; ++c)
+                    if (c0 + c < n) plog.at_row[(size_t)k * n + c0 + c] = plog.last[(size_t)k * n + c0 + c];
+            }
+        }
+    }
 
     // Pivot row segment -> registers.  Column k gets NaN: skip j == k.  Columns past the end
     // of the row are CLAMPED to the last in-range vector and their pivot set to NaN: the
@@ -165,8 +171,7 @@ __global__ __launch_bounds__(256, MINW) void relax_k(T *rate, int32_t *next, int
                     changed = true;
                     if (HAS_NEXT) next[off + c] = s_ncol[r];
                     if (HAS_HOPS) hops[off + c] = s_hcol[r] + phops[cv + c];
-                    if (HAS_NEXT && plog.head)
-                        log_update(plog, (size_t)i * n + cv + c, k, bid & (FWX_UPDATE_SHARDS_K - 1));
+                    if (HAS_NEXT && plog.last) plog.last[(size_t)i * n + cv + c] = k;
                     if (COUNT) ++my_updates;
                 }
             }
@@ -239,17 +244,15 @@ __global__ __launch_bounds__(M * RG) void small_solve(T *rate, int32_t *next, in
     __shared__ int32_t rowH[2][HAS_HOPS && !IDXL ? M : 1], colH[2][HAS_HOPS && !IDXL ? M : 1];
     __shared__ int32_t colN[2][HAS_NEXT && !IDXL ? M : 1];
     __shared__ int32_t NX[NXL ? M : 1][NXL ? M + 1 : 1], HP[HPL ? M : 1][HPL ? M + 1 : 1];
-    __shared__ unsigned int s_cnt, s_log;
+    __shared__ unsigned int s_cnt;
     const int tid = threadIdx.x;
     // a wave never straddles two rows: r0 is wave-uniform, say so (scalar row tests, fewer VGPRs)
     const int c = tid & (M - 1), r0 = __builtin_amdgcn_readfirstlane(tid >> LOG_M);
-    if (tid == 0) { s_cnt = 0; s_log = 0; }
+    if (tid == 0) s_cnt = 0;
     const int off0 = r0 * n + c, off_step = RG * n;   // entry (r0 + RG*m, c) is at off0 + m*off_step
-    // Update log of this launch (one workgroup = shard 0): records are numbered by an LDS counter
-    // and each thread keeps the newest record of its own entries in a register, so appending is
-    // two fire-and-forget stores; heads and the record count go to memory once, at the end.
-    const unsigned int log_base = LOG ? (unsigned int)plog.base[0] : 0u;
-    const unsigned int log_cap = LOG ? (unsigned int)(plog.base[1] - plog.base[0]) : 0u;
+    // LOG: the path trace (see PathLog).  hd[m] = pivot of the newest update of this thread's m-th
+    // entry; its snapshots for step k are stored by the owners of row k / column k when they
+    // publish their operands, the final values at the end.
 
     T x[E];
     int32_t nx[HAS_NEXT && !IDXL ? E : 1], hp[HAS_HOPS && !IDXL ? E : 1], hd[LOG ? E : 1];
@@ -259,6 +262,7 @@ __global__ __launch_bounds__(M * RG) void small_solve(T *rate, int32_t *next, in
             if (r0 + RG * m == k) {           // scalar
                 rowR[b][c] = x[m];
                 if constexpr (HAS_HOPS && !IDXL) rowH[b][c] = hp[m];
+                if constexpr (LOG) { if (c < n) plog.at_row[(size_t)k * n + c] = hd[m]; }
             }
         }
         if (c == k) {                         // one lane of the wave that holds column k
@@ -268,6 +272,7 @@ __global__ __launch_bounds__(M * RG) void small_solve(T *rate, int32_t *next, in
                 colR[b][r] = r == k ? quiet_nan<T>() : x[m];   // skip i == k: NaN at the source
                 if constexpr (HAS_NEXT && !IDXL) colN[b][r] = nx[m];
                 if constexpr (HAS_HOPS && !IDXL) colH[b][r] = hp[m];
+                if constexpr (LOG) { if (r < n) plog.at_col[(size_t)r * n + k] = hd[m]; }
             }
         }
     };
@@ -325,14 +330,7 @@ __global__ __launch_bounds__(M * RG) void small_solve(T *rate, int32_t *next, in
                     if constexpr (HAS_HOPS) HP[r][c] = ch + hkc;
                 }
                 mine += (unsigned int)__builtin_popcountll(__ballot(p));   // scalar; wave total
-                if (LOG && p) {
-                    const unsigned int idx = atomicAdd(&s_log, 1u);
-                    if (idx < log_cap) {
-                        plog.rec_k[log_base + idx] = k;
-                        plog.rec_prev[log_base + idx] = hd[m];
-                        hd[m] = (int32_t)(log_base + idx);
-                    }
-                }
+                if constexpr (LOG) hd[m] = p ? k : hd[m];
             }
         }
         if (k + 1 < k_end) publish(k + 1, b ^ 1);
@@ -347,12 +345,8 @@ __global__ __launch_bounds__(M * RG) void small_solve(T *rate, int32_t *next, in
             else if constexpr (HAS_NEXT) next[off0 + m * off_step] = nx[m];
             if constexpr (HPL) hops[off0 + m * off_step] = HP[r][c];
             else if constexpr (HAS_HOPS) hops[off0 + m * off_step] = hp[m];
-            if constexpr (LOG) plog.head[off0 + m * off_step] = hd[m];
+            if constexpr (LOG) plog.last[off0 + m * off_step] = hd[m];
         }
-    }
-    if (LOG) {
-        __syncthreads();
-        if (tid == 0) plog.count[0] = s_log;     // may exceed the capacity: overflow is visible
     }
     if (updates) {
         if (mine && (tid & 63) == 0) atomicAdd(&s_cnt, mine);   // `mine` is a wave total
@@ -372,7 +366,7 @@ hipError_t launch_small_solve(T *rate, int32_t *next, int32_t *hops, int n, int 
                        next, hops, n, k_begin, k_end, updates, plog)
 #define FWX_SMALL_M(M, RG)                                                                         \
     do {                                                                                           \
-        const bool lg = next && plog.head;                                                         \
+        const bool lg = next && plog.last;                                                         \
         if (hops) { if (lg) FWX_SMALL(M, RG, true, true, true); else FWX_SMALL(M, RG, true, true, false); }    \
         else if (next) { if (lg) FWX_SMALL(M, RG, true, false, true); else FWX_SMALL(M, RG, true, false, false); } \
         else FWX_SMALL(M, RG, false, false, false);                                                \

@@ -119,8 +119,8 @@ class DeviceMatrix:
         return float(r.value), [int(x) for x in out[:ln]]
 
     def enable_path_log(self):
-        """Record every successful relaxation so that query_exact can rebuild the reference's
-        `_path` lists exactly (see fwx.h); solve() then runs a counting pass and a logged pass."""
+        """Keep the path trace (three n x n int32 matrices, see fwx.h) so that query_exact can
+        rebuild the reference's `_path` lists exactly; a traced solve() needs a fresh upload()."""
         check(lib().fwx_matrix_enable_path_log(self._h), "fwx_matrix_enable_path_log")
 
     def path_log_count(self):

@@ -118,18 +118,18 @@ int fwx_matrix_destroy(fwx_matrix *m);
  * keeps, per entry, the list it concatenated when the entry was last improved
  * (`_path = ikPath ++ kjPath`, Algorithms.hs:55), and under exact ties (its built-in 1.0 edges
  * between the same currency on two exchanges make them common) that list can be a different,
- * longer route of equal rate.  With the update log enabled every successful relaxation appends
- * one 8-byte record on the device, and fwx_matrix_query_exact rebuilds the reference's list
- * exactly.  Enable after create; needs the next-hop matrix.  fwx_matrix_solve then (1) runs a
- * counting solve, (2) sizes the log exactly (sharded by workgroup so appends do not contend),
- * (3) restores the input from a pristine device copy and replays the solve with logging -- on the
- * per-k engine, whole pivot range only.  Costs twice the solve time and twice the memory.  A handle
- * that has solved before sizes the log from the previous solve's counts (+25 %) and needs one pass
- * (replayed only if a shard outgrows that); for n <= 128 the log is sized for the bound U <= n^3
- * and the solve is a single launch.
- * A logged solve always starts from the uploaded input (solving twice gives the same
- * matrix).  query_exact before a completed logged solve of the current upload: FWX_ERR_INVALID.
- * path_out receives the vertices after src up to dst; returns the length.                       */
+ * longer route of equal rate.  With the PATH TRACE enabled the solve keeps three more n x n int32
+ * matrices on the device -- for every entry the pivot of its newest successful relaxation, at the
+ * end of the solve, at the start of the step named by its column index and at the start of the
+ * step named by its row index -- from which fwx_matrix_query_exact rebuilds the reference's list
+ * exactly: path(i,j) = path_q(i,q) ++ path_q(q,j) with q the newest pivot of (i,j), and a
+ * sub-entry is only ever needed "as of the step named by one of its own indices".  No lists, no
+ * update records, one pass; any n.  Enable after create; needs the next-hop matrix; runs on the
+ * per-k engine (one launch for n <= 128), whole pivot range only, and starts from an uploaded
+ * input (fwx_matrix_solve on an already solved traced matrix: FWX_ERR_INVALID -- upload first).
+ * query_exact before a completed traced solve of the current upload: FWX_ERR_INVALID.
+ * fwx_matrix_path_log_count: U of that solve.  path_out receives the vertices after src up to
+ * dst; returns the length.                                                                      */
 int fwx_matrix_enable_path_log(fwx_matrix *m);
 int fwx_matrix_path_log_count(fwx_matrix *m, uint64_t *count_out);
 int fwx_matrix_query_exact(fwx_matrix *m, int32_t src, int32_t dst, double *rate_out,

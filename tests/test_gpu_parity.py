@@ -767,10 +767,9 @@ def test_exact_path_lists_dense_kinds(kind):
     _exact_paths_case(lf.from_dense(vertices, rate, nxt))
 
 
-def test_path_log_hinted_single_pass_and_overflow_replay():
-    """A handle that has solved before sizes its log from the previous per-shard counts (+25 %):
-    a similar matrix is then logged in ONE pass; a matrix with many more updates overflows that
-    guess and is replayed with exact sizes.  Either way every list equals the reference's."""
+def test_path_trace_on_a_reused_handle():
+    """One handle, several uploads of different matrices (few updates, many updates, few again):
+    the trace of each solve stands alone; every list equals the reference's."""
     n = 136                                              # > 128: the per-k engine writes the log
     vertices = [("X", "C%03d" % i) for i in range(n)]
     refs = {}
@@ -791,20 +790,20 @@ def test_path_log_hinted_single_pass_and_overflow_replay():
             assert tuple(dm.query_exact(i, j)[1]) == refs[name][i][j]
 
     sparse = synth.make("t2", n, np.float64, seed=5)     # few updates
-    dense = synth.make("t1", n, np.float64, seed=6)      # many more: overflows the sparse hint
+    dense = synth.make("t1", n, np.float64, seed=6)      # many more
     with engine.DeviceMatrix(n, np.float64, with_next=True, with_hops=True) as dm:
         dm.enable_path_log()
-        check(dm, "sparse", *sparse)                     # counting pass + logged pass
-        check(dm, "sparse", *sparse)                     # hinted: one pass
-        check(dm, "dense", *dense)                       # hint too small: replay with exact sizes
-        check(dm, "dense", *dense)                       # hinted again
-        check(dm, "sparse", *sparse)                     # generous hint: one pass
+        check(dm, "sparse", *sparse)
+        check(dm, "sparse", *sparse)
+        check(dm, "dense", *dense)
+        check(dm, "dense", *dense)
+        check(dm, "sparse", *sparse)
 
 
 def test_path_log_lifecycle():
-    """query_exact needs a completed logged solve of the CURRENT upload; a logged solve always
-    replays from the uploaded input, so solving twice gives the same matrix; k-ranges and the
-    fused engine are refused for logged matrices."""
+    """query_exact needs a completed traced solve of the CURRENT upload; a traced solve starts from
+    an uploaded input (solving the solved matrix again is refused); k-ranges and the fused engine
+    are refused for traced matrices."""
     n = 96
     rate, nxt, _ = synth.make("t1", n, np.float32, seed=5)
     want_r, want_n = rate.copy(), nxt.copy()
@@ -819,8 +818,9 @@ def test_path_log_lifecycle():
         with pytest.raises(engine.FwxError):
             dm.solve(engine=engine.FWX_ENGINE_FUSED)
         u1 = dm.solve(count_updates=True)
-        u2 = dm.solve(count_updates=True)
-        assert u1 == u2 == dm.path_log_count()
+        assert u1 == dm.path_log_count()
+        with pytest.raises(engine.FwxError):              # a traced solve needs a fresh upload
+            dm.solve()
         r, nx = dm.download()[:2]
         assert_bits_equal(r, want_r, "rate")
         assert np.array_equal(nx, want_n)

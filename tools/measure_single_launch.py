@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Latency of the single-launch solve (small_solve, n <= 128) against the per-k engine on the same
 matrices: device-resident f64 + next + hops (what the host mirror solves), restore-from-pristine
-cost subtracted; and of a logged solve through fwx_matrix_solve (one launch for n <= 128)."""
+cost subtracted; and of a solve with the path trace through fwx_matrix_solve (upload time subtracted)."""
 import sys
 import time
 
@@ -45,7 +45,11 @@ for n in (4, 16, 48, 64, 65, 96, 120, 128):
         line += "  %s %.1f us" % (name, 1e6 * (timed(run) - t_restore))
     with engine.DeviceMatrix(n, np.float64, with_next=True, with_hops=True) as dm:
         dm.enable_path_log()
-        dm.upload(rate, nxt, hops)
-        line += "  logged solve %.1f us" % (1e6 * timed(dm.solve))
-        line += "  [per-k logged %.1f us]" % (1e6 * timed(lambda: dm.solve(engine=engine.FWX_ENGINE_PERK)))
+        t_up = timed(lambda: dm.upload(rate, nxt, hops))
+
+        def traced(code):
+            dm.upload(rate, nxt, hops)
+            dm.solve(engine=code)
+        line += "  traced solve %.1f us" % (1e6 * (timed(lambda: traced(engine.FWX_ENGINE_AUTO)) - t_up))
+        line += "  [per-k traced %.1f us]" % (1e6 * (timed(lambda: traced(engine.FWX_ENGINE_PERK)) - t_up))
     print(line, flush=True)
