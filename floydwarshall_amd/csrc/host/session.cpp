@@ -53,10 +53,10 @@ int Session::ensure_solved()
     if (dev_ && dev_n_ != m.n()) drop_device();
     vertices_ = m.vertices;
     if (m.n() > 0) {
-        // The solve keeps an update log (fwx_matrix_enable_path_log), from which
+        // The solve keeps the path trace (fwx_matrix_enable_path_log), from which
         // fwx_matrix_query_exact rebuilds the reference's `_path` lists -- under exact ties (the
         // 1.0 edges of Algorithms.hs:35 make them common) the list the reference stored can be a
-        // longer route than the one the next-hops describe.  Logged solves run as one launch for
+        // longer route than the one the next-hops describe.  Traced solves run as one launch for
         // n <= 128 and on the per-k engine above; both carry `hops`.
         int rc = FWX_OK;
         if (!dev_) {
@@ -100,7 +100,7 @@ OptimumResult Session::find_best_rate(const Vertex &src, const Vertex &dest)
     const int32_t d = s < 0 ? -1 : idx(dest);
     if (s >= 0 && d < 0) { res.error = dest.show() + " is not entered before"; }
     if (s >= 0 && d >= 0) {
-        // the reference's `_path`, exactly (update log); the buffer grows for arbitrage blow-ups
+        // the reference's `_path`, exactly (path trace); the buffer grows for arbitrage blow-ups
         std::vector<int32_t> path((size_t)(4 * n > 64 ? 4 * n : 64));
         double rate = 0.0;
         int len = fwx_matrix_query_exact(dev_, s, d, &rate, path.data(), (int32_t)path.size());

@@ -60,7 +60,7 @@ typedef enum fwx_dtype { FWX_F32 = 0, FWX_F64 = 1 } fwx_dtype;
  * otherwise PERK.  The fused kernels need rows that are a multiple of 16 bytes: fwx_solve_f32/f64
  * (host buffers) pad an odd-sized matrix on the device, the entry points that work on device
  * memory they do not own (fwx_matrix_*, fwx_dev_*) fall back to PERK under AUTO and refuse an
- * explicit FUSED (FWX_ERR_UNSUPPORTED).  A matrix with an update log takes the single launch
+ * explicit FUSED (FWX_ERR_UNSUPPORTED).  A matrix with the path trace takes the single launch
  * (n <= 128) or PERK.                                                                            */
 typedef enum fwx_engine {
     FWX_ENGINE_AUTO = 0,

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Long-running fuzz (developer tool, not part of the test-suite): hostile-valued matrices through
-every engine against the dense oracle, and logged solves against the list-faithful restatement.
+every engine against the dense oracle, and traced solves (exact `_path` lists) against the list-faithful restatement.
 usage: fuzz_long.py [seconds [max_n]]"""
 import os
 import sys
@@ -46,7 +46,7 @@ with np.errstate(all="ignore"):
                     dm.enable_path_log()
                     dm.upload(rate, nxt, hops)
                     dm.solve(engine=eng)
-                    dm.upload(rate, nxt, hops)       # second solve on the same handle: hinted path
+                    dm.upload(rate, nxt, hops)       # second solve on the same handle
                     dm.solve(engine=eng)
                     _, _, hp = dm.download()
                     for i in range(m):

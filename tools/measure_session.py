@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Latency of the host mirror (C++ Session over the GPU engine): rate update -> first best-rate
-query (buildMatrix + counting solve + logged solve + exact path), then cached queries."""
+query (buildMatrix + traced solve + exact path), then cached queries."""
 import sys
 import time
 
