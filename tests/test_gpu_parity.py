@@ -907,3 +907,35 @@ def test_per_k_relax_with_a_skipped_row_range(dtype):
     assert np.array_equal(got_n[lo:hi], nxt[lo:hi])
     with pytest.raises(engine.FwxError):
         engine.dev_relax(r_t, n, 0, k0, k1, pivots_t=w, next_t=n_t, skip=(lo + 2, hi))
+
+
+@pytest.mark.parametrize("dtype,n", [(np.float64, 1100), (np.float32, 2100)])
+def test_path_trace_with_several_strips_and_chunks(dtype, n):
+    """Sizes at which relax_k runs several column strips (the row-k snapshot is written by the
+    first chunk of EVERY strip, the column-k snapshot by the first strip of every chunk).  The
+    market-like input has no exact ties, so the reference's list is the next-hop walk: the trace
+    must reproduce it for every sampled pair, and the product of the input rates along it must be
+    the solved rate up to rounding."""
+    rate, nxt, _ = synth.make("d2", n, dtype, seed=91)
+    with engine.DeviceMatrix(n, dtype, with_next=True) as dm:
+        dm.enable_path_log()
+        dm.upload(rate, nxt)
+        u = dm.solve(count_updates=True)
+        assert u == dm.path_log_count() > 0
+        r, nx, _ = dm.download()
+        rnd = np.random.default_rng(n)
+        longest = 0
+        for _ in range(400):
+            i, j = (int(x) for x in rnd.integers(0, n, size=2))
+            q_rate, q_path = dm.query_exact(i, j)
+            if i == j:
+                assert q_path == []
+                continue
+            assert q_path == engine.follow_path(nx, i, j) and q_path[-1] == j
+            prod, cur = 1.0, i
+            for v in q_path:
+                prod *= float(rate[cur, v])
+                cur = v
+            assert abs(prod - float(r[i, j])) <= 1e-5 * abs(float(r[i, j]))
+            longest = max(longest, len(q_path))
+        assert longest >= 3
