@@ -156,7 +156,7 @@ struct SideStream {
 
 template <typename T>
 int fused_range(T *rate, int32_t *next, int n, int k_begin, int k_end, void *ws,
-                unsigned long long *d_updates, hipStream_t s)
+                unsigned long long *d_updates, hipStream_t s, fwx::PathLog plog = fwx::PathLog())
 {
     char *p = (char *)ws;
     const int ld = (n + 3) & ~3;
@@ -185,11 +185,13 @@ int fused_range(T *rate, int32_t *next, int n, int k_begin, int k_end, void *ws,
     fwx::FusedArgs<T> a;
     a.rate = rate; a.next = next; a.rows = n; a.n = n; a.row0 = 0;
     a.ct = ct; a.cnt = next ? cnt : nullptr; a.ct_ld = ld; a.updates = d_updates; a.nonneg = nonneg;
+    a.plog = plog;         // path trace: kept by all three kernels of a pass (needs next)
 
     int bi = 0;
     {
         const int bt = k_end - k_begin < FWX_FUSED_B ? k_end - k_begin : FWX_FUSED_B;
-        FWX_HIP(fwx::launch_fused_panel<T>(rate + (size_t)k_begin * n, n, k_begin, bt, wbuf[0], diag, s));
+        FWX_HIP(fwx::launch_fused_panel<T>(rate + (size_t)k_begin * n, n, k_begin, bt, wbuf[0], diag, s,
+                                           plog));
     }
     for (int k0 = k_begin; k0 < k_end; k0 += FWX_FUSED_B, bi ^= 1) {
         const int bt = k_end - k0 < FWX_FUSED_B ? k_end - k0 : FWX_FUSED_B;
@@ -204,7 +206,7 @@ int fused_range(T *rate, int32_t *next, int n, int k_begin, int k_end, void *ws,
             FWX_HIP(hipStreamWaitEvent(side.s, side.rows_done, 0));
             // ... their snapshot panel on the side stream ...
             FWX_HIP(fwx::launch_fused_panel<T>(rate + (size_t)k1 * n, n, k1, bt1, wbuf[bi ^ 1], diag,
-                                               side.s));
+                                               side.s, plog));
             FWX_HIP(hipEventRecord(side.panel_done, side.s));
             // ... while the rest of the matrix is relaxed on the main stream
             if (k1 % 8 == 0 && bt1 % 8 == 0) {
@@ -444,19 +446,17 @@ int matrix_solve_typed(fwx_matrix *m, const Opts &op, unsigned long long *upd, h
 {
     const int n = m->n;
     T *r = (T *)m->rate;
-    const bool logging = m->plog.last != nullptr;
-    if (op.engine == FWX_ENGINE_FUSED && (logging || !fused_ok<T>(n, r, m->hops)))
-        return FWX_ERR_UNSUPPORTED;                 // the path trace rides on per-k / small_solve
+    if (op.engine == FWX_ENGINE_FUSED && !fused_ok<T>(n, r, m->hops)) return FWX_ERR_UNSUPPORTED;
     if (op.engine == FWX_ENGINE_AUTO && n <= FWX_SMALL_N) {
         FWX_HIP(fwx::launch_small_solve<T>(r, m->next, m->hops, n, op.k_begin, op.k_end, upd,
                                            m->plog, s));
         return FWX_OK;
     }
-    if (!logging && pick_fused<T>(op.engine, n, r, m->hops)) {
+    if (pick_fused<T>(op.engine, n, r, m->hops)) {
         DevBuf ws;
         int rc = ws.alloc(fused_ws_bytes(n, sizeof(T)));
         if (rc) return rc;
-        rc = fused_range<T>(r, m->next, n, op.k_begin, op.k_end, ws.p, upd, s);
+        rc = fused_range<T>(r, m->next, n, op.k_begin, op.k_end, ws.p, upd, s, m->plog);
         if (rc) return rc;
         FWX_HIP(hipStreamSynchronize(s));
         return FWX_OK;
@@ -470,11 +470,11 @@ int matrix_solve_typed(fwx_matrix *m, const Opts &op, unsigned long long *upd, h
 // it on every successful relaxation and copy its column k / row k into at_col / at_row at step k.
 int logged_solve(fwx_matrix *m, const Opts &op_in, hipStream_t s)
 {
-    if (op_in.k_begin != 0 || op_in.k_end != m->n || op_in.engine == FWX_ENGINE_FUSED)
-        return FWX_ERR_UNSUPPORTED;              // the trace covers whole solves of the per-k kind
+    if (op_in.k_begin != 0 || op_in.k_end != m->n)
+        return FWX_ERR_UNSUPPORTED;              // the trace covers whole solves
     if (!m->fresh) return FWX_ERR_INVALID;       // a traced solve starts from an uploaded input
-    Opts op = op_in;
-    if (m->n > FWX_SMALL_N) op.engine = FWX_ENGINE_PERK;
+    const Opts &op = op_in;                      // engines as for any matrix: single launch, fused
+                                                 //   (no hops), per-k -- all three keep the trace
     const size_t nn = (size_t)m->n * (size_t)m->n;
     FWX_HIP(hipMemsetAsync(m->plog.last, 0xFF, nn * 4, s));
     FWX_HIP(hipMemsetAsync(m->plog.at_col, 0xFF, nn * 4, s));

@@ -130,9 +130,13 @@ __device__ __forceinline__ void gather_column(const T (&p)[SB], int src_lane, T 
 // diagonal block itself (lanes = block columns) to obtain Cd[r][t] = D_t[k0+r][k0+t] in LDS --
 // redundant across workgroups, but it removes a kernel boundary and a single-workgroup launch from
 // the critical path -- and then its own strip of 64 columns.
-template <typename T>
+// HAS_LAST: also keeps the path trace of the pivot rows (PathLog): `last` of each entry is carried
+// through the 64 pivots beside its rate, and at_row[k0+t][j] = last of (k0+t, j) at time k0+t is
+// exported with the snapshot.  last_rows / at_rows point at row k0 of the n x n matrices.
+template <typename T, bool HAS_LAST>
 __global__ __launch_bounds__(PANEL_THREADS) void fused_rowpanel(const T *rows, int n, int k0, int bt,
-                                                      T *w_out)
+                                                      T *w_out, const int32_t *last_rows,
+                                                      int32_t *at_rows)
 {
     __shared__ T s_line[B][64];                    // published pivot rows (time-t), per phase
     __shared__ T s_cd[B][B];                       // s_cd[t][r] = D_t[k0+r][k0+t]
@@ -195,10 +199,12 @@ __global__ __launch_bounds__(PANEL_THREADS) void fused_rowpanel(const T *rows, i
     const int j = blockIdx.x * 64 + lane;
     const bool valid = j < n;
     const int jc = valid ? j : n - 1;
+    int32_t lp[HAS_LAST ? SB : 1];
 #pragma unroll
     for (int q = 0; q < SB; ++q) {
         const int r = wave * SB + q;
         p[q] = r < bt ? rows[(size_t)r * n + jc] : qnan<T>();
+        if (HAS_LAST) lp[q] = r < bt ? last_rows[(size_t)r * n + jc] : -1;
     }
     // a column inside the block carries one diagonal entry: published from memory, untouched
     const bool in_blk = valid && j >= k0 && j < k0 + bt;
@@ -215,13 +221,16 @@ __global__ __launch_bounds__(PANEL_THREADS) void fused_rowpanel(const T *rows, i
                 T w = p[tq];
                 if (j == k0 + t) w = dorig;
                 if (valid) w_out[(size_t)t * n + j] = w;          // the snapshot
+                if (HAS_LAST && valid) at_rows[(size_t)t * n + j] = j == k0 + t ? -1 : lp[tq];
                 if (j == k0 + t) w = qnan<T>();                   // skip j == k
                 s_line[t][lane] = w;
 #pragma unroll
                 for (int q = 0; q < SB; ++q) {
                     if (q == tq) continue;                        // skip i == k
                     const T cand = s_cd[t][b * SB + q] * w;
-                    p[q] = (p[q] < cand) ? cand : p[q];
+                    const bool up = p[q] < cand;
+                    p[q] = up ? cand : p[q];
+                    if (HAS_LAST) lp[q] = up ? k0 + t : lp[q];
                 }
             }
         }
@@ -235,7 +244,9 @@ __global__ __launch_bounds__(PANEL_THREADS) void fused_rowpanel(const T *rows, i
 #pragma unroll
                 for (int q = 0; q < SB; ++q) {
                     const T cand = s_cd[t][wave * SB + q] * w;
-                    p[q] = (p[q] < cand) ? cand : p[q];
+                    const bool up = p[q] < cand;
+                    p[q] = up ? cand : p[q];
+                    if (HAS_LAST) lp[q] = up ? k0 + t : lp[q];
                 }
             }
         }
@@ -244,10 +255,14 @@ __global__ __launch_bounds__(PANEL_THREADS) void fused_rowpanel(const T *rows, i
 
 // Column panel: time-t snapshots of the 64 pivot columns for 64 rows per workgroup (lanes = rows).
 // Needs only the block columns of W (Wd[t][c] = W[t][k0+c]), so it runs on every rank.
-template <typename T, bool HAS_NEXT>
+// HAS_LAST: the path trace of the pivot columns (PathLog): `last` of each block entry is carried
+// beside its rate, and at_col[i][k0+t] = last of (i, k0+t) at time k0+t is stored directly into the
+// n x n matrix (single-GPU solves only: rows are global rows).
+template <typename T, bool HAS_NEXT, bool HAS_LAST>
 __global__ __launch_bounds__(PANEL_THREADS) void fused_colpanel(const T *rate, const int32_t *next, int rows,
                                                       int n, int row0, int k0, int bt, const T *w,
-                                                      T *ct, int32_t *cnt, int ct_ld)
+                                                      T *ct, int32_t *cnt, int ct_ld,
+                                                      const int32_t *last, int32_t *at_col)
 {
     __shared__ T s_line[B][64];                    // published pivot columns (time-t, NaN at i==k)
     __shared__ int32_t s_nline[HAS_NEXT ? B : 1][64];
@@ -265,13 +280,14 @@ __global__ __launch_bounds__(PANEL_THREADS) void fused_colpanel(const T *rate, c
     }
 
     T d[SB];
-    int32_t nx[SB];
+    int32_t nx[SB], lp[HAS_LAST ? SB : 1];
 #pragma unroll
     for (int q = 0; q < SB; ++q) {
         const int c = wave * SB + q;
         const size_t off = (size_t)ic * n + k0 + (c < bt ? c : 0);
         d[q] = c < bt ? rate[off] : qnan<T>();
         nx[q] = (HAS_NEXT && c < bt) ? next[off] : -1;
+        if (HAS_LAST) lp[q] = c < bt ? last[off] : -1;
     }
     __syncthreads();
 
@@ -291,6 +307,7 @@ __global__ __launch_bounds__(PANEL_THREADS) void fused_colpanel(const T *rate, c
                 if (valid) {
                     ct[(size_t)t * ct_ld + il] = c;
                     if (HAS_NEXT) cnt[(size_t)t * ct_ld + il] = cn;
+                    if (HAS_LAST) at_col[(size_t)il * n + k0 + t] = gi == k0 + t ? -1 : lp[tq];
                 }
 #pragma unroll
                 for (int q = 0; q < SB; ++q) {
@@ -299,6 +316,7 @@ __global__ __launch_bounds__(PANEL_THREADS) void fused_colpanel(const T *rate, c
                     const bool up = d[q] < cand;
                     d[q] = up ? cand : d[q];
                     if (HAS_NEXT) nx[q] = up ? cn : nx[q];
+                    if (HAS_LAST) lp[q] = up ? k0 + t : lp[q];
                 }
             }
         }
@@ -316,6 +334,7 @@ __global__ __launch_bounds__(PANEL_THREADS) void fused_colpanel(const T *rate, c
                     const bool up = d[q] < cand;
                     d[q] = up ? cand : d[q];
                     if (HAS_NEXT) nx[q] = up ? cn : nx[q];
+                    if (HAS_LAST) lp[q] = up ? k0 + t : lp[q];
                 }
             }
         }
@@ -327,13 +346,15 @@ __global__ __launch_bounds__(PANEL_THREADS) void fused_colpanel(const T *rate, c
 // workgroup at 32 KiB of LDS and <= 128 VGPRs: 4 workgroups = 16 waves per CU.  The loop is pure
 // VALU (v_pk_mul_f32 + v_cmp + v_cndmask per pair of relaxations) and one wave alone issues at
 // half rate on a SIMD-32, so occupancy, not bytes, is what this kernel needs.
-template <typename T, bool HAS_NEXT, bool COUNT, int BS, int MINW, int NH, int RI, bool MAXF = false>
+template <typename T, bool HAS_NEXT, bool COUNT, int BS, int MINW, int NH, int RI, bool MAXF = false,
+          bool HAS_LAST = false>
 __global__ __launch_bounds__(256, MINW) void fused_main(T *rate, int32_t *next, int rows, int n,
                                                         int row0, int k0, int bt, const T *w,
                                                         const T *ct, const int32_t *cnt, int ct_ld,
                                                         int skip_lo, int skip_hi,
-                                                        unsigned long long *updates)
+                                                        unsigned long long *updates, int32_t *last)
 {
+    static_assert(!HAS_LAST || HAS_NEXT, "the path trace rides on the next-hop variant");
     using V = typename Vec16<T>::type;
     using IV = typename IVec<Vec16<T>::W>::type;
     constexpr int VW = Vec16<T>::W;
@@ -367,6 +388,7 @@ __global__ __launch_bounds__(256, MINW) void fused_main(T *rate, int32_t *next, 
     }
     V x[RI][NH];
     IV nx[HAS_NEXT ? RI : 1][NH];
+    IV lp[HAS_LAST ? RI : 1][NH];    // path trace: pivot of the newest update in this pass, or -2
 #pragma unroll
     for (int r = 0; r < RI; ++r) {
         const int i = min(i0 + r, rows - 1);
@@ -378,6 +400,9 @@ __global__ __launch_bounds__(256, MINW) void fused_main(T *rate, int32_t *next, 
             if (HAS_NEXT)
 #pragma unroll
                 for (int e = 0; e < VW; ++e) nx[r][h][e] = -2;
+            if (HAS_LAST)
+#pragma unroll
+                for (int e = 0; e < VW; ++e) lp[r][h][e] = -2;
         }
     }
 
@@ -453,6 +478,7 @@ __global__ __launch_bounds__(256, MINW) void fused_main(T *rate, int32_t *next, 
                         }
                         x[r][h][e] = up ? cand : x[r][h][e];
                         if (HAS_NEXT) nx[r][h][e] = up ? cn[r] : nx[r][h][e];
+                        if (HAS_LAST) lp[r][h][e] = up ? k0 + s0 + tl : lp[r][h][e];
                     }
         }
     }
@@ -472,6 +498,7 @@ __global__ __launch_bounds__(256, MINW) void fused_main(T *rate, int32_t *next, 
                     const int e = gi - jcol[h];
                     x[r][h][e] = rate[off + e];
                     if (HAS_NEXT) nx[r][h][e] = -2;
+                    if (HAS_LAST) lp[r][h][e] = -2;
                 }
             }
             if (HAS_NEXT) {
@@ -486,6 +513,13 @@ __global__ __launch_bounds__(256, MINW) void fused_main(T *rate, int32_t *next, 
                         if (nx[r][h][e] == -2) nx[r][h][e] = old[e];
                     *reinterpret_cast<IV *>(next + off) = nx[r][h];
                     *reinterpret_cast<V *>(rate + off) = x[r][h];
+                    if (HAS_LAST) {      // same vectors, same components: changed <=> lp != -2
+                        const IV oldl = *reinterpret_cast<const IV *>(last + off);
+#pragma unroll
+                        for (int e = 0; e < VW; ++e)
+                            if (lp[r][h][e] == -2) lp[r][h][e] = oldl[e];
+                        *reinterpret_cast<IV *>(last + off) = lp[r][h];
+                    }
                 }
             } else {
                 *reinterpret_cast<V *>(rate + off) = x[r][h];
@@ -747,13 +781,13 @@ static bool launch_max_form(const FusedArgs<double> &a, dim3 grid, dim3 block, i
     if (small_tiles(a.n, a.rows))
         hipLaunchKernelGGL((fused_main<double, false, false, 16, 2, 1, 4, true>), grid, block, 0, s,
                            a.rate, a.next, a.rows, a.n, a.row0, a.k0, a.bt, a.w, a.ct, a.cnt,
-                           a.ct_ld, skip_lo, skip_hi, a.updates);
+                           a.ct_ld, skip_lo, skip_hi, a.updates, nullptr);
     else
         hipLaunchKernelGGL((fused_main<double, false, false, FusedCfg<double, false>::BS,
                                        FusedCfg<double, false>::MINW, FusedCfg<double, false>::NH, 8,
                                        true>),
                            grid, block, 0, s, a.rate, a.next, a.rows, a.n, a.row0, a.k0, a.bt, a.w,
-                           a.ct, a.cnt, a.ct_ld, skip_lo, skip_hi, a.updates);
+                           a.ct, a.cnt, a.ct_ld, skip_lo, skip_hi, a.updates, nullptr);
     return true;
 }
 
@@ -782,12 +816,17 @@ template <typename T> hipError_t launch_fused_colpanel(const FusedArgs<T> &a, hi
     hipError_t e = check_fused_args(a);
     if (e != hipSuccess) return e;
     const dim3 cgrid((unsigned)((a.rows + 63) / 64)), block(PANEL_THREADS);
-    if (a.next)
-        hipLaunchKernelGGL((fused_colpanel<T, true>), cgrid, block, 0, s, a.rate, a.next, a.rows,
-                           a.n, a.row0, a.k0, a.bt, a.w, a.ct, a.cnt, a.ct_ld);
+    if (a.plog.last && (!a.next || a.row0 != 0 || a.rows != a.n)) return hipErrorInvalidValue;
+    if (a.plog.last)
+        hipLaunchKernelGGL((fused_colpanel<T, true, true>), cgrid, block, 0, s, a.rate, a.next, a.rows,
+                           a.n, a.row0, a.k0, a.bt, a.w, a.ct, a.cnt, a.ct_ld, a.plog.last,
+                           a.plog.at_col);
+    else if (a.next)
+        hipLaunchKernelGGL((fused_colpanel<T, true, false>), cgrid, block, 0, s, a.rate, a.next, a.rows,
+                           a.n, a.row0, a.k0, a.bt, a.w, a.ct, a.cnt, a.ct_ld, nullptr, nullptr);
     else
-        hipLaunchKernelGGL((fused_colpanel<T, false>), cgrid, block, 0, s, a.rate, a.next, a.rows,
-                           a.n, a.row0, a.k0, a.bt, a.w, a.ct, a.cnt, a.ct_ld);
+        hipLaunchKernelGGL((fused_colpanel<T, false, false>), cgrid, block, 0, s, a.rate, a.next, a.rows,
+                           a.n, a.row0, a.k0, a.bt, a.w, a.ct, a.cnt, a.ct_ld, nullptr, nullptr);
     return hipGetLastError();
 }
 
@@ -813,28 +852,32 @@ hipError_t launch_fused_main(const FusedArgs<T> &full, int r_lo, int r_hi, hipSt
     a.row0 = full.row0 + r_lo;
     a.ct = full.ct + r_lo;
     a.cnt = full.cnt ? full.cnt + r_lo : nullptr;
+    int32_t *last = full.plog.last ? full.plog.last + (size_t)r_lo * full.n : nullptr;
+    if (last && !a.next) return hipErrorInvalidValue;
     const dim3 block(256);
     const bool small = small_tiles(a.n, a.rows);
     const int tj = 16 * VW * (small ? 1 : (a.next ? FusedCfg<T, true>::NH : FusedCfg<T, false>::NH));
     const int ti = small ? 64 : TI;
     const dim3 grid((unsigned)((a.n + tj - 1) / tj), (unsigned)((a.rows + ti - 1) / ti));
     if (launch_max_form(a, grid, block, skip_lo, skip_hi, s)) return hipGetLastError();
-#define FWX_FUSED_LAUNCH(HN, CN)                                                                   \
+#define FWX_FUSED_LAUNCH(HN, CN, HL)                                                               \
     do {                                                                                           \
         if (small)                                                                                 \
-            hipLaunchKernelGGL((fused_main<T, HN, CN, 16, 2, 1, 4>), grid, block, 0, s, a.rate,    \
-                               a.next, a.rows, a.n, a.row0, a.k0, a.bt, a.w, a.ct, a.cnt, a.ct_ld, \
-                               skip_lo, skip_hi, a.updates);                                       \
+            hipLaunchKernelGGL((fused_main<T, HN, CN, 16, 2, 1, 4, false, HL>), grid, block, 0, s, \
+                               a.rate, a.next, a.rows, a.n, a.row0, a.k0, a.bt, a.w, a.ct, a.cnt,  \
+                               a.ct_ld, skip_lo, skip_hi, a.updates, last);                        \
         else                                                                                       \
             hipLaunchKernelGGL((fused_main<T, HN, CN, FusedCfg<T, HN>::BS, FusedCfg<T, HN>::MINW,  \
-                                           FusedCfg<T, HN>::NH, 8>),                               \
+                                           FusedCfg<T, HN>::NH, 8, false, HL>),                    \
                                grid, block, 0, s, a.rate, a.next, a.rows, a.n, a.row0, a.k0, a.bt, \
-                               a.w, a.ct, a.cnt, a.ct_ld, skip_lo, skip_hi, a.updates);            \
+                               a.w, a.ct, a.cnt, a.ct_ld, skip_lo, skip_hi, a.updates, last);      \
     } while (0)
-    if (a.next) {
-        if (a.updates) FWX_FUSED_LAUNCH(true, true); else FWX_FUSED_LAUNCH(true, false);
+    if (last) {
+        if (a.updates) FWX_FUSED_LAUNCH(true, true, true); else FWX_FUSED_LAUNCH(true, false, true);
+    } else if (a.next) {
+        if (a.updates) FWX_FUSED_LAUNCH(true, true, false); else FWX_FUSED_LAUNCH(true, false, false);
     } else {
-        if (a.updates) FWX_FUSED_LAUNCH(false, true); else FWX_FUSED_LAUNCH(false, false);
+        if (a.updates) FWX_FUSED_LAUNCH(false, true, false); else FWX_FUSED_LAUNCH(false, false, false);
     }
 #undef FWX_FUSED_LAUNCH
     return hipGetLastError();
@@ -850,13 +893,18 @@ hipError_t launch_fused_relax(const FusedArgs<T> &a, hipStream_t s, int skip_lo,
 
 template <typename T>
 hipError_t launch_fused_panel(const T *rows_base, int n, int k0, int bt, T *w, T *diag_ws,
-                              hipStream_t s)
+                              hipStream_t s, PathLog plog)
 {
     (void)diag_ws;   // kept in the ABI: the diagonal block is now evolved inside fused_rowpanel
     if (n <= 0 || bt <= 0) return hipSuccess;
     if (bt > B) return hipErrorInvalidValue;
-    hipLaunchKernelGGL((fused_rowpanel<T>), dim3((unsigned)((n + 63) / 64)), dim3(PANEL_THREADS), 0, s,
-                       rows_base, n, k0, bt, w);
+    const dim3 grid((unsigned)((n + 63) / 64)), block(PANEL_THREADS);
+    if (plog.last)   // rows_base is row k0 of the whole matrix: same offset into the trace
+        hipLaunchKernelGGL((fused_rowpanel<T, true>), grid, block, 0, s, rows_base, n, k0, bt, w,
+                           plog.last + (size_t)k0 * n, plog.at_row + (size_t)k0 * n);
+    else
+        hipLaunchKernelGGL((fused_rowpanel<T, false>), grid, block, 0, s, rows_base, n, k0, bt, w,
+                           nullptr, nullptr);
     return hipGetLastError();
 }
 
@@ -869,8 +917,8 @@ template hipError_t launch_fused_main<float>(const FusedArgs<float> &, int, int,
 template hipError_t launch_fused_main<double>(const FusedArgs<double> &, int, int, hipStream_t, int,
                                               int);
 template hipError_t launch_fused_panel<float>(const float *, int, int, int, float *, float *,
-                                              hipStream_t);
+                                              hipStream_t, PathLog);
 template hipError_t launch_fused_panel<double>(const double *, int, int, int, double *, double *,
-                                               hipStream_t);
+                                               hipStream_t, PathLog);
 
 }  // namespace fwx

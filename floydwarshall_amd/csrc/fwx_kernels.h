@@ -69,6 +69,7 @@ template <typename T> struct FusedArgs {
                            // staging loads 16-byte aligned)
     unsigned long long *updates;
     bool nonneg;           // caller verified: every matrix entry is >= +0 and not NaN (max form)
+    PathLog plog = PathLog();   // path trace (needs next; single-GPU solves of the whole matrix only)
 };
 
 // Clears *flag (device int, preset to 1) if any of `count` f32 values is negative, -0 or NaN.
@@ -89,7 +90,7 @@ hipError_t launch_fused_main(const FusedArgs<T> &a, int r_lo, int r_hi, hipStrea
 // is not modified.  diag_ws: 2 * FWX_FUSED_B^2 elements of scratch.
 template <typename T>
 hipError_t launch_fused_panel(const T *rows_base, int n, int k0, int bt, T *w, T *diag_ws,
-                              hipStream_t s);
+                              hipStream_t s, PathLog plog = PathLog());
 
 }  // namespace fwx
 #endif

@@ -56,15 +56,18 @@ int Session::ensure_solved()
         // The solve keeps the path trace (fwx_matrix_enable_path_log), from which
         // fwx_matrix_query_exact rebuilds the reference's `_path` lists -- under exact ties (the
         // 1.0 edges of Algorithms.hs:35 make them common) the list the reference stored can be a
-        // longer route than the one the next-hops describe.  Traced solves run as one launch for
-        // n <= 128 and on the per-k engine above; both carry `hops`.
+        // longer route than the one the next-hops describe.  Requests need rates and paths, not
+        // `hops`: from kFusedFrom vertices on the device matrix carries none, so that the solve
+        // takes the fused engine (64 pivots per pass); solved_matrix() computes them on demand.
         int rc = FWX_OK;
+        dev_hops_ = m.n() < kFusedFrom;
         if (!dev_) {
-            if ((rc = fwx_matrix_create(&dev_, m.n(), FWX_F64, 1, 1, device_))) return rc;
+            if ((rc = fwx_matrix_create(&dev_, m.n(), FWX_F64, 1, dev_hops_ ? 1 : 0, device_))) return rc;
             dev_n_ = m.n();
             if ((rc = fwx_matrix_enable_path_log(dev_))) { drop_device(); return rc; }
         }
-        if ((rc = fwx_matrix_upload(dev_, m.rate.data(), m.next.data(), m.hops.data())) ||
+        if ((rc = fwx_matrix_upload(dev_, m.rate.data(), m.next.data(),
+                                    dev_hops_ ? m.hops.data() : nullptr)) ||
             (rc = fwx_matrix_solve(dev_, nullptr))) {               // runAlgo 0, on the GPU
             drop_device();
             return rc;
@@ -139,7 +142,18 @@ int Session::solved_matrix(DenseMatrix &out)
     out.next.assign(n * n, -1);
     out.hops.assign(n * n, 0);
     if (n == 0) return FWX_OK;
-    return fwx_matrix_download(dev_, out.rate.data(), out.next.data(), out.hops.data());
+    if (dev_hops_)
+        return fwx_matrix_download(dev_, out.rate.data(), out.next.data(), out.hops.data());
+    // large matrix: the resident solve carries no `hops` (length _path); this rarely used call
+    // solves the initial matrix once more with them, on the engine that carries hops
+    out.rate = initial_.rate;
+    out.next = initial_.next;
+    out.hops = initial_.hops;
+    fwx_opts o;
+    memset(&o, 0, sizeof(o));
+    o.struct_size = sizeof(o);
+    o.device = device_;
+    return fwx_solve_f64((int32_t)n, out.rate.data(), out.next.data(), out.hops.data(), &o);
 }
 
 std::vector<std::string> Session::serve_line(const std::string &line)

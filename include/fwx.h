@@ -60,8 +60,7 @@ typedef enum fwx_dtype { FWX_F32 = 0, FWX_F64 = 1 } fwx_dtype;
  * otherwise PERK.  The fused kernels need rows that are a multiple of 16 bytes: fwx_solve_f32/f64
  * (host buffers) pad an odd-sized matrix on the device, the entry points that work on device
  * memory they do not own (fwx_matrix_*, fwx_dev_*) fall back to PERK under AUTO and refuse an
- * explicit FUSED (FWX_ERR_UNSUPPORTED).  A matrix with the path trace takes the single launch
- * (n <= 128) or PERK.                                                                            */
+ * explicit FUSED (FWX_ERR_UNSUPPORTED).                                                          */
 typedef enum fwx_engine {
     FWX_ENGINE_AUTO = 0,
     FWX_ENGINE_PERK = 1,  /* one N x N launch per pivot k (HBM-bound streaming kernel)            */
@@ -124,9 +123,9 @@ int fwx_matrix_destroy(fwx_matrix *m);
  * step named by its row index -- from which fwx_matrix_query_exact rebuilds the reference's list
  * exactly: path(i,j) = path_q(i,q) ++ path_q(q,j) with q the newest pivot of (i,j), and a
  * sub-entry is only ever needed "as of the step named by one of its own indices".  No lists, no
- * update records, one pass; any n.  Enable after create; needs the next-hop matrix; runs on the
- * per-k engine (one launch for n <= 128), whole pivot range only, and starts from an uploaded
- * input (fwx_matrix_solve on an already solved traced matrix: FWX_ERR_INVALID -- upload first).
+ * update records, one pass; any n.  Enable after create; needs the next-hop matrix; every engine
+ * keeps it (engine choice as for any matrix); whole pivot range only, and the solve starts from an
+ * uploaded input (fwx_matrix_solve on an already solved traced matrix: FWX_ERR_INVALID).
  * query_exact before a completed traced solve of the current upload: FWX_ERR_INVALID.
  * fwx_matrix_path_log_count: U of that solve.  path_out receives the vertices after src up to
  * dst; returns the length.                                                                      */

@@ -82,17 +82,20 @@ def test_find_best_rate_unknown_vertices_keep_state_and_cache():
     assert s.solves == 1 and s.state == host.INSYNC
 
 
-def test_session_on_a_larger_market_matches_list_faithful_oracle():
-    """40 exchanges x 6 currencies, quotes with a spread (no arbitrage): every (src, dst) answer of
-    the GPU-backed session -- rate AND whole path -- equals the list-faithful restatement of
-    floydWarshall + optimum."""
+@pytest.mark.parametrize("n_exch,n_ccy", [(8, 6), (24, 12)])
+def test_session_on_a_larger_market_matches_list_faithful_oracle(n_exch, n_ccy):
+    """Exchanges x currencies, quotes with a spread (no arbitrage): every sampled (src, dst) answer
+    of the GPU-backed session -- rate AND whole path -- equals the list-faithful restatement of
+    floydWarshall + optimum.  8 x 6: single-launch solve.  24 x 12 (up to 288 vertices): the
+    resident matrix carries no hops and is solved by the fused engine with the path trace;
+    solved_matrix() computes the hops on the side."""
     rnd = np.random.default_rng(5)
-    ccys = ["AAA", "BBB", "CCC", "DDD", "EEE", "FFF"]
+    ccys = ["C%02d" % i for i in range(n_ccy)]
     price = dict(zip(ccys, 0.5 + 1.5 * rnd.random(len(ccys))))
     s = host.Session(device=0)
     rates = {}
-    for e in range(8):
-        exch = "EX" + "ABCDEFGH"[e]
+    for e in range(n_exch):
+        exch = "EX" + "ABCDEFGHIJKLMNOPQRSTUVWXYZ"[e]
         for i in range(len(ccys)):
             for j in range(i + 1, len(ccys)):
                 if rnd.random() < 0.6:
@@ -104,6 +107,7 @@ def test_session_on_a_larger_market_matches_list_faithful_oracle():
                     rates[((exch, b), (exch, a))] = bkd
     m = lf.floyd_warshall(rates)
     vertices = [row[0][1] for row in m]
+    assert len(vertices) < 64 if n_exch == 8 else len(vertices) >= 256
     grate, gnext, ghops = s.solved_matrix()
     _, erate, enext, ehops = lf.to_dense(m)
     assert_bits_equal(grate, erate, "rate")

@@ -725,14 +725,15 @@ def _exact_paths_case(m0, dtype=np.float64, solve_engine=engine.FWX_ENGINE_AUTO)
     _, erate, enext, ehops = lf.to_dense(ref, dtype)
     u = engine.solve(rate.copy(), nxt.copy(), hops.copy(), count_updates=True,
                      engine=engine.FWX_ENGINE_PERK)
-    dm = engine.DeviceMatrix(n, dtype, with_next=True, with_hops=True)
+    with_hops = solve_engine != engine.FWX_ENGINE_FUSED        # the fused engine carries no hops
+    dm = engine.DeviceMatrix(n, dtype, with_next=True, with_hops=with_hops)
     dm.enable_path_log()
-    dm.upload(rate, nxt, hops)
-    assert dm.solve(count_updates=True, engine=solve_engine) == u   # counting pass + logged replay
+    dm.upload(rate, nxt, hops if with_hops else None)
+    assert dm.solve(count_updates=True, engine=solve_engine) == u
     assert dm.path_log_count() == u
     r, nx, hp = dm.download()
     assert_bits_equal(r, erate, "rate")
-    assert np.array_equal(nx, enext) and np.array_equal(hp, ehops)
+    assert np.array_equal(nx, enext) and (hp is None or np.array_equal(hp, ehops))
     differs_from_walk = 0
     for i in range(n):
         for j in range(n):
@@ -759,12 +760,32 @@ def test_exact_path_lists_on_a_tie_heavy_market():
     assert differs > 0          # the case really exercises what the plain walk cannot give
 
 
+@pytest.mark.parametrize("solve_engine", [engine.FWX_ENGINE_AUTO, engine.FWX_ENGINE_FUSED])
 @pytest.mark.parametrize("kind", ["d1", "t1", "t2", "t3"])
-def test_exact_path_lists_dense_kinds(kind):
+def test_exact_path_lists_dense_kinds(kind, solve_engine):
     n = 20
     rate, nxt, _ = synth.make(kind, n, np.float64, seed=77)
     vertices = [("X", "C%03d" % i) for i in range(n)]
-    _exact_paths_case(lf.from_dense(vertices, rate, nxt))
+    _exact_paths_case(lf.from_dense(vertices, rate, nxt), solve_engine=solve_engine)
+
+
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+def test_exact_path_lists_fused_engine_three_passes(dtype):
+    """n = 136 (three 64-pivot passes, ragged last pass and ragged tiles): the trace kept by
+    fused_rowpanel / fused_colpanel / fused_main against the list-faithful restatement, ties and
+    sparse inputs, every entry."""
+    n = 136
+    vertices = [("X", "C%03d" % i) for i in range(n)]
+    for kind in ("t1", "t2"):
+        rate, nxt, _ = synth.make(kind, n, dtype, seed=12)
+        ref = lf.path_indices(lf.run_algo(lf.from_dense(vertices, rate, nxt), dtype))
+        with engine.DeviceMatrix(n, dtype, with_next=True) as dm:
+            dm.enable_path_log()
+            dm.upload(rate, nxt)
+            dm.solve(engine=engine.FWX_ENGINE_FUSED)
+            for i in range(0, n, 3):
+                for j in range(n):
+                    assert tuple(dm.query_exact(i, j)[1]) == ref[i][j], (kind, i, j)
 
 
 def test_path_trace_on_a_reused_handle():
@@ -802,8 +823,8 @@ def test_path_trace_on_a_reused_handle():
 
 def test_path_log_lifecycle():
     """query_exact needs a completed traced solve of the CURRENT upload; a traced solve starts from
-    an uploaded input (solving the solved matrix again is refused); k-ranges and the fused engine
-    are refused for traced matrices."""
+    an uploaded input (solving the solved matrix again is refused); pivot ranges are refused for
+    traced matrices."""
     n = 96
     rate, nxt, _ = synth.make("t1", n, np.float32, seed=5)
     want_r, want_n = rate.copy(), nxt.copy()
@@ -815,8 +836,6 @@ def test_path_log_lifecycle():
             dm.query_exact(0, 1)
         with pytest.raises(engine.FwxError):
             dm.solve(k_begin=0, k_end=n // 2)
-        with pytest.raises(engine.FwxError):
-            dm.solve(engine=engine.FWX_ENGINE_FUSED)
         u1 = dm.solve(count_updates=True)
         assert u1 == dm.path_log_count()
         with pytest.raises(engine.FwxError):              # a traced solve needs a fresh upload
@@ -831,10 +850,12 @@ def test_path_log_lifecycle():
             dm.query_exact(3, 7)
 
 
-@pytest.mark.parametrize("solve_engine", [engine.FWX_ENGINE_AUTO, engine.FWX_ENGINE_PERK])
+@pytest.mark.parametrize("solve_engine", [engine.FWX_ENGINE_AUTO, engine.FWX_ENGINE_PERK,
+                                          engine.FWX_ENGINE_FUSED])
 def test_exact_path_lists_80_vertices(solve_engine):
-    """n = 80: AUTO writes the log from the 128-wide single launch, PERK from relax_k (the kernel
-    that logs for n > 128); both must rebuild every list of the reference."""
+    """n = 80: AUTO keeps the path trace in the 128-wide single launch, PERK in relax_k, FUSED in
+    the three kernels of a 64-pivot pass (two passes here); all must rebuild every list of the
+    reference."""
     m0 = lf.build_matrix(_market_rates(10, 8, seed=23))
     assert 64 < len(m0) <= 80
     assert _exact_paths_case(m0, solve_engine=solve_engine) > 0
