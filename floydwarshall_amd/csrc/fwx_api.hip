@@ -479,17 +479,23 @@ int logged_solve(fwx_matrix *m, const Opts &op_in, hipStream_t s)
     FWX_HIP(hipMemsetAsync(m->plog.last, 0xFF, nn * 4, s));
     FWX_HIP(hipMemsetAsync(m->plog.at_col, 0xFF, nn * 4, s));
     FWX_HIP(hipMemsetAsync(m->plog.at_row, 0xFF, nn * 4, s));
-    FWX_HIP(hipMemsetAsync(m->upd, 0, FWX_UPDATE_SHARDS * 8, s));
+    unsigned long long *upd = op.updates_out ? m->upd : nullptr;   // counting costs registers
+    if (upd) FWX_HIP(hipMemsetAsync(upd, 0, FWX_UPDATE_SHARDS * 8, s));
     m->fresh = 0;
-    const int rc = m->dtype == FWX_F64 ? matrix_solve_typed<double>(m, op, m->upd, s)
-                                       : matrix_solve_typed<float>(m, op, m->upd, s);
+    m->last_u = 0;
+    const int rc = m->dtype == FWX_F64 ? matrix_solve_typed<double>(m, op, upd, s)
+                                       : matrix_solve_typed<float>(m, op, upd, s);
     if (rc) return rc;
-    uint64_t u = 0;
-    const int rc2 = sum_updates(m->upd, &u, s);  // synchronises
-    if (rc2) return rc2;
-    m->last_u = u;
+    if (upd) {
+        uint64_t u = 0;
+        const int rc2 = sum_updates(upd, &u, s);   // synchronises
+        if (rc2) return rc2;
+        m->last_u = u;
+        *op.updates_out = u;
+    } else {
+        FWX_HIP(hipStreamSynchronize(s));
+    }
     m->rec_ready = 1;
-    if (op.updates_out) *op.updates_out = u;
     return FWX_OK;
 }
 

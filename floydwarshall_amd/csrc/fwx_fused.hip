@@ -723,7 +723,8 @@ __global__ __launch_bounds__(256) void nonneg_check_f32(const float *rate, size_
 // Stage size / occupancy target per variant (LDS = BS * (TJ + TI) * sizeof(T) [+ BS*TI*4]).
 template <typename T, bool HAS_NEXT> struct FusedCfg;
 // The next-hop variant doubles the register tile (rate + next), so it takes a half-width tile
-// (NH = 1: one 16-byte vector per thread and row) to stay at 4 waves per SIMD.
+// (NH = 1: one 16-byte vector per thread and row) to stay at 4 waves per SIMD; with the path trace
+// (a third register tile) it runs at 3 waves per SIMD rather than spill, at 2 when it also counts.
 template <> struct FusedCfg<float, false> { static constexpr int BS = 32, MINW = 4, NH = 2; };
 template <> struct FusedCfg<float, true> { static constexpr int BS = 16, MINW = 4, NH = 1; };
 // f64: 16 pivots per stage and 3+ waves per SIMD (tools/measure_f64.py: N=16384 rates only 500 ms
@@ -867,7 +868,9 @@ hipError_t launch_fused_main(const FusedArgs<T> &full, int r_lo, int r_hi, hipSt
                                a.rate, a.next, a.rows, a.n, a.row0, a.k0, a.bt, a.w, a.ct, a.cnt,  \
                                a.ct_ld, skip_lo, skip_hi, a.updates, last);                        \
         else                                                                                       \
-            hipLaunchKernelGGL((fused_main<T, HN, CN, FusedCfg<T, HN>::BS, FusedCfg<T, HN>::MINW,  \
+            hipLaunchKernelGGL((fused_main<T, HN, CN, FusedCfg<T, HN>::BS,                         \
+                                           HL ? (CN ? 2 : (FusedCfg<T, HN>::MINW > 3 ? 3 : FusedCfg<T, HN>::MINW)) \
+                                              : FusedCfg<T, HN>::MINW,                             \
                                            FusedCfg<T, HN>::NH, 8, false, HL>),                    \
                                grid, block, 0, s, a.rate, a.next, a.rows, a.n, a.row0, a.k0, a.bt, \
                                a.w, a.ct, a.cnt, a.ct_ld, skip_lo, skip_hi, a.updates, last);      \

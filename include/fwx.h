@@ -127,8 +127,8 @@ int fwx_matrix_destroy(fwx_matrix *m);
  * keeps it (engine choice as for any matrix); whole pivot range only, and the solve starts from an
  * uploaded input (fwx_matrix_solve on an already solved traced matrix: FWX_ERR_INVALID).
  * query_exact before a completed traced solve of the current upload: FWX_ERR_INVALID.
- * fwx_matrix_path_log_count: U of that solve.  path_out receives the vertices after src up to
- * dst; returns the length.                                                                      */
+ * fwx_matrix_path_log_count: U of that solve if it was asked to count (fwx_opts.updates_out),
+ * else 0.  path_out receives the vertices after src up to dst; returns the length.              */
 int fwx_matrix_enable_path_log(fwx_matrix *m);
 int fwx_matrix_path_log_count(fwx_matrix *m, uint64_t *count_out);
 int fwx_matrix_query_exact(fwx_matrix *m, int32_t src, int32_t dst, double *rate_out,
