@@ -125,10 +125,15 @@ int fused_block(T *rate, int32_t *next, int rows, int n, int row0, int k0, int b
     return FWX_OK;
 }
 
-// Can the fused engine run this matrix?  (16-byte vectors along rows, no hops.)
+// Can the fused kernels read this matrix?  (16-byte vectors along rows.)
+template <typename T> bool fused_dims_ok(int n, const void *rate)
+{
+    return n % (16 / (int)sizeof(T)) == 0 && ((uintptr_t)rate % 16) == 0;
+}
+// ... and without further ado (a matrix with `hops` needs the whole pivot range: fused_with_hops)
 template <typename T> bool fused_ok(int n, const void *rate, const int32_t *hops)
 {
-    return hops == nullptr && n % (16 / (int)sizeof(T)) == 0 && ((uintptr_t)rate % 16) == 0;
+    return hops == nullptr && fused_dims_ok<T>(n, rate);
 }
 
 // Single-GPU solve of pivots [k_begin,k_end) with the fused engine.  Per block of <= 64 pivots:
@@ -261,6 +266,89 @@ struct DevBuf {
     }
 };
 
+// ---- hops from the fused engine ------------------------------------------------------------------
+// The fused kernels carry no `hops` (= length _path).  They can keep the path trace, though, and the
+// lengths follow from it in O(n^2): with lcol[a][k] = hops of (a,k) at time k and lrow[k][b] = hops
+// of (k,b) at time k, an entry last improved by pivot q has hops = lcol[a][q] + lrow[q][b] -- the
+// very sum the per-k engine formed at step q (Algorithms.hs:55: path = ikPath ++ kjPath) -- and
+// lcol / lrow themselves obey the same rule through at_col / at_row, which only point at smaller
+// pivots: one tiny launch per pivot, in order.  Entries never improved keep their input hops.
+__global__ __launch_bounds__(256) void hops_dp_step(const int32_t *at_col, const int32_t *at_row,
+                                                    const int32_t *hops0, int32_t *lcol,
+                                                    int32_t *lrow, int n, int k)
+{
+    const int t = blockIdx.x * 256 + threadIdx.x;
+    if (t < n) {                                     // column k: entry (a, k) as of step k
+        const size_t off = (size_t)t * n + k;
+        const int q = at_col[off];
+        lcol[off] = q < 0 ? hops0[off]
+                          : (int32_t)((uint32_t)lcol[(size_t)t * n + q] + (uint32_t)lrow[(size_t)q * n + k]);
+    } else if (t < 2 * n) {                          // row k: entry (k, b) as of step k
+        const int b = t - n;
+        const size_t off = (size_t)k * n + b;
+        const int q = at_row[off];
+        lrow[off] = q < 0 ? hops0[off]
+                          : (int32_t)((uint32_t)lcol[(size_t)k * n + q] + (uint32_t)lrow[(size_t)q * n + b]);
+    }
+}
+
+__global__ __launch_bounds__(256) void hops_final(const int32_t *last, const int32_t *lcol,
+                                                  const int32_t *lrow, int32_t *hops, int n)
+{
+    const size_t nn = (size_t)n * n;
+    for (size_t off = (size_t)blockIdx.x * 256 + threadIdx.x; off < nn; off += (size_t)gridDim.x * 256) {
+        const int q = last[off];
+        if (q >= 0) {
+            const size_t a = off / n, b = off % n;
+            hops[off] = (int32_t)((uint32_t)lcol[a * n + q] + (uint32_t)lrow[(size_t)q * n + b]);
+        }
+    }
+}
+
+// Whole solve of a matrix WITH hops on the fused engine: order n, pivots [0, pivots) (pivots < n
+// only for a matrix padded by the host-buffer path).  plog: the caller's path trace if it keeps
+// one, else a temporary one is used.
+template <typename T>
+int fused_with_hops(T *rate, int32_t *next, int32_t *hops, int n, int pivots,
+                    unsigned long long *d_updates, hipStream_t s, fwx::PathLog plog)
+{
+    const size_t nn = (size_t)n * n;
+    DevBuf t_last, t_col, t_row, d_lcol, d_lrow, d_ws;
+    int rc;
+    if (!plog.last) {
+        if ((rc = t_last.alloc(nn * 4)) || (rc = t_col.alloc(nn * 4)) || (rc = t_row.alloc(nn * 4))) return rc;
+        plog.last = (int32_t *)t_last.p; plog.at_col = (int32_t *)t_col.p; plog.at_row = (int32_t *)t_row.p;
+        FWX_HIP(hipMemsetAsync(plog.last, 0xFF, nn * 4, s));
+        FWX_HIP(hipMemsetAsync(plog.at_col, 0xFF, nn * 4, s));
+        FWX_HIP(hipMemsetAsync(plog.at_row, 0xFF, nn * 4, s));
+    }
+    if ((rc = d_lcol.alloc(nn * 4)) || (rc = d_lrow.alloc(nn * 4)) ||
+        (rc = d_ws.alloc(fused_ws_bytes(n, sizeof(T)))))
+        return rc;
+    if ((rc = fused_range<T>(rate, next, n, 0, pivots, d_ws.p, d_updates, s, plog))) return rc;
+    const dim3 grid((unsigned)((2 * (size_t)n + 255) / 256)), block(256);
+    for (int k = 0; k < pivots; ++k)
+        hipLaunchKernelGGL(hops_dp_step, grid, block, 0, s, plog.at_col, plog.at_row, hops,
+                           (int32_t *)d_lcol.p, (int32_t *)d_lrow.p, n, k);
+    FWX_HIP(hipGetLastError());
+    size_t blocks = (nn + 255) / 256;
+    if (blocks > 65536) blocks = 65536;
+    hipLaunchKernelGGL(hops_final, dim3((unsigned)blocks), block, 0, s, plog.last, (int32_t *)d_lcol.p,
+                       (int32_t *)d_lrow.p, hops, n);
+    FWX_HIP(hipGetLastError());
+    FWX_HIP(hipStreamSynchronize(s));      // the scratch is released at scope exit
+    return FWX_OK;
+}
+
+// AUTO / FUSED for a matrix that carries hops: whole range, next present, readable dimensions.
+template <typename T>
+bool pick_fused_hops(int engine, int n, const void *rate, const int32_t *next, const int32_t *hops,
+                     bool whole_range)
+{
+    if (!hops || !next || engine == FWX_ENGINE_PERK || !fused_dims_ok<T>(n, rate)) return false;
+    return whole_range && (engine == FWX_ENGINE_FUSED || n >= 256);
+}
+
 template <typename T>
 int solve_host(int32_t n, T *rate, int32_t *next, int32_t *hops, const fwx_opts *o)
 {
@@ -280,8 +368,9 @@ int solve_host(int32_t n, T *rate, int32_t *next, int32_t *hops, const fwx_opts 
     // padding entry is never a pivot row or column -- and a +0.0 target is never improved
     // (0 < +-0 and 0 < NaN are false), so U is unchanged too.  The caller's arrays stay n x n.
     constexpr int VW = 16 / (int)sizeof(T);
-    const bool to_fused = !hops && (op.engine == FWX_ENGINE_FUSED ||
-                                    (op.engine == FWX_ENGINE_AUTO && n >= 256));
+    const bool whole = op.k_begin == 0 && op.k_end == n;
+    const bool to_fused = (!hops || (next && whole)) &&
+                          (op.engine == FWX_ENGINE_FUSED || (op.engine == FWX_ENGINE_AUTO && n >= 256));
     const int nd = (to_fused && n % VW) ? (n + VW - 1) / VW * VW : n;
     const size_t nn = (size_t)nd * (size_t)nd;
     DevBuf d_rate, d_next, d_hops, d_upd;
@@ -302,6 +391,7 @@ int solve_host(int32_t n, T *rate, int32_t *next, int32_t *hops, const fwx_opts 
     if (nd != n) {
         FWX_HIP(hipMemsetAsync(d_rate.p, 0, nn * sizeof(T), s));                  // +0.0
         if (next) FWX_HIP(hipMemsetAsync(d_next.p, 0xFF, nn * sizeof(int32_t), s));   // -1
+        if (hops) FWX_HIP(hipMemsetAsync(d_hops.p, 0, nn * sizeof(int32_t), s));
     }
     if ((rc = copy2d(d_rate.p, nd, rate, n, sizeof(T), hipMemcpyHostToDevice))) return rc;
     if (next && (rc = copy2d(d_next.p, nd, next, n, sizeof(int32_t), hipMemcpyHostToDevice))) return rc;
@@ -311,11 +401,16 @@ int solve_host(int32_t n, T *rate, int32_t *next, int32_t *hops, const fwx_opts 
     T *dr = (T *)d_rate.p;
     int32_t *dh = (int32_t *)d_hops.p;
     unsigned long long *upd = op.updates_out ? (unsigned long long *)d_upd.p : nullptr;
-    if (op.engine == FWX_ENGINE_FUSED && !fused_ok<T>(nd, dr, dh)) return FWX_ERR_UNSUPPORTED;
+    const bool hops_fused = pick_fused_hops<T>(op.engine, nd, dr, (int32_t *)d_next.p, dh, whole);
+    if (op.engine == FWX_ENGINE_FUSED && !hops_fused && !fused_ok<T>(nd, dr, dh))
+        return FWX_ERR_UNSUPPORTED;
     if (op.engine == FWX_ENGINE_AUTO && n <= FWX_SMALL_N) {
         // the reference's own regime: the whole solve in one single-workgroup launch
         FWX_HIP(fwx::launch_small_solve<T>(dr, (int32_t *)d_next.p, dh, n, op.k_begin, op.k_end, upd,
                                            fwx::PathLog(), s));
+    } else if (hops_fused) {
+        // (a padded matrix is solved over its real pivots only: the padding is inert)
+        if ((rc = fused_with_hops<T>(dr, (int32_t *)d_next.p, dh, nd, n, upd, s, fwx::PathLog()))) return rc;
     } else if (pick_fused<T>(op.engine, nd, dr, dh)) {
         DevBuf d_ws;
         if ((rc = d_ws.alloc(fused_ws_bytes(nd, sizeof(T))))) return rc;
@@ -446,12 +541,16 @@ int matrix_solve_typed(fwx_matrix *m, const Opts &op, unsigned long long *upd, h
 {
     const int n = m->n;
     T *r = (T *)m->rate;
-    if (op.engine == FWX_ENGINE_FUSED && !fused_ok<T>(n, r, m->hops)) return FWX_ERR_UNSUPPORTED;
+    const bool hops_fused = pick_fused_hops<T>(op.engine, n, r, m->next, m->hops,
+                                               op.k_begin == 0 && op.k_end == n);
+    if (op.engine == FWX_ENGINE_FUSED && !hops_fused && !fused_ok<T>(n, r, m->hops))
+        return FWX_ERR_UNSUPPORTED;
     if (op.engine == FWX_ENGINE_AUTO && n <= FWX_SMALL_N) {
         FWX_HIP(fwx::launch_small_solve<T>(r, m->next, m->hops, n, op.k_begin, op.k_end, upd,
                                            m->plog, s));
         return FWX_OK;
     }
+    if (hops_fused) return fused_with_hops<T>(r, m->next, m->hops, n, n, upd, s, m->plog);
     if (pick_fused<T>(op.engine, n, r, m->hops)) {
         DevBuf ws;
         int rc = ws.alloc(fused_ws_bytes(n, sizeof(T)));

@@ -274,8 +274,11 @@ def test_fused_engine_golden_4x4():
 def test_fused_engine_k_range_and_unsupported():
     rate, nxt, hops = synth.make("d2", 300, np.float64, seed=22)
     _solve_and_compare(rate, nxt, None, engine=engine.FWX_ENGINE_FUSED, k_begin=37, k_end=211)
-    with pytest.raises(engine.FwxError) as e:           # hops ride on the per-k engine only
-        engine.solve(rate.copy(), nxt.copy(), hops.copy(), engine=engine.FWX_ENGINE_FUSED)
+    # hops on the fused engine come from the path trace, which needs the WHOLE pivot range
+    _solve_and_compare(rate, nxt, hops, engine=engine.FWX_ENGINE_FUSED)
+    with pytest.raises(engine.FwxError) as e:
+        engine.solve(rate.copy(), nxt.copy(), hops.copy(), engine=engine.FWX_ENGINE_FUSED,
+                     k_begin=37, k_end=211)
     assert e.value.status == -7
     # n not a multiple of the 16-byte vector width: the device-pointer API refuses the fused engine
     # (it cannot pad memory it does not own) ...
@@ -960,3 +963,26 @@ def test_path_trace_with_several_strips_and_chunks(dtype, n):
             assert abs(prod - float(r[i, j])) <= 1e-5 * abs(float(r[i, j]))
             longest = max(longest, len(q_path))
         assert longest >= 3
+
+
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+@pytest.mark.parametrize("kind", ["d2", "t1", "t2", "t3"])
+def test_hops_from_the_fused_engine(kind, dtype):
+    """`hops` (= length _path) from the fused engine: lengths rebuilt from the path trace in pivot
+    order.  Same integers as the per-k engine forms step by step -- ties, unreachable pairs,
+    arbitrage blow-ups (wrapping sums) included -- through the host-buffer API (AUTO at n >= 256,
+    odd sizes padded) and the handle API."""
+    for n in (300, 257):
+        rate, nxt, hops = synth.make(kind, n, dtype, seed=400 + n)
+        _solve_and_compare(rate, nxt, hops)                                   # AUTO -> fused + trace
+        _solve_and_compare(rate, nxt, hops, engine=engine.FWX_ENGINE_FUSED)
+    n = 384
+    rate, nxt, hops = synth.make(kind, n, dtype, seed=9)
+    er, en, eh = rate.copy(), nxt.copy(), hops.copy()
+    oracle.relax(er, en, eh)
+    with engine.DeviceMatrix(n, dtype, with_next=True, with_hops=True) as dm:
+        dm.upload(rate, nxt, hops)
+        dm.solve()                                                            # AUTO -> fused
+        r, nx, hp = dm.download()
+        assert_bits_equal(r, er, "rate")
+        assert np.array_equal(nx, en) and np.array_equal(hp, eh)
