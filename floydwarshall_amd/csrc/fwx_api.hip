@@ -346,7 +346,9 @@ bool pick_fused_hops(int engine, int n, const void *rate, const int32_t *next, c
                      bool whole_range)
 {
     if (!hops || !next || engine == FWX_ENGINE_PERK || !fused_dims_ok<T>(n, rate)) return false;
-    return whole_range && (engine == FWX_ENGINE_FUSED || n >= 256);
+    // tools/measure_hops.py: the per-k engine is ahead up to n ~ 2048 (7 against 22 ms at 1024),
+    // the fused route from there on (38 against 72 ms at 4096, 0.86 against ~3 s at 16384)
+    return whole_range && (engine == FWX_ENGINE_FUSED || n >= 3072);
 }
 
 template <typename T>
@@ -370,7 +372,8 @@ int solve_host(int32_t n, T *rate, int32_t *next, int32_t *hops, const fwx_opts 
     constexpr int VW = 16 / (int)sizeof(T);
     const bool whole = op.k_begin == 0 && op.k_end == n;
     const bool to_fused = (!hops || (next && whole)) &&
-                          (op.engine == FWX_ENGINE_FUSED || (op.engine == FWX_ENGINE_AUTO && n >= 256));
+                          (op.engine == FWX_ENGINE_FUSED ||
+                           (op.engine == FWX_ENGINE_AUTO && n >= (hops ? 3072 : 256)));
     const int nd = (to_fused && n % VW) ? (n + VW - 1) / VW * VW : n;
     const size_t nn = (size_t)nd * (size_t)nd;
     DevBuf d_rate, d_next, d_hops, d_upd;

@@ -57,8 +57,8 @@ typedef enum fwx_dtype { FWX_F32 = 0, FWX_F64 = 1 } fwx_dtype;
 
 /* Which relaxation engine runs the pivots.  All are bit-exact with the reference loop.
  * AUTO: n <= 128 -> the whole solve in one single-workgroup launch; n >= 256 -> FUSED (a matrix
- * with hops: whole pivot range only -- the lengths are rebuilt from the path trace the fused
- * kernels keep, which costs 5 n^2 int32 of scratch); otherwise PERK.  The fused kernels need rows that are a multiple of 16 bytes: fwx_solve_f32/f64
+ * with hops: from n = 3072 and for the whole pivot range only -- the lengths are rebuilt from the
+ * path trace the fused kernels keep, which costs 5 n^2 int32 of scratch); otherwise PERK.  The fused kernels need rows that are a multiple of 16 bytes: fwx_solve_f32/f64
  * (host buffers) pad an odd-sized matrix on the device, the entry points that work on device
  * memory they do not own (fwx_matrix_*, fwx_dev_*) fall back to PERK under AUTO and refuse an
  * explicit FUSED (FWX_ERR_UNSUPPORTED).                                                          */

@@ -970,11 +970,10 @@ def test_path_trace_with_several_strips_and_chunks(dtype, n):
 def test_hops_from_the_fused_engine(kind, dtype):
     """`hops` (= length _path) from the fused engine: lengths rebuilt from the path trace in pivot
     order.  Same integers as the per-k engine forms step by step -- ties, unreachable pairs,
-    arbitrage blow-ups (wrapping sums) included -- through the host-buffer API (AUTO at n >= 256,
-    odd sizes padded) and the handle API."""
+    arbitrage blow-ups (wrapping sums) included -- through the host-buffer API (odd sizes padded)
+    and the handle API.  (AUTO takes this route from n = 3072: test_hops_auto_large.)"""
     for n in (300, 257):
         rate, nxt, hops = synth.make(kind, n, dtype, seed=400 + n)
-        _solve_and_compare(rate, nxt, hops)                                   # AUTO -> fused + trace
         _solve_and_compare(rate, nxt, hops, engine=engine.FWX_ENGINE_FUSED)
     n = 384
     rate, nxt, hops = synth.make(kind, n, dtype, seed=9)
@@ -982,7 +981,14 @@ def test_hops_from_the_fused_engine(kind, dtype):
     oracle.relax(er, en, eh)
     with engine.DeviceMatrix(n, dtype, with_next=True, with_hops=True) as dm:
         dm.upload(rate, nxt, hops)
-        dm.solve()                                                            # AUTO -> fused
+        dm.solve(engine=engine.FWX_ENGINE_FUSED)
         r, nx, hp = dm.download()
         assert_bits_equal(r, er, "rate")
         assert np.array_equal(nx, en) and np.array_equal(hp, eh)
+
+
+def test_hops_auto_large():
+    """AUTO with hops at n = 3100 (> 3072, not a multiple of 4: padded): fused engine + path trace +
+    length reconstruction, against the oracle on all three fields."""
+    rate, nxt, hops = synth.make("d2", 3100, np.float32, seed=77)
+    _solve_and_compare(rate, nxt, hops)

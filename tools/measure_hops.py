@@ -1,8 +1,16 @@
-import sys, time
-sys.path.insert(0, '/root/repo')
+#!/usr/bin/env python3
+"""fwx_solve_f32 with rate + next + hops (host buffers, PCIe included): fused engine + path trace +
+length reconstruction against the per-k engine."""
+import sys
+import time
+
 import numpy as np
-from floydwarshall_amd import engine, synth
-for n in (4096, 16384):
+
+sys.path.insert(0, __file__.rsplit("/", 2)[0])
+from floydwarshall_amd import engine, synth  # noqa: E402
+
+engine.solve(np.ones((8, 8), dtype=np.float32))          # runtime start-up out of the way
+for n in (1024, 4096, 16384):
     rate, nxt = synth.d1_uniform(n, np.float32, 5)
     hops = (nxt >= 0).astype(np.int32)
     for name, code in (("fused + trace + lengths", engine.FWX_ENGINE_AUTO), ("per-k", engine.FWX_ENGINE_PERK)):
