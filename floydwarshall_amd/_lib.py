@@ -71,6 +71,7 @@ SIGNATURES = {
     "fwx_matrix_path_log_count": (ctypes.c_int, [c_vp, ctypes.POINTER(ctypes.c_uint64)]),
     "fwx_matrix_query_exact": (ctypes.c_int, [c_vp, c_i32, c_i32, ctypes.POINTER(ctypes.c_double),
                                               c_vp, c_i32]),
+    "fwx_matrix_query_exact_batch": (ctypes.c_int, [c_vp, c_i32, c_vp, c_vp, c_vp, c_vp, c_i32]),
     "fwx_dev_relax": (ctypes.c_int, [ctypes.POINTER(FwxSlab), ctypes.POINTER(FwxPivots), c_i32,
                                      c_vp, c_vp]),
     "fwx_dev_relax_skip": (ctypes.c_int, [ctypes.POINTER(FwxSlab), ctypes.POINTER(FwxPivots), c_i32,

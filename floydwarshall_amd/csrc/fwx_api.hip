@@ -633,6 +633,41 @@ __global__ void exact_path_kernel(fwx::PathLog plog, const int32_t *next0, int n
     }
     *len_out = len;
 }
+
+// Batch form: one thread per (src[q], dst[q]); query q writes its list to paths + q*cap and uses
+// stacks + q*3*cap as its stack.  len_out[q] = length, FWX_ERR_CAPACITY if it does not fit.
+__global__ __launch_bounds__(64) void exact_paths_kernel(fwx::PathLog plog, const int32_t *next0, int n,
+                                                         int count, const int32_t *src,
+                                                         const int32_t *dst, int32_t *paths,
+                                                         int32_t *stacks, int cap, int32_t *len_out)
+{
+    enum { FINAL = 0, AS_COLUMN = 1, AS_ROW = 2 };
+    const int qi = blockIdx.x * 64 + threadIdx.x;
+    if (qi >= count) return;
+    const int s0 = src[qi], d0 = dst[qi];
+    if (s0 < 0 || d0 < 0 || s0 >= n || d0 >= n) { len_out[qi] = FWX_ERR_INVALID; return; }
+    int32_t *out = paths + (size_t)qi * cap;
+    int32_t *stack = stacks + (size_t)qi * 3 * cap;
+    int sp = 0, len = 0;
+    stack[0] = s0; stack[1] = d0; stack[2] = FINAL; sp = 1;
+    while (sp > 0) {
+        --sp;
+        const int a = stack[3 * sp], b = stack[3 * sp + 1], kind = stack[3 * sp + 2];
+        const size_t off = (size_t)a * n + b;
+        const int q = kind == FINAL ? plog.last[off] : kind == AS_COLUMN ? plog.at_col[off] : plog.at_row[off];
+        if (q < 0) {
+            if (next0[off] >= 0) {
+                if (len >= cap) { len_out[qi] = FWX_ERR_CAPACITY; return; }
+                out[len++] = b;
+            }
+        } else {
+            if (sp + 2 > cap) { len_out[qi] = FWX_ERR_CAPACITY; return; }
+            stack[3 * sp] = q; stack[3 * sp + 1] = b; stack[3 * sp + 2] = AS_ROW; ++sp;
+            stack[3 * sp] = a; stack[3 * sp + 1] = q; stack[3 * sp + 2] = AS_COLUMN; ++sp;
+        }
+    }
+    len_out[qi] = len;
+}
 }  // namespace
 
 extern "C" {
@@ -814,6 +849,32 @@ int fwx_matrix_query_exact(fwx_matrix *m, int32_t src, int32_t dst, double *rate
     FWX_HIP(hipMemcpy(&len, len_dev, 4, hipMemcpyDeviceToHost));
     if (len > 0) FWX_HIP(hipMemcpy(path_out, m->walk, (size_t)len * 4, hipMemcpyDeviceToHost));
     return len;
+}
+
+int fwx_matrix_query_exact_batch(fwx_matrix *m, int32_t count, const int32_t *src, const int32_t *dst,
+                                 int32_t *len_out, int32_t *path_out, int32_t cap)
+{
+    if (!m || count < 0 || cap <= 0) return FWX_ERR_INVALID;
+    if (count == 0) return FWX_OK;
+    if (!src || !dst || !len_out || !path_out || !m->plog.last) return FWX_ERR_INVALID;
+    DeviceGuard g;
+    int rc = g.enter(m->device);
+    if (rc) return rc;
+    if (!m->rec_ready) return FWX_ERR_INVALID;
+    DevBuf d_src, d_dst, d_len, d_paths, d_stacks;
+    const size_t c = (size_t)count;
+    if ((rc = d_src.alloc(c * 4)) || (rc = d_dst.alloc(c * 4)) || (rc = d_len.alloc(c * 4)) ||
+        (rc = d_paths.alloc(c * cap * 4)) || (rc = d_stacks.alloc(c * cap * 12)))
+        return rc;
+    FWX_HIP(hipMemcpy(d_src.p, src, c * 4, hipMemcpyHostToDevice));
+    FWX_HIP(hipMemcpy(d_dst.p, dst, c * 4, hipMemcpyHostToDevice));
+    hipLaunchKernelGGL(exact_paths_kernel, dim3((unsigned)((c + 63) / 64)), dim3(64), 0, nullptr, m->plog,
+                       m->next0, m->n, count, (const int32_t *)d_src.p, (const int32_t *)d_dst.p,
+                       (int32_t *)d_paths.p, (int32_t *)d_stacks.p, cap, (int32_t *)d_len.p);
+    FWX_HIP(hipGetLastError());
+    FWX_HIP(hipMemcpy(len_out, d_len.p, c * 4, hipMemcpyDeviceToHost));
+    FWX_HIP(hipMemcpy(path_out, d_paths.p, c * cap * 4, hipMemcpyDeviceToHost));
+    return FWX_OK;
 }
 
 int fwx_matrix_download(fwx_matrix *m, void *rate, int32_t *next, int32_t *hops)

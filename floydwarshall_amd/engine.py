@@ -137,6 +137,22 @@ class DeviceMatrix:
                                                 _np_ptr(out), cap), "fwx_matrix_query_exact")
         return float(r.value), [int(x) for x in out[:ln]]
 
+    def query_exact_batch(self, src, dst, cap=None):
+        """Exact `_path` lists of many (src[q], dst[q]) pairs in one launch -> list of lists
+        (FwxError if one does not fit into cap entries)."""
+        src = np.ascontiguousarray(src, dtype=np.int32)
+        dst = np.ascontiguousarray(dst, dtype=np.int32)
+        assert src.shape == dst.shape and src.ndim == 1
+        cap = cap or max(4 * self.n, 64)
+        lens = np.empty(len(src), dtype=np.int32)
+        paths = np.empty((len(src), cap), dtype=np.int32)
+        check(lib().fwx_matrix_query_exact_batch(self._h, len(src), _np_ptr(src), _np_ptr(dst),
+                                                 _np_ptr(lens), _np_ptr(paths), cap),
+              "fwx_matrix_query_exact_batch")
+        if len(lens) and int(lens.min()) < 0:
+            raise FwxError(int(lens.min()), "fwx_matrix_query_exact_batch: a list did not fit")
+        return [[int(v) for v in paths[q, :lens[q]]] for q in range(len(src))]
+
     def close(self):
         if self._h:
             lib().fwx_matrix_destroy(self._h)

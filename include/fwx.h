@@ -134,6 +134,11 @@ int fwx_matrix_enable_path_log(fwx_matrix *m);
 int fwx_matrix_path_log_count(fwx_matrix *m, uint64_t *count_out);
 int fwx_matrix_query_exact(fwx_matrix *m, int32_t src, int32_t dst, double *rate_out,
                            int32_t *path_out, int32_t cap);
+/* Batch form: count (src, dst) pairs in one launch (one thread per pair).  len_out[q] = length of
+ * list q or a negative fwx_status (FWX_ERR_CAPACITY: longer than cap); path_out + q*cap receives
+ * it.  Host arrays in and out.                                                                  */
+int fwx_matrix_query_exact_batch(fwx_matrix *m, int32_t count, const int32_t *src, const int32_t *dst,
+                                 int32_t *len_out, int32_t *path_out, int32_t cap);
 
 /* ---- device-pointer step API (caller-owned DEVICE memory, caller's stream) --------------------
  * Used by the benchmark and by the row-partitioned multi-GPU driver, which own their buffers

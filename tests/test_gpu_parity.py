@@ -948,6 +948,14 @@ def test_path_trace_with_several_strips_and_chunks(dtype, n):
         assert u == dm.path_log_count() > 0
         r, nx, _ = dm.download()
         rnd = np.random.default_rng(n)
+        # the batch form answers 20000 pairs in one launch: every list must end at its destination
+        # and agree with the one-pair form
+        bs, bd = rnd.integers(0, n, size=20000), rnd.integers(0, n, size=20000)
+        batch = dm.query_exact_batch(bs, bd, cap=64)
+        for q in range(0, 20000, 997):
+            assert batch[q] == dm.query_exact(int(bs[q]), int(bd[q]))[1]
+        assert all((len(p) == 0) == (int(bs[q]) == int(bd[q])) and (not p or p[-1] == int(bd[q]))
+                   for q, p in enumerate(batch))
         longest = 0
         for _ in range(400):
             i, j = (int(x) for x in rnd.integers(0, n, size=2))
