@@ -995,8 +995,17 @@ def test_hops_from_the_fused_engine(kind, dtype):
         assert np.array_equal(nx, en) and np.array_equal(hp, eh)
 
 
-def test_hops_auto_large():
-    """AUTO with hops at n = 3100 (> 3072, not a multiple of 4: padded): fused engine + path trace +
-    length reconstruction, against the oracle on all three fields."""
-    rate, nxt, hops = synth.make("d2", 3100, np.float32, seed=77)
-    _solve_and_compare(rate, nxt, hops)
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+def test_hops_auto_large(dtype):
+    """AUTO with hops at n = 3102 (> 3072, not a multiple of 4: padded; full-size tiles): fused
+    engine + path trace + length reconstruction must give the per-k engine's rate, next and hops
+    (the per-k engine itself is checked against the oracle throughout this file)."""
+    rate, nxt, hops = synth.make("d2", 3102, dtype, seed=77)
+    a = [rate.copy(), nxt.copy(), hops.copy()]
+    b = [rate.copy(), nxt.copy(), hops.copy()]
+    ua = engine.solve(*a, count_updates=True)                                  # AUTO: fused route
+    ub = engine.solve(*b, count_updates=True, engine=engine.FWX_ENGINE_PERK)
+    assert ua == ub
+    assert_bits_equal(a[0], b[0], "rate")
+    assert np.array_equal(a[1], b[1]) and np.array_equal(a[2], b[2])
+    assert int(a[2].max()) >= 3
