@@ -10,9 +10,8 @@
 
 namespace fwx {
 
-// Update log for exact `_path` reconstruction (Algorithms.hs:55 concatenates the time-k paths of
-// (i,k) and (k,j)): every successful relaxation appends one record {k, previous record of the same
-// entry}; head[i*n+j] is the entry's newest record.  All device pointers; head == nullptr = off.
+// Path trace for exact `_path` reconstruction (Algorithms.hs:55 concatenates the time-k paths of
+// (i,k) and (k,j) whenever (i,j) improves).
 struct PathLog {
     // What the reference's `_path` lists (Algorithms.hs:55) need, without storing a single list or
     // update record: three n x n int32 matrices.

@@ -184,7 +184,7 @@ def engine_follow(nxt, i, j):
 
 
 def test_no_device_memory_leak_over_many_sessions_and_logged_solves():
-    """Handles own device memory (solved matrix, pristine copies, update log, walk buffers): a few
+    """Handles own device memory (solved matrix, path trace, walk buffers): a few
     hundred create / solve / query / destroy cycles must leave the free HBM where it was."""
     import torch
     from floydwarshall_amd import engine, synth

@@ -697,7 +697,7 @@ def test_index_math_beyond_2_to_31_elements():
 
 
 # ---------------------------------------------------------------------------------------------
-# Exact `_path` lists: update log + fwx_matrix_query_exact
+# Exact `_path` lists: path trace + fwx_matrix_query_exact
 # ---------------------------------------------------------------------------------------------
 
 def _market_rates(n_exch, n_ccy, seed, density=0.5):

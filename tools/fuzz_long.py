@@ -33,7 +33,7 @@ with np.errstate(all="ignore"):
         _solve_and_compare(rate, None, None, engine=engine.FWX_ENGINE_FUSED)
         cases += 1
         if cases % 5 == 0:
-            # logged solve vs the list-faithful `_path` lists (small n: the python restatement is O(n^3))
+            # traced solve vs the list-faithful `_path` lists (small n: the python restatement is O(n^3))
             m = int(rnd.integers(2, 40))
             rate, nxt, hops = _hostile_matrix(rnd, m, np.float64)
             nxt[np.arange(m), np.arange(m)] = -1
