@@ -34,21 +34,25 @@ with np.errstate(all="ignore"):
         cases += 1
         if cases % 5 == 0:
             # traced solve vs the list-faithful `_path` lists (small n: the python restatement is O(n^3))
-            m = int(rnd.integers(2, 40))
+            m = 2 * int(rnd.integers(1, 20)) if cases % 25 else 2 * int(rnd.integers(33, 80))
             rate, nxt, hops = _hostile_matrix(rnd, m, np.float64)
             nxt[np.arange(m), np.arange(m)] = -1
             hops = (nxt >= 0).astype(np.int32)
             vertices = [("X", "C%03d" % i) for i in range(m)]
             ref = lf.run_algo(lf.from_dense(vertices, rate, nxt), np.float64)
             ref_paths = lf.path_indices(ref)
-            for eng in (engine.FWX_ENGINE_AUTO, engine.FWX_ENGINE_PERK):
+            er, en, eh = rate.copy(), nxt.copy(), hops.copy()
+            oracle.relax(er, en, eh)
+            for eng in (engine.FWX_ENGINE_AUTO, engine.FWX_ENGINE_PERK, engine.FWX_ENGINE_FUSED):
                 with engine.DeviceMatrix(m, np.float64, with_next=True, with_hops=True) as dm:
                     dm.enable_path_log()
                     dm.upload(rate, nxt, hops)
                     dm.solve(engine=eng)
                     dm.upload(rate, nxt, hops)       # second solve on the same handle
                     dm.solve(engine=eng)
-                    _, _, hp = dm.download()
+                    gr, gn, hp = dm.download()       # FUSED: hops rebuilt from the trace
+                    assert_bits_equal(gr, er, "rate")
+                    assert np.array_equal(gn, en) and np.array_equal(hp, eh)
                     for i in range(m):
                         for j in range(m):
                             if hp[i, j] > 8 * m:
