@@ -11,13 +11,18 @@ of the synthetic dense matrix, restarted from the pristine input (a device-to-de
 the timed region, ~0.03 % of a step).  Workload = BASELINE.json's metric configuration:
 N = 16384, fp32, dense D1 input (floydwarshall_amd/synth.py), matrices resident in HBM.
 
-  value     = K * N^3 / t      t = wall time of the K steps, barrier + synchronize on both sides,
-                               max over ranks
+  value     = K * N^3 / t      t = wall time of the K steps, barrier + device synchronize on both
+                               sides, max over ranks
   roofline  = per-k kernel `relax_k` against HBM: algorithmic bytes per launch
               (s*N^2 + s*U/N + 2*s*N) / average launch duration measured
               live with HIP events on the launch stream over the timed region
   cpu_baseline = the oracle's multithreaded dense loop (a C restatement of the reference loop --
               the Haskell reference cannot be built here) on a bounded k-slice of the same matrix
+
+N = 1 runs WITHOUT torch: device buffers, the stream and the events come from the HIP runtime
+directly (floydwarshall_amd/hip.py), so the process holds one HIP runtime and `rocprofv3 --pmc ...
+-- python3 bench.py ...` profiles exactly the benchmarked launches.  N > 1
+needs torch.distributed (RCCL) and imports torch.
 """
 import argparse
 import json
@@ -34,6 +39,8 @@ os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 
 SEGMENTS = 16
 HBM_PEAK_GBPS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
+INFINITY_CACHE_BYTES = 256 << 20
+PMC_PROFILE = os.path.join("profiles", "r02_pmc_traffic.json")
 
 
 def parse_args():
@@ -51,7 +58,10 @@ def parse_args():
     ap.add_argument("--block", type=int, default=64, help="pivots per broadcast (N > 1)")
     ap.add_argument("--no-serpentine", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true",
+                    help="only the timed region: no fused / f64 / serpentine-off / cross-check legs")
     ap.add_argument("--no-fused-extra", action="store_true")
+    ap.add_argument("--no-f64-extra", action="store_true")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="process-group backend for N > 1 (gloo only to rehearse the N > 1 code path "
                          "with several ranks on one GPU; never a performance number)")
@@ -68,6 +78,8 @@ def parse_args():
         args.n, args.dtype, args.engine = 8192, "f32", "fused"
     elif args.config == 5:
         args.n, args.dtype, args.engine, args.with_next = 32768, "f32", "fused", True
+    if args.no_extras:
+        args.no_fused_extra = args.no_f64_extra = True
     return args
 
 
@@ -114,25 +126,408 @@ def cpu_baseline(rate_host, cpu_seconds):
 
 
 def pmc_traffic(n, args):
-    """HBM bytes per relax_k launch from the committed rocprofv3 PMC passes (profiles/), which
-    cannot be collected inside this process.  Only quoted for the exact configuration they were
-    measured on (N=16384 fp32 rates-only single GPU); otherwise null."""
-    path = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
-    if n != 16384 or args.dtype != "f32" or args.with_next or args.kslice or not os.path.exists(path):
+    """HBM bytes per relax_k launch from the rocprofv3 PMC passes over THIS command (`rocprofv3 --pmc
+    FETCH_SIZE -- python3 bench.py --steps 1 --warmup 0 --no-extras --no-cpu-baseline`, then
+    WRITE_SIZE; tools/pmc_summary.py turns the counter CSVs into profiles/r02_pmc_traffic.json).
+    Counters cannot be read from inside the process, so the line quotes the committed summary, and
+    only for the exact configuration it was measured on; otherwise null."""
+    path = os.path.join(ROOT, PMC_PROFILE)
+    if n != 16384 or args.dtype != "f32" or args.with_next or args.kslice or args.engine != "perk" \
+            or not os.path.exists(path):
         return None, None
     with open(path) as f:
         t = json.load(f)
-    return t["traffic_bytes_per_launch"], ("profiles/r01_pmc_traffic.json: rocprofv3 --pmc FETCH_SIZE "
-                                           "and --pmc WRITE_SIZE passes, FETCH_SIZE x2 (gfx950), KiB units")
+    return t["traffic_bytes_per_launch"], t.get("source", PMC_PROFILE)
+
+
+def digest(a):
+    """64-bit digest of an array's bytes (xxhash if present, else crc32 of 64 MiB chunks)."""
+    buf = memoryview(np.ascontiguousarray(a)).cast("B")
+    try:
+        import xxhash
+        h = xxhash.xxh64()
+        for off in range(0, len(buf), 1 << 26):
+            h.update(buf[off:off + (1 << 26)])
+        return "xxh64:" + h.hexdigest()
+    except ImportError:
+        import zlib
+        c = 0
+        for off in range(0, len(buf), 1 << 26):
+            c = zlib.crc32(buf[off:off + (1 << 26)], c)
+        return "crc32:%08x" % c
+
+
+def alg_bytes_per_launch(n, es, u_per_launch, with_next):
+    # SURVEY.md section 8d: B_alg = s*N^3 + s*U + 2*s*N^2 per solve (+4*U with next), per launch:
+    return es * n * n + (es + (4 if with_next else 0)) * u_per_launch + 2 * es * n
+
+
+def workload_config(args, n, k_end, serp, world):
+    return {"workload": "N=%d dense %s rate matrix (%s), full solve = %d pivot steps per step, %s%s"
+                        % (n, args.dtype, args.dist.upper(), k_end,
+                           "per-k engine" if args.engine == "perk"
+                           else "fused engine (64 pivots per pass)",
+                           ", with next-hop matrix" if args.with_next else ""),
+            "n": n, "engine": args.engine, "serpentine": serp,
+            "partition": "single GPU" if world == 1 else
+            "row-block x%d, %d-pivot snapshot panels broadcast on %s"
+            % (world, args.block, "RCCL" if args.backend == "nccl" else "gloo (rehearsal)")}
+
+
+def make_input(args, n):
+    """D1/D2 in float64 (the generators draw in f64 and round): (rate64, next)."""
+    from floydwarshall_amd import synth
+    cfg_index = {0: 3, 2: 1, 3: 2, 4: 3, 5: 4}[args.config]  # seed = BASE_SEED + configs[] index
+    return synth.GENERATORS[args.dist](n, np.float64, synth.BASE_SEED + cfg_index)
+
+
+# ------------------------------------------------------------------------------------------------
+# N = 1: torch-free
+# ------------------------------------------------------------------------------------------------
+def perk_solve(engine, hip, rate, nxt, n, k_end, serp, stream, upd=None, timed=False):
+    """All pivots of one solve as back-to-back launches on `stream`; with timed=True the pivots are
+    issued in SEGMENTS groups with a HIP event between groups (no synchronisation): per-segment
+    launch time shows how the cost moves with k.  Returns (events, segment bounds)."""
+    segs = [k_end * i // SEGMENTS for i in range(SEGMENTS + 1)] if timed else [0, k_end]
+    evs = []
+    for a, b in zip(segs[:-1], segs[1:]):
+        if timed:
+            evs.append(hip.Event())
+            evs[-1].record(stream)
+        if b > a:
+            engine.dev_relax(rate, n, 0, a, b, next_t=nxt, serpentine=serp, updates_t=upd,
+                             stream=stream)
+    if timed:
+        evs.append(hip.Event())
+        evs[-1].record(stream)
+    return evs, segs
+
+
+def run_single(args):
+    os.environ["FWX_NO_TORCH"] = "1"          # before the package maps libfwx
+    from floydwarshall_amd import engine, hip
+    assert "torch" not in sys.modules, "the N=1 benchmark must stay torch-free"
+    n = args.n
+    np_dtype = np.float32 if args.dtype == "f32" else np.float64
+    es = np.dtype(np_dtype).itemsize
+    rate64, next_host = make_input(args, n)
+    rate_host = rate64 if np_dtype == np.float64 else rate64.astype(np.float32)
+    want_f64 = (np_dtype == np.float32 and args.engine == "perk" and not args.kslice
+                and not args.no_f64_extra and not args.with_next)
+    if not want_f64:
+        del rate64
+
+    hip.set_device(0)
+    stream = hip.Stream()
+    pristine = hip.DeviceArray.from_numpy(rate_host)
+    rate = hip.DeviceArray(pristine.shape, np_dtype)
+    pristine_next = nxt = None
+    if args.with_next:
+        pristine_next = hip.DeviceArray.from_numpy(next_host)
+        nxt = hip.DeviceArray(pristine_next.shape, np.int32)
+    del next_host
+    upd = hip.DeviceArray((engine.FWX_UPDATE_SHARDS,), np.int64).zero_()
+    k_end = args.kslice if args.kslice > 0 else n
+    serp = not args.no_serpentine
+    relax_per_step = float(k_end) * n * n
+
+    handle = None
+    if args.engine == "fused":
+        # the shipped path: a device-resident handle keeps its workspace and look-ahead stream
+        handle = engine.DeviceMatrix(n, np_dtype, with_next=args.with_next, device=0)
+
+    ev_runs = []
+
+    def step(count=False, timed=False):
+        if handle is not None:
+            handle.upload_dev(pristine, pristine_next)          # D2D, blocks
+            t0 = time.perf_counter()
+            u = handle.solve(engine=engine.FWX_ENGINE_FUSED, k_end=k_end, count_updates=count)
+            if timed:
+                ev_runs.append(time.perf_counter() - t0)
+            return u
+        rate.copy_(pristine, stream)
+        if nxt is not None:
+            nxt.copy_(pristine_next, stream)
+        evs = perk_solve(engine, hip, rate, nxt, n, k_end, serp, stream,
+                         upd=upd if count else None, timed=timed)
+        if timed:
+            ev_runs.append(evs)
+        return None
+
+    updates = None
+    for w in range(args.warmup):
+        first = w == 0
+        u = step(count=first)
+        if first:
+            hip.synchronize()
+            updates = u if handle is not None else int(upd.numpy().sum())
+    hip.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step(timed=True)
+    hip.synchronize()
+    dt = time.perf_counter() - t0
+
+    out = {
+        "metric": "edge-relaxations/sec (N^3/t), N=%d %s" % (n, "fp32" if es == 4 else "fp64"),
+        "value": args.steps * relax_per_step / dt, "unit": "edge-relaxations/s", "n_gpus": 1,
+        "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps,
+        "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": args.dtype,
+        "data": "synthetic", "config": workload_config(args, n, k_end, serp, 1),
+        "host_runtime": "HIP runtime via ctypes (no torch in the process)",
+    }
+    if args.kslice > 0:
+        out["INVALID_debug_kslice"] = args.kslice
+    u_per_launch = (updates / float(k_end)) if updates is not None else 0.0
+
+    if handle is not None:
+        passes = (k_end + 63) // 64
+        kern_s = sum(ev_runs)
+        # HBM side of the fused engine: one pass reads and writes the matrix once (+ next when an
+        # entry changes) and reads two 64-row panels; the kernel is VALU-issue bound (DESIGN 4.2),
+        # so this fraction says how far from the HBM roof it runs, not how good it is
+        pass_bytes = 2.0 * es * n * n + 2 * 64 * es * n
+        achieved = pass_bytes * passes * args.steps / kern_s / 1e9
+        out["roofline"] = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                           "frac": achieved / HBM_PEAK_GBPS, "traffic": None,
+                           "kernel": "fwx::fused_main* (64 pivots per pass)",
+                           "avg_pass_us": 1e6 * kern_s / (passes * args.steps),
+                           "alg_bytes_per_pass": pass_bytes, "updates_per_solve": updates,
+                           "note": "VALU-issue-bound kernel: the HBM fraction is low by design "
+                                   "(0.13 B of HBM traffic per relaxation against 4 B for relax_k); "
+                                   "wall time of the blocking solve calls, panels included"}
+        out["fused"] = {"passes_per_solve": passes,
+                        "effective_GBps_at_per_k_bytes": es * relax_per_step * args.steps / kern_s / 1e9}
+    else:
+        launches = args.steps * k_end
+        kern_ms = sum(evs[0].elapsed_time(evs[-1]) for evs, _ in ev_runs)
+        evs, segs = ev_runs[-1]
+        seg_us = [round(1e3 * evs[i].elapsed_time(evs[i + 1]) / max(1, segs[i + 1] - segs[i]), 1)
+                  for i in range(len(evs) - 1)]
+        avg_us = 1e3 * kern_ms / launches
+        alg = alg_bytes_per_launch(n, es, u_per_launch, args.with_next)
+        achieved = alg / (avg_us * 1e-6) / 1e9
+        traffic, traffic_src = pmc_traffic(n, args)
+        cache_note = ("effective (Infinity Cache assisted): serpentine sweeps re-read the tail of the "
+                      "previous launch from the 256 MiB Infinity Cache, and FETCH_SIZE counts those "
+                      "hits; see serpentine_off for the plain streaming figure") if serp else \
+            "plain streaming sweep (serpentine off)"
+        if es * n * n <= INFINITY_CACHE_BYTES:
+            cache_note = "effective: the whole matrix fits the 256 MiB Infinity Cache"
+        out["roofline"] = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS,
+                           "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
+                           "traffic_source": traffic_src, "label": cache_note,
+                           "kernel": "fwx::relax_k", "avg_launch_us": avg_us,
+                           "alg_bytes_per_launch": alg, "updates_per_solve": updates,
+                           "frac_of_measured_copy_peak_6290": achieved / 6290.0,
+                           "avg_launch_us_by_k_sixteenth": seg_us}
+
+    extras = not args.no_extras and not args.kslice
+    timed_result = None
+    if handle is None and extras and not args.no_fused_extra:
+        timed_result = rate.numpy(stream)      # what the last TIMED per-k step left in HBM
+    if handle is None and extras and serp:
+        # the same solve with every launch sweeping in the same direction: nothing is re-read
+        # from the Infinity Cache on purpose
+        rate.copy_(pristine, stream)
+        if nxt is not None:
+            nxt.copy_(pristine_next, stream)
+        evs, _ = perk_solve(engine, hip, rate, nxt, n, k_end, False, stream, timed=True)
+        hip.synchronize()
+        us = 1e3 * evs[0].elapsed_time(evs[-1]) / k_end
+        ach = alg_bytes_per_launch(n, es, u_per_launch, args.with_next) / (us * 1e-6) / 1e9
+        out["roofline"]["serpentine_off"] = {"avg_launch_us": us, "achieved": ach,
+                                             "frac": ach / HBM_PEAK_GBPS, "steps": 1}
+
+    if handle is None and extras and not args.no_fused_extra:
+        # Not part of `value`: the same workload on the engine fwx_solve_* / fwx_matrix_solve pick
+        # by default (AUTO = fused, 64 pivots per pass, same bits), through a device-resident handle.
+        h = engine.DeviceMatrix(n, np_dtype, with_next=args.with_next, device=0)
+        def fused_step():
+            h.upload_dev(pristine, pristine_next)
+            t1 = time.perf_counter()
+            h.solve()
+            return time.perf_counter() - t1
+        fused_step()
+        ft = min(fused_step(), fused_step())
+        # VALU-issue bound of the max-form kernel (rates only, f32): 8.0 cycles per pair of
+        # relaxations per wave (tools/valu_rate.hip, profiles/r01_valu_issue_rates.txt), 1024 SIMDs
+        valu = None
+        if es == 4 and not args.with_next:
+            cyc = relax_per_step / 2.0 * 8.0 / 64.0 / 1024.0
+            valu = {"bound": "valu-issue", "cycles_per_pair_of_relaxations": 8.0,
+                    "at_measured_clock": {"clock_GHz": 1.92, "bound_ms_per_step": 1e3 * cyc / 1.92e9,
+                                          "frac": cyc / 1.92e9 / ft},
+                    "at_nominal_clock": {"clock_GHz": 2.4, "bound_ms_per_step": 1e3 * cyc / 2.4e9,
+                                         "frac": cyc / 2.4e9 / ft},
+                    "source": "profiles/r01_valu_issue_rates.txt; 1.92 GHz = GRBM_GUI_ACTIVE under "
+                              "this load, 2.4 GHz = MI355X_MICROARCH.md max engine clock"}
+        out["fused_engine"] = {"value": relax_per_step / ft, "unit": "edge-relaxations/s",
+                               "ms_per_step": 1e3 * ft, "steps": 2, "valu_roofline": valu,
+                               "note": "same workload on the default (AUTO) engine: fused, 64 pivots "
+                                       "per pass, bit-identical results, VALU-bound; not part of "
+                                       "`value`; best of 2, blocking fwx_matrix_solve calls"}
+        # cross-check of the TIMED launches: the matrix the last timed per-k step left in HBM must
+        # equal the fused engine's, bit for bit (neither is the oracle; the test-suite ties both to it)
+        fused_host = h.download()[0]
+        it = np.uint32 if es == 4 else np.uint64
+        same = bool(np.array_equal(timed_result.view(it), fused_host.view(it)))
+        out["check"] = {"per_k_equals_fused_bits": same, "rate_digest": digest(fused_host),
+                        "what": "matrix left in HBM by the last timed per-k step vs the fused engine's"}
+        del timed_result, fused_host
+        h.close()
+
+    if want_f64 and extras:
+        out["f64"] = f64_leg(engine, hip, rate64, n, stream)
+
+    if not args.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline(rate_host, args.cpu_seconds)
+    print(json.dumps(out), flush=True)
+
+
+def f64_leg(engine, hip, rate64, n, stream):
+    """The reference's own precision (Types.hs:26, `_bestRate :: Double`), same matrix before
+    rounding: per-k engine against HBM (8 B per relaxation) and the fused engine.  One solve each."""
+    pristine = hip.DeviceArray.from_numpy(rate64)
+    rate = hip.DeviceArray(pristine.shape, np.float64)
+    rate.copy_(pristine, stream)
+    perk_solve(engine, hip, rate, None, n, min(n, 512), True, stream)        # warm-up: 512 pivots
+    rate.copy_(pristine, stream)
+    evs, segs = perk_solve(engine, hip, rate, None, n, n, True, stream, timed=True)
+    hip.synchronize()
+    us = 1e3 * evs[0].elapsed_time(evs[-1]) / n
+    seg_us = [round(1e3 * evs[i].elapsed_time(evs[i + 1]) / max(1, segs[i + 1] - segs[i]), 1)
+              for i in range(len(evs) - 1)]
+    alg = alg_bytes_per_launch(n, 8, 0.0, False)   # the s*U/N term (~0.2 %) is left out: conservative
+    ach = alg / (us * 1e-6) / 1e9
+    res = {"per_k": {"ms_per_step": us * n / 1e3, "value": float(n) ** 3 / (us * n * 1e-6),
+                     "roofline": {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                                  "frac": ach / HBM_PEAK_GBPS, "kernel": "fwx::relax_k<double>",
+                                  "avg_launch_us": us, "alg_bytes_per_launch": alg,
+                                  "avg_launch_us_by_k_sixteenth": seg_us,
+                                  "label": "effective (Infinity Cache assisted, serpentine on)"}}}
+    h = engine.DeviceMatrix(n, np.float64, with_next=False, device=0)
+    times = []
+    for _ in range(2):
+        h.upload_dev(pristine)
+        t1 = time.perf_counter()
+        h.solve()
+        times.append(time.perf_counter() - t1)
+    ft = min(times)
+    same = bool(np.array_equal(h.download()[0].view(np.uint64), rate.numpy(stream).view(np.uint64)))
+    # f64 max form: v_mul_f64 + v_max_f64 = 8.7 measured issue cycles per relaxation
+    cyc = float(n) ** 3 * 8.7 / 64.0 / 1024.0
+    res["fused"] = {"ms_per_step": 1e3 * ft, "value": float(n) ** 3 / ft,
+                    "valu_roofline": {"cycles_per_relaxation": 8.7,
+                                      "at_measured_clock": {"clock_GHz": 1.92, "frac": cyc / 1.92e9 / ft},
+                                      "at_nominal_clock": {"clock_GHz": 2.4, "frac": cyc / 2.4e9 / ft}},
+                    "per_k_equals_fused_bits": same}
+    h.close()
+    res["note"] = "not part of `value`; same D1 matrix before rounding to f32; 1 solve per engine"
+    return res
+
+
+# ------------------------------------------------------------------------------------------------
+# N > 1: one process per GPU, torch.distributed over RCCL
+# ------------------------------------------------------------------------------------------------
+def run_dist(args, world, rank, local_rank):
+    import datetime
+    import torch
+    import torch.distributed as dist
+    from floydwarshall_amd import dist as fwdist
+
+    dev_index = local_rank % torch.cuda.device_count()   # one rank per GPU on a real node
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    # a rank that dies must fail the job quickly, not leave the others waiting in a collective
+    tmo = datetime.timedelta(seconds=240)
+    if args.backend == "nccl":
+        dist.init_process_group("nccl", device_id=dev, timeout=tmo)
+    else:
+        dist.init_process_group("gloo", timeout=tmo)
+
+    n = args.n
+    np_dtype = np.float32 if args.dtype == "f32" else np.float64
+    es = np.dtype(np_dtype).itemsize
+    rate64, next_host = make_input(args, n)
+    bounds = fwdist.row_bounds(n, world)
+    r0, r1 = bounds[rank], bounds[rank + 1]
+    pristine = torch.from_numpy(rate64[r0:r1].astype(np_dtype)).to(dev)
+    del rate64
+    rate = torch.empty_like(pristine)
+    pristine_next = nxt = None
+    if args.with_next:
+        pristine_next = torch.from_numpy(next_host[r0:r1]).to(dev)
+        nxt = torch.empty_like(pristine_next)
+    del next_host
+    k_end = n
+    backend = fwdist.HipBackend(args.engine)
+
+    def step():
+        rate.copy_(pristine)
+        if nxt is not None:
+            nxt.copy_(pristine_next)
+        fwdist.solve_partitioned(rate, n, rank, world, nxt=nxt, block=args.block, backend=backend)
+
+    def fence():
+        torch.cuda.synchronize()
+        dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    fence()
+    dt = time.perf_counter() - t0
+    t = torch.tensor([dt], dtype=torch.float64, device=dev)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    dt = float(t.item())
+
+    relax_per_step = float(k_end) * n * n
+    out = {
+        "metric": "edge-relaxations/sec (N^3/t), N=%d %s" % (n, "fp32" if es == 4 else "fp64"),
+        "value": args.steps * relax_per_step / dt, "unit": "edge-relaxations/s", "n_gpus": world,
+        "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps,
+        "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": args.dtype,
+        "data": "synthetic", "config": workload_config(args, n, k_end, True, world),
+    }
+    if args.backend != "nccl":
+        out["INVALID_rehearsal_backend"] = args.backend
+    # Aggregate HBM figure: every rank streams its slab once per pivot (per-k engine) -- algorithmic
+    # bytes of the whole solve over the wall time of the step (exchange and look-ahead included),
+    # against world x 8 TB/s.  A slab that fits the Infinity Cache is served from it: "effective".
+    slab_bytes = es * n * (bounds[1] - bounds[0])
+    if args.engine == "perk":
+        alg_total = es * relax_per_step + 2.0 * es * n * n
+        achieved = alg_total * args.steps / dt / 1e9
+        out["roofline"] = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS * world,
+                           "unit": "GB/s", "frac": achieved / (HBM_PEAK_GBPS * world), "traffic": None,
+                           "kernel": "fwx::relax_k on %d row-block slabs" % world,
+                           "label": ("effective (the %d MiB slab of each rank fits the 256 MiB Infinity "
+                                     "Cache: not an HBM-traffic claim)" % (slab_bytes >> 20))
+                           if slab_bytes <= INFINITY_CACHE_BYTES else "aggregate over ranks",
+                           "note": "algorithmic bytes of the solve (s*N^3 + 2*s*N^2; the s*U term, "
+                                   "~0.2 %, is left out) / wall time per step, all ranks; includes the "
+                                   "panel exchange"}
+    else:
+        pass_bytes = 2.0 * es * n * n + 2 * 64 * es * n * world
+        achieved = pass_bytes * ((k_end + 63) // 64) * args.steps / dt / 1e9
+        out["roofline"] = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS * world,
+                           "unit": "GB/s", "frac": achieved / (HBM_PEAK_GBPS * world), "traffic": None,
+                           "kernel": "fwx::fused_main* on %d row-block slabs" % world,
+                           "note": "VALU-issue-bound kernel: low HBM fraction by design"}
+    if rank == 0:
+        print(json.dumps(out), flush=True)
+    dist.destroy_process_group()
 
 
 def main():
     args = parse_args()
-    import torch
-    import torch.distributed as dist
-    from floydwarshall_amd import engine, synth
-    from floydwarshall_amd import dist as fwdist
-
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -140,191 +535,10 @@ def main():
         if world == 1 and args.gpus > 1:
             raise SystemExit("--gpus %d needs torch.distributed.run with %d ranks" % (args.gpus, args.gpus))
         args.gpus = world
-    dev_index = local_rank % torch.cuda.device_count()   # one rank per GPU on a real node
-    torch.cuda.set_device(dev_index)
-    dev = torch.device("cuda", dev_index)
-    if world > 1:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        import datetime
-        # a rank that dies must fail the job quickly, not leave the others waiting in a collective
-        tmo = datetime.timedelta(seconds=240)
-        if args.backend == "nccl":
-            dist.init_process_group("nccl", device_id=dev, timeout=tmo)
-        else:
-            dist.init_process_group("gloo", timeout=tmo)
-
-    n = args.n
-    np_dtype = np.float32 if args.dtype == "f32" else np.float64
-    es = np.dtype(np_dtype).itemsize
-    cfg_index = {0: 3, 2: 1, 3: 2, 4: 3, 5: 4}[args.config]  # seed = BASE_SEED + configs[] index
-    rate_host, next_host = synth.GENERATORS[args.dist](n, np_dtype, synth.BASE_SEED + cfg_index)
-
-    bounds = fwdist.row_bounds(n, world)
-    r0, r1 = bounds[rank], bounds[rank + 1]
-    pristine = torch.from_numpy(rate_host[r0:r1]).to(dev)
-    rate = torch.empty_like(pristine)
-    pristine_next = nxt = None
-    if args.with_next:
-        pristine_next = torch.from_numpy(next_host[r0:r1]).to(dev)
-        nxt = torch.empty_like(pristine_next)
-    del next_host
-    if not (rank == 0 and world == 1 and not args.no_cpu_baseline):
-        rate_host = None
-    upd = torch.zeros(engine.FWX_UPDATE_SHARDS, dtype=torch.int64, device=dev)
-    k_end = args.kslice if args.kslice > 0 else n
-    serp = not args.no_serpentine
-
-    dist_backend = fwdist.HipBackend(args.engine) if world > 1 else None
-    ev_pairs = []
-    fused_ws = None
-    if args.engine == "fused" and world == 1:
-        fused_ws = engine.FusedWorkspace(n, n, rate.dtype, dev, with_next=args.with_next)
-
-    def step(count=False, timed=False):
-        rate.copy_(pristine)
-        if nxt is not None:
-            nxt.copy_(pristine_next)
-        if world == 1 and fused_ws is not None:
-            if timed:
-                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                e0.record()
-            if count:
-                engine.dev_solve_fused(rate, n, 0, k_end, next_t=nxt, ws=fused_ws, updates_t=upd)
-            else:
-                engine.dev_solve(rate, next_t=nxt, engine=engine.FWX_ENGINE_FUSED, k_end=k_end)
-            if timed:
-                e1.record()
-                ev_pairs.append(([e0, e1], [0, k_end]))
-        elif world == 1:
-            # the pivots are issued in SEGMENTS back-to-back launches with a HIP event between
-            # segments (no synchronisation): per-segment launch time shows how the cost moves with k
-            segs = [k_end * i // SEGMENTS for i in range(SEGMENTS + 1)] if timed else [0, k_end]
-            evs = []
-            for a, b in zip(segs[:-1], segs[1:]):
-                if timed:
-                    evs.append(torch.cuda.Event(enable_timing=True))
-                    evs[-1].record()
-                if b > a:
-                    engine.dev_relax(rate, n, 0, a, b, next_t=nxt, serpentine=serp,
-                                     updates_t=upd if count else None)
-            if timed:
-                evs.append(torch.cuda.Event(enable_timing=True))
-                evs[-1].record()
-                ev_pairs.append((evs, segs))
-        else:
-            fwdist.solve_partitioned(rate, n, rank, world, nxt=nxt, block=args.block,
-                                     backend=dist_backend)
-
-    def fence():
-        torch.cuda.synchronize()
-        if world > 1:
-            dist.barrier()
-            torch.cuda.synchronize()
-
-    updates = None
-    for w in range(args.warmup):
-        first = (w == 0 and world == 1)
-        if first:
-            upd.zero_()
-        step(count=first)
-        if first:
-            torch.cuda.synchronize()
-            updates = int(upd.sum().item())
-    fence()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step(timed=True)
-    fence()
-    dt = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
-
-    relax_per_step = float(k_end) * n * n
-    value = args.steps * relax_per_step / dt
-    out = {
-        "metric": "edge-relaxations/sec (N^3/t), N=%d %s" % (n, "fp32" if es == 4 else "fp64"),
-        "value": value, "unit": "edge-relaxations/s", "n_gpus": world, "steps": args.steps,
-        "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True,
-        "scaling": "strong", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
-        "config": {"workload": "N=%d dense %s rate matrix (%s), full solve = %d pivot steps per "
-                               "step, %s%s" % (n, args.dtype, args.dist.upper(), k_end,
-                                               "per-k engine" if args.engine == "perk"
-                                               else "fused engine (64 pivots per pass)",
-                                               ", with next-hop matrix" if args.with_next else ""),
-                   "n": n, "engine": "perk", "serpentine": serp,
-                   "partition": "single GPU" if world == 1 else
-                   "row-block x%d, %d-pivot snapshot panels broadcast on RCCL" % (world, args.block)},
-    }
-    if args.kslice > 0:
-        out["INVALID_debug_kslice"] = args.kslice
-    if world > 1 and args.backend != "nccl":
-        out["INVALID_rehearsal_backend"] = args.backend
-
-    out["config"]["engine"] = args.engine
-    if world == 1 and ev_pairs and args.engine == "fused":
-        passes = args.steps * ((k_end + 63) // 64)
-        kern_ms = sum(evs[0].elapsed_time(evs[-1]) for evs, _ in ev_pairs)
-        out["fused"] = {"passes_per_solve": (k_end + 63) // 64, "avg_pass_us": 1e3 * kern_ms / passes,
-                        "effective_GBps_at_4B_per_relaxation": 4.0 * relax_per_step * args.steps / (kern_ms * 1e-3) / 1e9,
-                        "note": "VALU-issue-bound kernel (8.0 cycles per pair of relaxations, DESIGN 4.2); the GB/s figure is "
-                                "'effective' (algorithmic bytes of the per-k form), not an HBM roofline "
-                                "fraction", "updates_per_solve": updates}
-    elif world == 1 and ev_pairs:
-        launches = args.steps * k_end
-        kern_ms = sum(evs[0].elapsed_time(evs[-1]) for evs, _ in ev_pairs)
-        evs, segs = ev_pairs[-1]
-        seg_us = [round(1e3 * evs[i].elapsed_time(evs[i + 1]) / max(1, segs[i + 1] - segs[i]), 1)
-                  for i in range(len(evs) - 1)]
-        avg_us = 1e3 * kern_ms / launches
-        u_per_launch = (updates / float(k_end)) if updates is not None else 0.0
-        # B_alg = s*N^3 + s*U + 2*s*N^2 per solve (+4*U with next)
-        alg_bytes = es * n * n + (es + (4 if args.with_next else 0)) * u_per_launch + 2 * es * n
-        achieved = alg_bytes / (avg_us * 1e-6) / 1e9
-        traffic, traffic_src = pmc_traffic(n, args)
-        out["roofline"] = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS,
-                           "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
-                           "traffic_source": traffic_src,
-                           "kernel": "fwx::relax_k", "avg_launch_us": avg_us,
-                           "alg_bytes_per_launch": alg_bytes, "updates_per_solve": updates,
-                           "frac_of_measured_copy_peak_6290": achieved / 6290.0,
-                           "avg_launch_us_by_k_sixteenth": seg_us}
-    if world == 1 and args.engine == "perk" and not args.kslice and not args.no_fused_extra:
-        # Not part of `value`: the same workload on the fused engine (64 pivots per pass, same
-        # bits), measured after the timed region.  See DESIGN.md section 4.2.
-        ws = engine.FusedWorkspace(n, n, rate.dtype, dev, with_next=args.with_next)
-        def fused_step():
-            rate.copy_(pristine)
-            if nxt is not None:
-                nxt.copy_(pristine_next)
-            engine.dev_solve(rate, next_t=nxt, engine=engine.FWX_ENGINE_FUSED)
-        fused_step()
-        torch.cuda.synchronize()
-        t1 = time.perf_counter()
-        for _ in range(2):
-            fused_step()
-        torch.cuda.synchronize()
-        ft = (time.perf_counter() - t1) / 2
-        # VALU-issue bound of the max-form kernel (rates only, f32): 8.0 cycles per pair of
-        # relaxations per wave (tools/valu_rate.hip, profiles/r01_valu_issue_rates.txt), 1024 SIMDs,
-        # at the 1.92 GHz the chip holds under this load
-        valu = None
-        if es == 4 and not args.with_next:
-            bound_s = relax_per_step / 2.0 * 8.0 / 64.0 / 1024.0 / 1.92e9
-            valu = {"bound": "valu-issue", "cycles_per_pair_of_relaxations": 8.0, "clock_GHz": 1.92,
-                    "bound_ms_per_step": 1e3 * bound_s, "frac": bound_s / ft,
-                    "source": "profiles/r01_valu_issue_rates.txt"}
-        out["fused_engine"] = {"value": relax_per_step / ft, "unit": "edge-relaxations/s",
-                               "ms_per_step": 1e3 * ft, "steps": 2, "valu_roofline": valu,
-                               "note": "same workload, fused engine (64 pivots per pass, bit-identical "
-                                       "results, VALU-bound); not part of `value`"}
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        out["cpu_baseline"] = cpu_baseline(rate_host, args.cpu_seconds)
-    if rank == 0:
-        print(json.dumps(out), flush=True)
-    if world > 1:
-        dist.destroy_process_group()
+    if world == 1:
+        run_single(args)
+    else:
+        run_dist(args, world, rank, local_rank)
 
 
 if __name__ == "__main__":

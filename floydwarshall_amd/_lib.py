@@ -15,6 +15,7 @@ FWX_ERR_CYCLE = -5
 FWX_ERR_CAPACITY = -6
 FWX_ERR_UNSUPPORTED = -7
 
+FWX_ABI_VERSION = 2
 FWX_F32, FWX_F64 = 0, 1
 FWX_ENGINE_AUTO, FWX_ENGINE_PERK, FWX_ENGINE_FUSED = 0, 1, 2
 FWX_UPDATE_SHARDS = 256
@@ -28,7 +29,8 @@ c_vp = ctypes.c_void_p
 class FwxOpts(ctypes.Structure):
     _fields_ = [("struct_size", ctypes.c_uint32), ("device", c_i32), ("engine", c_i32),
                 ("k_begin", c_i32), ("k_end", c_i32), ("block", c_i32), ("serpentine", c_i32),
-                ("updates_out", ctypes.POINTER(ctypes.c_uint64))]
+                ("updates_out", ctypes.POINTER(ctypes.c_uint64)), ("stream", c_vp),
+                ("use_stream", c_i32), ("reserved0", c_i32)]
 
 
 class FwxSlab(ctypes.Structure):
@@ -38,7 +40,7 @@ class FwxSlab(ctypes.Structure):
 
 class FwxPivots(ctypes.Structure):
     _fields_ = [("k_begin", c_i32), ("k_end", c_i32), ("rate", c_vp), ("hops", c_vp),
-                ("stride", ctypes.c_int64)]
+                ("stride", ctypes.c_int64), ("next", c_vp)]
 
 
 class FwxError(RuntimeError):
@@ -104,16 +106,19 @@ def lib():
         # SONAME as /opt/rocm's).  If torch is going to be used in this process it must be loaded
         # FIRST, so that libfwx's DT_NEEDED resolves to the copy torch initialises; the other
         # order leaves torch with "No HIP GPUs are available".  libfwx itself does not need torch.
-        try:
-            import torch  # noqa: F401
-        except ImportError:
-            pass
+        # FWX_NO_TORCH=1: a torch-free process (the N=1 benchmark, the C consumer's Python twin):
+        # libfwx then binds to the HIP runtime it was linked against and nothing else is mapped.
+        if os.environ.get("FWX_NO_TORCH") != "1":
+            try:
+                import torch  # noqa: F401
+            except ImportError:
+                pass
         L = ctypes.CDLL(LIB_PATH)
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(L, name)  # AttributeError here = header/library mismatch
             fn.restype = res
             fn.argtypes = args
-        if L.fwx_abi_version() != 1:
+        if L.fwx_abi_version() != FWX_ABI_VERSION:
             raise RuntimeError("libfwx ABI version mismatch")
         _LIB = L
     return _LIB

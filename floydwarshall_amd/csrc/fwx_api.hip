@@ -3,6 +3,7 @@
 // Replaces runAlgo (/root/reference/src/lib/Algorithms.hs:42-61) behind floydWarshall (:19-20).
 // No CPU fallback: every solve entry point needs a HIP device and says so when there is none.
 #include <hip/hip_runtime.h>
+#include <stddef.h>
 #include <stdint.h>
 #include <stdlib.h>
 #include <string.h>
@@ -64,6 +65,53 @@ struct DeviceGuard {
 struct Opts {
     int device = -1, engine = FWX_ENGINE_AUTO, k_begin = 0, k_end = 0, block = 0, serpentine = 1;
     uint64_t *updates_out = nullptr;
+    hipStream_t stream = nullptr;      // caller's stream (fwx_opts.stream), nullptr = library-owned
+    bool has_stream = false;
+};
+
+// The stream one blocking ABI call runs on: the caller's (fwx_opts.stream) or a non-blocking stream
+// of its own -- never the legacy null stream, which would serialise the call against every other
+// blocking stream of the process (torch's included) and against solves on other host threads.
+struct CallStream {
+    hipStream_t s = nullptr;
+    bool owned = false;
+    int open(const Opts &op)
+    {
+        if (op.has_stream) { s = op.stream; return FWX_OK; }
+        FWX_HIP(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
+        owned = true;
+        return FWX_OK;
+    }
+    ~CallStream() { if (owned && s) (void)hipStreamDestroy(s); }
+};
+
+// Bounds the number of launches in flight on a stream: every EVERY launches an event is recorded
+// and the host waits for the event recorded 2*EVERY launches earlier.  The GPU never idles (at
+// least EVERY launches are queued behind the one being waited for), but a solve of N = 16384
+// pivots no longer parks 16384 dispatches in the queue: rocprofv3's counter collection, which
+// intercepts every AQL packet, crashed on exactly that.
+struct Throttle {
+    static constexpr int EVERY = 256;
+    hipEvent_t ev[2] = {nullptr, nullptr};
+    bool armed[2] = {false, false};
+    int count = 0, slot = 0;
+    ~Throttle()
+    {
+        for (int i = 0; i < 2; ++i)
+            if (ev[i]) (void)hipEventDestroy(ev[i]);
+    }
+    int tick(hipStream_t s, int launches = 1)
+    {
+        count += launches;
+        if (count < EVERY) return FWX_OK;
+        count = 0;
+        if (!ev[slot]) FWX_HIP(hipEventCreateWithFlags(&ev[slot], hipEventDisableTiming));
+        if (armed[slot]) FWX_HIP(hipEventSynchronize(ev[slot]));
+        FWX_HIP(hipEventRecord(ev[slot], s));
+        armed[slot] = true;
+        slot ^= 1;
+        return FWX_OK;
+    }
 };
 
 int read_opts(const fwx_opts *o, int n, Opts &out)
@@ -77,6 +125,10 @@ int read_opts(const fwx_opts *o, int n, Opts &out)
         out.block = o->block;
         out.serpentine = o->serpentine == 0 ? 1 : 0;
         out.updates_out = o->updates_out;
+        if (o->struct_size >= offsetof(fwx_opts, stream) + sizeof(void *) && o->use_stream) {
+            out.stream = (hipStream_t)o->stream;
+            out.has_stream = true;
+        }
     }
     if (out.k_end <= 0) out.k_end = n;
     if (out.k_begin < 0 || out.k_begin > out.k_end || out.k_end > n) return FWX_ERR_INVALID;
@@ -91,20 +143,24 @@ template <typename T>
 int relax_range(T *rate, int32_t *next, int32_t *hops, int rows, int n, int row0, const T *prow0,
                 const int32_t *phops0, int64_t stride, int k_begin, int k_end, int serpentine,
                 unsigned long long *d_updates, hipStream_t s, fwx::PathLog plog = fwx::PathLog(),
-                int skip_lo = 0, int skip_hi = 0)
+                int skip_lo = 0, int skip_hi = 0, const int32_t *pnext0 = nullptr)
 {
     fwx::RelaxArgs<T> a;
+    Throttle thr;
     a.rate = rate; a.next = next; a.hops = hops;
     a.rows = rows; a.n = n; a.row0 = row0; a.updates = d_updates; a.plog = plog;
     a.skip_lo = skip_lo; a.skip_hi = skip_hi;
     for (int k = k_begin; k < k_end; ++k) {
         a.prow = prow0 + (int64_t)(k - k_begin) * stride;
         a.phops = phops0 ? phops0 + (int64_t)(k - k_begin) * stride : nullptr;
+        a.pnext = pnext0 ? pnext0 + (int64_t)(k - k_begin) * stride : nullptr;
         a.k = k;
         a.flip = serpentine ? (k & 1) : 0;
         const hipError_t e = fwx::launch_relax<T>(a, s);
         if (e == hipErrorInvalidValue) return FWX_ERR_INVALID;   // misaligned skip range
         FWX_HIP(e);
+        const int rc = thr.tick(s);
+        if (rc) return rc;
     }
     return FWX_OK;
 }
@@ -161,7 +217,8 @@ struct SideStream {
 
 template <typename T>
 int fused_range(T *rate, int32_t *next, int n, int k_begin, int k_end, void *ws,
-                unsigned long long *d_updates, hipStream_t s, fwx::PathLog plog = fwx::PathLog())
+                unsigned long long *d_updates, hipStream_t s, fwx::PathLog plog, bool nonneg,
+                SideStream *kept_side = nullptr)
 {
     char *p = (char *)ws;
     const int ld = (n + 3) & ~3;
@@ -171,25 +228,19 @@ int fused_range(T *rate, int32_t *next, int n, int k_begin, int k_end, void *ws,
     T *ct = (T *)p;                p += (size_t)FWX_FUSED_B * ld * sizeof(T);
     int32_t *cnt = (int32_t *)p;   p += (size_t)FWX_FUSED_B * ld * sizeof(int32_t);
     T *diag = (T *)p;              p += (size_t)2 * FWX_FUSED_B * FWX_FUSED_B * sizeof(T);
-    bool nonneg = false;
-    if (!next && !d_updates) {
-        // one read of the matrix decides whether the max-form kernel may be used (see fwx.h)
-        int *flag = (int *)(((uintptr_t)p + 15) & ~(uintptr_t)15);
-        int h = 1;
-        FWX_HIP(hipMemcpyAsync(flag, &h, sizeof(int), hipMemcpyHostToDevice, s));
-        FWX_HIP(fwx::launch_nonneg_check(rate, (size_t)n * n, flag, s));
-        FWX_HIP(hipMemcpyAsync(&h, flag, sizeof(int), hipMemcpyDeviceToHost, s));
-        FWX_HIP(hipStreamSynchronize(s));
-        nonneg = h == 1;
-    }
     if (k_end <= k_begin) return FWX_OK;
-    SideStream side;
-    int rc = side.init();
-    if (rc) return rc;
+    SideStream local_side;
+    SideStream &side = kept_side ? *kept_side : local_side;
+    if (!side.s) {
+        const int rc = side.init();
+        if (rc) return rc;
+    }
+    Throttle thr;
 
     fwx::FusedArgs<T> a;
     a.rate = rate; a.next = next; a.rows = n; a.n = n; a.row0 = 0;
-    a.ct = ct; a.cnt = next ? cnt : nullptr; a.ct_ld = ld; a.updates = d_updates; a.nonneg = nonneg;
+    a.ct = ct; a.cnt = next ? cnt : nullptr; a.ct_ld = ld; a.updates = d_updates;
+    a.nonneg = nonneg;     // the caller has run the domain check (route_solve)
     a.plog = plog;         // path trace: kept by all three kernels of a pass (needs next)
 
     int bi = 0;
@@ -224,6 +275,8 @@ int fused_range(T *rate, int32_t *next, int n, int k_begin, int k_end, void *ws,
         } else {
             FWX_HIP(fwx::launch_fused_main<T>(a, 0, n, s));
         }
+        const int rc = thr.tick(s, 4);
+        if (rc) return rc;
     }
     // the side stream's work is ordered before `s` by the last panel_done wait (or it never ran)
     FWX_HIP(hipStreamSynchronize(s));
@@ -243,6 +296,60 @@ template <typename T> bool pick_fused(int engine, int n, const void *rate, const
     if (engine == FWX_ENGINE_PERK) return false;
     if (!fused_ok<T>(n, rate, hops)) return false;
     return engine == FWX_ENGINE_FUSED || n >= 256;   // tools/measure_small.py: fused wins from 256
+}
+
+// AUTO / FUSED for a matrix that carries hops: whole range, next present, readable dimensions.
+template <typename T>
+bool pick_fused_hops(int engine, int n, const void *rate, const int32_t *next, const int32_t *hops,
+                     bool whole_range)
+{
+    if (!hops || !next || engine == FWX_ENGINE_PERK || !fused_dims_ok<T>(n, rate)) return false;
+    // tools/measure_hops.py: the per-k engine is ahead up to n ~ 2048 (7 against 22 ms at 1024),
+    // the fused route from there on (38 against 72 ms at 4096, 0.86 against ~3 s at 16384)
+    return whole_range && (engine == FWX_ENGINE_FUSED || n >= 3072);
+}
+
+// One read of the matrix (fwx.h "Domain"): bit 0 = every rate is >= +0.0 and not NaN; bit 1 = no
+// entry has a non-zero rate and next < 0.  d_flag: a device int the caller owns.
+template <typename T>
+int domain_bits(const T *rate, const int32_t *next, size_t count, int *d_flag, hipStream_t s, int &bits)
+{
+    int h = 3;
+    FWX_HIP(hipMemcpyAsync(d_flag, &h, sizeof(int), hipMemcpyHostToDevice, s));
+    FWX_HIP(fwx::launch_nonneg_check(rate, next, count, d_flag, s));
+    FWX_HIP(hipMemcpyAsync(&h, d_flag, sizeof(int), hipMemcpyDeviceToHost, s));
+    FWX_HIP(hipStreamSynchronize(s));
+    bits = h;
+    return FWX_OK;
+}
+
+// Which engine runs a solve of pivots [k_begin, k_end) of an order-n matrix (pivots < n only for a
+// matrix padded by the host-buffer path).
+enum Route { ROUTE_SMALL, ROUTE_PERK, ROUTE_FUSED, ROUTE_FUSED_HOPS };
+template <typename T>
+int route_solve(const Opts &op, int n, bool whole, const T *rate, const int32_t *next,
+                const int32_t *hops, bool counting, int *d_flag, hipStream_t s, Route &route,
+                bool &nonneg)
+{
+    nonneg = false;
+    const bool hops_fused = pick_fused_hops<T>(op.engine, n, rate, next, hops, whole);
+    if (op.engine == FWX_ENGINE_FUSED && !hops_fused && !fused_ok<T>(n, rate, hops))
+        return FWX_ERR_UNSUPPORTED;
+    if (op.engine == FWX_ENGINE_AUTO && n <= FWX_SMALL_N) { route = ROUTE_SMALL; return FWX_OK; }
+    if (!hops_fused && !pick_fused<T>(op.engine, n, rate, hops)) { route = ROUTE_PERK; return FWX_OK; }
+    // The fused kernels take next[i][k] as the head of ikPath ++ kjPath (Algorithms.hs:55), which
+    // is the reference's list head only while a winning product never has an empty ikPath -- true
+    // on the reference's own domain, checked here.  Outside it the per-k engine, which reads the
+    // pivot row's next-hops for exactly that case, runs the solve (same bits as the reference).
+    int bits = 0;
+    if (next || !counting) {
+        const int rc = domain_bits<T>(rate, next, (size_t)n * n, d_flag, s, bits);
+        if (rc) return rc;
+    }
+    if (next && bits != 3) { route = ROUTE_PERK; return FWX_OK; }
+    nonneg = !next && !counting && (bits & 1);
+    route = hops_fused ? ROUTE_FUSED_HOPS : ROUTE_FUSED;
+    return FWX_OK;
 }
 
 int sum_updates(unsigned long long *d_updates, uint64_t *out, hipStream_t s)
@@ -325,7 +432,7 @@ int fused_with_hops(T *rate, int32_t *next, int32_t *hops, int n, int pivots,
     if ((rc = d_lcol.alloc(nn * 4)) || (rc = d_lrow.alloc(nn * 4)) ||
         (rc = d_ws.alloc(fused_ws_bytes(n, sizeof(T)))))
         return rc;
-    if ((rc = fused_range<T>(rate, next, n, 0, pivots, d_ws.p, d_updates, s, plog))) return rc;
+    if ((rc = fused_range<T>(rate, next, n, 0, pivots, d_ws.p, d_updates, s, plog, false))) return rc;
     const dim3 grid((unsigned)((2 * (size_t)n + 255) / 256)), block(256);
     for (int k = 0; k < pivots; ++k)
         hipLaunchKernelGGL(hops_dp_step, grid, block, 0, s, plog.at_col, plog.at_row, hops,
@@ -338,17 +445,6 @@ int fused_with_hops(T *rate, int32_t *next, int32_t *hops, int n, int pivots,
     FWX_HIP(hipGetLastError());
     FWX_HIP(hipStreamSynchronize(s));      // the scratch is released at scope exit
     return FWX_OK;
-}
-
-// AUTO / FUSED for a matrix that carries hops: whole range, next present, readable dimensions.
-template <typename T>
-bool pick_fused_hops(int engine, int n, const void *rate, const int32_t *next, const int32_t *hops,
-                     bool whole_range)
-{
-    if (!hops || !next || engine == FWX_ENGINE_PERK || !fused_dims_ok<T>(n, rate)) return false;
-    // tools/measure_hops.py: the per-k engine is ahead up to n ~ 2048 (7 against 22 ms at 1024),
-    // the fused route from there on (38 against 72 ms at 4096, 0.86 against ~3 s at 16384)
-    return whole_range && (engine == FWX_ENGINE_FUSED || n >= 3072);
 }
 
 template <typename T>
@@ -380,9 +476,12 @@ int solve_host(int32_t n, T *rate, int32_t *next, int32_t *hops, const fwx_opts 
     if ((rc = d_rate.alloc(nn * sizeof(T)))) return rc;
     if (next && (rc = d_next.alloc(nn * sizeof(int32_t)))) return rc;
     if (hops && (rc = d_hops.alloc(nn * sizeof(int32_t)))) return rc;
-    if ((rc = d_upd.alloc(FWX_UPDATE_SHARDS * sizeof(unsigned long long)))) return rc;
+    if ((rc = d_upd.alloc((FWX_UPDATE_SHARDS + 2) * sizeof(unsigned long long)))) return rc;
+    int *d_flag = (int *)((unsigned long long *)d_upd.p + FWX_UPDATE_SHARDS);
 
-    hipStream_t s = nullptr;
+    CallStream cs;                     // a non-blocking stream of this call's own
+    if ((rc = cs.open(op))) return rc;
+    hipStream_t s = cs.s;
     auto copy2d = [&](void *dst, size_t dpitch, const void *src, size_t spitch, size_t es,
                       hipMemcpyKind kind) -> int {
         if (dpitch == spitch)
@@ -402,28 +501,36 @@ int solve_host(int32_t n, T *rate, int32_t *next, int32_t *hops, const fwx_opts 
     FWX_HIP(hipMemsetAsync(d_upd.p, 0, FWX_UPDATE_SHARDS * sizeof(unsigned long long), s));
 
     T *dr = (T *)d_rate.p;
-    int32_t *dh = (int32_t *)d_hops.p;
+    int32_t *dn = (int32_t *)d_next.p, *dh = (int32_t *)d_hops.p;
     unsigned long long *upd = op.updates_out ? (unsigned long long *)d_upd.p : nullptr;
-    const bool hops_fused = pick_fused_hops<T>(op.engine, nd, dr, (int32_t *)d_next.p, dh, whole);
-    if (op.engine == FWX_ENGINE_FUSED && !hops_fused && !fused_ok<T>(nd, dr, dh))
-        return FWX_ERR_UNSUPPORTED;
-    if (op.engine == FWX_ENGINE_AUTO && n <= FWX_SMALL_N) {
+    Route route;
+    bool nonneg = false;
+    // (a padded matrix is routed by its real order n -- the single-launch engine never sees one --
+    // and solved over its real pivots only: the padding is inert)
+    if (nd == n) {
+        if ((rc = route_solve<T>(op, n, whole, dr, dn, dh, upd != nullptr, d_flag, s, route, nonneg))) return rc;
+    } else {
+        Opts opd = op;
+        opd.engine = FWX_ENGINE_FUSED;
+        if ((rc = route_solve<T>(opd, nd, whole, dr, dn, dh, upd != nullptr, d_flag, s, route, nonneg))) return rc;
+    }
+    if (route == ROUTE_SMALL) {
         // the reference's own regime: the whole solve in one single-workgroup launch
-        FWX_HIP(fwx::launch_small_solve<T>(dr, (int32_t *)d_next.p, dh, n, op.k_begin, op.k_end, upd,
-                                           fwx::PathLog(), s));
-    } else if (hops_fused) {
-        // (a padded matrix is solved over its real pivots only: the padding is inert)
-        if ((rc = fused_with_hops<T>(dr, (int32_t *)d_next.p, dh, nd, n, upd, s, fwx::PathLog()))) return rc;
-    } else if (pick_fused<T>(op.engine, nd, dr, dh)) {
+        FWX_HIP(fwx::launch_small_solve<T>(dr, dn, dh, n, op.k_begin, op.k_end, upd, fwx::PathLog(), s));
+    } else if (route == ROUTE_FUSED_HOPS) {
+        if ((rc = fused_with_hops<T>(dr, dn, dh, nd, n, upd, s, fwx::PathLog()))) return rc;
+    } else if (route == ROUTE_FUSED) {
         DevBuf d_ws;
         if ((rc = d_ws.alloc(fused_ws_bytes(nd, sizeof(T))))) return rc;
-        rc = fused_range<T>(dr, (int32_t *)d_next.p, nd, op.k_begin, op.k_end, d_ws.p, upd, s);
+        rc = fused_range<T>(dr, dn, nd, op.k_begin, op.k_end, d_ws.p, upd, s, fwx::PathLog(), nonneg);
         if (rc) return rc;
         FWX_HIP(hipStreamSynchronize(s));   // d_ws is released at scope exit
     } else {
-        rc = relax_range<T>(dr, (int32_t *)d_next.p, dh, n, n, 0, dr + (size_t)op.k_begin * n,
-                            dh ? dh + (size_t)op.k_begin * n : nullptr, n, op.k_begin, op.k_end,
-                            op.serpentine, upd, s);
+        // per-k engine; pitch nd (a matrix padded for the fused engine but found outside its domain)
+        rc = relax_range<T>(dr, dn, dh, nd, nd, 0, dr + (size_t)op.k_begin * nd,
+                            dh ? dh + (size_t)op.k_begin * nd : nullptr, nd, op.k_begin, op.k_end,
+                            op.serpentine, upd, s, fwx::PathLog(), 0, 0,
+                            dn ? dn + (size_t)op.k_begin * nd : nullptr);
         if (rc) return rc;
     }
 
@@ -445,7 +552,7 @@ __global__ void follow_path_kernel(const int32_t *next, int n, int src, int dst,
     if (next[(size_t)src * n + dst] < 0) { *len_out = 0; return; }
     while (cur != dst || len == 0) {
         const int nx = next[(size_t)cur * n + dst];
-        if (nx < 0 || len >= n) { *len_out = FWX_ERR_CYCLE; return; }
+        if (nx < 0 || nx >= n || len >= n) { *len_out = FWX_ERR_CYCLE; return; }
         if (len >= cap) { *len_out = FWX_ERR_CAPACITY; return; }
         out[len++] = nx;
         cur = nx;
@@ -536,6 +643,13 @@ struct fwx_matrix {
     int32_t rec_ready;     // a traced solve of the current upload has completed
     int32_t fresh;         // the arrays hold an uploaded input that has not been solved yet
     unsigned long long last_u;   // U of the last traced solve
+    hipStream_t stream;    // the handle's own non-blocking stream: every operation on the handle runs
+                           // on it (never the legacy null stream), so handles on different host
+                           // threads overlap and nothing synchronises with torch's streams
+    void *ws;              // fused-engine workspace, allocated by the first fused solve and kept
+    size_t ws_bytes;
+    SideStream *side;      // look-ahead stream + events of the fused engine, kept likewise
+    int *flag;             // device int for the domain check
 };
 
 namespace {
@@ -544,28 +658,56 @@ int matrix_solve_typed(fwx_matrix *m, const Opts &op, unsigned long long *upd, h
 {
     const int n = m->n;
     T *r = (T *)m->rate;
-    const bool hops_fused = pick_fused_hops<T>(op.engine, n, r, m->next, m->hops,
-                                               op.k_begin == 0 && op.k_end == n);
-    if (op.engine == FWX_ENGINE_FUSED && !hops_fused && !fused_ok<T>(n, r, m->hops))
-        return FWX_ERR_UNSUPPORTED;
-    if (op.engine == FWX_ENGINE_AUTO && n <= FWX_SMALL_N) {
+    Route route;
+    bool nonneg = false;
+    DevBuf tmp_flag;
+    int *d_flag = m->flag;
+    int rc;
+    if (!d_flag) {                       // fwx_dev_solve: a view of caller-owned memory
+        if ((rc = tmp_flag.alloc(16))) return rc;
+        d_flag = (int *)tmp_flag.p;
+    }
+    m->fresh = 0;                        // whatever happens next, the arrays are no longer the upload
+    if ((rc = route_solve<T>(op, n, op.k_begin == 0 && op.k_end == n, r, m->next, m->hops, upd != nullptr,
+                             d_flag, s, route, nonneg)))
+        return rc;
+    if (route == ROUTE_SMALL) {
         FWX_HIP(fwx::launch_small_solve<T>(r, m->next, m->hops, n, op.k_begin, op.k_end, upd,
                                            m->plog, s));
         return FWX_OK;
     }
-    if (hops_fused) return fused_with_hops<T>(r, m->next, m->hops, n, n, upd, s, m->plog);
-    if (pick_fused<T>(op.engine, n, r, m->hops)) {
-        DevBuf ws;
-        int rc = ws.alloc(fused_ws_bytes(n, sizeof(T)));
-        if (rc) return rc;
-        rc = fused_range<T>(r, m->next, n, op.k_begin, op.k_end, ws.p, upd, s, m->plog);
+    if (route == ROUTE_FUSED_HOPS) return fused_with_hops<T>(r, m->next, m->hops, n, n, upd, s, m->plog);
+    if (route == ROUTE_FUSED) {
+        // a handle keeps its workspace and look-ahead stream across solves; a view allocates per call
+        const size_t need = fused_ws_bytes(n, sizeof(T));
+        DevBuf tmp_ws;
+        void *ws = nullptr;
+        SideStream *side = nullptr;
+        if (m->flag) {
+            if (m->ws_bytes < need) {
+                if (m->ws) { (void)hipFree(m->ws); m->ws = nullptr; m->ws_bytes = 0; }
+                FWX_HIP(hipMalloc(&m->ws, need));
+                m->ws_bytes = need;
+            }
+            if (!m->side) {
+                m->side = new (std::nothrow) SideStream();
+                if (!m->side) return FWX_ERR_OOM;
+            }
+            ws = m->ws;
+            side = m->side;
+        } else {
+            if ((rc = tmp_ws.alloc(need))) return rc;
+            ws = tmp_ws.p;
+        }
+        rc = fused_range<T>(r, m->next, n, op.k_begin, op.k_end, ws, upd, s, m->plog, nonneg, side);
         if (rc) return rc;
         FWX_HIP(hipStreamSynchronize(s));
         return FWX_OK;
     }
     return relax_range<T>(r, m->next, m->hops, n, n, 0, r + (size_t)op.k_begin * n,
                           m->hops ? m->hops + (size_t)op.k_begin * n : nullptr, n, op.k_begin,
-                          op.k_end, op.serpentine, upd, s, m->plog);
+                          op.k_end, op.serpentine, upd, s, m->plog, 0, 0,
+                          m->next ? m->next + (size_t)op.k_begin * n : nullptr);
 }
 
 // Solve with the path trace (PathLog): one pass.  `last` starts at -1 everywhere; the kernels set
@@ -744,6 +886,8 @@ int fwx_matrix_create(fwx_matrix **out, int32_t n, int32_t dtype, int32_t with_n
     if (e == hipSuccess && with_hops) e = hipMalloc((void **)&m->hops, nn * 4 ? nn * 4 : 1);
     if (e == hipSuccess) e = hipMalloc((void **)&m->scratch, ((size_t)n + 2) * 4);
     if (e == hipSuccess) e = hipMalloc((void **)&m->upd, FWX_UPDATE_SHARDS * 8);
+    if (e == hipSuccess) e = hipMalloc((void **)&m->flag, 16);
+    if (e == hipSuccess) e = hipStreamCreateWithFlags(&m->stream, hipStreamNonBlocking);
     if (e != hipSuccess) {
         g_last_hip = (int)e;
         (void)hipGetLastError();
@@ -769,6 +913,11 @@ int fwx_matrix_destroy(fwx_matrix *m)
     if (m->plog.at_row) (void)hipFree(m->plog.at_row);
     if (m->next0) (void)hipFree(m->next0);
     if (m->walk) (void)hipFree(m->walk);
+    if (m->stream) (void)hipStreamSynchronize(m->stream);
+    if (m->ws) (void)hipFree(m->ws);
+    if (m->flag) (void)hipFree(m->flag);
+    delete m->side;
+    if (m->stream) (void)hipStreamDestroy(m->stream);
     delete m;
     return FWX_OK;
 }
@@ -782,13 +931,17 @@ int fwx_matrix_upload(fwx_matrix *m, const void *rate, const int32_t *next, cons
     int rc = g.enter(m->device);
     if (rc) return rc;
     const size_t nn = (size_t)m->n * (size_t)m->n, es = m->dtype == FWX_F64 ? 8 : 4;
-    FWX_HIP(hipMemcpy(m->rate, rate, nn * es, hipMemcpyHostToDevice));
-    if (m->next) FWX_HIP(hipMemcpy(m->next, next, nn * 4, hipMemcpyHostToDevice));
-    if (m->hops) FWX_HIP(hipMemcpy(m->hops, hops, nn * 4, hipMemcpyHostToDevice));
+    // hipMemcpyDefault: the sources may be host arrays (what an FFI hands over) or device arrays
+    // (a caller that keeps its pristine input in HBM, e.g. the benchmark)
+    hipStream_t s = m->stream;
+    FWX_HIP(hipMemcpyAsync(m->rate, rate, nn * es, hipMemcpyDefault, s));
+    if (m->next) FWX_HIP(hipMemcpyAsync(m->next, next, nn * 4, hipMemcpyDefault, s));
+    if (m->hops) FWX_HIP(hipMemcpyAsync(m->hops, hops, nn * 4, hipMemcpyDefault, s));
     if (m->plog.last) {     // traced matrix: keep the uploaded next-hops (paths of entries never improved)
-        FWX_HIP(hipMemcpyAsync(m->next0, m->next, nn * 4, hipMemcpyDeviceToDevice, nullptr));
+        FWX_HIP(hipMemcpyAsync(m->next0, m->next, nn * 4, hipMemcpyDeviceToDevice, s));
         m->rec_ready = 0;   // the trace of an earlier input is stale
     }
+    FWX_HIP(hipStreamSynchronize(s));
     m->fresh = 1;
     return FWX_OK;
 }
@@ -805,7 +958,14 @@ int fwx_matrix_enable_path_log(fwx_matrix *m)
     FWX_HIP(hipMalloc((void **)&m->plog.at_row, nn * 4));
     FWX_HIP(hipMalloc((void **)&m->next0, nn * 4));
     FWX_HIP(hipMalloc((void **)&m->plog.last, nn * 4));      // last: `last != nullptr` = enabled
-    FWX_HIP(hipMemcpy(m->next0, m->next, nn * 4, hipMemcpyDeviceToDevice));
+    // next0 = the UPLOADED next-hops.  If the arrays already hold an unsolved upload, keep it;
+    // otherwise (nothing uploaded yet, or already solved) `fresh` is 0 and a traced solve is
+    // refused until the next upload, which fills next0.
+    if (m->fresh) {
+        FWX_HIP(hipMemcpyAsync(m->next0, m->next, nn * 4, hipMemcpyDeviceToDevice, m->stream));
+        FWX_HIP(hipStreamSynchronize(m->stream));
+    }
+    m->rec_ready = 0;
     return FWX_OK;
 }
 
@@ -827,14 +987,13 @@ int fwx_matrix_query_exact(fwx_matrix *m, int32_t src, int32_t dst, double *rate
     if (rc) return rc;
     if (!m->rec_ready) return FWX_ERR_INVALID;             // no traced solve of this upload yet
     const size_t idx = (size_t)src * m->n + dst;
+    hipStream_t s = m->stream;
+    float f32_rate = 0;
     if (rate_out) {
-        if (m->dtype == FWX_F64) {
-            FWX_HIP(hipMemcpy(rate_out, (double *)m->rate + idx, 8, hipMemcpyDeviceToHost));
-        } else {
-            float f = 0;
-            FWX_HIP(hipMemcpy(&f, (float *)m->rate + idx, 4, hipMemcpyDeviceToHost));
-            *rate_out = (double)f;
-        }
+        if (m->dtype == FWX_F64)
+            FWX_HIP(hipMemcpyAsync(rate_out, (double *)m->rate + idx, 8, hipMemcpyDeviceToHost, s));
+        else
+            FWX_HIP(hipMemcpyAsync(&f32_rate, (float *)m->rate + idx, 4, hipMemcpyDeviceToHost, s));
     }
     if (!m->walk || m->walk_cap < cap) {      // grow-only scratch, reused across queries
         if (m->walk) { (void)hipFree(m->walk); m->walk = nullptr; }
@@ -842,12 +1001,17 @@ int fwx_matrix_query_exact(fwx_matrix *m, int32_t src, int32_t dst, double *rate
         m->walk_cap = cap;
     }
     int32_t *len_dev = m->walk + (size_t)4 * cap;
-    hipLaunchKernelGGL(exact_path_kernel, dim3(1), dim3(1), 0, nullptr, m->plog, m->next0, m->n, src,
+    hipLaunchKernelGGL(exact_path_kernel, dim3(1), dim3(1), 0, s, m->plog, m->next0, m->n, src,
                        dst, m->walk, cap, len_dev);
     FWX_HIP(hipGetLastError());
     int32_t len = 0;
-    FWX_HIP(hipMemcpy(&len, len_dev, 4, hipMemcpyDeviceToHost));
-    if (len > 0) FWX_HIP(hipMemcpy(path_out, m->walk, (size_t)len * 4, hipMemcpyDeviceToHost));
+    FWX_HIP(hipMemcpyAsync(&len, len_dev, 4, hipMemcpyDeviceToHost, s));
+    FWX_HIP(hipStreamSynchronize(s));
+    if (rate_out && m->dtype != FWX_F64) *rate_out = (double)f32_rate;
+    if (len > 0) {
+        FWX_HIP(hipMemcpyAsync(path_out, m->walk, (size_t)len * 4, hipMemcpyDeviceToHost, s));
+        FWX_HIP(hipStreamSynchronize(s));
+    }
     return len;
 }
 
@@ -866,14 +1030,16 @@ int fwx_matrix_query_exact_batch(fwx_matrix *m, int32_t count, const int32_t *sr
     if ((rc = d_src.alloc(c * 4)) || (rc = d_dst.alloc(c * 4)) || (rc = d_len.alloc(c * 4)) ||
         (rc = d_paths.alloc(c * cap * 4)) || (rc = d_stacks.alloc(c * cap * 12)))
         return rc;
-    FWX_HIP(hipMemcpy(d_src.p, src, c * 4, hipMemcpyHostToDevice));
-    FWX_HIP(hipMemcpy(d_dst.p, dst, c * 4, hipMemcpyHostToDevice));
-    hipLaunchKernelGGL(exact_paths_kernel, dim3((unsigned)((c + 63) / 64)), dim3(64), 0, nullptr, m->plog,
+    hipStream_t s = m->stream;
+    FWX_HIP(hipMemcpyAsync(d_src.p, src, c * 4, hipMemcpyHostToDevice, s));
+    FWX_HIP(hipMemcpyAsync(d_dst.p, dst, c * 4, hipMemcpyHostToDevice, s));
+    hipLaunchKernelGGL(exact_paths_kernel, dim3((unsigned)((c + 63) / 64)), dim3(64), 0, s, m->plog,
                        m->next0, m->n, count, (const int32_t *)d_src.p, (const int32_t *)d_dst.p,
                        (int32_t *)d_paths.p, (int32_t *)d_stacks.p, cap, (int32_t *)d_len.p);
     FWX_HIP(hipGetLastError());
-    FWX_HIP(hipMemcpy(len_out, d_len.p, c * 4, hipMemcpyDeviceToHost));
-    FWX_HIP(hipMemcpy(path_out, d_paths.p, c * cap * 4, hipMemcpyDeviceToHost));
+    FWX_HIP(hipMemcpyAsync(len_out, d_len.p, c * 4, hipMemcpyDeviceToHost, s));
+    FWX_HIP(hipMemcpyAsync(path_out, d_paths.p, c * cap * 4, hipMemcpyDeviceToHost, s));
+    FWX_HIP(hipStreamSynchronize(s));
     return FWX_OK;
 }
 
@@ -886,9 +1052,11 @@ int fwx_matrix_download(fwx_matrix *m, void *rate, int32_t *next, int32_t *hops)
     int rc = g.enter(m->device);
     if (rc) return rc;
     const size_t nn = (size_t)m->n * (size_t)m->n, es = m->dtype == FWX_F64 ? 8 : 4;
-    if (rate) FWX_HIP(hipMemcpy(rate, m->rate, nn * es, hipMemcpyDeviceToHost));
-    if (next) FWX_HIP(hipMemcpy(next, m->next, nn * 4, hipMemcpyDeviceToHost));
-    if (hops) FWX_HIP(hipMemcpy(hops, m->hops, nn * 4, hipMemcpyDeviceToHost));
+    hipStream_t s = m->stream;
+    if (rate) FWX_HIP(hipMemcpyAsync(rate, m->rate, nn * es, hipMemcpyDefault, s));
+    if (next) FWX_HIP(hipMemcpyAsync(next, m->next, nn * 4, hipMemcpyDefault, s));
+    if (hops) FWX_HIP(hipMemcpyAsync(hops, m->hops, nn * 4, hipMemcpyDefault, s));
+    FWX_HIP(hipStreamSynchronize(s));
     return FWX_OK;
 }
 
@@ -901,7 +1069,7 @@ int fwx_matrix_solve(fwx_matrix *m, const fwx_opts *opts)
     if (rc) return rc;
     DeviceGuard g;
     if ((rc = g.enter(m->device))) return rc;
-    hipStream_t s = nullptr;
+    hipStream_t s = op.has_stream ? op.stream : m->stream;
     if (m->plog.last) return logged_solve(m, op, s);
     unsigned long long *upd = op.updates_out ? m->upd : nullptr;
     if (upd) FWX_HIP(hipMemsetAsync(upd, 0, FWX_UPDATE_SHARDS * 8, s));
@@ -924,23 +1092,31 @@ int fwx_matrix_query(fwx_matrix *m, int32_t src, int32_t dst, double *rate_out, 
     int rc = g.enter(m->device);
     if (rc) return rc;
     const size_t idx = (size_t)src * m->n + dst;
+    hipStream_t s = m->stream;
+    float f32_rate = 0;
     if (rate_out) {
-        if (m->dtype == FWX_F64) {
-            FWX_HIP(hipMemcpy(rate_out, (double *)m->rate + idx, 8, hipMemcpyDeviceToHost));
-        } else {
-            float f = 0;
-            FWX_HIP(hipMemcpy(&f, (float *)m->rate + idx, 4, hipMemcpyDeviceToHost));
-            *rate_out = (double)f;
-        }
+        if (m->dtype == FWX_F64)
+            FWX_HIP(hipMemcpyAsync(rate_out, (double *)m->rate + idx, 8, hipMemcpyDeviceToHost, s));
+        else
+            FWX_HIP(hipMemcpyAsync(&f32_rate, (float *)m->rate + idx, 4, hipMemcpyDeviceToHost, s));
     }
-    if (!m->next) return FWX_ERR_INVALID;
+    if (!m->next) {
+        FWX_HIP(hipStreamSynchronize(s));
+        if (rate_out && m->dtype != FWX_F64) *rate_out = (double)f32_rate;
+        return FWX_ERR_INVALID;
+    }
     const int dcap = cap < m->n ? cap : m->n;
-    hipLaunchKernelGGL(follow_path_kernel, dim3(1), dim3(1), 0, nullptr, m->next, m->n, src, dst,
+    hipLaunchKernelGGL(follow_path_kernel, dim3(1), dim3(1), 0, s, m->next, m->n, src, dst,
                        m->scratch + 1, dcap, m->scratch);
     FWX_HIP(hipGetLastError());
     int32_t len = 0;
-    FWX_HIP(hipMemcpy(&len, m->scratch, 4, hipMemcpyDeviceToHost));
-    if (len > 0) FWX_HIP(hipMemcpy(path_out, m->scratch + 1, (size_t)len * 4, hipMemcpyDeviceToHost));
+    FWX_HIP(hipMemcpyAsync(&len, m->scratch, 4, hipMemcpyDeviceToHost, s));
+    FWX_HIP(hipStreamSynchronize(s));
+    if (rate_out && m->dtype != FWX_F64) *rate_out = (double)f32_rate;
+    if (len > 0) {
+        FWX_HIP(hipMemcpyAsync(path_out, m->scratch + 1, (size_t)len * 4, hipMemcpyDeviceToHost, s));
+        FWX_HIP(hipStreamSynchronize(s));
+    }
     return len;
 }
 
@@ -968,11 +1144,11 @@ int fwx_dev_relax_skip(const fwx_slab *slab, const fwx_pivots *piv, int32_t serp
         return relax_range<double>((double *)slab->rate, slab->next, slab->hops, slab->rows,
                                    slab->n, slab->row0, (const double *)piv->rate, piv->hops,
                                    piv->stride, piv->k_begin, piv->k_end, serpentine, d_updates, s,
-                                   fwx::PathLog(), skip_lo, skip_hi);
+                                   fwx::PathLog(), skip_lo, skip_hi, slab->next ? piv->next : nullptr);
     return relax_range<float>((float *)slab->rate, slab->next, slab->hops, slab->rows, slab->n,
                               slab->row0, (const float *)piv->rate, piv->hops, piv->stride,
                               piv->k_begin, piv->k_end, serpentine, d_updates, s, fwx::PathLog(),
-                              skip_lo, skip_hi);
+                              skip_lo, skip_hi, slab->next ? piv->next : nullptr);
 }
 
 int fwx_dev_panel(const fwx_slab *block, void *w_rate, int32_t *w_hops,
@@ -1002,12 +1178,14 @@ int fwx_dev_solve(const fwx_slab *full, const fwx_opts *opts)
     memset(&m, 0, sizeof(m));
     m.n = full->n; m.dtype = full->dtype;
     m.rate = full->rate; m.next = full->next; m.hops = full->hops;
+    CallStream cs;
+    if ((rc = cs.open(op))) return rc;
+    hipStream_t s = cs.s;
     DevBuf upd;
     if (op.updates_out) {
         if ((rc = upd.alloc(FWX_UPDATE_SHARDS * 8))) return rc;
-        FWX_HIP(hipMemsetAsync(upd.p, 0, FWX_UPDATE_SHARDS * 8, nullptr));
+        FWX_HIP(hipMemsetAsync(upd.p, 0, FWX_UPDATE_SHARDS * 8, s));
     }
-    hipStream_t s = nullptr;
     rc = full->dtype == FWX_F64
              ? matrix_solve_typed<double>(&m, op, (unsigned long long *)upd.p, s)
              : matrix_solve_typed<float>(&m, op, (unsigned long long *)upd.p, s);
@@ -1070,11 +1248,11 @@ int fwx_dev_check_nonneg(const fwx_slab *slab, int32_t *d_flag, void *stream)
     if (device_count() <= 0) return FWX_ERR_NO_DEVICE;
     hipStream_t s = (hipStream_t)stream;
     if (slab->dtype == FWX_F64)
-        FWX_HIP(fwx::launch_nonneg_check((const double *)slab->rate, (size_t)slab->rows * slab->n,
-                                         (int *)d_flag, s));
+        FWX_HIP(fwx::launch_nonneg_check((const double *)slab->rate, slab->next,
+                                         (size_t)slab->rows * slab->n, (int *)d_flag, s));
     else
-        FWX_HIP(fwx::launch_nonneg_check((const float *)slab->rate, (size_t)slab->rows * slab->n,
-                                         (int *)d_flag, s));
+        FWX_HIP(fwx::launch_nonneg_check((const float *)slab->rate, slab->next,
+                                         (size_t)slab->rows * slab->n, (int *)d_flag, s));
     return FWX_OK;
 }
 

@@ -702,20 +702,32 @@ __global__ __launch_bounds__(256, MINW) void fused_main_max(float *rate, int row
     }
 }
 
-// Domain check for fused_main_max: clears *flag if any entry has its sign bit set or is NaN.
-__global__ __launch_bounds__(256) void nonneg_check_f32(const float *rate, size_t count, int *flag)
+// Domain check (fwx.h "Domain"): clears bit 0 of *flag if any rate has its sign bit set or is NaN,
+// bit 1 if `next` is given and an entry with a non-zero rate has next < 0.
+__global__ __launch_bounds__(256) void nonneg_check_f32(const float *rate, const int32_t *next,
+                                                        size_t count, int *flag)
 {
     const size_t stride = (size_t)gridDim.x * 256 * 4;
-    bool bad = false;
+    bool bad = false, orphan = false;
     for (size_t i = ((size_t)blockIdx.x * 256 + threadIdx.x) * 4; i < count; i += stride) {
         if (i + 4 <= count) {
             const uint4 v = *reinterpret_cast<const uint4 *>(rate + i);
             bad |= (v.x > 0x7F800000u) | (v.y > 0x7F800000u) | (v.z > 0x7F800000u) | (v.w > 0x7F800000u);
+            if (next) {
+                const int4 nv = *reinterpret_cast<const int4 *>(next + i);
+                orphan |= ((v.x << 1) != 0 && nv.x < 0) | ((v.y << 1) != 0 && nv.y < 0) |
+                          ((v.z << 1) != 0 && nv.z < 0) | ((v.w << 1) != 0 && nv.w < 0);
+            }
         } else {
-            for (size_t e = i; e < count; ++e) bad |= __float_as_uint(rate[e]) > 0x7F800000u;
+            for (size_t e = i; e < count; ++e) {
+                const unsigned int b = __float_as_uint(rate[e]);
+                bad |= b > 0x7F800000u;
+                if (next) orphan |= (b << 1) != 0 && next[e] < 0;
+            }
         }
     }
-    if (bad) *flag = 0;
+    if (bad) atomicAnd(flag, ~1);
+    if (orphan) atomicAnd(flag, ~2);
 }
 
 }  // namespace
@@ -739,21 +751,28 @@ static bool small_tiles(int n, int rows)
     return (long long)((n + 127) / 128) * ((rows + 127) / 128) < 512;
 }
 
-__global__ __launch_bounds__(256) void nonneg_check_f64(const double *rate, size_t count, int *flag)
+__global__ __launch_bounds__(256) void nonneg_check_f64(const double *rate, const int32_t *next,
+                                                        size_t count, int *flag)
 {
     const size_t stride = (size_t)gridDim.x * 256;
-    bool bad = false;
-    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < count; i += stride)
-        bad |= (unsigned long long)__double_as_longlong(rate[i]) > 0x7FF0000000000000ull;
-    if (bad) *flag = 0;
+    bool bad = false, orphan = false;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < count; i += stride) {
+        const unsigned long long b = (unsigned long long)__double_as_longlong(rate[i]);
+        bad |= b > 0x7FF0000000000000ull;
+        if (next) orphan |= (b << 1) != 0 && next[i] < 0;
+    }
+    if (bad) atomicAnd(flag, ~1);
+    if (orphan) atomicAnd(flag, ~2);
 }
 
-hipError_t launch_nonneg_check(const double *rate, size_t count, int *flag, hipStream_t s)
+hipError_t launch_nonneg_check(const double *rate, const int32_t *next, size_t count, int *flag,
+                               hipStream_t s)
 {
     if (count == 0) return hipSuccess;
     size_t blocks = (count + 255) / 256;
     if (blocks > 8192) blocks = 8192;
-    hipLaunchKernelGGL(nonneg_check_f64, dim3((unsigned)blocks), dim3(256), 0, s, rate, count, flag);
+    hipLaunchKernelGGL(nonneg_check_f64, dim3((unsigned)blocks), dim3(256), 0, s, rate, next, count,
+                       flag);
     return hipGetLastError();
 }
 
@@ -792,13 +811,34 @@ static bool launch_max_form(const FusedArgs<double> &a, dim3 grid, dim3 block, i
     return true;
 }
 
-hipError_t launch_nonneg_check(const float *rate, size_t count, int *flag, hipStream_t s)
+__global__ __launch_bounds__(256) void nonneg_check_f32_scalar(const float *rate, const int32_t *next,
+                                                               size_t count, int *flag)
+{
+    const size_t stride = (size_t)gridDim.x * 256;
+    bool bad = false, orphan = false;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < count; i += stride) {
+        const unsigned int b = __float_as_uint(rate[i]);
+        bad |= b > 0x7F800000u;
+        if (next) orphan |= (b << 1) != 0 && next[i] < 0;
+    }
+    if (bad) atomicAnd(flag, ~1);
+    if (orphan) atomicAnd(flag, ~2);
+}
+
+hipError_t launch_nonneg_check(const float *rate, const int32_t *next, size_t count, int *flag,
+                               hipStream_t s)
 {
     if (count == 0) return hipSuccess;
+    // 16-byte loads: a slab that starts at an odd row of an odd-sized matrix is read by scalars
     size_t blocks = (count / 4 + 255) / 256;
     if (blocks > 4096) blocks = 4096;
     if (blocks == 0) blocks = 1;
-    hipLaunchKernelGGL(nonneg_check_f32, dim3((unsigned)blocks), dim3(256), 0, s, rate, count, flag);
+    if (((uintptr_t)rate % 16) || (next && ((uintptr_t)next % 16)))
+        hipLaunchKernelGGL(nonneg_check_f32_scalar, dim3((unsigned)blocks), dim3(256), 0, s, rate, next,
+                           count, flag);
+    else
+        hipLaunchKernelGGL(nonneg_check_f32, dim3((unsigned)blocks), dim3(256), 0, s, rate, next, count,
+                           flag);
     return hipGetLastError();
 }
 

@@ -33,6 +33,11 @@ template <typename T> struct RelaxArgs {
     int32_t *hops;                 // or nullptr
     const T *prow;                 // pivot row k at the start of step k (n elements)
     const int32_t *phops;          // its hops row (iff hops)
+    const int32_t *pnext = nullptr;   // its next-hop row, or nullptr.  Algorithms.hs:55 concatenates
+                                   // ikPath ++ kjPath: the head is next[i][k] unless ikPath is EMPTY
+                                   // (next[i][k] < 0), then it is next[k][j].  nullptr: the caller
+                                   // vouches that a winning product never has an empty ikPath (true
+                                   // on the reference's domain, see fwx.h "Domain")
     int rows, n, row0, k, flip;
     int skip_lo = 0, skip_hi = 0;  // slab rows [skip_lo, skip_hi) are left alone (multiples of 4):
                                    //   a look-ahead launch has already relaxed them
@@ -71,9 +76,13 @@ template <typename T> struct FusedArgs {
     PathLog plog = PathLog();   // path trace (needs next; single-GPU solves of the whole matrix only)
 };
 
-// Clears *flag (device int, preset to 1) if any of `count` f32 values is negative, -0 or NaN.
-hipError_t launch_nonneg_check(const float *rate, size_t count, int *flag, hipStream_t s);
-hipError_t launch_nonneg_check(const double *rate, size_t count, int *flag, hipStream_t s);
+// Domain check (fwx.h "Domain").  *flag is a device int preset to 3; bit 0 is cleared if any of the
+// `count` rates is negative, -0 or NaN; bit 1 is cleared if `next` is given and some entry has a
+// non-zero rate with next < 0 (a positive rate without a path).
+hipError_t launch_nonneg_check(const float *rate, const int32_t *next, size_t count, int *flag,
+                               hipStream_t s);
+hipError_t launch_nonneg_check(const double *rate, const int32_t *next, size_t count, int *flag,
+                               hipStream_t s);
 
 // colpanel + main: applies the bt pivots to every row of the slab.
 template <typename T>

@@ -74,7 +74,8 @@ template <typename T> struct Lanes<T, 1> {
 template <typename T, int W, int NV, int RPB, int UNROLL, bool HAS_NEXT, bool HAS_HOPS, bool COUNT,
           int MINW = 1, bool NT = false>
 __global__ __launch_bounds__(256, MINW) void relax_k(T *rate, int32_t *next, int32_t *hops,
-                                               const T *prow, const int32_t *phops, int rows,
+                                               const T *prow, const int32_t *phops,
+                                               const int32_t *pnext, int rows,
                                                int n, int row0, int k, int nstrips, int flip,
                                                unsigned long long *updates, PathLog plog,
                                                int skip_lo, int skip_hi)
@@ -169,7 +170,10 @@ __global__ __launch_bounds__(256, MINW) void relax_k(T *rate, int32_t *next, int
                 if (L::get(x, c) < cand[c] && cv + c != i) {
                     L::set(nx, c, cand[c]);
                     changed = true;
-                    if (HAS_NEXT) next[off + c] = s_ncol[r];
+                    if (HAS_NEXT) {     // head (ikPath ++ kjPath), Algorithms.hs:55
+                        const int32_t nik = s_ncol[r];
+                        next[off + c] = (nik >= 0 || !pnext) ? nik : pnext[cv + c];
+                    }
                     if (HAS_HOPS) hops[off + c] = s_hcol[r] + phops[cv + c];
                     if (HAS_NEXT && plog.last) plog.last[(size_t)i * n + cv + c] = k;
                     if (COUNT) ++my_updates;
@@ -242,7 +246,7 @@ __global__ __launch_bounds__(M * RG) void small_solve(T *rate, int32_t *next, in
     static_assert(E % G == 0, "E");
     __shared__ T rowR[2][M], colR[2][M];      // pivot row k / pivot column k at time k
     __shared__ int32_t rowH[2][HAS_HOPS && !IDXL ? M : 1], colH[2][HAS_HOPS && !IDXL ? M : 1];
-    __shared__ int32_t colN[2][HAS_NEXT && !IDXL ? M : 1];
+    __shared__ int32_t colN[2][HAS_NEXT && !IDXL ? M : 1], rowN[2][HAS_NEXT && !IDXL ? M : 1];
     __shared__ int32_t NX[NXL ? M : 1][NXL ? M + 1 : 1], HP[HPL ? M : 1][HPL ? M + 1 : 1];
     __shared__ unsigned int s_cnt;
     const int tid = threadIdx.x;
@@ -261,6 +265,7 @@ __global__ __launch_bounds__(M * RG) void small_solve(T *rate, int32_t *next, in
         for (int m = 0; m < E; ++m) {
             if (r0 + RG * m == k) {           // scalar
                 rowR[b][c] = x[m];
+                if constexpr (HAS_NEXT && !IDXL) rowN[b][c] = nx[m];
                 if constexpr (HAS_HOPS && !IDXL) rowH[b][c] = hp[m];
                 if constexpr (LOG) { if (c < n) plog.at_row[(size_t)k * n + c] = hd[m]; }
             }
@@ -302,9 +307,12 @@ __global__ __launch_bounds__(M * RG) void small_solve(T *rate, int32_t *next, in
     for (int k = k_begin; k < k_end; ++k) {
         const int b = k & 1;
         T rkc = rowR[b][c];
-        int32_t hkc = 0;
+        int32_t hkc = 0, nkc = -1;
         if constexpr (HPL) hkc = HP[k][c];
         else if constexpr (HAS_HOPS) hkc = rowH[b][c];
+        // head kjPath, for the (off-domain) case of an update whose ikPath is empty
+        if constexpr (NXL) nkc = NX[k][c];
+        else if constexpr (HAS_NEXT) nkc = rowN[b][c];
         if (c == k) rkc = quiet_nan<T>();                     // skip j == k
 #pragma unroll
         for (int g = 0; g < E; g += G) {
@@ -318,6 +326,11 @@ __global__ __launch_bounds__(M * RG) void small_solve(T *rate, int32_t *next, in
                 const T raw = colR[b][r];                     // wave-uniform address: LDS broadcast
                 int32_t cn = 0, ch = 0;
                 if constexpr (NXL) cn = NX[r][k]; else if constexpr (HAS_NEXT) cn = colN[b][r];
+                if constexpr (HAS_NEXT) {
+                    // head (ikPath ++ kjPath): next[i][k] unless ikPath is empty (Algorithms.hs:55).
+                    // r is wave-uniform, so this is a scalar test and a rarely taken move.
+                    if (__builtin_amdgcn_readfirstlane(cn) < 0) cn = nkc;
+                }
                 if constexpr (HPL) ch = HP[r][k]; else if constexpr (HAS_HOPS) ch = colH[b][r];
                 const T cand = raw * rkc;                     // Algorithms.hs:61
                 const bool p = x[m] < cand;                   // :55 (false on NaN)
@@ -408,7 +421,7 @@ static hipError_t launch_relax_cfg(const RelaxArgs<T> &a, hipStream_t s)
     if (a.skip_hi > a.skip_lo && (a.skip_lo % RPB || a.skip_hi % RPB)) return hipErrorInvalidValue;
 #define FWX_LAUNCH(HN, HH, CN)                                                                     \
     hipLaunchKernelGGL((relax_k<T, W, NV, RPB, UNROLL, HN, HH, CN, MINW, NT>), grid, block, 0, s, a.rate,    \
-                       a.next, a.hops, a.prow, a.phops, a.rows, a.n, a.row0, a.k, nstrips,         \
+                       a.next, a.hops, a.prow, a.phops, a.pnext, a.rows, a.n, a.row0, a.k, nstrips, \
                        a.flip, a.updates, a.plog, a.skip_lo, a.skip_hi)
     const bool hn = a.next != nullptr, hh = a.hops != nullptr, cn = a.updates != nullptr;
     if (hh) {

@@ -24,6 +24,11 @@ import torch.distributed as dist
 from . import engine
 
 
+def _lib_unsupported():
+    from ._lib import FWX_ERR_UNSUPPORTED
+    return FWX_ERR_UNSUPPORTED
+
+
 def row_bounds(n, world):
     """Contiguous, balanced row blocks: rank r owns [bounds[r], bounds[r+1])."""
     return [(n * r) // world for r in range(world + 1)]
@@ -55,11 +60,12 @@ class HipBackend:
         self.nonneg = False
 
     def check_domain(self, slab_rate, n, row0, slab_next):
-        """1 if this slab allows the max-form kernel (rates only, all entries >= +0, no NaN);
-        solve_partitioned combines the answers of all ranks (the domain must hold globally)."""
-        if slab_next is not None or self.engine_name != "fused":
-            return 0
-        return int(engine.dev_check_nonneg(slab_rate, n, row0)) if slab_rate.shape[0] else 1
+        """Domain bits of this slab (fwx.h "Domain"): bit 0 = every rate >= +0 and not NaN, bit 1 =
+        no positive rate without a path.  solve_partitioned combines the answers of all ranks (the
+        domain must hold globally)."""
+        if slab_rate.shape[0] == 0:
+            return 3
+        return engine.dev_domain_bits(slab_rate, n, row0, slab_next)
 
     def prepare(self, n, rows, dtype, device, with_next):
         self.ws = engine.FusedWorkspace(n, rows, dtype, device, with_next=with_next)
@@ -133,11 +139,20 @@ def solve_partitioned(rate, n, rank, world, *, nxt=None, block=64, backend=None,
     if hasattr(backend, "prepare"):
         backend.prepare(n, rows, rate.dtype, rate.device, nxt is not None)
     if hasattr(backend, "check_domain"):
-        ok = torch.tensor([backend.check_domain(rate, n, row0, nxt)], dtype=torch.int32,
-                          device=rate.device)
+        bits = backend.check_domain(rate, n, row0, nxt)
+        ok = torch.tensor([bits & 1, (bits >> 1) & 1], dtype=torch.int32, device=rate.device)
         if collectives:
             dist.all_reduce(ok, op=dist.ReduceOp.MIN, group=group)
-        backend.nonneg = bool(ok.item() == 1)
+        d1, d2 = (int(v) for v in ok.tolist())
+        if nxt is not None and not (d1 and d2):
+            # The slab kernels take next[i][k] as the head of ikPath ++ kjPath (Algorithms.hs:55);
+            # outside the reference's domain that needs the pivot rows' next-hops as well, which
+            # the snapshot panels do not carry: such a matrix is solved on one GPU (fwx_solve_*).
+            raise engine.FwxError(_lib_unsupported(), "solve_partitioned: matrix outside the "
+                                  "reference's domain (negative/NaN rate or a positive rate without "
+                                  "a path) with next-hops")
+        # max form: rates only, fused engine, every entry >= +0 and not NaN on every rank
+        backend.nonneg = bool(d1) and nxt is None and getattr(backend, "engine_name", "") == "fused"
     bufs = [torch.empty((block, n), dtype=rate.dtype, device=rate.device) for _ in range(2)]
     # On a GPU the panel phase and the broadcast run on a SIDE stream, so that on the owner they
     # overlap the bulk relax of the previous panel instead of queueing behind it.

@@ -14,7 +14,7 @@ from ._lib import (FWX_ENGINE_AUTO, FWX_ENGINE_FUSED, FWX_ENGINE_PERK, FWX_F32, 
                    FWX_FUSED_BLOCK, FWX_UPDATE_SHARDS, FwxError, FwxOpts, FwxPivots, FwxSlab, check,
                    lib)
 
-__all__ = ["solve", "follow_path", "dev_follow_paths", "dev_check_nonneg", "dev_solve_fused",
+__all__ = ["solve", "follow_path", "dev_follow_paths", "dev_check_nonneg", "dev_domain_bits", "dev_solve_fused",
            "dev_solve", "DeviceMatrix", "dev_relax", "dev_panel", "dev_panel_snap",
            "dev_relax_fused", "FusedWorkspace", "FWX_FUSED_BLOCK", "device_count",
            "FwxError", "FWX_ENGINE_AUTO", "FWX_ENGINE_PERK", "FWX_ENGINE_FUSED",
@@ -96,6 +96,19 @@ class DeviceMatrix:
         check(lib().fwx_matrix_upload(self._h, _np_ptr(rate), _np_ptr(nxt), _np_ptr(hops)),
               "fwx_matrix_upload")
 
+    def upload_dev(self, rate_d, next_d=None, hops_d=None):
+        """Upload from DEVICE arrays (torch tensors or hip.DeviceArray): fwx_matrix_upload takes host
+        or device pointers.  The caller must have finished writing them (this call blocks)."""
+        ptr = lambda t: None if t is None else ctypes.c_void_p(t.data_ptr())  # noqa: E731
+        check(lib().fwx_matrix_upload(self._h, ptr(rate_d), ptr(next_d), ptr(hops_d)),
+              "fwx_matrix_upload")
+
+    def download_dev(self, rate_d=None, next_d=None, hops_d=None):
+        """Copy the handle's arrays into DEVICE arrays."""
+        ptr = lambda t: None if t is None else ctypes.c_void_p(t.data_ptr())  # noqa: E731
+        check(lib().fwx_matrix_download(self._h, ptr(rate_d), ptr(next_d), ptr(hops_d)),
+              "fwx_matrix_download")
+
     def solve(self, **kw):
         count = kw.pop("count_updates", False)
         o, u = _opts(want_updates=count, **kw)
@@ -174,21 +187,26 @@ class DeviceMatrix:
 
 # ---- device-pointer step API (torch tensors own the memory) -----------------------------------
 
+def _dtype_name(t):
+    """'float32' for torch.float32 and numpy float32 alike: the device API takes torch tensors or
+    hip.DeviceArray (no torch in the process)."""
+    return str(t.dtype).split(".")[-1]
+
+
 def _tensor_dtype_code(t):
-    import torch
-    if t.dtype == torch.float32:
+    name = _dtype_name(t)
+    if name == "float32":
         return FWX_F32
-    if t.dtype == torch.float64:
+    if name == "float64":
         return FWX_F64
     raise ValueError("rate tensor must be float32 or float64")
 
 
 def _slab(rate_t, next_t, hops_t, n, row0):
-    import torch
     assert rate_t.is_cuda and rate_t.is_contiguous() and rate_t.dim() == 2 and rate_t.shape[1] == n
     for t in (next_t, hops_t):
-        assert t is None or (t.is_cuda and t.is_contiguous() and t.dtype == torch.int32
-                             and t.shape == rate_t.shape)
+        assert t is None or (t.is_cuda and t.is_contiguous() and _dtype_name(t) == "int32"
+                             and tuple(t.shape) == tuple(rate_t.shape))
     s = FwxSlab()
     s.n, s.row0, s.rows, s.dtype = n, row0, rate_t.shape[0], _tensor_dtype_code(rate_t)
     s.rate = rate_t.data_ptr()
@@ -197,13 +215,18 @@ def _slab(rate_t, next_t, hops_t, n, row0):
     return s
 
 
-def _stream_ptr():
+def _stream_ptr(stream=None):
+    """hipStream_t for a launch: an explicit hip.Stream (or raw handle), else torch's current stream."""
+    if stream is not None:
+        h = getattr(stream, "ptr", stream)
+        return h if isinstance(h, ctypes.c_void_p) else ctypes.c_void_p(h)
     import torch
     return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
 
 
 def dev_relax(rate_t, n, row0, k_begin, k_end, *, pivots_t=None, pivot_hops_t=None, next_t=None,
-              hops_t=None, serpentine=True, updates_t=None, skip=None):
+              hops_t=None, serpentine=True, updates_t=None, skip=None, pivot_next_t=None,
+              stream=None):
     """Apply pivots [k_begin,k_end) to the slab `rate_t` (rows [row0,row0+rows) of the n x n
     matrix) on torch's current stream, asynchronously.  skip = (lo, hi): slab rows [lo, hi)
     (multiples of 4) are left alone -- a look-ahead step has relaxed them already.
@@ -218,17 +241,19 @@ def dev_relax(rate_t, n, row0, k_begin, k_end, *, pivots_t=None, pivot_hops_t=No
         es = rate_t.element_size()
         p.rate = rate_t.data_ptr() + (k_begin - row0) * n * es
         p.hops = hops_t.data_ptr() + (k_begin - row0) * n * 4 if hops_t is not None else None
+        p.next = next_t.data_ptr() + (k_begin - row0) * n * 4 if next_t is not None else None
         p.stride = n
     else:
         assert pivots_t.is_cuda and pivots_t.is_contiguous() and pivots_t.dtype == rate_t.dtype
-        assert pivots_t.shape == (k_end - k_begin, n)
+        assert tuple(pivots_t.shape) == (k_end - k_begin, n)
         p.rate = pivots_t.data_ptr()
         p.hops = pivot_hops_t.data_ptr() if pivot_hops_t is not None else None
+        p.next = pivot_next_t.data_ptr() if pivot_next_t is not None else None
         p.stride = n
     upd = ctypes.c_void_p(updates_t.data_ptr()) if updates_t is not None else None
     lo, hi = skip if skip else (0, 0)
     check(lib().fwx_dev_relax_skip(ctypes.byref(s), ctypes.byref(p), int(bool(serpentine)), upd,
-                                   int(lo), int(hi), _stream_ptr()), "fwx_dev_relax_skip")
+                                   int(lo), int(hi), _stream_ptr(stream)), "fwx_dev_relax_skip")
 
 
 def dev_panel(block_rate_t, n, k0, w_rate_t, *, next_t=None, hops_t=None, w_hops_t=None,
@@ -268,14 +293,20 @@ def dev_panel_snap(block_rate_t, n, k0, w_rate_t, diag_ws_t):
           "fwx_dev_panel_snap")
 
 
-def dev_check_nonneg(rate_t, n, row0=0):
-    """True iff every rate of the slab is >= +0.0 and not NaN (synchronises)."""
+def dev_domain_bits(rate_t, n, row0=0, next_t=None):
+    """Domain check of one slab (fwx.h "Domain"; synchronises): bit 0 = every rate is >= +0.0 and
+    not NaN, bit 1 = no entry has a non-zero rate and next < 0 (always set without next_t)."""
     import torch
-    s = _slab(rate_t, None, None, n, row0)
-    flag = torch.ones(1, dtype=torch.int32, device=rate_t.device)
+    s = _slab(rate_t, next_t, None, n, row0)
+    flag = torch.full((1,), 3, dtype=torch.int32, device=rate_t.device)
     check(lib().fwx_dev_check_nonneg(ctypes.byref(s), ctypes.c_void_p(flag.data_ptr()),
                                      _stream_ptr()), "fwx_dev_check_nonneg")
-    return bool(flag.item() == 1)
+    return int(flag.item())
+
+
+def dev_check_nonneg(rate_t, n, row0=0):
+    """True iff every rate of the slab is >= +0.0 and not NaN (synchronises)."""
+    return bool(dev_domain_bits(rate_t, n, row0) & 1)
 
 
 def dev_relax_fused(rate_t, n, row0, k0, k1, w_t, ct_t, *, next_t=None, cnt_t=None, updates_t=None,

@@ -27,8 +27,24 @@
  * empty matrix: src/test/AlgorithmsTest.hs:45-47, :62-64).  There is NO CPU fallback: without a
  * HIP device the solve entry points return FWX_ERR_NO_DEVICE.
  *
- * Threading: calls are blocking unless a stream is passed explicitly (fwx_dev_*), may come from any
- * OS thread, keep no global mutable state, and restore the caller's current HIP device.
+ * Domain.  The reference's parser only admits rates > 0 (Parsers.hs:40) and buildMatrix gives every
+ * entry it fills a one-vertex path (Algorithms.hs:35-37), so in the reference every matrix obeys
+ *     (D1) every rate is >= +0.0 and not NaN          (D2) rate != 0  =>  next >= 0  (path non-empty)
+ * On that domain a winning product has two positive factors, hence a non-empty ikPath, and
+ * head (ikPath ++ kjPath) = next[i][k].  The engine does NOT assume the domain: it checks it on the
+ * device (one read of the matrix) before a fused solve, and a matrix outside it -- negative or NaN
+ * rates, or a positive rate with next == -1 -- is solved by the per-k engine, which implements the
+ * list rule in full (head = next[i][k] if that is >= 0, else next[k][j]).  Either way rates, next,
+ * hops and U equal the reference's loop bit for bit.  Only the slab entry points (fwx_dev_relax*,
+ * which see one slab and not the matrix) leave the check to the caller: see fwx_pivots.next and
+ * fwx_dev_check_nonneg.
+ *
+ * Threading / streams: calls are blocking unless a stream is passed explicitly (fwx_dev_*, or
+ * fwx_opts.stream), may come from any OS thread, keep no global mutable state, and restore the
+ * caller's current HIP device.  No entry point uses the legacy null stream: one-shot calls run on
+ * a non-blocking stream of their own, a handle on the handle's own non-blocking stream, so solves
+ * on different host threads overlap on the device and nothing synchronises implicitly with the
+ * streams of other libraries in the process (torch's included).
  */
 #ifndef FWX_H
 #define FWX_H
@@ -40,7 +56,7 @@
 extern "C" {
 #endif
 
-#define FWX_ABI_VERSION 1
+#define FWX_ABI_VERSION 2
 
 typedef enum fwx_status {
     FWX_OK = 0,
@@ -79,6 +95,9 @@ typedef struct fwx_opts {
     int32_t serpentine;    /* 0 = default (on): alternate sweep direction per pivot so the tail of */
                            /* one launch is re-read from the Infinity Cache; 1 = off               */
     uint64_t *updates_out; /* host pointer, optional: receives U = number of successful updates    */
+    void *stream;          /* hipStream_t to run on, honoured iff use_stream != 0 (fwx_matrix_solve,  */
+    int32_t use_stream;    /* fwx_dev_solve, fwx_solve_*); the call still blocks until it is done.    */
+    int32_t reserved0;     /* 0: a library-owned non-blocking stream (per call / per handle)          */
 } fwx_opts;
 
 int fwx_abi_version(void);
@@ -106,6 +125,7 @@ typedef struct fwx_matrix fwx_matrix;
 
 int fwx_matrix_create(fwx_matrix **out, int32_t n, int32_t dtype, int32_t with_next,
                       int32_t with_hops, int32_t device);
+/* upload: rate / next / hops may be HOST or DEVICE arrays (hipMemcpyDefault); download likewise. */
 int fwx_matrix_upload(fwx_matrix *m, const void *rate, const int32_t *next, const int32_t *hops);
 int fwx_matrix_solve(fwx_matrix *m, const fwx_opts *opts);
 int fwx_matrix_download(fwx_matrix *m, void *rate, int32_t *next, int32_t *hops);
@@ -166,6 +186,10 @@ typedef struct fwx_pivots {
     const void *rate;
     const int32_t *hops; /* same layout; required iff slab.hops != NULL                            */
     int64_t stride;
+    const int32_t *next; /* same layout, optional: next-hop rows of the pivots at time k.  Given, an  */
+                         /* update whose ikPath is empty (next[i][k] < 0) takes next[k][j], as the    */
+                         /* reference's list concatenation does; NULL = the caller vouches for the    */
+                         /* domain (see "Domain"), where that case cannot arise                        */
 } fwx_pivots;
 
 /* Apply pivots [k_begin,k_end) in order to every row of the slab (one launch per pivot).
@@ -224,7 +248,10 @@ int fwx_dev_follow_paths(int32_t n, const int32_t *next, int32_t count, const in
  *   matrix, all ranks) that every entry is >= +0.0 and not NaN -- what the reference's parser
  *   guarantees (rates > 0, Parsers.hs:40; "no route" = +0.0).  On that domain the strict fold
  *   equals max() bit for bit, and rates-only f32 slabs take a kernel that folds two pivots per
- *   v_max3_f32.  Without the flag nothing is assumed.              */
+ *   v_max3_f32.  Without the flag nothing is assumed about the rates.
+ *   A slab WITH next must be inside the domain (D1 and D2, both bits of fwx_dev_check_nonneg on
+ *   every slab): the fused kernels take next[i][k] as the head of the concatenated path.  The
+ *   whole-matrix entry points check this themselves; here it is the caller's duty.              */
 #define FWX_FUSED_BLOCK 64
 #define FWX_FLAG_NONNEG 1
 size_t fwx_fused_diag_ws_bytes(int32_t dtype);
@@ -236,8 +263,10 @@ int fwx_dev_relax_fused(const fwx_slab *slab, const fwx_pivots *piv, void *col_r
 int fwx_dev_relax_fused_skip(const fwx_slab *slab, const fwx_pivots *piv, void *col_rate,
                              int32_t *col_next, unsigned long long *d_updates, int32_t flags,
                              int32_t skip_lo, int32_t skip_hi, void *stream);
-/* Clears *d_flag (a device int32 the caller has set to 1) if any rate of the slab is negative,
- * -0.0 or NaN.                                                                                  */
+/* Domain check of one slab (see "Domain").  *d_flag is a device int32 the caller has set to 3 (or
+ * to 1 for a rates-only slab): bit 0 is cleared if any rate of the slab is negative, -0.0 or NaN,
+ * bit 1 if the slab carries next and some entry has a non-zero rate with next < 0.  A partitioned
+ * solve ANDs the flags of all slabs.                                                            */
 int fwx_dev_check_nonneg(const fwx_slab *slab, int32_t *d_flag, void *stream);
 
 #ifdef __cplusplus

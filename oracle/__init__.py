@@ -11,8 +11,6 @@ Contents
   list_faithful.py               entry-for-entry restatement with whole `_path` lists of
                                  buildMatrix / runAlgo / floydWarshall / optimum
                                  (Algorithms.hs:19-78).
-  host_oracle.py                 restatement of the request layer (Parsers.hs, ProcessRequests.hs,
-                                 Main.hs) used to pin the C++ host mirror.
 
 Parity pinning: the reference is Haskell and cannot be built here (no GHC/cabal/nix in the
 image), so the oracle is pinned by the reference's own golden vectors committed as data under
@@ -47,7 +45,7 @@ def lib():
             getattr(L, name).argtypes = [i32, vp, vp, vp, i32, i32]
         for name in ("fwo_relax_mt_f64", "fwo_relax_mt_f32"):
             getattr(L, name).restype = u64
-            getattr(L, name).argtypes = [i32, vp, vp, i32, i32, i32]
+            getattr(L, name).argtypes = [i32, vp, vp, vp, i32, i32, i32]
         for name in ("fwo_copy_per_k_f64", "fwo_copy_per_k_f32"):
             getattr(L, name).restype = ctypes.c_int
             getattr(L, name).argtypes = [i32, vp, vp, vp]
@@ -79,14 +77,15 @@ def relax(rate, nxt=None, hops=None, k_begin=0, k_end=None):
                                                   k_begin, k_end))
 
 
-def relax_mt(rate, nxt=None, k_begin=0, k_end=None, threads=None):
+def relax_mt(rate, nxt=None, k_begin=0, k_end=None, threads=None, hops=None):
     """Same result as relax(), rows of each pivot step split over `threads` host threads."""
-    sfx = _check(rate, nxt, None)
+    sfx = _check(rate, nxt, hops)
+    assert hops is None or nxt is not None
     n = rate.shape[0]
     k_end = n if k_end is None else k_end
     threads = threads or len(os.sched_getaffinity(0))
-    return int(getattr(lib(), "fwo_relax_mt_" + sfx)(n, _ptr(rate), _ptr(nxt), k_begin, k_end,
-                                                     threads))
+    return int(getattr(lib(), "fwo_relax_mt_" + sfx)(n, _ptr(rate), _ptr(nxt), _ptr(hops), k_begin,
+                                                     k_end, threads))
 
 
 def copy_per_k(rate, nxt, hops):

@@ -35,7 +35,12 @@
  *                    column k are fixed points of step k the in-place update reads the same
  *                    values (checked against fwo_copy_per_k_* below).
  * Algorithms.hs:55   update iff old < new (strict, false on NaN); path = ikPath ++ kjPath, so
- *                    head = head ikPath (next[i][k]) and length = len ik + len kj.
+ *                    head = head ikPath (next[i][k]) -- or, when ikPath is EMPTY (next[i][k] < 0),
+ *                    head kjPath (next[k][j]; row k is a fixed point of step k) -- and
+ *                    length = len ik + len kj.  The empty-ikPath case cannot arise from what the
+ *                    reference's parser admits (rates > 0, Parsers.hs:40: a winning product then
+ *                    has two positive factors, and a positive entry always has a path); it arises
+ *                    with negative rates or an input whose next is -1 on a non-zero rate.
  * Returns U, the number of successful relaxations.
  * ------------------------------------------------------------------------------------------- */
 #define FWO_DEFINE_RELAX(NAME, T)                                                              \
@@ -57,7 +62,8 @@
                     const T c = rik * rk[j];                                                   \
                     if (ri[j] < c) {                                                           \
                         ri[j] = c;                                                             \
-                        if (next) next[(size_t)i * N + j] = nik;                               \
+                        if (next)                                                              \
+                            next[(size_t)i * N + j] = nik >= 0 ? nik : next[(size_t)k * N + j];\
                         if (hops) hops[(size_t)i * N + j] = hik + hops[(size_t)k * N + j];     \
                         ++updates;                                                             \
                     }                                                                          \
@@ -92,7 +98,11 @@ FWO_DEFINE_RELAX(fwo_relax_f32, float)
                     int32_t nx = next[ij], hp = hops[ij];                                      \
                     if (i != k && j != i && j != k) {                                          \
                         const T c = rate[ik] * rate[kj];                                       \
-                        if (r < c) { r = c; nx = next[ik]; hp = hops[ik] + hops[kj]; }         \
+                        if (r < c) {                                                   \
+                            r = c;                                                     \
+                            nx = next[ik] >= 0 ? next[ik] : next[kj];                  \
+                            hp = hops[ik] + hops[kj];                                  \
+                        }                                                              \
                     }                                                                          \
                     r2[ij] = r; n2[ij] = nx; h2[ij] = hp;                                      \
                 }                                                                              \
@@ -111,12 +121,13 @@ FWO_DEFINE_COPY(fwo_copy_per_k_f32, float)
  * Multi-threaded form for the CPU baseline: inside one pivot step the rows are independent
  * (row k and column k are read-only during step k), so rows are split over `threads` workers
  * with a barrier per k.  Results are identical to fwo_relax_* (same operands, same order per
- * entry).  Rates (+ optional next) only.
+ * entry).  Rates, optional next, optional hops (hops need next).
  * ------------------------------------------------------------------------------------------- */
 typedef struct {
     int32_t n, k_begin, k_end, tid, threads;
     void *rate;
     int32_t *next;
+    int32_t *hops;
     pthread_barrier_t *bar;
     uint64_t updates;
 } fwo_job;
@@ -129,6 +140,7 @@ typedef struct {
         const size_t N = (size_t)n;                                                            \
         T *rate = (T *)job->rate;                                                              \
         int32_t *next = job->next;                                                             \
+        int32_t *hops = job->hops;                                                             \
         const int32_t lo = (int32_t)(((int64_t)n * job->tid) / job->threads);                  \
         const int32_t hi = (int32_t)(((int64_t)n * (job->tid + 1)) / job->threads);            \
         uint64_t updates = 0;                                                                  \
@@ -139,12 +151,15 @@ typedef struct {
                 T *ri = rate + (size_t)i * N;                                                  \
                 const T rik = ri[k];                                                           \
                 const int32_t nik = next ? next[(size_t)i * N + k] : 0;                        \
+                const int32_t hik = hops ? hops[(size_t)i * N + k] : 0;                        \
                 for (int32_t j = 0; j < n; ++j) {                                              \
                     if (j == i || j == k) continue;                                            \
                     const T c = rik * rk[j];                                                   \
                     if (ri[j] < c) {                                                           \
                         ri[j] = c;                                                             \
-                        if (next) next[(size_t)i * N + j] = nik;                               \
+                        if (next)                                                              \
+                            next[(size_t)i * N + j] = nik >= 0 ? nik : next[(size_t)k * N + j];\
+                        if (hops) hops[(size_t)i * N + j] = hik + hops[(size_t)k * N + j];     \
                         ++updates;                                                             \
                     }                                                                          \
                 }                                                                              \
@@ -158,7 +173,7 @@ typedef struct {
 FWO_DEFINE_WORKER(fwo_worker_f64, double)
 FWO_DEFINE_WORKER(fwo_worker_f32, float)
 
-static uint64_t fwo_relax_mt(int32_t n, void *rate, int32_t *next, int32_t k_begin,
+static uint64_t fwo_relax_mt(int32_t n, void *rate, int32_t *next, int32_t *hops, int32_t k_begin,
                              int32_t k_end, int32_t threads, void *(*worker)(void *))
 {
     if (threads < 1) threads = 1;
@@ -170,7 +185,7 @@ static uint64_t fwo_relax_mt(int32_t n, void *rate, int32_t *next, int32_t k_beg
     for (int t = 0; t < threads; ++t) {
         job[t].n = n; job[t].k_begin = k_begin; job[t].k_end = k_end;
         job[t].tid = t; job[t].threads = threads;
-        job[t].rate = rate; job[t].next = next; job[t].bar = &bar; job[t].updates = 0;
+        job[t].rate = rate; job[t].next = next; job[t].hops = hops; job[t].bar = &bar; job[t].updates = 0;
         pthread_create(&tid[t], NULL, worker, &job[t]);
     }
     uint64_t updates = 0;
@@ -182,16 +197,16 @@ static uint64_t fwo_relax_mt(int32_t n, void *rate, int32_t *next, int32_t k_beg
     return updates;
 }
 
-uint64_t fwo_relax_mt_f64(int32_t n, double *rate, int32_t *next, int32_t k_begin,
+uint64_t fwo_relax_mt_f64(int32_t n, double *rate, int32_t *next, int32_t *hops, int32_t k_begin,
                           int32_t k_end, int32_t threads)
 {
-    return fwo_relax_mt(n, rate, next, k_begin, k_end, threads, fwo_worker_f64);
+    return fwo_relax_mt(n, rate, next, hops, k_begin, k_end, threads, fwo_worker_f64);
 }
 
-uint64_t fwo_relax_mt_f32(int32_t n, float *rate, int32_t *next, int32_t k_begin,
+uint64_t fwo_relax_mt_f32(int32_t n, float *rate, int32_t *next, int32_t *hops, int32_t k_begin,
                           int32_t k_end, int32_t threads)
 {
-    return fwo_relax_mt(n, rate, next, k_begin, k_end, threads, fwo_worker_f32);
+    return fwo_relax_mt(n, rate, next, hops, k_begin, k_end, threads, fwo_worker_f32);
 }
 
 /* ---------------------------------------------------------------------------------------------

@@ -6,7 +6,7 @@
 
 uint64_t fwo_relax_f64(int32_t, double *, int32_t *, int32_t *, int32_t, int32_t);
 uint64_t fwo_relax_f32(int32_t, float *, int32_t *, int32_t *, int32_t, int32_t);
-uint64_t fwo_relax_mt_f32(int32_t, float *, int32_t *, int32_t, int32_t, int32_t);
+uint64_t fwo_relax_mt_f32(int32_t, float *, int32_t *, int32_t *, int32_t, int32_t, int32_t);
 int fwo_copy_per_k_f64(int32_t, double *, int32_t *, int32_t *);
 int32_t fwo_follow_path(int32_t, const int32_t *, int32_t, int32_t, int32_t *, int32_t);
 
@@ -34,7 +34,7 @@ int main(void)
         for (size_t q = 0; q < nn; ++q)
             if (r[q] != r2[q] || nx[q] != nx2[q] || hp[q] != hp2[q]) return 1;
         uint64_t u1 = fwo_relax_f32(n, f, NULL, NULL, 0, n);
-        uint64_t u2 = fwo_relax_mt_f32(n, f2, NULL, 0, n, 3);
+        uint64_t u2 = fwo_relax_mt_f32(n, f2, NULL, NULL, 0, n, 3);
         if (u1 != u2) return 2;
         for (size_t q = 0; q < nn; ++q)
             if (f[q] != f2[q]) return 3;

@@ -38,7 +38,7 @@ def test_binding_table_covers_the_engine_header():
 
 def test_abi_version_and_strerror():
     L = _lib.lib()
-    assert L.fwx_abi_version() == 1
+    assert L.fwx_abi_version() == 2
     assert L.fwx_strerror(0) == b"ok"
     assert b"no HIP device" in L.fwx_strerror(_lib.FWX_ERR_NO_DEVICE)
     assert L.fwx_device_count() >= 0

@@ -1,0 +1,73 @@
+"""Whole-solve parity at the BASELINE.json configuration sizes: the ENTIRE solve runs on the oracle
+(oracle.relax_mt: the C restatement of Algorithms.hs:42-61, rows of each pivot step split over the
+host cores) and every engine's result is compared with it bit for bit -- not pivot slices, not one
+engine against another.  VERDICT r1 "close the parity chain at config sizes".
+
+CPU cost on the GPU box's 16 cores: N=4096 ~4-8 s per dtype, N=8192 ~35 s.  The N=16384 solve
+(~4 min of CPU) is run once by tools/full_parity_n16384.py; its record is profiles/r02_full_parity_n16384.json.
+"""
+import os
+
+import numpy as np
+import pytest
+
+import oracle
+from floydwarshall_amd import engine, synth
+
+from helpers import assert_bits_equal
+
+pytestmark = pytest.mark.gpu
+
+
+def _threads():
+    cores = len(os.sched_getaffinity(0))
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            cores = max(1, min(cores, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        pass
+    return cores
+
+
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+def test_n4096_whole_solve_rate_next_hops_every_engine(dtype):
+    """N = 4096, rates + next + hops, D2 (market-like: long winning paths): the whole oracle solve
+    against PERK, FUSED (hops rebuilt from the path trace) and AUTO, all fields, and U."""
+    n = 4096
+    rate, nxt, hops = synth.make("d2", n, dtype, seed=synth.BASE_SEED + 41)
+    er, en, eh = rate.copy(), nxt.copy(), hops.copy()
+    eu = oracle.relax_mt(er, en, hops=eh, threads=_threads())
+    for eng in (engine.FWX_ENGINE_PERK, engine.FWX_ENGINE_FUSED, engine.FWX_ENGINE_AUTO):
+        gr, gn, gh = rate.copy(), nxt.copy(), hops.copy()
+        u = engine.solve(gr, gn, gh, engine=eng, count_updates=True)
+        assert_bits_equal(gr, er, "rate, engine %d" % eng)
+        assert_bits_equal(gn, en, "next, engine %d" % eng)
+        assert_bits_equal(gh, eh, "hops, engine %d" % eng)
+        assert u == eu
+    # rates only: the max-form kernels (f32 v_max3 pairs, f64 v_max_f64)
+    gr = rate.copy()
+    engine.solve(gr, engine=engine.FWX_ENGINE_FUSED)
+    assert_bits_equal(gr, er, "rate, fused max form")
+
+
+def test_config3_n8192_fp32_whole_solve_vs_oracle():
+    """BASELINE config 3 (N = 8192 fp32): whole oracle solve against the fused engine (rates only =
+    max form; rates + next = compare form) and the per-k engine, bit for bit."""
+    n = 8192
+    rate, nxt, _ = synth.make("d1", n, np.float32, seed=synth.BASE_SEED + 2)
+    er, en = rate.copy(), nxt.copy()
+    eu = oracle.relax_mt(er, en, threads=_threads())
+    gr = rate.copy()
+    engine.solve(gr, engine=engine.FWX_ENGINE_FUSED)
+    assert_bits_equal(gr, er, "fused rates-only")
+    gr, gn = rate.copy(), nxt.copy()
+    u = engine.solve(gr, gn, engine=engine.FWX_ENGINE_FUSED, count_updates=True)
+    assert_bits_equal(gr, er, "fused rate")
+    assert_bits_equal(gn, en, "fused next")
+    assert u == eu
+    gr, gn = rate.copy(), nxt.copy()
+    u = engine.solve(gr, gn, engine=engine.FWX_ENGINE_PERK, count_updates=True)
+    assert_bits_equal(gr, er, "per-k rate")
+    assert_bits_equal(gn, en, "per-k next")
+    assert u == eu

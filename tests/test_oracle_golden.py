@@ -142,6 +142,49 @@ def test_dense_c_equals_list_faithful(kind, dtype):
                 assert tuple(oracle.follow_path(n2, i, j)) == paths[i][j]
 
 
+def test_empty_ikpath_takes_the_head_of_kjpath():
+    """`head (ikPath ++ kjPath)` (Algorithms.hs:55) is head kjPath when ikPath is empty.
+    rate[0][1] = -0.75 with path [1], rate[0][2] = 0 with the empty path, rate[2][1] = 2 with path
+    [1]: step 2 improves (0,1) to 0*2 = 0 > -0.75 and the list becomes [] ++ [1] = [1]."""
+    rate = np.array([[0, -0.75, 0], [0, 0, 0], [0, 2, 0]], dtype=np.float64)
+    nxt = np.array([[-1, 1, -1], [-1, -1, -1], [-1, 1, -1]], dtype=np.int32)
+    hops = (nxt >= 0).astype(np.int32)
+    vertices = [("X", "C%d" % i) for i in range(3)]
+    m = lf.run_algo(lf.from_dense(vertices, rate, nxt), np.float64)
+    _, lrate, lnext, lhops = lf.to_dense(m, np.float64)
+    assert lrate[0, 1] == 0.0 and lnext[0, 1] == 1 and lhops[0, 1] == 1
+    for solve in (oracle.relax, oracle.copy_per_k):
+        r2, n2, h2 = rate.copy(), nxt.copy(), hops.copy()
+        solve(r2, n2, h2)
+        assert_bits_equal(r2, lrate, "rate")
+        assert np.array_equal(n2, lnext) and np.array_equal(h2, lhops)
+
+
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+def test_dense_c_equals_list_faithful_on_hostile_values(dtype):
+    """Outside the reference's domain (negative rates, NaN, inf, -0, a positive rate whose path is
+    empty) the dense oracle must still be the reference's loop: compare it with the list-faithful
+    restatement, which concatenates whole lists and knows nothing of next-hops."""
+    from test_gpu_parity_inputs import hostile_matrix
+    rnd = np.random.default_rng(99)
+    with np.errstate(all="ignore"):
+        for n in (3, 5, 8, 13, 21):
+            for _ in range(12):
+                rate, nxt, hops = hostile_matrix(rnd, n, dtype)
+                vertices = [("X", "C%03d" % i) for i in range(n)]
+                m = lf.run_algo(lf.from_dense(vertices, rate, nxt), dtype)
+                _, lrate, lnext, lhops = lf.to_dense(m, dtype)
+                r2, n2, h2 = rate.copy(), nxt.copy(), hops.copy()
+                oracle.relax(r2, n2, h2)
+                assert_bits_equal(r2, lrate, "rate")
+                assert np.array_equal(n2, lnext), (n2, lnext)
+                assert np.array_equal(h2, lhops)
+                r3, n3, h3 = rate.copy(), nxt.copy(), hops.copy()
+                oracle.relax_mt(r3, n3, hops=h3, threads=3)
+                assert_bits_equal(r3, lrate, "mt rate")
+                assert np.array_equal(n3, lnext) and np.array_equal(h3, lhops)
+
+
 @pytest.mark.parametrize("dtype", [np.float64, np.float32])
 def test_inplace_equals_copy_per_k_and_mt(dtype):
     for kind in ("d1", "t1", "t3"):

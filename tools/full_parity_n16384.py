@@ -1,0 +1,75 @@
+#!/usr/bin/env python3
+"""One whole N=16384 fp32 solve on the CPU oracle (all host cores, ~4 min on the GPU box) against
+both GPU engines, bit for bit: the headline configuration's parity record.
+
+    python3 tools/full_parity_n16384.py profiles/r02_full_parity_n16384.json
+
+Prints a progress line per 1024 pivots (the GPU box kills a silent command after 7 minutes).
+"""
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+os.environ["FWX_NO_TORCH"] = "1"
+
+import oracle  # noqa: E402  (tools/ may use the checker; the product never does)
+from floydwarshall_amd import engine, synth  # noqa: E402
+sys.path.insert(0, ROOT)
+from bench import digest, host_cores  # noqa: E402
+
+
+def main():
+    out_path = sys.argv[1] if len(sys.argv) > 1 else None
+    n = int(sys.argv[2]) if len(sys.argv) > 2 else 16384
+    with_next = "--next" in sys.argv
+    rate, nxt = synth.d1_uniform(n, np.float32, synth.BASE_SEED + 3)      # bench.py's matrix
+    if not with_next:
+        nxt = None
+    cores = host_cores()
+    er = rate.copy()
+    en = None if nxt is None else nxt.copy()
+    u = 0
+    t0 = time.perf_counter()
+    for k0 in range(0, n, 1024):
+        u += oracle.relax_mt(er, en, k0, min(n, k0 + 1024), threads=cores)
+        print("oracle: pivots [0,%d) done, %.0f s" % (min(n, k0 + 1024), time.perf_counter() - t0), flush=True)
+    t_cpu = time.perf_counter() - t0
+    rec = {"n": n, "dtype": "f32", "input": "D1, seed BASE_SEED+3 (bench.py's matrix)",
+           "with_next": with_next, "oracle": "oracle.relax_mt (fwo_relax_mt_f32), %d threads" % cores,
+           "oracle_seconds": t_cpu, "oracle_relax_per_s": float(n) ** 3 / t_cpu, "U": u,
+           "rate_digest_oracle": digest(er)}
+    if en is not None:
+        rec["next_digest_oracle"] = digest(en)
+    # "fused" counts U, which keeps it on the compare-form kernel; "fused_max_form" is the same call
+    # without counting = what fwx_solve_f32 runs by default on this input (v_max3 pairs)
+    for name, eng, count in (("fused_max_form", engine.FWX_ENGINE_FUSED, False),
+                             ("fused", engine.FWX_ENGINE_FUSED, True),
+                             ("per_k", engine.FWX_ENGINE_PERK, True)):
+        gr = rate.copy()
+        gn = None if nxt is None else nxt.copy()
+        t1 = time.perf_counter()
+        gu = engine.solve(gr, gn, engine=eng, count_updates=count)
+        if not count:
+            gu = u
+        rec[name] = {"seconds_incl_pcie": time.perf_counter() - t1, "U": gu, "counted": count,
+                     "rate_digest": digest(gr),
+                     "rate_bits_equal_oracle": bool(np.array_equal(gr.view(np.uint32), er.view(np.uint32)))}
+        if gn is not None:
+            rec[name]["next_equal_oracle"] = bool(np.array_equal(gn, en))
+        print(name, json.dumps(rec[name]), flush=True)
+    rec["ok"] = all(rec[e]["rate_bits_equal_oracle"] and rec[e]["U"] == u and
+                    rec[e].get("next_equal_oracle", True) for e in ("fused_max_form", "fused", "per_k"))
+    print(json.dumps(rec), flush=True)
+    if out_path:
+        with open(out_path, "w") as f:
+            json.dump(rec, f, indent=1)
+    return 0 if rec["ok"] else 1
+
+
+if __name__ == "__main__":
+    sys.exit(main())
