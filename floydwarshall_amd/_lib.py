@@ -14,6 +14,7 @@ FWX_ERR_OOM = -4
 FWX_ERR_CYCLE = -5
 FWX_ERR_CAPACITY = -6
 FWX_ERR_UNSUPPORTED = -7
+FWX_ERR_RCCL = -8
 
 FWX_ABI_VERSION = 2
 FWX_F32, FWX_F64 = 0, 1
@@ -21,6 +22,8 @@ FWX_ENGINE_AUTO, FWX_ENGINE_PERK, FWX_ENGINE_FUSED = 0, 1, 2
 FWX_UPDATE_SHARDS = 256
 FWX_FUSED_BLOCK = 64
 FWX_FLAG_NONNEG = 1
+FWX_XCHG_AUTO, FWX_XCHG_PEER, FWX_XCHG_RCCL = 0, 1, 2
+FWX_MAX_PARTS = 32
 
 c_i32 = ctypes.c_int32
 c_vp = ctypes.c_void_p
@@ -74,6 +77,13 @@ SIGNATURES = {
     "fwx_matrix_query_exact": (ctypes.c_int, [c_vp, c_i32, c_i32, ctypes.POINTER(ctypes.c_double),
                                               c_vp, c_i32]),
     "fwx_matrix_query_exact_batch": (ctypes.c_int, [c_vp, c_i32, c_vp, c_vp, c_vp, c_vp, c_i32]),
+    "fwx_matrix_create_multi": (ctypes.c_int, [ctypes.POINTER(c_vp), c_i32, c_i32, c_i32, c_i32, c_i32,
+                                               ctypes.POINTER(c_i32), c_i32]),
+    "fwx_matrix_parts": (ctypes.c_int, [c_vp, ctypes.POINTER(c_i32)]),
+    "fwx_solve_multi_f64": (ctypes.c_int, [c_i32, c_vp, c_vp, c_vp, c_i32, ctypes.POINTER(c_i32), c_i32,
+                                           ctypes.POINTER(FwxOpts)]),
+    "fwx_solve_multi_f32": (ctypes.c_int, [c_i32, c_vp, c_vp, c_vp, c_i32, ctypes.POINTER(c_i32), c_i32,
+                                           ctypes.POINTER(FwxOpts)]),
     "fwx_dev_relax": (ctypes.c_int, [ctypes.POINTER(FwxSlab), ctypes.POINTER(FwxPivots), c_i32,
                                      c_vp, c_vp]),
     "fwx_dev_relax_skip": (ctypes.c_int, [ctypes.POINTER(FwxSlab), ctypes.POINTER(FwxPivots), c_i32,

@@ -17,7 +17,7 @@ CSRC = os.path.join(PKG, "csrc")
 LIB = os.path.join(PKG, "libfwx.so")
 CLI = os.path.join(PKG, "fwx_cli")
 
-HIP_SOURCES = ["fwx_kernels.hip", "fwx_fused.hip", "fwx_api.hip"]
+HIP_SOURCES = ["fwx_kernels.hip", "fwx_fused.hip", "fwx_api.hip", "fwx_multi.hip"]
 CXX_SOURCES = []  # host mirror sources are appended below when present
 HOST_DIR = os.path.join(CSRC, "host")
 
@@ -61,7 +61,7 @@ def build_lib(force=False, verbose=False):
     hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
     if not os.path.exists(hipcc):
         raise RuntimeError("hipcc not found: libfwx can only be built with the ROCm toolchain")
-    cmd = [hipcc] + HIPCC_FLAGS + ["-x", "hip"] + _sources() + ["-o", LIB + ".tmp"]
+    cmd = [hipcc] + HIPCC_FLAGS + ["-x", "hip"] + _sources() + ["-o", LIB + ".tmp", "-ldl"]
     if verbose:
         print(" ".join(cmd))
     subprocess.run(cmd, check=True)

@@ -11,132 +11,12 @@
 #include <new>
 
 #include "fwx.h"
+#include "fwx_internal.h"
 #include "fwx_kernels.h"
 
-static_assert(FWX_UPDATE_SHARDS == FWX_UPDATE_SHARDS_K, "shard count mismatch");
+using namespace fwxi;
 
 namespace {
-
-thread_local int g_last_hip = 0;
-
-#define FWX_HIP(call)                                                                              \
-    do {                                                                                           \
-        hipError_t e__ = (call);                                                                   \
-        if (e__ != hipSuccess) {                                                                   \
-            g_last_hip = (int)e__;                                                                 \
-            (void)hipGetLastError();                                                               \
-            return e__ == hipErrorOutOfMemory ? FWX_ERR_OOM : FWX_ERR_HIP;                         \
-        }                                                                                          \
-    } while (0)
-
-int device_count()
-{
-    int c = 0;
-    if (hipGetDeviceCount(&c) != hipSuccess) {
-        (void)hipGetLastError();
-        return 0;
-    }
-    return c;
-}
-
-// Sets the requested device for the scope of one ABI call and restores the caller's.
-struct DeviceGuard {
-    int prev = -1;
-    bool changed = false;
-    int enter(int device)
-    {
-        const int cnt = device_count();
-        if (cnt <= 0) return FWX_ERR_NO_DEVICE;
-        if (hipGetDevice(&prev) != hipSuccess) return FWX_ERR_HIP;
-        if (device < 0) return FWX_OK;
-        if (device >= cnt) return FWX_ERR_INVALID;
-        if (device != prev) {
-            FWX_HIP(hipSetDevice(device));
-            changed = true;
-        }
-        return FWX_OK;
-    }
-    ~DeviceGuard()
-    {
-        if (changed) (void)hipSetDevice(prev);
-    }
-};
-
-struct Opts {
-    int device = -1, engine = FWX_ENGINE_AUTO, k_begin = 0, k_end = 0, block = 0, serpentine = 1;
-    uint64_t *updates_out = nullptr;
-    hipStream_t stream = nullptr;      // caller's stream (fwx_opts.stream), nullptr = library-owned
-    bool has_stream = false;
-};
-
-// The stream one blocking ABI call runs on: the caller's (fwx_opts.stream) or a non-blocking stream
-// of its own -- never the legacy null stream, which would serialise the call against every other
-// blocking stream of the process (torch's included) and against solves on other host threads.
-struct CallStream {
-    hipStream_t s = nullptr;
-    bool owned = false;
-    int open(const Opts &op)
-    {
-        if (op.has_stream) { s = op.stream; return FWX_OK; }
-        FWX_HIP(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
-        owned = true;
-        return FWX_OK;
-    }
-    ~CallStream() { if (owned && s) (void)hipStreamDestroy(s); }
-};
-
-// Bounds the number of launches in flight on a stream: every EVERY launches an event is recorded
-// and the host waits for the event recorded 2*EVERY launches earlier.  The GPU never idles (at
-// least EVERY launches are queued behind the one being waited for), but a solve of N = 16384
-// pivots no longer parks 16384 dispatches in the queue: rocprofv3's counter collection, which
-// intercepts every AQL packet, crashed on exactly that.
-struct Throttle {
-    static constexpr int EVERY = 256;
-    hipEvent_t ev[2] = {nullptr, nullptr};
-    bool armed[2] = {false, false};
-    int count = 0, slot = 0;
-    ~Throttle()
-    {
-        for (int i = 0; i < 2; ++i)
-            if (ev[i]) (void)hipEventDestroy(ev[i]);
-    }
-    int tick(hipStream_t s, int launches = 1)
-    {
-        count += launches;
-        if (count < EVERY) return FWX_OK;
-        count = 0;
-        if (!ev[slot]) FWX_HIP(hipEventCreateWithFlags(&ev[slot], hipEventDisableTiming));
-        if (armed[slot]) FWX_HIP(hipEventSynchronize(ev[slot]));
-        FWX_HIP(hipEventRecord(ev[slot], s));
-        armed[slot] = true;
-        slot ^= 1;
-        return FWX_OK;
-    }
-};
-
-int read_opts(const fwx_opts *o, int n, Opts &out)
-{
-    if (o) {
-        if (o->struct_size < sizeof(fwx_opts)) return FWX_ERR_INVALID;
-        out.device = o->device;
-        out.engine = o->engine;
-        out.k_begin = o->k_begin;
-        out.k_end = o->k_end;
-        out.block = o->block;
-        out.serpentine = o->serpentine == 0 ? 1 : 0;
-        out.updates_out = o->updates_out;
-        if (o->struct_size >= offsetof(fwx_opts, stream) + sizeof(void *) && o->use_stream) {
-            out.stream = (hipStream_t)o->stream;
-            out.has_stream = true;
-        }
-    }
-    if (out.k_end <= 0) out.k_end = n;
-    if (out.k_begin < 0 || out.k_begin > out.k_end || out.k_end > n) return FWX_ERR_INVALID;
-    if (out.engine != FWX_ENGINE_AUTO && out.engine != FWX_ENGINE_PERK &&
-        out.engine != FWX_ENGINE_FUSED)
-        return FWX_ERR_INVALID;
-    return FWX_OK;
-}
 
 // One launch per pivot over a slab; pivot rows from `prow0 + (k-k_begin)*stride`.
 template <typename T>
@@ -197,24 +77,6 @@ template <typename T> bool fused_ok(int n, const void *rate, const int32_t *hops
 // Look-ahead: the panel chain of block b+1 only needs the 64 pivot ROWS of b+1 at time k1, so
 // main(b) runs on those rows first, then the snapshot panel of b+1 runs on a side stream while
 // main(b) sweeps the rest of the matrix.  ws: see fused_ws_bytes.
-struct SideStream {
-    hipStream_t s = nullptr;
-    hipEvent_t rows_done = nullptr, panel_done = nullptr;
-    ~SideStream()
-    {
-        if (rows_done) (void)hipEventDestroy(rows_done);
-        if (panel_done) (void)hipEventDestroy(panel_done);
-        if (s) (void)hipStreamDestroy(s);
-    }
-    int init()
-    {
-        FWX_HIP(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
-        FWX_HIP(hipEventCreateWithFlags(&rows_done, hipEventDisableTiming));
-        FWX_HIP(hipEventCreateWithFlags(&panel_done, hipEventDisableTiming));
-        return FWX_OK;
-    }
-};
-
 template <typename T>
 int fused_range(T *rate, int32_t *next, int n, int k_begin, int k_end, void *ws,
                 unsigned long long *d_updates, hipStream_t s, fwx::PathLog plog, bool nonneg,
@@ -247,7 +109,7 @@ int fused_range(T *rate, int32_t *next, int n, int k_begin, int k_end, void *ws,
     {
         const int bt = k_end - k_begin < FWX_FUSED_B ? k_end - k_begin : FWX_FUSED_B;
         FWX_HIP(fwx::launch_fused_panel<T>(rate + (size_t)k_begin * n, n, k_begin, bt, wbuf[0], diag, s,
-                                           plog));
+                                           plog_rows(plog, (size_t)k_begin * n)));
     }
     for (int k0 = k_begin; k0 < k_end; k0 += FWX_FUSED_B, bi ^= 1) {
         const int bt = k_end - k0 < FWX_FUSED_B ? k_end - k0 : FWX_FUSED_B;
@@ -262,7 +124,7 @@ int fused_range(T *rate, int32_t *next, int n, int k_begin, int k_end, void *ws,
             FWX_HIP(hipStreamWaitEvent(side.s, side.rows_done, 0));
             // ... their snapshot panel on the side stream ...
             FWX_HIP(fwx::launch_fused_panel<T>(rate + (size_t)k1 * n, n, k1, bt1, wbuf[bi ^ 1], diag,
-                                               side.s, plog));
+                                               side.s, plog_rows(plog, (size_t)k1 * n)));
             FWX_HIP(hipEventRecord(side.panel_done, side.s));
             // ... while the rest of the matrix is relaxed on the main stream
             if (k1 % 8 == 0 && bt1 % 8 == 0) {
@@ -283,13 +145,6 @@ int fused_range(T *rate, int32_t *next, int n, int k_begin, int k_end, void *ws,
     return FWX_OK;
 }
 
-size_t fused_ws_bytes(int n, size_t es)
-{
-    const size_t ld = ((size_t)n + 3) & ~(size_t)3;
-    return (size_t)FWX_FUSED_B * n * 2 * es + (size_t)FWX_FUSED_B * ld * (es + 4) +
-           (size_t)2 * FWX_FUSED_B * FWX_FUSED_B * es + 256;
-}
-
 // AUTO: the fused engine wherever it applies and the matrix is big enough to fill the chip.
 template <typename T> bool pick_fused(int engine, int n, const void *rate, const int32_t *hops)
 {
@@ -307,20 +162,6 @@ bool pick_fused_hops(int engine, int n, const void *rate, const int32_t *next, c
     // tools/measure_hops.py: the per-k engine is ahead up to n ~ 2048 (7 against 22 ms at 1024),
     // the fused route from there on (38 against 72 ms at 4096, 0.86 against ~3 s at 16384)
     return whole_range && (engine == FWX_ENGINE_FUSED || n >= 3072);
-}
-
-// One read of the matrix (fwx.h "Domain"): bit 0 = every rate is >= +0.0 and not NaN; bit 1 = no
-// entry has a non-zero rate and next < 0.  d_flag: a device int the caller owns.
-template <typename T>
-int domain_bits(const T *rate, const int32_t *next, size_t count, int *d_flag, hipStream_t s, int &bits)
-{
-    int h = 3;
-    FWX_HIP(hipMemcpyAsync(d_flag, &h, sizeof(int), hipMemcpyHostToDevice, s));
-    FWX_HIP(fwx::launch_nonneg_check(rate, next, count, d_flag, s));
-    FWX_HIP(hipMemcpyAsync(&h, d_flag, sizeof(int), hipMemcpyDeviceToHost, s));
-    FWX_HIP(hipStreamSynchronize(s));
-    bits = h;
-    return FWX_OK;
 }
 
 // Which engine runs a solve of pivots [k_begin, k_end) of an order-n matrix (pivots < n only for a
@@ -351,27 +192,6 @@ int route_solve(const Opts &op, int n, bool whole, const T *rate, const int32_t 
     route = hops_fused ? ROUTE_FUSED_HOPS : ROUTE_FUSED;
     return FWX_OK;
 }
-
-int sum_updates(unsigned long long *d_updates, uint64_t *out, hipStream_t s)
-{
-    unsigned long long h[FWX_UPDATE_SHARDS];
-    FWX_HIP(hipMemcpyAsync(h, d_updates, sizeof(h), hipMemcpyDeviceToHost, s));
-    FWX_HIP(hipStreamSynchronize(s));
-    uint64_t u = 0;
-    for (int i = 0; i < FWX_UPDATE_SHARDS; ++i) u += h[i];
-    *out = u;
-    return FWX_OK;
-}
-
-struct DevBuf {
-    void *p = nullptr;
-    ~DevBuf() { if (p) (void)hipFree(p); }
-    int alloc(size_t bytes)
-    {
-        FWX_HIP(hipMalloc(&p, bytes ? bytes : 1));
-        return FWX_OK;
-    }
-};
 
 // ---- hops from the fused engine ------------------------------------------------------------------
 // The fused kernels carry no `hops` (= length _path).  They can keep the path trace, though, and the
@@ -631,27 +451,6 @@ int panel_impl(const fwx_slab *b, T *w, int32_t *w_hops, unsigned long long *d_u
 
 }  // namespace
 
-struct fwx_matrix {
-    int32_t n, dtype, device;
-    void *rate;
-    int32_t *next, *hops, *scratch;
-    unsigned long long *upd;
-    fwx::PathLog plog;     // path trace for exact `_path` lists (last == nullptr: disabled)
-    int32_t *next0;        // the uploaded next-hop matrix: the path of an entry never improved
-    int32_t *walk;         // scratch of the exact-path walk (stack + output)
-    int32_t walk_cap;      // capacity (path entries) `walk` was sized for
-    int32_t rec_ready;     // a traced solve of the current upload has completed
-    int32_t fresh;         // the arrays hold an uploaded input that has not been solved yet
-    unsigned long long last_u;   // U of the last traced solve
-    hipStream_t stream;    // the handle's own non-blocking stream: every operation on the handle runs
-                           // on it (never the legacy null stream), so handles on different host
-                           // threads overlap and nothing synchronises with torch's streams
-    void *ws;              // fused-engine workspace, allocated by the first fused solve and kept
-    size_t ws_bytes;
-    SideStream *side;      // look-ahead stream + events of the fused engine, kept likewise
-    int *flag;             // device int for the domain check
-};
-
 namespace {
 template <typename T>
 int matrix_solve_typed(fwx_matrix *m, const Opts &op, unsigned long long *upd, hipStream_t s)
@@ -901,6 +700,11 @@ int fwx_matrix_create(fwx_matrix **out, int32_t n, int32_t dtype, int32_t with_n
 int fwx_matrix_destroy(fwx_matrix *m)
 {
     if (!m) return FWX_OK;
+    if (m->multi) {
+        multi_destroy(m);
+        delete m;
+        return FWX_OK;
+    }
     DeviceGuard g;
     (void)g.enter(m->device);
     if (m->rate) (void)hipFree(m->rate);
@@ -927,6 +731,7 @@ int fwx_matrix_upload(fwx_matrix *m, const void *rate, const int32_t *next, cons
     if (!m) return FWX_ERR_INVALID;
     if (m->n == 0) return FWX_OK;
     if (!rate || (m->next && !next) || (m->hops && !hops)) return FWX_ERR_INVALID;
+    if (m->multi) return multi_upload(m, rate, next);
     DeviceGuard g;
     int rc = g.enter(m->device);
     if (rc) return rc;
@@ -950,6 +755,7 @@ int fwx_matrix_enable_path_log(fwx_matrix *m)
 {
     if (!m || !m->next || m->plog.last) return FWX_ERR_INVALID;
     if (m->n == 0) return FWX_OK;
+    if (m->multi) return multi_enable_path_log(m);
     DeviceGuard g;
     int rc = g.enter(m->device);
     if (rc) return rc;
@@ -982,10 +788,11 @@ int fwx_matrix_query_exact(fwx_matrix *m, int32_t src, int32_t dst, double *rate
     if (!m || src < 0 || dst < 0 || src >= m->n || dst >= m->n || cap <= 0 || !path_out)
         return FWX_ERR_INVALID;
     if (!m->plog.last) return FWX_ERR_INVALID;
+    if (!m->rec_ready) return FWX_ERR_INVALID;             // no traced solve of this upload yet
+    if (m->multi) return multi_query_exact(m, src, dst, rate_out, path_out, cap);
     DeviceGuard g;
     int rc = g.enter(m->device);
     if (rc) return rc;
-    if (!m->rec_ready) return FWX_ERR_INVALID;             // no traced solve of this upload yet
     const size_t idx = (size_t)src * m->n + dst;
     hipStream_t s = m->stream;
     float f32_rate = 0;
@@ -1021,10 +828,11 @@ int fwx_matrix_query_exact_batch(fwx_matrix *m, int32_t count, const int32_t *sr
     if (!m || count < 0 || cap <= 0) return FWX_ERR_INVALID;
     if (count == 0) return FWX_OK;
     if (!src || !dst || !len_out || !path_out || !m->plog.last) return FWX_ERR_INVALID;
+    if (!m->rec_ready) return FWX_ERR_INVALID;
+    if (m->multi) return multi_query_exact_batch(m, count, src, dst, len_out, path_out, cap);
     DeviceGuard g;
     int rc = g.enter(m->device);
     if (rc) return rc;
-    if (!m->rec_ready) return FWX_ERR_INVALID;
     DevBuf d_src, d_dst, d_len, d_paths, d_stacks;
     const size_t c = (size_t)count;
     if ((rc = d_src.alloc(c * 4)) || (rc = d_dst.alloc(c * 4)) || (rc = d_len.alloc(c * 4)) ||
@@ -1048,6 +856,7 @@ int fwx_matrix_download(fwx_matrix *m, void *rate, int32_t *next, int32_t *hops)
     if (!m) return FWX_ERR_INVALID;
     if (m->n == 0) return FWX_OK;
     if ((next && !m->next) || (hops && !m->hops)) return FWX_ERR_INVALID;
+    if (m->multi) return multi_download(m, rate, next);
     DeviceGuard g;
     int rc = g.enter(m->device);
     if (rc) return rc;
@@ -1067,6 +876,7 @@ int fwx_matrix_solve(fwx_matrix *m, const fwx_opts *opts)
     Opts op;
     int rc = read_opts(opts, m->n, op);
     if (rc) return rc;
+    if (m->multi) return multi_solve(m, op);
     DeviceGuard g;
     if ((rc = g.enter(m->device))) return rc;
     hipStream_t s = op.has_stream ? op.stream : m->stream;
@@ -1088,6 +898,7 @@ int fwx_matrix_query(fwx_matrix *m, int32_t src, int32_t dst, double *rate_out, 
 {
     if (!m || src < 0 || dst < 0 || src >= m->n || dst >= m->n || cap < 0 || (cap > 0 && !path_out))
         return FWX_ERR_INVALID;
+    if (m->multi) return multi_query(m, src, dst, rate_out, path_out, cap);
     DeviceGuard g;
     int rc = g.enter(m->device);
     if (rc) return rc;

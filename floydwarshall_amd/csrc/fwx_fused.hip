@@ -857,7 +857,8 @@ template <typename T> hipError_t launch_fused_colpanel(const FusedArgs<T> &a, hi
     hipError_t e = check_fused_args(a);
     if (e != hipSuccess) return e;
     const dim3 cgrid((unsigned)((a.rows + 63) / 64)), block(PANEL_THREADS);
-    if (a.plog.last && (!a.next || a.row0 != 0 || a.rows != a.n)) return hipErrorInvalidValue;
+    // (the trace matrices of a slab are indexed by LOCAL row, like its rate / next)
+    if (a.plog.last && !a.next) return hipErrorInvalidValue;
     if (a.plog.last)
         hipLaunchKernelGGL((fused_colpanel<T, true, true>), cgrid, block, 0, s, a.rate, a.next, a.rows,
                            a.n, a.row0, a.k0, a.bt, a.w, a.ct, a.cnt, a.ct_ld, a.plog.last,
@@ -942,9 +943,9 @@ hipError_t launch_fused_panel(const T *rows_base, int n, int k0, int bt, T *w, T
     if (n <= 0 || bt <= 0) return hipSuccess;
     if (bt > B) return hipErrorInvalidValue;
     const dim3 grid((unsigned)((n + 63) / 64)), block(PANEL_THREADS);
-    if (plog.last)   // rows_base is row k0 of the whole matrix: same offset into the trace
+    if (plog.last)   // plog points at the SAME rows as rows_base (pivot row k0 of the trace matrices)
         hipLaunchKernelGGL((fused_rowpanel<T, true>), grid, block, 0, s, rows_base, n, k0, bt, w,
-                           plog.last + (size_t)k0 * n, plog.at_row + (size_t)k0 * n);
+                           plog.last, plog.at_row);
     else
         hipLaunchKernelGGL((fused_rowpanel<T, false>), grid, block, 0, s, rows_base, n, k0, bt, w,
                            nullptr, nullptr);

@@ -1,0 +1,255 @@
+// fwx_internal.h -- pieces shared by the translation units behind the C ABI (fwx_api.hip: one
+// device; fwx_multi.hip: the row-partitioned multi-device handle).  Not installed, not part of the ABI.
+#ifndef FWX_INTERNAL_H
+#define FWX_INTERNAL_H
+
+#include <hip/hip_runtime.h>
+#include <stddef.h>
+#include <stdint.h>
+
+#include "fwx.h"
+#include "fwx_kernels.h"
+
+static_assert(FWX_UPDATE_SHARDS == FWX_UPDATE_SHARDS_K, "shard count mismatch");
+
+namespace fwxi {
+
+inline thread_local int g_last_hip = 0;
+
+#define FWX_HIP(call)                                                                              \
+    do {                                                                                           \
+        hipError_t e__ = (call);                                                                   \
+        if (e__ != hipSuccess) {                                                                   \
+            g_last_hip = (int)e__;                                                                 \
+            (void)hipGetLastError();                                                               \
+            return e__ == hipErrorOutOfMemory ? FWX_ERR_OOM : FWX_ERR_HIP;                         \
+        }                                                                                          \
+    } while (0)
+
+inline int device_count()
+{
+    int c = 0;
+    if (hipGetDeviceCount(&c) != hipSuccess) {
+        (void)hipGetLastError();
+        return 0;
+    }
+    return c;
+}
+
+// Sets the requested device for the scope of one ABI call and restores the caller's.
+struct DeviceGuard {
+    int prev = -1;
+    bool changed = false;
+    int enter(int device)
+    {
+        const int cnt = device_count();
+        if (cnt <= 0) return FWX_ERR_NO_DEVICE;
+        if (hipGetDevice(&prev) != hipSuccess) return FWX_ERR_HIP;
+        if (device < 0) return FWX_OK;
+        if (device >= cnt) return FWX_ERR_INVALID;
+        if (device != prev) {
+            FWX_HIP(hipSetDevice(device));
+            changed = true;
+        }
+        return FWX_OK;
+    }
+    ~DeviceGuard()
+    {
+        if (changed) (void)hipSetDevice(prev);
+    }
+};
+
+struct Opts {
+    int device = -1, engine = FWX_ENGINE_AUTO, k_begin = 0, k_end = 0, block = 0, serpentine = 1;
+    uint64_t *updates_out = nullptr;
+    hipStream_t stream = nullptr;      // caller's stream (fwx_opts.stream), nullptr = library-owned
+    bool has_stream = false;
+};
+
+// The stream one blocking ABI call runs on: the caller's (fwx_opts.stream) or a non-blocking stream
+// of its own -- never the legacy null stream, which would serialise the call against every other
+// blocking stream of the process (torch's included) and against solves on other host threads.
+struct CallStream {
+    hipStream_t s = nullptr;
+    bool owned = false;
+    int open(const Opts &op)
+    {
+        if (op.has_stream) { s = op.stream; return FWX_OK; }
+        FWX_HIP(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
+        owned = true;
+        return FWX_OK;
+    }
+    ~CallStream() { if (owned && s) (void)hipStreamDestroy(s); }
+};
+
+// Bounds the number of launches in flight on a stream: every EVERY launches an event is recorded
+// and the host waits for the event recorded 2*EVERY launches earlier.  The GPU never idles (at
+// least EVERY launches are queued behind the one being waited for), but a solve of N = 16384
+// pivots no longer parks 16384 dispatches in the queue: rocprofv3's counter collection, which
+// intercepts every AQL packet, crashed on exactly that.
+struct Throttle {
+    static constexpr int EVERY = 256;
+    hipEvent_t ev[2] = {nullptr, nullptr};
+    bool armed[2] = {false, false};
+    int count = 0, slot = 0;
+    ~Throttle()
+    {
+        for (int i = 0; i < 2; ++i)
+            if (ev[i]) (void)hipEventDestroy(ev[i]);
+    }
+    int tick(hipStream_t s, int launches = 1)
+    {
+        count += launches;
+        if (count < EVERY) return FWX_OK;
+        count = 0;
+        if (!ev[slot]) FWX_HIP(hipEventCreateWithFlags(&ev[slot], hipEventDisableTiming));
+        if (armed[slot]) FWX_HIP(hipEventSynchronize(ev[slot]));
+        FWX_HIP(hipEventRecord(ev[slot], s));
+        armed[slot] = true;
+        slot ^= 1;
+        return FWX_OK;
+    }
+};
+
+inline int read_opts(const fwx_opts *o, int n, Opts &out)
+{
+    if (o) {
+        // v1 callers pass the struct up to and including updates_out; later fields are optional
+        if (o->struct_size < offsetof(fwx_opts, stream)) return FWX_ERR_INVALID;
+        out.device = o->device;
+        out.engine = o->engine;
+        out.k_begin = o->k_begin;
+        out.k_end = o->k_end;
+        out.block = o->block;
+        out.serpentine = o->serpentine == 0 ? 1 : 0;
+        out.updates_out = o->updates_out;
+        if (o->struct_size >= offsetof(fwx_opts, use_stream) + sizeof(int32_t) && o->use_stream) {
+            out.stream = (hipStream_t)o->stream;
+            out.has_stream = true;
+        }
+    }
+    if (out.k_end <= 0) out.k_end = n;
+    if (out.k_begin < 0 || out.k_begin > out.k_end || out.k_end > n) return FWX_ERR_INVALID;
+    if (out.engine != FWX_ENGINE_AUTO && out.engine != FWX_ENGINE_PERK &&
+        out.engine != FWX_ENGINE_FUSED)
+        return FWX_ERR_INVALID;
+    return FWX_OK;
+}
+
+
+inline int sum_updates(unsigned long long *d_updates, uint64_t *out, hipStream_t s)
+{
+    unsigned long long h[FWX_UPDATE_SHARDS];
+    FWX_HIP(hipMemcpyAsync(h, d_updates, sizeof(h), hipMemcpyDeviceToHost, s));
+    FWX_HIP(hipStreamSynchronize(s));
+    uint64_t u = 0;
+    for (int i = 0; i < FWX_UPDATE_SHARDS; ++i) u += h[i];
+    *out = u;
+    return FWX_OK;
+}
+
+
+struct DevBuf {
+    void *p = nullptr;
+    ~DevBuf() { if (p) (void)hipFree(p); }
+    int alloc(size_t bytes)
+    {
+        FWX_HIP(hipMalloc(&p, bytes ? bytes : 1));
+        return FWX_OK;
+    }
+};
+
+
+struct SideStream {
+    hipStream_t s = nullptr;
+    hipEvent_t rows_done = nullptr, panel_done = nullptr;
+    ~SideStream()
+    {
+        if (rows_done) (void)hipEventDestroy(rows_done);
+        if (panel_done) (void)hipEventDestroy(panel_done);
+        if (s) (void)hipStreamDestroy(s);
+    }
+    int init()
+    {
+        FWX_HIP(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
+        FWX_HIP(hipEventCreateWithFlags(&rows_done, hipEventDisableTiming));
+        FWX_HIP(hipEventCreateWithFlags(&panel_done, hipEventDisableTiming));
+        return FWX_OK;
+    }
+};
+
+
+inline size_t fused_ws_bytes(int n, size_t es)
+{
+    const size_t ld = ((size_t)n + 3) & ~(size_t)3;
+    return (size_t)FWX_FUSED_B * n * 2 * es + (size_t)FWX_FUSED_B * ld * (es + 4) +
+           (size_t)2 * FWX_FUSED_B * FWX_FUSED_B * es + 256;
+}
+
+
+// One read of the matrix (fwx.h "Domain"): bit 0 = every rate is >= +0.0 and not NaN; bit 1 = no
+// entry has a non-zero rate and next < 0.  d_flag: a device int the caller owns.
+template <typename T>
+int domain_bits(const T *rate, const int32_t *next, size_t count, int *d_flag, hipStream_t s, int &bits)
+{
+    int h = 3;
+    FWX_HIP(hipMemcpyAsync(d_flag, &h, sizeof(int), hipMemcpyHostToDevice, s));
+    FWX_HIP(fwx::launch_nonneg_check(rate, next, count, d_flag, s));
+    FWX_HIP(hipMemcpyAsync(&h, d_flag, sizeof(int), hipMemcpyDeviceToHost, s));
+    FWX_HIP(hipStreamSynchronize(s));
+    bits = h;
+    return FWX_OK;
+}
+
+
+// The path trace `off` elements further on (e.g. at pivot row k0: off = k0 * n); null stays null.
+inline fwx::PathLog plog_rows(fwx::PathLog p, size_t off)
+{
+    if (p.last) { p.last += off; p.at_col += off; p.at_row += off; }
+    return p;
+}
+
+struct MultiState;   // fwx_multi.hip: the partitions of a multi-device handle
+
+}  // namespace fwxi
+
+struct fwx_matrix {
+    int32_t n, dtype, device;
+    void *rate;
+    int32_t *next, *hops, *scratch;
+    unsigned long long *upd;
+    fwx::PathLog plog;     // path trace for exact `_path` lists (last == nullptr: disabled)
+    int32_t *next0;        // the uploaded next-hop matrix: the path of an entry never improved
+    int32_t *walk;         // scratch of the exact-path walk (stack + output)
+    int32_t walk_cap;      // capacity (path entries) `walk` was sized for
+    int32_t rec_ready;     // a traced solve of the current upload has completed
+    int32_t fresh;         // the arrays hold an uploaded input that has not been solved yet
+    unsigned long long last_u;   // U of the last traced solve
+    hipStream_t stream;    // the handle's own non-blocking stream: every operation on the handle runs
+                           // on it (never the legacy null stream), so handles on different host
+                           // threads overlap and nothing synchronises with torch's streams
+    void *ws;              // fused-engine workspace, allocated by the first fused solve and kept
+    size_t ws_bytes;
+    fwxi::SideStream *side;      // look-ahead stream + events of the fused engine, kept likewise
+    int *flag;             // device int for the domain check
+    fwxi::MultiState *multi;   // non-null: a row-partitioned handle (fwx_matrix_create_multi); the
+                           // single-device arrays above are then unused
+};
+
+
+
+// fwx_multi.hip: what the handle entry points of fwx_api.hip call for a handle with m->multi
+namespace fwxi {
+int multi_upload(fwx_matrix *m, const void *rate, const int32_t *next);
+int multi_download(fwx_matrix *m, void *rate, int32_t *next);
+int multi_solve(fwx_matrix *m, const Opts &op);
+int multi_enable_path_log(fwx_matrix *m);
+int multi_query(fwx_matrix *m, int32_t src, int32_t dst, double *rate_out, int32_t *path_out, int32_t cap);
+int multi_query_exact(fwx_matrix *m, int32_t src, int32_t dst, double *rate_out, int32_t *path_out,
+                      int32_t cap);
+int multi_query_exact_batch(fwx_matrix *m, int32_t count, const int32_t *src, const int32_t *dst,
+                            int32_t *len_out, int32_t *path_out, int32_t cap);
+void multi_destroy(fwx_matrix *m);
+}  // namespace fwxi
+
+#endif

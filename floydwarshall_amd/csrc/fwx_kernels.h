@@ -42,8 +42,9 @@ template <typename T> struct RelaxArgs {
     int skip_lo = 0, skip_hi = 0;  // slab rows [skip_lo, skip_hi) are left alone (multiples of 4):
                                    //   a look-ahead launch has already relaxed them
     unsigned long long *updates;   // FWX_UPDATE_SHARDS_K counters or nullptr
-    PathLog plog;                  // plog.last == nullptr: no tracing (slab must be the whole matrix
-                                   // when tracing: the three matrices are indexed by global row)
+    PathLog plog;                  // plog.last == nullptr: no tracing (per-k engine: the slab must be the
+                                   // whole matrix when tracing, the three matrices are indexed by
+                                   // global row)
 };
 
 template <typename T> hipError_t launch_relax(const RelaxArgs<T> &a, hipStream_t s);
@@ -73,7 +74,7 @@ template <typename T> struct FusedArgs {
                            // staging loads 16-byte aligned)
     unsigned long long *updates;
     bool nonneg;           // caller verified: every matrix entry is >= +0 and not NaN (max form)
-    PathLog plog = PathLog();   // path trace (needs next; single-GPU solves of the whole matrix only)
+    PathLog plog = PathLog();   // path trace (needs next): rows x n like rate / next, LOCAL rows
 };
 
 // Domain check (fwx.h "Domain").  *flag is a device int preset to 3; bit 0 is cleared if any of the
@@ -95,7 +96,8 @@ hipError_t launch_fused_main(const FusedArgs<T> &a, int r_lo, int r_hi, hipStrea
                              int skip_lo = 0, int skip_hi = 0);
 
 // diag + rowpanel: snapshot panel of the pivot rows `rows_base` (bt x n, at time k0); the matrix
-// is not modified.  diag_ws: 2 * FWX_FUSED_B^2 elements of scratch.
+// is not modified.  diag_ws: unused (kept for the ABI).  plog: the path trace AT THE SAME ROWS as
+// rows_base (plog.last / plog.at_row point at pivot row k0; at_col is not touched).
 template <typename T>
 hipError_t launch_fused_panel(const T *rows_base, int n, int k0, int bt, T *w, T *diag_ws,
                               hipStream_t s, PathLog plog = PathLog());

@@ -1,0 +1,736 @@
+// fwx_multi.hip -- the row-partitioned solve behind the C ABI: ONE process, several devices.
+//
+// The reference's loop has one call site (ProcessRequests.hs:82-84 -> floydWarshall,
+// /root/reference/src/lib/Algorithms.hs:19-20); a host bound to that one call reaches the whole
+// node through fwx_matrix_create_multi / fwx_solve_multi_*.  Step k of runAlgo (:42-61) needs, for
+// a local row i, r[i][k] and next[i][k] (local) and pivot row k AS IT STANDS AT THE START OF STEP
+// k -- nothing else -- so the only exchange is the snapshot panel of 64 pivot rows per pass, sent by
+// the partition that owns them: ncclBroadcast on RCCL (distinct devices) or hipMemcpyPeerAsync
+// (also when a device is listed more than once: logical partitions, which is how this schedule
+// is tested on one GPU).  Same kernels, same operands, same order as the single-device fused
+// engine: bit-identical results.
+//
+// Streams per partition: `main` runs colpanel + main kernels, `side` runs the owner's snapshot
+// panel and the exchange, so that with look-ahead neither sits on the critical path.  One host
+// thread enqueues everything; ordering is by events only (no host synchronisation inside a solve
+// apart from the in-flight throttle).
+#include <dlfcn.h>
+#include <hip/hip_runtime.h>
+#include <rccl/rccl.h>      // types and prototypes only: librccl.so.1 is dlopen()ed on first use
+#include <stdint.h>
+#include <string.h>
+
+#include <mutex>
+#include <new>
+#include <vector>
+
+#include "fwx.h"
+#include "fwx_internal.h"
+#include "fwx_kernels.h"
+
+namespace fwxi {
+
+// ---- RCCL, loaded lazily -------------------------------------------------------------------------
+struct RcclApi {
+    void *lib = nullptr;
+    decltype(&ncclCommInitAll) CommInitAll = nullptr;
+    decltype(&ncclCommDestroy) CommDestroy = nullptr;
+    decltype(&ncclBroadcast) Broadcast = nullptr;
+    decltype(&ncclGroupStart) GroupStart = nullptr;
+    decltype(&ncclGroupEnd) GroupEnd = nullptr;
+    bool ok = false;
+};
+
+static RcclApi &rccl()
+{
+    static RcclApi api;
+    static std::once_flag once;
+    std::call_once(once, [] {
+        // by SONAME: a process that already holds an RCCL (torch bundles one) gets that mapping
+        api.lib = dlopen("librccl.so.1", RTLD_NOW | RTLD_LOCAL);
+        if (!api.lib) return;
+        api.CommInitAll = (decltype(api.CommInitAll))dlsym(api.lib, "ncclCommInitAll");
+        api.CommDestroy = (decltype(api.CommDestroy))dlsym(api.lib, "ncclCommDestroy");
+        api.Broadcast = (decltype(api.Broadcast))dlsym(api.lib, "ncclBroadcast");
+        api.GroupStart = (decltype(api.GroupStart))dlsym(api.lib, "ncclGroupStart");
+        api.GroupEnd = (decltype(api.GroupEnd))dlsym(api.lib, "ncclGroupEnd");
+        api.ok = api.CommInitAll && api.CommDestroy && api.Broadcast && api.GroupStart && api.GroupEnd;
+    });
+    return api;
+}
+
+#define FWX_NCCL(call)                                                                             \
+    do {                                                                                           \
+        if ((call) != ncclSuccess) return FWX_ERR_RCCL;                                            \
+    } while (0)
+
+// ---- partitions -----------------------------------------------------------------------------------
+struct Part {
+    int device = 0, row0 = 0, rows = 0;    // rows [row0, row0 + rows) of the nd x nd device matrix
+    void *rate = nullptr;
+    int32_t *next = nullptr;
+    fwx::PathLog plog;                      // slab-local trace matrices (rows x nd), or null
+    int32_t *next0 = nullptr;
+    void *w[2] = {nullptr, nullptr};        // snapshot panels, 64 x nd
+    void *ct = nullptr;                     // pivot-column snapshots, 64 x ct_ld
+    int32_t *cnt = nullptr;
+    int ct_ld = 0;
+    unsigned long long *upd = nullptr;
+    int *flag = nullptr;
+    hipStream_t main = nullptr, side = nullptr;
+    hipEvent_t rows_done = nullptr, w_ready[2] = {nullptr, nullptr}, main_free[2] = {nullptr, nullptr};
+};
+
+struct MultiState {
+    int parts = 0;
+    int nd = 0;                 // device order: n rounded up to a multiple of 16 bytes of elements
+    int exchange = FWX_XCHG_PEER;
+    Part part[FWX_MAX_PARTS];
+    ncclComm_t comm[FWX_MAX_PARTS];
+    bool have_comm = false;
+    int32_t *qscratch = nullptr;   // query scratch on partition 0's device
+    int32_t qcap = 0;
+};
+
+// Everything a query kernel needs to address entry (a, b) of a partitioned matrix.
+struct SlabTab {
+    int parts, n;                              // n = device pitch
+    int row0[FWX_MAX_PARTS + 1];
+    const int32_t *next[FWX_MAX_PARTS], *last[FWX_MAX_PARTS], *at_col[FWX_MAX_PARTS],
+        *at_row[FWX_MAX_PARTS], *next0[FWX_MAX_PARTS];
+    __device__ __forceinline__ size_t locate(int a, int b, int &p) const
+    {
+        p = 0;
+        while (p + 1 < parts && a >= row0[p + 1]) ++p;
+        return (size_t)(a - row0[p]) * n + b;
+    }
+};
+
+static SlabTab make_tab(const MultiState &M)
+{
+    SlabTab t;
+    memset(&t, 0, sizeof(t));
+    t.parts = M.parts;
+    t.n = M.nd;
+    for (int p = 0; p < M.parts; ++p) {
+        const Part &q = M.part[p];
+        t.row0[p] = q.row0;
+        t.next[p] = q.next;
+        t.last[p] = q.plog.last;
+        t.at_col[p] = q.plog.at_col;
+        t.at_row[p] = q.plog.at_row;
+        t.next0[p] = q.next0;
+    }
+    t.row0[M.parts] = M.nd;
+    return t;
+}
+
+__global__ void multi_follow_path_kernel(SlabTab t, int n_real, int src, int dst, int32_t *out, int cap,
+                                         int32_t *len_out)
+{
+    int len = 0, cur = src, p;
+    {
+        const size_t off = t.locate(src, dst, p);
+        if (t.next[p][off] < 0) { *len_out = 0; return; }
+    }
+    while (cur != dst || len == 0) {
+        const size_t off = t.locate(cur, dst, p);
+        const int nx = t.next[p][off];
+        if (nx < 0 || nx >= n_real || len >= n_real) { *len_out = FWX_ERR_CYCLE; return; }
+        if (len >= cap) { *len_out = FWX_ERR_CAPACITY; return; }
+        out[len++] = nx;
+        cur = nx;
+    }
+    *len_out = len;
+}
+
+// Same walk as exact_path(s)_kernel in fwx_api.hip (see there), entries addressed through the table.
+__global__ __launch_bounds__(64) void multi_exact_paths_kernel(SlabTab t, int n_real, int count,
+                                                               const int32_t *src, const int32_t *dst,
+                                                               int32_t *paths, int32_t *stacks, int cap,
+                                                               int32_t *len_out)
+{
+    enum { FINAL = 0, AS_COLUMN = 1, AS_ROW = 2 };
+    const int qi = blockIdx.x * 64 + threadIdx.x;
+    if (qi >= count) return;
+    const int s0 = src[qi], d0 = dst[qi];
+    if (s0 < 0 || d0 < 0 || s0 >= n_real || d0 >= n_real) { len_out[qi] = FWX_ERR_INVALID; return; }
+    int32_t *out = paths + (size_t)qi * cap;
+    int32_t *stack = stacks + (size_t)qi * 3 * cap;
+    int sp = 0, len = 0;
+    stack[0] = s0; stack[1] = d0; stack[2] = FINAL; sp = 1;
+    while (sp > 0) {
+        --sp;
+        const int a = stack[3 * sp], b = stack[3 * sp + 1], kind = stack[3 * sp + 2];
+        int p;
+        const size_t off = t.locate(a, b, p);
+        const int q = kind == FINAL ? t.last[p][off] : kind == AS_COLUMN ? t.at_col[p][off] : t.at_row[p][off];
+        if (q < 0) {
+            if (t.next0[p][off] >= 0) {
+                if (len >= cap) { len_out[qi] = FWX_ERR_CAPACITY; return; }
+                out[len++] = b;
+            }
+        } else {
+            if (sp + 2 > cap) { len_out[qi] = FWX_ERR_CAPACITY; return; }
+            stack[3 * sp] = q; stack[3 * sp + 1] = b; stack[3 * sp + 2] = AS_ROW; ++sp;
+            stack[3 * sp] = a; stack[3 * sp + 1] = q; stack[3 * sp + 2] = AS_COLUMN; ++sp;
+        }
+    }
+    len_out[qi] = len;
+}
+
+static int set_dev(int d)
+{
+    FWX_HIP(hipSetDevice(d));
+    return FWX_OK;
+}
+
+// Restores the caller's device when a multi call returns.
+struct DevRestore {
+    int prev = -1;
+    DevRestore() { if (hipGetDevice(&prev) != hipSuccess) prev = -1; }
+    ~DevRestore() { if (prev >= 0) (void)hipSetDevice(prev); }
+};
+
+static void multi_free(MultiState *M)
+{
+    if (!M) return;
+    DevRestore keep;
+    for (int p = 0; p < M->parts; ++p) {
+        Part &q = M->part[p];
+        if (hipSetDevice(q.device) != hipSuccess) continue;
+        if (q.main) (void)hipStreamSynchronize(q.main);
+        if (q.side) (void)hipStreamSynchronize(q.side);
+    }
+    if (M->have_comm)
+        for (int p = 0; p < M->parts; ++p) (void)rccl().CommDestroy(M->comm[p]);
+    for (int p = 0; p < M->parts; ++p) {
+        Part &q = M->part[p];
+        if (hipSetDevice(q.device) != hipSuccess) continue;
+        void *bufs[] = {q.rate, q.next, q.plog.last, q.plog.at_col, q.plog.at_row, q.next0, q.w[0], q.w[1],
+                        q.ct, q.cnt, q.upd, q.flag};
+        for (void *b : bufs)
+            if (b) (void)hipFree(b);
+        hipEvent_t evs[] = {q.rows_done, q.w_ready[0], q.w_ready[1], q.main_free[0], q.main_free[1]};
+        for (hipEvent_t e : evs)
+            if (e) (void)hipEventDestroy(e);
+        if (q.main) (void)hipStreamDestroy(q.main);
+        if (q.side) (void)hipStreamDestroy(q.side);
+        if (p == 0 && M->qscratch) (void)hipFree(M->qscratch);
+    }
+    delete M;
+}
+
+static int multi_alloc(fwx_matrix *m, int n_parts, const int32_t *devices, int exchange)
+{
+    const size_t es = m->dtype == FWX_F64 ? 8 : 4;
+    const int vw = (int)(16 / es);
+    MultiState *M = new (std::nothrow) MultiState();
+    if (!M) return FWX_ERR_OOM;
+    m->multi = M;
+    M->parts = n_parts;
+    M->nd = (m->n + vw - 1) / vw * vw;
+    bool distinct = true;
+    for (int p = 0; p < n_parts; ++p)
+        for (int q = 0; q < p; ++q) distinct = distinct && devices[p] != devices[q];
+    if (exchange == FWX_XCHG_AUTO) exchange = (distinct && n_parts >= 2) ? FWX_XCHG_RCCL : FWX_XCHG_PEER;
+    if (exchange == FWX_XCHG_RCCL && !distinct) return FWX_ERR_INVALID;
+    M->exchange = exchange;
+    const int nd = M->nd;
+    for (int p = 0; p < n_parts; ++p) {
+        Part &q = M->part[p];
+        q.device = devices[p];
+        q.row0 = (int)((int64_t)m->n * p / n_parts);
+        const int r1 = p + 1 == n_parts ? nd : (int)((int64_t)m->n * (p + 1) / n_parts);   // padding rows: last
+        q.rows = r1 - q.row0;
+        q.ct_ld = (q.rows + 3) & ~3;
+        int rc = set_dev(q.device);
+        if (rc) return rc;
+        const size_t cells = (size_t)q.rows * nd;
+        FWX_HIP(hipMalloc(&q.rate, cells * es ? cells * es : 16));
+        if (m->next) FWX_HIP(hipMalloc((void **)&q.next, cells * 4 ? cells * 4 : 16));
+        FWX_HIP(hipMalloc(&q.w[0], (size_t)FWX_FUSED_BLOCK * nd * es));
+        FWX_HIP(hipMalloc(&q.w[1], (size_t)FWX_FUSED_BLOCK * nd * es));
+        FWX_HIP(hipMalloc(&q.ct, (size_t)FWX_FUSED_BLOCK * (q.ct_ld ? q.ct_ld : 4) * es));
+        if (m->next) FWX_HIP(hipMalloc((void **)&q.cnt, (size_t)FWX_FUSED_BLOCK * (q.ct_ld ? q.ct_ld : 4) * 4));
+        FWX_HIP(hipMalloc((void **)&q.upd, FWX_UPDATE_SHARDS * 8));
+        FWX_HIP(hipMalloc((void **)&q.flag, 16));
+        FWX_HIP(hipStreamCreateWithFlags(&q.main, hipStreamNonBlocking));
+        FWX_HIP(hipStreamCreateWithFlags(&q.side, hipStreamNonBlocking));
+        hipEvent_t *evs[] = {&q.rows_done, &q.w_ready[0], &q.w_ready[1], &q.main_free[0], &q.main_free[1]};
+        for (hipEvent_t *e : evs) FWX_HIP(hipEventCreateWithFlags(e, hipEventDisableTiming));
+    }
+    // queries walk every slab from partition 0's device: distinct devices need peer access
+    for (int p = 0; p < n_parts; ++p)
+        for (int q = 0; q < n_parts; ++q) {
+            if (devices[p] == devices[q]) continue;
+            int rc = set_dev(devices[p]);
+            if (rc) return rc;
+            const hipError_t e = hipDeviceEnablePeerAccess(devices[q], 0);
+            if (e != hipSuccess && e != hipErrorPeerAccessAlreadyEnabled) {
+                g_last_hip = (int)e;
+                (void)hipGetLastError();
+                return FWX_ERR_HIP;
+            }
+            (void)hipGetLastError();
+        }
+    if (exchange == FWX_XCHG_RCCL) {
+        RcclApi &api = rccl();
+        if (!api.ok) return FWX_ERR_RCCL;
+        int devs[FWX_MAX_PARTS];
+        for (int p = 0; p < n_parts; ++p) devs[p] = devices[p];
+        FWX_NCCL(api.CommInitAll(M->comm, n_parts, devs));
+        M->have_comm = true;
+    }
+    // placeholders: the single-device code paths test m->next for "carries next-hops"
+    return FWX_OK;
+}
+
+// The arrays of partition p hold rows [row0, row0 + rows) at pitch nd; the caller's are n x n.
+static int multi_copy(fwx_matrix *m, void *host_rate, int32_t *host_next, bool to_device)
+{
+    MultiState &M = *m->multi;
+    const size_t es = m->dtype == FWX_F64 ? 8 : 4;
+    const int n = m->n, nd = M.nd;
+    for (int p = 0; p < M.parts; ++p) {
+        Part &q = M.part[p];
+        int rc = set_dev(q.device);
+        if (rc) return rc;
+        const int real = (q.row0 + q.rows <= n ? q.rows : n - q.row0);   // rows that exist in the caller's arrays
+        if (to_device && nd != n) {
+            FWX_HIP(hipMemsetAsync(q.rate, 0, (size_t)q.rows * nd * es, q.main));              // +0.0
+            if (q.next) FWX_HIP(hipMemsetAsync(q.next, 0xFF, (size_t)q.rows * nd * 4, q.main));   // -1
+        }
+        if (real <= 0) continue;
+        auto copy = [&](void *dev, char *host, size_t e) -> int {
+            if (!host) return FWX_OK;
+            host += (size_t)q.row0 * n * e;
+            if (to_device)
+                FWX_HIP(hipMemcpy2DAsync(dev, (size_t)nd * e, host, (size_t)n * e, (size_t)n * e, (size_t)real,
+                                         hipMemcpyDefault, q.main));
+            else
+                FWX_HIP(hipMemcpy2DAsync(host, (size_t)n * e, dev, (size_t)nd * e, (size_t)n * e, (size_t)real,
+                                         hipMemcpyDefault, q.main));
+            return FWX_OK;
+        };
+        if ((rc = copy(q.rate, (char *)host_rate, es))) return rc;
+        if (q.next && (rc = copy(q.next, (char *)host_next, 4))) return rc;
+        if (to_device && q.plog.last)
+            FWX_HIP(hipMemcpyAsync(q.next0, q.next, (size_t)q.rows * nd * 4, hipMemcpyDeviceToDevice, q.main));
+    }
+    for (int p = 0; p < M.parts; ++p) {
+        int rc = set_dev(M.part[p].device);
+        if (rc) return rc;
+        FWX_HIP(hipStreamSynchronize(M.part[p].main));
+    }
+    return FWX_OK;
+}
+
+struct Block { int k0, bt, owner; };
+
+template <typename T> static fwx::FusedArgs<T> part_args(const MultiState &M, const Part &q, bool nonneg,
+                                                         bool counting)
+{
+    fwx::FusedArgs<T> a;
+    a.rate = (T *)q.rate; a.next = q.next; a.rows = q.rows; a.n = M.nd; a.row0 = q.row0;
+    a.ct = (T *)q.ct; a.cnt = q.next ? q.cnt : nullptr; a.ct_ld = q.ct_ld;
+    a.updates = counting ? q.upd : nullptr; a.nonneg = nonneg; a.plog = q.plog;
+    return a;
+}
+
+// Snapshot panel of block b on its owner's side stream + its exchange into slot b & 1 of every
+// partition.  Precondition: the owner's main stream has recorded rows_done after bringing the
+// block's rows up to time k0.
+template <typename T> static int issue_panel(MultiState &M, const Block &blk, int slot)
+{
+    Part &o = M.part[blk.owner];
+    const size_t bytes = (size_t)blk.bt * M.nd * sizeof(T);
+    int rc = set_dev(o.device);
+    if (rc) return rc;
+    FWX_HIP(hipStreamWaitEvent(o.side, o.rows_done, 0));
+    FWX_HIP(hipStreamWaitEvent(o.side, o.main_free[slot], 0));       // own main kernels are done with this slot
+    if (M.exchange == FWX_XCHG_PEER)
+        for (int r = 0; r < M.parts; ++r)      // nobody is still copying the previous panel out of this slot
+            if (r != blk.owner) FWX_HIP(hipStreamWaitEvent(o.side, M.part[r].w_ready[slot], 0));
+    const size_t row_off = (size_t)(blk.k0 - o.row0) * M.nd;
+    FWX_HIP(fwx::launch_fused_panel<T>((const T *)o.rate + row_off, M.nd, blk.k0, blk.bt, (T *)o.w[slot],
+                                       nullptr, o.side, plog_rows(o.plog, row_off)));
+    FWX_HIP(hipEventRecord(o.w_ready[slot], o.side));
+    if (M.exchange == FWX_XCHG_PEER) {
+        for (int r = 0; r < M.parts; ++r) {
+            if (r == blk.owner) continue;
+            Part &q = M.part[r];
+            if ((rc = set_dev(q.device))) return rc;
+            FWX_HIP(hipStreamWaitEvent(q.side, q.main_free[slot], 0));
+            FWX_HIP(hipStreamWaitEvent(q.side, o.w_ready[slot], 0));
+            if (q.device == o.device)
+                FWX_HIP(hipMemcpyAsync(q.w[slot], o.w[slot], bytes, hipMemcpyDeviceToDevice, q.side));
+            else
+                FWX_HIP(hipMemcpyPeerAsync(q.w[slot], q.device, o.w[slot], o.device, bytes, q.side));
+            FWX_HIP(hipEventRecord(q.w_ready[slot], q.side));
+        }
+    } else {
+        RcclApi &api = rccl();
+        for (int r = 0; r < M.parts; ++r) {
+            if (r == blk.owner) continue;
+            if ((rc = set_dev(M.part[r].device))) return rc;
+            FWX_HIP(hipStreamWaitEvent(M.part[r].side, M.part[r].main_free[slot], 0));
+        }
+        FWX_NCCL(api.GroupStart());
+        for (int r = 0; r < M.parts; ++r) {
+            Part &q = M.part[r];
+            if ((rc = set_dev(q.device))) return rc;
+            FWX_NCCL(api.Broadcast(q.w[slot], q.w[slot], (size_t)blk.bt * M.nd,
+                                   sizeof(T) == 8 ? ncclFloat64 : ncclFloat32, blk.owner, M.comm[r], q.side));
+        }
+        FWX_NCCL(api.GroupEnd());
+        for (int r = 0; r < M.parts; ++r) {
+            Part &q = M.part[r];
+            if ((rc = set_dev(q.device))) return rc;
+            FWX_HIP(hipEventRecord(q.w_ready[slot], q.side));
+        }
+    }
+    return FWX_OK;
+}
+
+template <typename T> static int multi_solve_typed(fwx_matrix *m, const Opts &op)
+{
+    MultiState &M = *m->multi;
+    const int nd = M.nd, P = M.parts;
+    const bool counting = op.updates_out != nullptr;
+    const bool with_next = m->next != nullptr;
+    int rc;
+    // domain (fwx.h "Domain"), every slab
+    int bits = 3;
+    for (int p = 0; p < P; ++p) {
+        Part &q = M.part[p];
+        if (q.rows == 0) continue;
+        if ((rc = set_dev(q.device))) return rc;
+        int b = 3;
+        if ((rc = domain_bits<T>((const T *)q.rate, q.next, (size_t)q.rows * nd, q.flag, q.main, b))) return rc;
+        bits &= b;
+    }
+    if (with_next && bits != 3) return FWX_ERR_UNSUPPORTED;   // see fwx.h: solved on one device
+    const bool nonneg = !with_next && !counting && (bits & 1);
+    for (int p = 0; p < P; ++p) {
+        Part &q = M.part[p];
+        if ((rc = set_dev(q.device))) return rc;
+        const size_t cells = (size_t)q.rows * nd;
+        if (q.plog.last) {
+            FWX_HIP(hipMemsetAsync(q.plog.last, 0xFF, cells * 4, q.main));
+            FWX_HIP(hipMemsetAsync(q.plog.at_col, 0xFF, cells * 4, q.main));
+            FWX_HIP(hipMemsetAsync(q.plog.at_row, 0xFF, cells * 4, q.main));
+        }
+        if (counting) FWX_HIP(hipMemsetAsync(q.upd, 0, FWX_UPDATE_SHARDS * 8, q.main));
+    }
+    // pivot blocks of at most 64 that never straddle two owners; real pivots only (padding is inert)
+    std::vector<Block> blocks;
+    for (int p = 0; p < P; ++p) {
+        const Part &q = M.part[p];
+        int k0 = q.row0 > op.k_begin ? q.row0 : op.k_begin;
+        const int hi = q.row0 + q.rows < op.k_end ? q.row0 + q.rows : op.k_end;
+        while (k0 < hi) {
+            const int bt = hi - k0 < FWX_FUSED_BLOCK ? hi - k0 : FWX_FUSED_BLOCK;
+            blocks.push_back({k0, bt, p});
+            k0 += bt;
+        }
+    }
+    if (blocks.empty()) return FWX_OK;
+    Throttle thr;
+    {   // the first panel: its rows are at time k0 already
+        Part &o = M.part[blocks[0].owner];
+        if ((rc = set_dev(o.device))) return rc;
+        FWX_HIP(hipEventRecord(o.rows_done, o.main));
+        if ((rc = issue_panel<T>(M, blocks[0], 0))) return rc;
+    }
+    for (size_t b = 0; b < blocks.size(); ++b) {
+        const Block &blk = blocks[b];
+        const int slot = (int)(b & 1);
+        const bool more = b + 1 < blocks.size();
+        // pivot-column snapshots on every partition
+        for (int p = 0; p < P; ++p) {
+            Part &q = M.part[p];
+            if (q.rows == 0) continue;
+            if ((rc = set_dev(q.device))) return rc;
+            FWX_HIP(hipStreamWaitEvent(q.main, q.w_ready[slot], 0));
+            fwx::FusedArgs<T> a = part_args<T>(M, q, nonneg, counting);
+            a.k0 = blk.k0; a.bt = blk.bt; a.w = (const T *)q.w[slot];
+            FWX_HIP(fwx::launch_fused_colpanel<T>(a, q.main));
+        }
+        int la_lo = 0, la_hi = 0, la_owner = -1;
+        if (more) {
+            // look-ahead: the rows of the next panel first, then their snapshot + exchange on the side
+            const Block &nb = blocks[b + 1];
+            Part &o = M.part[nb.owner];
+            la_owner = nb.owner; la_lo = nb.k0 - o.row0; la_hi = la_lo + nb.bt;
+            if ((rc = set_dev(o.device))) return rc;
+            fwx::FusedArgs<T> a = part_args<T>(M, o, nonneg, counting);
+            a.k0 = blk.k0; a.bt = blk.bt; a.w = (const T *)o.w[slot];
+            FWX_HIP(fwx::launch_fused_main<T>(a, la_lo, la_hi, o.main));
+            FWX_HIP(hipEventRecord(o.rows_done, o.main));
+            if ((rc = issue_panel<T>(M, nb, slot ^ 1))) return rc;
+        }
+        for (int p = 0; p < P; ++p) {
+            Part &q = M.part[p];
+            if ((rc = set_dev(q.device))) return rc;
+            if (q.rows > 0) {
+                fwx::FusedArgs<T> a = part_args<T>(M, q, nonneg, counting);
+                a.k0 = blk.k0; a.bt = blk.bt; a.w = (const T *)q.w[slot];
+                if (p != la_owner) {
+                    FWX_HIP(fwx::launch_fused_main<T>(a, 0, q.rows, q.main));
+                } else if (la_lo % 8 == 0 && la_hi % 8 == 0) {
+                    FWX_HIP(fwx::launch_fused_main<T>(a, 0, q.rows, q.main, la_lo, la_hi));
+                } else {
+                    FWX_HIP(fwx::launch_fused_main<T>(a, 0, la_lo, q.main));
+                    FWX_HIP(fwx::launch_fused_main<T>(a, la_hi, q.rows, q.main));
+                }
+            }
+            FWX_HIP(hipEventRecord(q.main_free[slot], q.main));
+        }
+        if ((rc = set_dev(M.part[0].device))) return rc;
+        if ((rc = thr.tick(M.part[0].main, 4))) return rc;
+    }
+    uint64_t total = 0;
+    for (int p = 0; p < P; ++p) {
+        Part &q = M.part[p];
+        if ((rc = set_dev(q.device))) return rc;
+        FWX_HIP(hipStreamSynchronize(q.side));
+        FWX_HIP(hipStreamSynchronize(q.main));
+        if (counting) {
+            uint64_t u = 0;
+            if ((rc = sum_updates(q.upd, &u, q.main))) return rc;
+            total += u;
+        }
+    }
+    if (counting) *op.updates_out = total;
+    m->last_u = total;
+    return FWX_OK;
+}
+
+// ---- entry points used by fwx_api.hip for handles with m->multi -----------------------------------
+int multi_upload(fwx_matrix *m, const void *rate, const int32_t *next)
+{
+    DevRestore keep;
+    const int rc = multi_copy(m, const_cast<void *>(rate), const_cast<int32_t *>(next), true);
+    if (rc) return rc;
+    if (m->plog.last) m->rec_ready = 0;
+    m->fresh = 1;
+    return FWX_OK;
+}
+
+int multi_download(fwx_matrix *m, void *rate, int32_t *next)
+{
+    DevRestore keep;
+    return multi_copy(m, rate, next, false);
+}
+
+int multi_solve(fwx_matrix *m, const Opts &op)
+{
+    if (op.k_begin != 0 || op.k_end != m->n) return FWX_ERR_UNSUPPORTED;
+    if (op.engine == FWX_ENGINE_PERK) return FWX_ERR_UNSUPPORTED;
+    if (m->plog.last && !m->fresh) return FWX_ERR_INVALID;   // a traced solve starts from an upload
+    DevRestore keep;
+    m->fresh = 0;
+    const int rc = m->dtype == FWX_F64 ? multi_solve_typed<double>(m, op) : multi_solve_typed<float>(m, op);
+    if (rc) return rc;
+    if (m->plog.last) m->rec_ready = 1;
+    return FWX_OK;
+}
+
+int multi_enable_path_log(fwx_matrix *m)
+{
+    MultiState &M = *m->multi;
+    DevRestore keep;
+    for (int p = 0; p < M.parts; ++p) {
+        Part &q = M.part[p];
+        int rc = set_dev(q.device);
+        if (rc) return rc;
+        const size_t bytes = (size_t)q.rows * M.nd * 4;
+        FWX_HIP(hipMalloc((void **)&q.plog.at_col, bytes ? bytes : 16));
+        FWX_HIP(hipMalloc((void **)&q.plog.at_row, bytes ? bytes : 16));
+        FWX_HIP(hipMalloc((void **)&q.next0, bytes ? bytes : 16));
+        FWX_HIP(hipMalloc((void **)&q.plog.last, bytes ? bytes : 16));
+        if (m->fresh) {
+            FWX_HIP(hipMemcpyAsync(q.next0, q.next, bytes, hipMemcpyDeviceToDevice, q.main));
+            FWX_HIP(hipStreamSynchronize(q.main));
+        }
+    }
+    m->plog.last = M.part[0].plog.last;     // "enabled" marker for the shared handle logic
+    m->rec_ready = 0;
+    return FWX_OK;
+}
+
+static int read_rate(fwx_matrix *m, int src, int dst, double *rate_out)
+{
+    MultiState &M = *m->multi;
+    int p = 0;
+    while (p + 1 < M.parts && src >= M.part[p + 1].row0) ++p;
+    Part &q = M.part[p];
+    int rc = set_dev(q.device);
+    if (rc) return rc;
+    const size_t off = (size_t)(src - q.row0) * M.nd + dst;
+    if (m->dtype == FWX_F64) {
+        FWX_HIP(hipMemcpyAsync(rate_out, (double *)q.rate + off, 8, hipMemcpyDeviceToHost, q.main));
+        FWX_HIP(hipStreamSynchronize(q.main));
+    } else {
+        float f = 0;
+        FWX_HIP(hipMemcpyAsync(&f, (float *)q.rate + off, 4, hipMemcpyDeviceToHost, q.main));
+        FWX_HIP(hipStreamSynchronize(q.main));
+        *rate_out = (double)f;
+    }
+    return FWX_OK;
+}
+
+static int query_scratch(MultiState &M, int32_t ints)
+{
+    if (M.qscratch && M.qcap >= ints) return FWX_OK;
+    if (M.qscratch) { (void)hipFree(M.qscratch); M.qscratch = nullptr; M.qcap = 0; }
+    FWX_HIP(hipMalloc((void **)&M.qscratch, (size_t)ints * 4));
+    M.qcap = ints;
+    return FWX_OK;
+}
+
+int multi_query(fwx_matrix *m, int32_t src, int32_t dst, double *rate_out, int32_t *path_out, int32_t cap)
+{
+    MultiState &M = *m->multi;
+    DevRestore keep;
+    int rc;
+    if (rate_out && (rc = read_rate(m, src, dst, rate_out))) return rc;
+    if (!m->next) return FWX_ERR_INVALID;
+    Part &z = M.part[0];
+    if ((rc = set_dev(z.device))) return rc;
+    const int dcap = cap < m->n ? cap : m->n;
+    if ((rc = query_scratch(M, m->n + 2))) return rc;
+    hipLaunchKernelGGL(multi_follow_path_kernel, dim3(1), dim3(1), 0, z.main, make_tab(M), m->n, src, dst,
+                       M.qscratch + 1, dcap, M.qscratch);
+    FWX_HIP(hipGetLastError());
+    int32_t len = 0;
+    FWX_HIP(hipMemcpyAsync(&len, M.qscratch, 4, hipMemcpyDeviceToHost, z.main));
+    FWX_HIP(hipStreamSynchronize(z.main));
+    if (len > 0) {
+        FWX_HIP(hipMemcpyAsync(path_out, M.qscratch + 1, (size_t)len * 4, hipMemcpyDeviceToHost, z.main));
+        FWX_HIP(hipStreamSynchronize(z.main));
+    }
+    return len;
+}
+
+int multi_query_exact_batch(fwx_matrix *m, int32_t count, const int32_t *src, const int32_t *dst,
+                            int32_t *len_out, int32_t *path_out, int32_t cap)
+{
+    MultiState &M = *m->multi;
+    DevRestore keep;
+    Part &z = M.part[0];
+    int rc = set_dev(z.device);
+    if (rc) return rc;
+    DevBuf d_src, d_dst, d_len, d_paths, d_stacks;
+    const size_t c = (size_t)count;
+    if ((rc = d_src.alloc(c * 4)) || (rc = d_dst.alloc(c * 4)) || (rc = d_len.alloc(c * 4)) ||
+        (rc = d_paths.alloc(c * cap * 4)) || (rc = d_stacks.alloc(c * cap * 12)))
+        return rc;
+    FWX_HIP(hipMemcpyAsync(d_src.p, src, c * 4, hipMemcpyHostToDevice, z.main));
+    FWX_HIP(hipMemcpyAsync(d_dst.p, dst, c * 4, hipMemcpyHostToDevice, z.main));
+    hipLaunchKernelGGL(multi_exact_paths_kernel, dim3((unsigned)((c + 63) / 64)), dim3(64), 0, z.main,
+                       make_tab(M), m->n, count, (const int32_t *)d_src.p, (const int32_t *)d_dst.p,
+                       (int32_t *)d_paths.p, (int32_t *)d_stacks.p, cap, (int32_t *)d_len.p);
+    FWX_HIP(hipGetLastError());
+    FWX_HIP(hipMemcpyAsync(len_out, d_len.p, c * 4, hipMemcpyDeviceToHost, z.main));
+    FWX_HIP(hipMemcpyAsync(path_out, d_paths.p, c * cap * 4, hipMemcpyDeviceToHost, z.main));
+    FWX_HIP(hipStreamSynchronize(z.main));
+    return FWX_OK;
+}
+
+int multi_query_exact(fwx_matrix *m, int32_t src, int32_t dst, double *rate_out, int32_t *path_out,
+                      int32_t cap)
+{
+    int rc;
+    {
+        DevRestore keep;
+        if (rate_out && (rc = read_rate(m, src, dst, rate_out))) return rc;
+    }
+    int32_t len = 0;
+    if ((rc = multi_query_exact_batch(m, 1, &src, &dst, &len, path_out, cap))) return rc;
+    return len;
+}
+
+void multi_destroy(fwx_matrix *m)
+{
+    multi_free(m->multi);
+    m->multi = nullptr;
+}
+
+}  // namespace fwxi
+
+using namespace fwxi;
+
+extern "C" {
+
+int fwx_matrix_create_multi(fwx_matrix **out, int32_t n, int32_t dtype, int32_t with_next,
+                            int32_t with_hops, int32_t n_parts, const int32_t *devices, int32_t exchange)
+{
+    if (!out || n < 0 || (dtype != FWX_F32 && dtype != FWX_F64) || n_parts < 1 ||
+        n_parts > FWX_MAX_PARTS || !devices ||
+        (exchange != FWX_XCHG_AUTO && exchange != FWX_XCHG_PEER && exchange != FWX_XCHG_RCCL))
+        return FWX_ERR_INVALID;
+    *out = nullptr;
+    if (with_hops) return FWX_ERR_UNSUPPORTED;
+    const int cnt = device_count();
+    if (cnt <= 0) return FWX_ERR_NO_DEVICE;
+    for (int p = 0; p < n_parts; ++p)
+        if (devices[p] < 0 || devices[p] >= cnt) return FWX_ERR_INVALID;
+    fwx_matrix *m = new (std::nothrow) fwx_matrix();
+    if (!m) return FWX_ERR_OOM;
+    memset(m, 0, sizeof(*m));
+    m->n = n; m->dtype = dtype; m->device = devices[0];
+    m->next = with_next ? (int32_t *)(uintptr_t)16 : nullptr;   // marker only: the slabs own the arrays
+    DevRestore keep;
+    const int rc = multi_alloc(m, n_parts, devices, exchange);
+    if (rc) {
+        multi_destroy(m);
+        delete m;
+        return rc;
+    }
+    *out = m;
+    return FWX_OK;
+}
+
+int fwx_matrix_parts(const fwx_matrix *m, int32_t *exchange_out)
+{
+    if (!m) return FWX_ERR_INVALID;
+    if (exchange_out) *exchange_out = m->multi ? m->multi->exchange : FWX_XCHG_PEER;
+    return m->multi ? m->multi->parts : 1;
+}
+
+static int solve_multi_host(int32_t n, int dtype, void *rate, int32_t *next, int32_t *hops, int32_t n_parts,
+                            const int32_t *devices, int32_t exchange, const fwx_opts *opts)
+{
+    if (n < 0) return FWX_ERR_INVALID;
+    if (n == 0) return FWX_OK;
+    if (!rate || (hops && !next)) return FWX_ERR_INVALID;
+    if (hops) return FWX_ERR_UNSUPPORTED;
+    Opts op;
+    int rc = read_opts(opts, n, op);
+    if (rc) return rc;
+    fwx_matrix *m = nullptr;
+    if ((rc = fwx_matrix_create_multi(&m, n, dtype, next != nullptr, 0, n_parts, devices, exchange))) return rc;
+    rc = multi_upload(m, rate, next);
+    if (!rc) rc = multi_solve(m, op);
+    if (!rc) rc = multi_download(m, rate, next);
+    fwx_matrix_destroy(m);
+    return rc;
+}
+
+int fwx_solve_multi_f64(int32_t n, double *rate, int32_t *next, int32_t *hops, int32_t n_parts,
+                        const int32_t *devices, int32_t exchange, const fwx_opts *opts)
+{
+    try { return solve_multi_host(n, FWX_F64, rate, next, hops, n_parts, devices, exchange, opts); }
+    catch (...) { return FWX_ERR_OOM; }
+}
+
+int fwx_solve_multi_f32(int32_t n, float *rate, int32_t *next, int32_t *hops, int32_t n_parts,
+                        const int32_t *devices, int32_t exchange, const fwx_opts *opts)
+{
+    try { return solve_multi_host(n, FWX_F32, rate, next, hops, n_parts, devices, exchange, opts); }
+    catch (...) { return FWX_ERR_OOM; }
+}
+
+}  // extern "C"

@@ -11,14 +11,14 @@ import numpy as np
 
 from . import _lib
 from ._lib import (FWX_ENGINE_AUTO, FWX_ENGINE_FUSED, FWX_ENGINE_PERK, FWX_F32, FWX_F64,
-                   FWX_FUSED_BLOCK, FWX_UPDATE_SHARDS, FwxError, FwxOpts, FwxPivots, FwxSlab, check,
-                   lib)
+                   FWX_FUSED_BLOCK, FWX_UPDATE_SHARDS, FWX_XCHG_AUTO, FWX_XCHG_PEER, FWX_XCHG_RCCL,
+                   FwxError, FwxOpts, FwxPivots, FwxSlab, check, lib)
 
 __all__ = ["solve", "follow_path", "dev_follow_paths", "dev_check_nonneg", "dev_domain_bits", "dev_solve_fused",
            "dev_solve", "DeviceMatrix", "dev_relax", "dev_panel", "dev_panel_snap",
            "dev_relax_fused", "FusedWorkspace", "FWX_FUSED_BLOCK", "device_count",
            "FwxError", "FWX_ENGINE_AUTO", "FWX_ENGINE_PERK", "FWX_ENGINE_FUSED",
-           "FWX_UPDATE_SHARDS"]
+           "FWX_UPDATE_SHARDS", "solve_multi", "FWX_XCHG_AUTO", "FWX_XCHG_PEER", "FWX_XCHG_RCCL"]
 
 
 def device_count():
@@ -67,6 +67,20 @@ def solve(rate, nxt=None, hops=None, *, device=-1, engine=FWX_ENGINE_AUTO, k_beg
     return int(u.value) if count_updates else None
 
 
+def solve_multi(rate, nxt=None, hops=None, *, devices=(0,), exchange=FWX_XCHG_AUTO,
+                count_updates=False):
+    """runAlgo in place on host numpy arrays, row-partitioned over `devices` (one partition per
+    entry; a device may repeat = logical partitions on one GPU) from ONE process:
+    fwx_solve_multi_f64 / _f32."""
+    _check_arrays(rate, nxt, hops)
+    o, u = _opts(want_updates=count_updates)
+    devs = (ctypes.c_int32 * len(devices))(*devices)
+    fn = lib().fwx_solve_multi_f64 if rate.dtype == np.float64 else lib().fwx_solve_multi_f32
+    check(fn(rate.shape[0], _np_ptr(rate), _np_ptr(nxt), _np_ptr(hops), len(devices), devs, exchange,
+             ctypes.byref(o)), "fwx_solve_multi")
+    return int(u.value) if count_updates else None
+
+
 def follow_path(nxt, src, dst):
     """Vertex indices after src up to and including dst; [] when there is no route."""
     n = nxt.shape[0]
@@ -79,16 +93,30 @@ def follow_path(nxt, src, dst):
 class DeviceMatrix:
     """fwx_matrix handle: the solved matrix stays in HBM across queries (InSync, Types.hs:35-37)."""
 
-    def __init__(self, n, dtype=np.float64, with_next=True, with_hops=False, device=-1):
+    def __init__(self, n, dtype=np.float64, with_next=True, with_hops=False, device=-1, devices=None,
+                 exchange=FWX_XCHG_AUTO):
+        """devices: a list of HIP ordinals = a ROW-PARTITIONED handle (fwx_matrix_create_multi), one
+        partition per entry, repeats allowed; None = one device."""
         self.n = int(n)
         self.dtype = np.dtype(dtype)
         self.with_next, self.with_hops = bool(with_next), bool(with_hops)
         h = ctypes.c_void_p()
-        check(lib().fwx_matrix_create(ctypes.byref(h), self.n,
-                                      FWX_F64 if self.dtype == np.float64 else FWX_F32,
-                                      int(self.with_next), int(self.with_hops), device),
-              "fwx_matrix_create")
+        code = FWX_F64 if self.dtype == np.float64 else FWX_F32
+        if devices is None:
+            check(lib().fwx_matrix_create(ctypes.byref(h), self.n, code, int(self.with_next),
+                                          int(self.with_hops), device), "fwx_matrix_create")
+        else:
+            devs = (ctypes.c_int32 * len(devices))(*devices)
+            check(lib().fwx_matrix_create_multi(ctypes.byref(h), self.n, code, int(self.with_next),
+                                                int(self.with_hops), len(devices), devs, exchange),
+                  "fwx_matrix_create_multi")
         self._h = h
+
+    def parts(self):
+        """(number of row partitions, exchange transport in use)."""
+        x = ctypes.c_int32(0)
+        p = check(lib().fwx_matrix_parts(self._h, ctypes.byref(x)), "fwx_matrix_parts")
+        return p, int(x.value)
 
     def upload(self, rate, nxt=None, hops=None):
         _check_arrays(rate, nxt, hops)

@@ -66,7 +66,8 @@ typedef enum fwx_status {
     FWX_ERR_OOM = -4,         /* device or host allocation failed                                 */
     FWX_ERR_CYCLE = -5,       /* fwx_follow_path: next-hops do not reach dst within n hops        */
     FWX_ERR_CAPACITY = -6,    /* fwx_follow_path: output buffer too small                         */
-    FWX_ERR_UNSUPPORTED = -7  /* option combination not implemented                               */
+    FWX_ERR_UNSUPPORTED = -7, /* option combination not implemented                               */
+    FWX_ERR_RCCL = -8         /* librccl.so.1 could not be loaded, or an RCCL call failed         */
 } fwx_status;
 
 typedef enum fwx_dtype { FWX_F32 = 0, FWX_F64 = 1 } fwx_dtype;
@@ -159,6 +160,52 @@ int fwx_matrix_query_exact(fwx_matrix *m, int32_t src, int32_t dst, double *rate
  * it.  Host arrays in and out.                                                                  */
 int fwx_matrix_query_exact_batch(fwx_matrix *m, int32_t count, const int32_t *src, const int32_t *dst,
                                  int32_t *len_out, int32_t *path_out, int32_t cap);
+
+/* ---- row-partitioned solve behind the same call: ONE process, several devices ------------------
+ * The reference has one call site, ProcessRequests.hs:82-84 -> floydWarshall (Algorithms.hs:19-20);
+ * a host bound to that one call gets the whole node through these entry points.  The matrix is cut
+ * into n_parts contiguous row blocks (partition p holds rows [n*p/P, n*(p+1)/P) of rate / next and
+ * of the path trace); step k needs, besides local values, only pivot row k AS IT STANDS AT THE
+ * START OF STEP k, so pivots travel FWX_FUSED_BLOCK at a time as one snapshot panel per block,
+ * produced by the partition that owns those rows and sent to all others, with look-ahead (the
+ * owner of the next block relaxes those rows first and runs their panel + the exchange on a side
+ * stream while every partition sweeps the rest of its slab).  No operand and no order changes:
+ * results are bit-identical to the single-device solve and to the reference loop.
+ *
+ * devices[p] = HIP ordinal of partition p.  A device may be listed MORE THAN ONCE (logical
+ * partitions on one GPU: how the partitioned schedule is tested where only one GPU exists).
+ * exchange:
+ *   FWX_XCHG_RCCL  ncclBroadcast of each panel on RCCL (ncclCommInitAll over the devices, one
+ *                  communicator per partition, calls grouped; librccl.so.1 is loaded on first use,
+ *                  libfwx does not link it).  Needs pairwise distinct devices.
+ *   FWX_XCHG_PEER  hipMemcpyPeerAsync from the owner's panel into every other partition's panel
+ *                  buffer (plain device-to-device copies when the device is the same).
+ *   FWX_XCHG_AUTO  RCCL when there are >= 2 partitions on pairwise distinct devices, else PEER.
+ * Distinct devices get peer access enabled pairwise (queries walk the slabs from one device).
+ *
+ * A multi handle is an fwx_matrix: upload / solve / download / query / enable_path_log /
+ * query_exact[_batch] / path_log_count / destroy work on it unchanged (whole pivot range only;
+ * fwx_opts.engine AUTO or FUSED; fwx_opts.device / stream are ignored).  Any n: rows are padded on
+ * the device to a multiple of 16 bytes.  Not (yet) carried through slabs: `hops` (with_hops != 0 is
+ * FWX_ERR_UNSUPPORTED) and matrices outside the reference's domain WITH next-hops (see "Domain":
+ * the slab kernels take next[i][k]; such a matrix returns FWX_ERR_UNSUPPORTED from solve and is
+ * solved on one device by fwx_solve_* / fwx_matrix_create).                                       */
+#define FWX_XCHG_AUTO 0
+#define FWX_XCHG_PEER 1
+#define FWX_XCHG_RCCL 2
+#define FWX_MAX_PARTS 32
+int fwx_matrix_create_multi(fwx_matrix **out, int32_t n, int32_t dtype, int32_t with_next,
+                            int32_t with_hops, int32_t n_parts, const int32_t *devices,
+                            int32_t exchange);
+/* Partitions of a handle (1 for a single-device handle); exchange_out (optional) receives the
+ * transport in use (FWX_XCHG_PEER / FWX_XCHG_RCCL).                                              */
+int fwx_matrix_parts(const fwx_matrix *m, int32_t *exchange_out);
+/* One-shot host-buffer form, same contract as fwx_solve_f64 / _f32 (in place, caller owns the
+ * arrays): create_multi + upload + solve + download + destroy.  opts: updates_out is honoured.    */
+int fwx_solve_multi_f64(int32_t n, double *rate, int32_t *next, int32_t *hops, int32_t n_parts,
+                        const int32_t *devices, int32_t exchange, const fwx_opts *opts);
+int fwx_solve_multi_f32(int32_t n, float *rate, int32_t *next, int32_t *hops, int32_t n_parts,
+                        const int32_t *devices, int32_t exchange, const fwx_opts *opts);
 
 /* ---- device-pointer step API (caller-owned DEVICE memory, caller's stream) --------------------
  * Used by the benchmark and by the row-partitioned multi-GPU driver, which own their buffers
