@@ -188,7 +188,7 @@ int route_solve(const Opts &op, int n, bool whole, const T *rate, const int32_t 
         if (rc) return rc;
     }
     if (next && bits != 3) { route = ROUTE_PERK; return FWX_OK; }
-    nonneg = !next && !counting && (bits & 1);
+    nonneg = !counting && (next ? bits == 3 : (bits & 1) != 0);   // max-form kernels allowed
     route = hops_fused ? ROUTE_FUSED_HOPS : ROUTE_FUSED;
     return FWX_OK;
 }
@@ -252,7 +252,9 @@ int fused_with_hops(T *rate, int32_t *next, int32_t *hops, int n, int pivots,
     if ((rc = d_lcol.alloc(nn * 4)) || (rc = d_lrow.alloc(nn * 4)) ||
         (rc = d_ws.alloc(fused_ws_bytes(n, sizeof(T)))))
         return rc;
-    if ((rc = fused_range<T>(rate, next, n, 0, pivots, d_ws.p, d_updates, s, plog, false))) return rc;
+    // (the caller routed here only inside the domain; counting keeps the compare form)
+    if ((rc = fused_range<T>(rate, next, n, 0, pivots, d_ws.p, d_updates, s, plog, d_updates == nullptr)))
+        return rc;
     const dim3 grid((unsigned)((2 * (size_t)n + 255) / 256)), block(256);
     for (int k = 0; k < pivots; ++k)
         hipLaunchKernelGGL(hops_dp_step, grid, block, 0, s, plog.at_col, plog.at_row, hops,

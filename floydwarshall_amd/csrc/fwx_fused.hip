@@ -27,6 +27,7 @@
 // so this kernel is VALU-bound (about 3 lane-ops per relaxation), not HBM-bound.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 
 #include "fwx_kernels.h"
 
@@ -551,7 +552,7 @@ __global__ __launch_bounds__(256, MINW) void fused_main(T *rate, int32_t *next, 
 // compare form.  The caller must have verified the domain
 // (fwx_dev_check_nonneg); the next-hop variant needs the compare and stays on fused_main.
 // ------------------------------------------------------------------------------------------------
-template <int MINW, int UNR, int RI, int NH>
+template <int MINW, int UNR, int RI, int NH, bool PIPE = false>
 __global__ __launch_bounds__(256, MINW) void fused_main_max(float *rate, int rows, int n, int row0,
                                                             int k0, int bt, const float *w,
                                                             const float *ct, int ct_ld, int ct_vec,
@@ -641,9 +642,8 @@ __global__ __launch_bounds__(256, MINW) void fused_main_max(float *rate, int row
         const bool more = s0 + BS < bt;
         if (more) prefetch(s0 + BS);             // in flight during the fold below
         const int np = skip ? 0 : (min(BS, bt - s0) + 1) / 2;
-#pragma unroll UNR
-        for (int tp = 0; tp < np; ++tp) {
-            float c[RI][2], wv[NH][4][2];          // [..][u]: pivot u of the pair
+        // operands of one pivot pair: LDS -> registers ([..][u]: pivot u of the pair)
+        auto load_ops = [&](int tp, float (&c)[RI][2], float (&wv)[NH][4][2]) {
 #pragma unroll
             for (int u = 0; u < 2; ++u) {
 #pragma unroll
@@ -659,6 +659,8 @@ __global__ __launch_bounds__(256, MINW) void fused_main_max(float *rate, int row
                     for (int e = 0; e < 4; ++e) wv[h][e][u] = wq[e];
                 }
             }
+        };
+        auto fold_pair = [&](const float (&c)[RI][2], const float (&wv)[NH][4][2]) {
 #pragma unroll
             for (int r = 0; r < RI; ++r) {
                 // All 16 products of this row first, then the 8 folds: a v_max3 never issues right
@@ -677,6 +679,29 @@ __global__ __launch_bounds__(256, MINW) void fused_main_max(float *rate, int row
 #pragma unroll
                     for (int e = 0; e < 4; ++e)
                         x[r][h][e] = __builtin_fmaxf(__builtin_fmaxf(x[r][h][e], p0[h][e]), p1[h][e]);
+            }
+        };
+        if (PIPE) {
+            // the operands of pair tp+1 are read from LDS while pair tp is folded: the ds_reads are
+            // in flight behind ~190 VALU instructions instead of in front of them (the waits then
+            // carry lgkmcnt(N > 0): LDS returns in order)
+            float cA[RI][2], wA[NH][4][2], cB[RI][2], wB[NH][4][2];
+            if (np > 0) load_ops(0, cA, wA);
+#pragma unroll 1
+            for (int tp = 0; tp < np; tp += 2) {
+                if (tp + 1 < np) load_ops(tp + 1, cB, wB);
+                fold_pair(cA, wA);
+                if (tp + 1 < np) {
+                    if (tp + 2 < np) load_ops(tp + 2, cA, wA);
+                    fold_pair(cB, wB);
+                }
+            }
+        } else {
+#pragma unroll UNR
+            for (int tp = 0; tp < np; ++tp) {
+                float c[RI][2], wv[NH][4][2];
+                load_ops(tp, c, wv);
+                fold_pair(c, wv);
             }
         }
         if (more) {
@@ -700,6 +725,185 @@ __global__ __launch_bounds__(256, MINW) void fused_main_max(float *rate, int row
             *reinterpret_cast<V4 *>(rate + off) = x[r][h];
         }
     }
+}
+
+// ------------------------------------------------------------------------------------------------
+// fused_main_arg: rates + next-hops (+ path trace) for f32 matrices INSIDE THE DOMAIN (fwx.h
+// "Domain": every rate >= +0 and not NaN, and a non-zero rate always has a path).
+//
+// On that domain the strict fold equals max bit for bit (see fused_main_max), and the head of the
+// reference's concatenated list (Algorithms.hs:55) is next[i][k] of the LAST successful
+// relaxation.  Within one pass that relaxation is the FIRST pivot t* whose product equals the pass
+// maximum -- the fold only moves on a strictly greater product, so it reaches its final value at
+// the first pivot that attains it and never moves again -- and it exists iff the maximum exceeds
+// the incoming value.  So instead of a compare and two selects per relaxation (12.1 issue cycles):
+//   1. fold the 64 pivots two at a time with v_max3_f32, exactly as fused_main_max does (4.0);
+//   2. every entry whose value changed becomes an ITEM (entry id, new value) in a per-wave list in
+//      LDS (ballot + mbcnt compaction: all 64 lanes of the re-scan below do useful work);
+//   3. one lane per item re-multiplies the 64 operand pairs -- all 64 pivots of the tile's C and W
+//      strips stay resident in LDS for this -- finds t* by equality, and writes
+//      next = CN[t*][i] (and last = k0 + t* for the path trace).
+// About 11 % of the entries change in an average pass of the N = 16384 benchmark solve (60 % in the
+// first sixteenth, 3.5 % in the last), and an item costs 64 x (2 LDS reads + mul + compare + select).
+// Bit-identical to the compare form: same products (one v_mul_f32 each), same winner, same t*.
+// No update counting (U is the number of strict increases along the fold: compare form only).
+// ------------------------------------------------------------------------------------------------
+template <int MINW, int RI, bool HAS_LAST>
+__global__ __launch_bounds__(256, MINW) void fused_main_arg(float *rate, int32_t *next, int rows, int n,
+                                                            int row0, int k0, int bt, const float *w,
+                                                            const float *ct, const int32_t *cnt,
+                                                            int ct_ld, int ct_vec, int skip_lo,
+                                                            int skip_hi, int32_t *last)
+{
+    typedef float V4 __attribute__((ext_vector_type(4)));
+    constexpr int TI = 16 * RI, TJ = 64, NP = B / 2, LCAP = 128;
+    // all 64 pivots of the tile's operand strips, as (t, t+1) pairs like fused_main_max
+    __shared__ __attribute__((aligned(16))) float sW[NP][2][TJ];
+    __shared__ __attribute__((aligned(16))) float sC[NP][2][TI];
+    __shared__ unsigned int l_id[4][LCAP];      // per-wave item lists: (row in tile) << 8 | column in tile
+    __shared__ float l_val[4][LCAP];            //                      the entry's new value
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int i_base = blockIdx.y * TI;
+    const int j_base = blockIdx.x * TJ;
+    const int ti = tid >> 4, tj = tid & 15;
+    const int i0 = i_base + ti * RI;
+    const bool skip = i0 >= skip_lo && i0 < skip_hi;   // rows done by the look-ahead launch
+    const float nanv = qnan<float>();
+
+    // ---- stage W (NaN at j == k and past the matrix) and C (NaN at i == k, from colpanel) -------
+    for (int idx = tid; idx < B * (TJ / 4); idx += 256) {
+        const int t = idx / (TJ / 4), v = idx % (TJ / 4);
+        const int j = j_base + v * 4;
+        V4 val = V4{nanv, nanv, nanv, nanv};
+        if (t < bt && j < n) {
+            val = *reinterpret_cast<const V4 *>(w + (size_t)t * n + j);
+            const int kcol = k0 + t - j;
+            if (kcol >= 0 && kcol < 4) val[kcol] = nanv;
+        }
+        *reinterpret_cast<V4 *>(&sW[t >> 1][t & 1][v * 4]) = val;
+    }
+    for (int idx = tid; idx < B * (TI / 4); idx += 256) {
+        const int t = idx / (TI / 4), v = idx % (TI / 4);
+        const int i = i_base + v * 4;
+        V4 val = V4{nanv, nanv, nanv, nanv};
+        if (t < bt) {
+            if (ct_vec && i + 4 <= rows) {
+                val = *reinterpret_cast<const V4 *>(ct + (size_t)t * ct_ld + i);
+            } else {
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    if (i + e < rows) val[e] = ct[(size_t)t * ct_ld + i + e];
+            }
+        }
+        *reinterpret_cast<V4 *>(&sC[t >> 1][t & 1][v * 4]) = val;
+    }
+
+    const int jcol = j_base + tj * 4;
+    const bool jok = jcol < n;
+    const int jc = jok ? jcol : n - 4;
+    V4 x[RI], xin[RI];
+#pragma unroll
+    for (int r = 0; r < RI; ++r) {
+        const int i = min(i0 + r, rows - 1);
+        x[r] = *reinterpret_cast<const V4 *>(rate + (size_t)i * n + jc);
+        xin[r] = x[r];
+    }
+    __syncthreads();
+
+    // ---- 1. the fold: two pivots per v_max3_f32 --------------------------------------------------
+    const int np = skip ? 0 : (bt + 1) / 2;
+#pragma unroll 1
+    for (int tp = 0; tp < np; ++tp) {
+        float c[RI][2], wv[4][2];
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+#pragma unroll
+            for (int q = 0; q < RI / 4; ++q) {
+                const V4 cv = *reinterpret_cast<const V4 *>(&sC[tp][u][ti * RI + q * 4]);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) c[q * 4 + e][u] = cv[e];
+            }
+            const V4 wq = *reinterpret_cast<const V4 *>(&sW[tp][u][tj * 4]);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) wv[e][u] = wq[e];
+        }
+#pragma unroll
+        for (int r = 0; r < RI; ++r) {
+            float p0[4], p1[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                asm("v_mul_f32 %0, %1, %2" : "=v"(p0[e]) : "v"(c[r][0]), "v"(wv[e][0]));
+                asm("v_mul_f32 %0, %1, %2" : "=v"(p1[e]) : "v"(c[r][1]), "v"(wv[e][1]));
+            }
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+                x[r][e] = __builtin_fmaxf(__builtin_fmaxf(x[r][e], p0[e]), p1[e]);
+        }
+    }
+
+    // ---- 2. + 3. changed entries -> items -> t* -> next (and last) -------------------------------
+    const int gi_lo = row0 + i_base;
+    const bool diag_tile = gi_lo < j_base + TJ && j_base < gi_lo + TI;
+    int count = 0;                                   // items in this wave's list (wave-uniform)
+    auto flush = [&]() {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        for (int base = 0; base < count; base += 64) {
+            const int it = base + lane;
+            const bool act = it < count;
+            const unsigned int id = l_id[wave][act ? it : 0];
+            const float v = act ? l_val[wave][it] : nanv;       // NaN never matches
+            const int il = (int)(id >> 8), jl = (int)(id & 255u);
+            int found = -1;
+#pragma unroll 8
+            for (int t = B - 1; t >= 0; --t) {       // descending: the smallest matching t wins
+                const float p = sC[t >> 1][t & 1][il] * sW[t >> 1][t & 1][jl];
+                found = (p == v) ? t : found;
+            }
+            if (act && found >= 0) {
+                const int i = i_base + il;
+                const size_t off = (size_t)i * n + j_base + jl;
+                next[off] = cnt[(size_t)found * ct_ld + i];
+                if (HAS_LAST) last[off] = k0 + found;
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+        count = 0;
+    };
+#pragma unroll
+    for (int r = 0; r < RI; ++r) {
+        const int i = i0 + r;
+        const bool row_ok = i < rows && !skip && jok;
+        bool ch[4];
+        bool any = false;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            // j == i is never touched (Algorithms.hs:54): the diagonal entry keeps its value
+            const bool is_diag = diag_tile && (row0 + i == jc + e);
+            if (is_diag) x[r][e] = xin[r][e];
+            ch[e] = row_ok && (x[r][e] != xin[r][e]);
+            any |= ch[e];
+        }
+        if (any) *reinterpret_cast<V4 *>(rate + (size_t)i * n + jc) = x[r];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const unsigned long long mask = __ballot(ch[e]);
+            if (mask) {                               // wave-uniform
+                const int pos = count + (int)__builtin_amdgcn_mbcnt_hi((unsigned int)(mask >> 32),
+                                             __builtin_amdgcn_mbcnt_lo((unsigned int)mask, 0u));
+                if (ch[e]) {
+                    l_id[wave][pos] = ((unsigned int)(ti * RI + r) << 8) | (unsigned int)(tj * 4 + e);
+                    l_val[wave][pos] = x[r][e];
+                }
+                count += __builtin_popcountll(mask);
+                if (count > LCAP - 64) flush();
+            }
+        }
+    }
+    if (count > 0) flush();
 }
 
 // Domain check (fwx.h "Domain"): clears bit 0 of *flag if any rate has its sign bit set or is NaN,
@@ -778,15 +982,51 @@ hipError_t launch_nonneg_check(const double *rate, const int32_t *next, size_t c
 
 // f32, rates only, no update counting, domain verified by the caller: the max3 kernel.
 static bool launch_max_form(const FusedArgs<float> &a, dim3 grid, dim3 block, int skip_lo,
-                            int skip_hi, hipStream_t s)
+                            int skip_hi, hipStream_t s, int32_t *last)
 {
-    if (!a.nonneg || a.next || a.updates) return false;
+    if (!a.nonneg || a.updates) return false;
     const int ct_vec = ((uintptr_t)a.ct % 16 == 0 && a.ct_ld % 4 == 0) ? 1 : 0;
+    if (a.next) {
+        // rates + next-hops (+ trace): max-form fold, then arg re-scan of the changed entries
+        if (small_tiles(a.n, a.rows)) {
+            const dim3 g((unsigned)((a.n + 63) / 64), (unsigned)((a.rows + 63) / 64));
+            if (last)
+                hipLaunchKernelGGL((fused_main_arg<3, 4, true>), g, block, 0, s, a.rate, a.next, a.rows,
+                                   a.n, a.row0, a.k0, a.bt, a.w, a.ct, a.cnt, a.ct_ld, ct_vec, skip_lo,
+                                   skip_hi, last);
+            else
+                hipLaunchKernelGGL((fused_main_arg<3, 4, false>), g, block, 0, s, a.rate, a.next, a.rows,
+                                   a.n, a.row0, a.k0, a.bt, a.w, a.ct, a.cnt, a.ct_ld, ct_vec, skip_lo,
+                                   skip_hi, last);
+        } else {
+            const dim3 g((unsigned)((a.n + 63) / 64), (unsigned)((a.rows + 127) / 128));
+            if (last)
+                hipLaunchKernelGGL((fused_main_arg<3, 8, true>), g, block, 0, s, a.rate, a.next, a.rows,
+                                   a.n, a.row0, a.k0, a.bt, a.w, a.ct, a.cnt, a.ct_ld, ct_vec, skip_lo,
+                                   skip_hi, last);
+            else
+                hipLaunchKernelGGL((fused_main_arg<3, 8, false>), g, block, 0, s, a.rate, a.next, a.rows,
+                                   a.n, a.row0, a.k0, a.bt, a.w, a.ct, a.cnt, a.ct_ld, ct_vec, skip_lo,
+                                   skip_hi, last);
+        }
+        return true;
+    }
     if (small_tiles(a.n, a.rows)) {
         const dim3 g((unsigned)((a.n + 63) / 64), (unsigned)((a.rows + 63) / 64));
         hipLaunchKernelGGL((fused_main_max<4, 1, 4, 1>), g, block, 0, s, a.rate, a.rows, a.n, a.row0,
                            a.k0, a.bt, a.w, a.ct, a.ct_ld, ct_vec, skip_lo, skip_hi);
     } else {
+        static const int variant = getenv("FWX_MAXF_VARIANT") ? atoi(getenv("FWX_MAXF_VARIANT")) : 0;
+        if (variant == 1)
+            hipLaunchKernelGGL((fused_main_max<2, 1, 8, 2, true>), grid, block, 0, s, a.rate, a.rows, a.n,
+                               a.row0, a.k0, a.bt, a.w, a.ct, a.ct_ld, ct_vec, skip_lo, skip_hi);
+        else if (variant == 2)
+            hipLaunchKernelGGL((fused_main_max<3, 1, 8, 2, true>), grid, block, 0, s, a.rate, a.rows, a.n,
+                               a.row0, a.k0, a.bt, a.w, a.ct, a.ct_ld, ct_vec, skip_lo, skip_hi);
+        else if (variant == 3)
+            hipLaunchKernelGGL((fused_main_max<2, 1, 8, 2, false>), grid, block, 0, s, a.rate, a.rows, a.n,
+                               a.row0, a.k0, a.bt, a.w, a.ct, a.ct_ld, ct_vec, skip_lo, skip_hi);
+        else
         hipLaunchKernelGGL((fused_main_max<3, 1, 8, 2>), grid, block, 0, s, a.rate, a.rows, a.n,
                            a.row0, a.k0, a.bt, a.w, a.ct, a.ct_ld, ct_vec, skip_lo, skip_hi);
     }
@@ -795,7 +1035,7 @@ static bool launch_max_form(const FusedArgs<float> &a, dim3 grid, dim3 block, in
 // f64 has no packed / three-operand forms: the max form is the generic kernel with
 // v_mul_f64 + v_max_f64 (2 instructions per relaxation instead of 4).
 static bool launch_max_form(const FusedArgs<double> &a, dim3 grid, dim3 block, int skip_lo,
-                            int skip_hi, hipStream_t s)
+                            int skip_hi, hipStream_t s, int32_t *)
 {
     if (!a.nonneg || a.next || a.updates) return false;
     if (small_tiles(a.n, a.rows))
@@ -901,7 +1141,7 @@ hipError_t launch_fused_main(const FusedArgs<T> &full, int r_lo, int r_hi, hipSt
     const int tj = 16 * VW * (small ? 1 : (a.next ? FusedCfg<T, true>::NH : FusedCfg<T, false>::NH));
     const int ti = small ? 64 : TI;
     const dim3 grid((unsigned)((a.n + tj - 1) / tj), (unsigned)((a.rows + ti - 1) / ti));
-    if (launch_max_form(a, grid, block, skip_lo, skip_hi, s)) return hipGetLastError();
+    if (launch_max_form(a, grid, block, skip_lo, skip_hi, s, last)) return hipGetLastError();
 #define FWX_FUSED_LAUNCH(HN, CN, HL)                                                               \
     do {                                                                                           \
         if (small)                                                                                 \

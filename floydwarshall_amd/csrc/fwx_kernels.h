@@ -73,7 +73,9 @@ template <typename T> struct FusedArgs {
     int ct_ld;             // leading dimension of ct / cnt (>= rows; a multiple of 4 keeps the
                            // staging loads 16-byte aligned)
     unsigned long long *updates;
-    bool nonneg;           // caller verified: every matrix entry is >= +0 and not NaN (max form)
+    bool nonneg;           // caller verified the domain (fwx.h "Domain"): every matrix entry is >= +0
+                           // and not NaN and, if next is carried, no positive rate lacks a path:
+                           // the max-form kernels may run (f32: rates only, or rates + next + trace)
     PathLog plog = PathLog();   // path trace (needs next): rows x n like rate / next, LOCAL rows
 };
 

@@ -411,7 +411,7 @@ template <typename T> static int multi_solve_typed(fwx_matrix *m, const Opts &op
         bits &= b;
     }
     if (with_next && bits != 3) return FWX_ERR_UNSUPPORTED;   // see fwx.h: solved on one device
-    const bool nonneg = !with_next && !counting && (bits & 1);
+    const bool nonneg = !counting && (with_next ? bits == 3 : (bits & 1) != 0);   // max-form kernels
     for (int p = 0; p < P; ++p) {
         Part &q = M.part[p];
         if ((rc = set_dev(q.device))) return rc;

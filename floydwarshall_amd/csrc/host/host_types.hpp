@@ -101,7 +101,8 @@ private:
     int device_;
     ExchRateTimes rates_;
     bool in_sync_ = false;      // what the reference's AppState would be
-    uint64_t version_ = 0;      // bumped by every accepted update
+    uint64_t version_ = 0;      // bumped by every accepted update that changes buildMatrix's output
+                                // (a re-quote of the same two prices with a newer time does not)
     uint64_t solved_version_ = ~0ull;
     std::vector<Vertex> vertices_;   // of the cached solve
     fwx_matrix *dev_ = nullptr;      // solved matrix, resident in HBM

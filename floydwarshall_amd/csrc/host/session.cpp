@@ -35,11 +35,20 @@ bool Session::update_rates(int64_t time, const Vertex &src, const Vertex &dest, 
     auto it = rates_.find(VertexPair(src, dest));
     const bool update_required = it == rates_.end() || it->second.second < time;
     if (!update_required) return false;
+    // The dense matrix buildMatrix produces (Algorithms.hs:26-40) is a function of the key set and
+    // of the rate VALUES only -- not of the timestamps.  An accepted update that re-quotes the same
+    // two prices with a newer time (the common heartbeat of a feed) leaves it bit-identical, so the
+    // solved matrix on the device is still floydWarshall of the new map: the visible state flips
+    // to OutSync exactly as in the reference (:101-102), but the next query reuses the solve.
+    auto same_bits = [](double a, double b) { return std::memcmp(&a, &b, sizeof(double)) == 0; };
+    auto bk = rates_.find(VertexPair(dest, src));
+    const bool matrix_unchanged = it != rates_.end() && bk != rates_.end() &&
+                                  same_bits(it->second.first, fwd) && same_bits(bk->second.first, bkd);
     // :101-102 OutSync $ updateMap [((dest,src),(bkdR,time)), ((src,dest),(fwdR,time))] exRates
     rates_[VertexPair(dest, src)] = std::make_pair(bkd, time);
     rates_[VertexPair(src, dest)] = std::make_pair(fwd, time);
     in_sync_ = false;
-    ++version_;
+    if (!matrix_unchanged) ++version_;
     return true;
 }
 

@@ -14,7 +14,7 @@ import           Foreign.C.Types              (CInt (..))
 import           Foreign.Ptr                  (Ptr, nullPtr)
 import           System.IO.Unsafe             (unsafePerformIO)
 
-import           Types                        (Matrix, RateEntry (..))
+import           Types                        (Matrix, RateEntry (..), Vertex)
 
 -- int fwx_solve_f64(int32_t n, double*, int32_t* next, int32_t* hops, const fwx_opts*);
 foreign import ccall safe "fwx.h fwx_solve_f64"
@@ -38,9 +38,16 @@ runAlgoGPU m
     vertices = V.map (_start . V.head) m              -- row i starts at vertex i
     vIdx v   = maybe (-1) fromIntegral (V.elemIndex v vertices)
     headIdx e = case _path e of { [] -> -1; (v:_) -> vIdx v }
-    -- `_path` = follow head-of-path from i until j  (Algorithms.hs:55 builds it by ++)
+    -- `_path` = follow head-of-path from i until j  (Algorithms.hs:55 builds it by ++).  The walk
+    -- is BOUNDED by n hops, like fwx_follow_path (FWX_ERR_CYCLE): an arbitrage cycle, which the
+    -- parser admits across exchanges, would otherwise build an infinite list where the
+    -- reference's `_path` is finite.  For the reference's exact lists under ties and cycles use
+    -- AlgorithmsFFILazy (fwx_matrix_query_exact).
     entry r nx i j =
-      let walk cur | nx S.! (cur*n + j) < 0 = []
-                   | otherwise = let h = fromIntegral (nx S.! (cur*n + j))
-                                 in (vertices V.! h) : (if h == j then [] else walk h)
-      in RateEntry (r S.! (i*n + j)) (vertices V.! i) (if i == j then [] else walk i)
+      let walk :: Int -> Int -> [Vertex]
+          walk hopsLeft cur
+            | nx S.! (cur*n + j) < 0 = []
+            | hopsLeft == 0 = error "fwx: next-hop walk does not reach the destination (cycle)"
+            | otherwise = let h = fromIntegral (nx S.! (cur*n + j))
+                          in (vertices V.! h) : (if h == j then [] else walk (hopsLeft - 1) h)
+      in RateEntry (r S.! (i*n + j)) (vertices V.! i) (if i == j then [] else walk n i)

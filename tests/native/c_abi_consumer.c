@@ -5,7 +5,8 @@
  *
  * 1. the reference's 4-vertex graph (src/test/MockData.hs:47-57) through fwx_solve_f64 and the
  *    expectations of src/test/AlgorithmsTest.hs:72-75;
- * 2. the same rates through the host mirror (updateRates -> findBestRate), README.md:188-246. */
+ * 2. the same rates through the host mirror (updateRates -> findBestRate), README.md:188-246;
+ * 3. the same matrix through fwx_solve_multi_f64 (row-partitioned, one process). */
 #include <math.h>
 #include <stdio.h>
 #include <stdlib.h>
@@ -51,6 +52,21 @@ int main(void)
     len = fwx_follow_path(4, next, 2, 3, path, 8);
     CHECK(len == 3 && path[0] == 0 && path[1] == 1 && path[2] == 3);
     CHECK(updates > 0);
+
+    {
+        /* 3. the same call with the whole node behind it (row e'): one process, P partitions.
+         * Here P = 3 LOGICAL partitions of device 0 (a device may be listed more than once);
+         * on an 8-GPU node the list is {0,...,7} and the panels travel on RCCL. */
+        double r2[16] = {0.0, 1001.0, 1.0, 0.0,   0.0008, 0.0, 0.0, 1.0,
+                         1.0, 0.0, 0.0, 1000.0,   0.0, 1.0, 0.0009, 0.0};
+        int32_t n2[16] = {-1, 1, 2, -1,   0, -1, -1, 3,   0, -1, -1, 3,   -1, 1, 2, -1};
+        const int32_t devices[3] = {0, 0, 0};
+        int i;
+        rc = fwx_solve_multi_f64(4, r2, n2, NULL, 3, devices, FWX_XCHG_AUTO, NULL);
+        if (rc) fprintf(stderr, "fwx_solve_multi_f64: %s\n", fwx_strerror(rc));
+        CHECK(rc == FWX_OK);
+        for (i = 0; i < 16; ++i) CHECK(r2[i] == rate[i] && n2[i] == next[i]);
+    }
 
     {
         fwxh_session *s = NULL;

@@ -65,6 +65,33 @@ def test_serve_req_find_best_rate_and_state_transitions():
     assert r == 1002.0 and s.solves == 2 and s.state == host.INSYNC
 
 
+def test_requotes_of_the_same_prices_reuse_the_solve():
+    """f3, the exact half: an accepted update that re-quotes the same two prices with a
+    newer timestamp flips the visible state to OutSync as in the reference
+    (ProcessRequests.hs:97-102), but buildMatrix's output is bit-identical (it does not depend on
+    the timestamps), so the solved matrix on the device is reused: `solves` does not move and the
+    answers are identical.  A changed price, or an older timestamp, behave as before."""
+    pr = load_golden("process_requests.json")
+    s = _session_with(pr["rates_ex2"])
+    first = s.find_best_rate(("KRAKEN", "BTC"), ("KRAKEN", "USD"))
+    assert s.solves == 1 and s.state == host.INSYNC
+    for minute in range(45, 55):
+        out = s.serve_line("2017-11-01T09:%02d:00+00:00 GDAX BTC USD 1001.0 0.0008" % minute)
+        assert out and out[-1] == ""                           # accepted: the rate list is printed
+        assert s.state == host.OUTSYNC                         # the reference's visible state
+        again = s.find_best_rate(("KRAKEN", "BTC"), ("KRAKEN", "USD"))
+        assert again == first
+        assert s.state == host.INSYNC and s.solves == 1        # ... without a new GPU solve
+    # a stale timestamp is ignored altogether (:97-98): still InSync
+    s.serve_line("2017-11-01T09:00:00+00:00 GDAX BTC USD 5.0 0.1")
+    assert s.state == host.INSYNC and s.solves == 1
+    # one changed price: the matrix differs, the next query solves again
+    s.serve_line("2017-11-01T10:00:00+00:00 GDAX BTC USD 1001.0 0.00081")
+    assert s.state == host.OUTSYNC
+    s.find_best_rate(("KRAKEN", "BTC"), ("KRAKEN", "USD"))
+    assert s.solves == 2
+
+
 def test_find_best_rate_unknown_vertices_keep_state_and_cache():
     pr = load_golden("process_requests.json")
     s = _session_with(pr["rates_ex2"])
