@@ -46,6 +46,14 @@ class FwxPivots(ctypes.Structure):
                 ("stride", ctypes.c_int64), ("next", c_vp)]
 
 
+class FwxTrace(ctypes.Structure):
+    _fields_ = [("last", c_vp), ("at_col", c_vp), ("at_row", c_vp)]
+
+
+class FwxFusedScratch(ctypes.Structure):
+    _fields_ = [("col_rate", c_vp), ("col_next", c_vp), ("col_hops", c_vp)]
+
+
 class FwxError(RuntimeError):
     def __init__(self, status, what):
         self.status = status
@@ -92,12 +100,15 @@ SIGNATURES = {
     "fwx_dev_solve": (ctypes.c_int, [ctypes.POINTER(FwxSlab), ctypes.POINTER(FwxOpts)]),
     "fwx_dev_follow_paths": (ctypes.c_int, [c_i32, c_vp, c_i32, c_vp, c_vp, c_vp, c_vp, c_i32, c_vp,
                                             c_vp, c_i32, c_vp]),
-    "fwx_fused_diag_ws_bytes": (ctypes.c_size_t, [c_i32]),
-    "fwx_dev_panel_snap": (ctypes.c_int, [ctypes.POINTER(FwxSlab), c_vp, c_vp, c_vp]),
-    "fwx_dev_relax_fused": (ctypes.c_int, [ctypes.POINTER(FwxSlab), ctypes.POINTER(FwxPivots), c_vp,
-                                           c_vp, c_vp, c_i32, c_vp]),
+    "fwx_dev_panel_snap": (ctypes.c_int, [ctypes.POINTER(FwxSlab), c_vp, c_vp, ctypes.POINTER(FwxTrace),
+                                          c_vp]),
+    "fwx_dev_relax_fused": (ctypes.c_int, [ctypes.POINTER(FwxSlab), ctypes.POINTER(FwxPivots),
+                                           ctypes.POINTER(FwxFusedScratch), ctypes.POINTER(FwxTrace),
+                                           c_vp, c_i32, c_vp]),
     "fwx_dev_relax_fused_skip": (ctypes.c_int, [ctypes.POINTER(FwxSlab), ctypes.POINTER(FwxPivots),
-                                                c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_vp]),
+                                                ctypes.POINTER(FwxFusedScratch),
+                                                ctypes.POINTER(FwxTrace), c_vp, c_i32, c_i32, c_i32,
+                                                c_vp]),
     "fwx_dev_check_nonneg": (ctypes.c_int, [ctypes.POINTER(FwxSlab), c_vp, c_vp]),
 }
 

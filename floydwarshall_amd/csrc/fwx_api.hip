@@ -46,15 +46,17 @@ int relax_range(T *rate, int32_t *next, int32_t *hops, int rows, int n, int row0
 }
 
 template <typename T>
-int fused_block(T *rate, int32_t *next, int rows, int n, int row0, int k0, int bt, const T *w, T *ct,
-                int32_t *cnt, unsigned long long *d_updates, bool nonneg, hipStream_t s,
-                int skip_lo = 0, int skip_hi = 0)
+int fused_block(const fwx_slab *sl, int k0, int bt, const T *w, const int32_t *wh,
+                const fwx_fused_scratch *sc, const fwx_trace *tr, unsigned long long *d_updates,
+                bool nonneg, hipStream_t s, int skip_lo = 0, int skip_hi = 0)
 {
     fwx::FusedArgs<T> a;
     a.nonneg = nonneg;
-    a.rate = rate; a.next = next; a.rows = rows; a.n = n; a.row0 = row0;
-    a.k0 = k0; a.bt = bt; a.w = w; a.ct = ct; a.cnt = cnt; a.updates = d_updates;
-    a.ct_ld = (rows + 3) & ~3;
+    a.rate = (T *)sl->rate; a.next = sl->next; a.rows = sl->rows; a.n = sl->n; a.row0 = sl->row0;
+    a.k0 = k0; a.bt = bt; a.w = w; a.ct = (T *)sc->col_rate; a.cnt = sc->col_next; a.updates = d_updates;
+    a.ct_ld = (sl->rows + 3) & ~3;
+    a.hops = sl->hops; a.wh = wh; a.cht = sc->col_hops;
+    if (tr) { a.plog.last = tr->last; a.plog.at_col = tr->at_col; a.plog.at_row = tr->at_row; }
     hipError_t e = fwx::launch_fused_relax<T>(a, s, skip_lo, skip_hi);
     if (e == hipErrorInvalidValue) return FWX_ERR_INVALID;
     FWX_HIP(e);
@@ -66,10 +68,9 @@ template <typename T> bool fused_dims_ok(int n, const void *rate)
 {
     return n % (16 / (int)sizeof(T)) == 0 && ((uintptr_t)rate % 16) == 0;
 }
-// ... and without further ado (a matrix with `hops` needs the whole pivot range: fused_with_hops)
-template <typename T> bool fused_ok(int n, const void *rate, const int32_t *hops)
+template <typename T> bool fused_ok(int n, const void *rate, const int32_t *)
 {
-    return hops == nullptr && fused_dims_ok<T>(n, rate);
+    return fused_dims_ok<T>(n, rate);
 }
 
 // Single-GPU solve of pivots [k_begin,k_end) with the fused engine.  Per block of <= 64 pivots:
@@ -78,18 +79,23 @@ template <typename T> bool fused_ok(int n, const void *rate, const int32_t *hops
 // main(b) runs on those rows first, then the snapshot panel of b+1 runs on a side stream while
 // main(b) sweeps the rest of the matrix.  ws: see fused_ws_bytes.
 template <typename T>
-int fused_range(T *rate, int32_t *next, int n, int k_begin, int k_end, void *ws,
+int fused_range(T *rate, int32_t *next, int32_t *hops, int n, int k_begin, int k_end, void *ws,
                 unsigned long long *d_updates, hipStream_t s, fwx::PathLog plog, bool nonneg,
                 SideStream *kept_side = nullptr)
 {
     char *p = (char *)ws;
     const int ld = (n + 3) & ~3;
     T *wbuf[2];
+    int32_t *whbuf[2] = {nullptr, nullptr}, *cht = nullptr;
     wbuf[0] = (T *)p;              p += (size_t)FWX_FUSED_B * n * sizeof(T);
     wbuf[1] = (T *)p;              p += (size_t)FWX_FUSED_B * n * sizeof(T);
     T *ct = (T *)p;                p += (size_t)FWX_FUSED_B * ld * sizeof(T);
     int32_t *cnt = (int32_t *)p;   p += (size_t)FWX_FUSED_B * ld * sizeof(int32_t);
-    T *diag = (T *)p;              p += (size_t)2 * FWX_FUSED_B * FWX_FUSED_B * sizeof(T);
+    if (hops) {                    // hops panels of the pivot rows + hops of the pivot columns
+        whbuf[0] = (int32_t *)p;   p += (size_t)FWX_FUSED_B * n * sizeof(int32_t);
+        whbuf[1] = (int32_t *)p;   p += (size_t)FWX_FUSED_B * n * sizeof(int32_t);
+        cht = (int32_t *)p;        p += (size_t)FWX_FUSED_B * ld * sizeof(int32_t);
+    }
     if (k_end <= k_begin) return FWX_OK;
     SideStream local_side;
     SideStream &side = kept_side ? *kept_side : local_side;
@@ -104,17 +110,20 @@ int fused_range(T *rate, int32_t *next, int n, int k_begin, int k_end, void *ws,
     a.ct = ct; a.cnt = next ? cnt : nullptr; a.ct_ld = ld; a.updates = d_updates;
     a.nonneg = nonneg;     // the caller has run the domain check (route_solve)
     a.plog = plog;         // path trace: kept by all three kernels of a pass (needs next)
+    a.hops = hops;         // hops: carried by the panels, written by the main kernel (needs next)
+    a.cht = cht;
 
     int bi = 0;
     {
         const int bt = k_end - k_begin < FWX_FUSED_B ? k_end - k_begin : FWX_FUSED_B;
-        FWX_HIP(fwx::launch_fused_panel<T>(rate + (size_t)k_begin * n, n, k_begin, bt, wbuf[0], diag, s,
-                                           plog_rows(plog, (size_t)k_begin * n)));
+        FWX_HIP(fwx::launch_fused_panel<T>(rate + (size_t)k_begin * n, n, k_begin, bt, wbuf[0], s,
+                                           plog_rows(plog, (size_t)k_begin * n),
+                                           hops ? hops + (size_t)k_begin * n : nullptr, whbuf[0]));
     }
     for (int k0 = k_begin; k0 < k_end; k0 += FWX_FUSED_B, bi ^= 1) {
         const int bt = k_end - k0 < FWX_FUSED_B ? k_end - k0 : FWX_FUSED_B;
         const int k1 = k0 + bt;
-        a.k0 = k0; a.bt = bt; a.w = wbuf[bi];
+        a.k0 = k0; a.bt = bt; a.w = wbuf[bi]; a.wh = whbuf[bi];
         FWX_HIP(fwx::launch_fused_colpanel<T>(a, s));
         if (k1 < k_end) {
             const int bt1 = k_end - k1 < FWX_FUSED_B ? k_end - k1 : FWX_FUSED_B;
@@ -123,8 +132,9 @@ int fused_range(T *rate, int32_t *next, int n, int k_begin, int k_end, void *ws,
             FWX_HIP(hipEventRecord(side.rows_done, s));
             FWX_HIP(hipStreamWaitEvent(side.s, side.rows_done, 0));
             // ... their snapshot panel on the side stream ...
-            FWX_HIP(fwx::launch_fused_panel<T>(rate + (size_t)k1 * n, n, k1, bt1, wbuf[bi ^ 1], diag,
-                                               side.s, plog_rows(plog, (size_t)k1 * n)));
+            FWX_HIP(fwx::launch_fused_panel<T>(rate + (size_t)k1 * n, n, k1, bt1, wbuf[bi ^ 1], side.s,
+                                               plog_rows(plog, (size_t)k1 * n),
+                                               hops ? hops + (size_t)k1 * n : nullptr, whbuf[bi ^ 1]));
             FWX_HIP(hipEventRecord(side.panel_done, side.s));
             // ... while the rest of the matrix is relaxed on the main stream
             if (k1 % 8 == 0 && bt1 % 8 == 0) {
@@ -153,31 +163,19 @@ template <typename T> bool pick_fused(int engine, int n, const void *rate, const
     return engine == FWX_ENGINE_FUSED || n >= 256;   // tools/measure_small.py: fused wins from 256
 }
 
-// AUTO / FUSED for a matrix that carries hops: whole range, next present, readable dimensions.
-template <typename T>
-bool pick_fused_hops(int engine, int n, const void *rate, const int32_t *next, const int32_t *hops,
-                     bool whole_range)
-{
-    if (!hops || !next || engine == FWX_ENGINE_PERK || !fused_dims_ok<T>(n, rate)) return false;
-    // tools/measure_hops.py: the per-k engine is ahead up to n ~ 2048 (7 against 22 ms at 1024),
-    // the fused route from there on (38 against 72 ms at 4096, 0.86 against ~3 s at 16384)
-    return whole_range && (engine == FWX_ENGINE_FUSED || n >= 3072);
-}
-
 // Which engine runs a solve of pivots [k_begin, k_end) of an order-n matrix (pivots < n only for a
 // matrix padded by the host-buffer path).
-enum Route { ROUTE_SMALL, ROUTE_PERK, ROUTE_FUSED, ROUTE_FUSED_HOPS };
+enum Route { ROUTE_SMALL, ROUTE_PERK, ROUTE_FUSED };
 template <typename T>
 int route_solve(const Opts &op, int n, bool whole, const T *rate, const int32_t *next,
                 const int32_t *hops, bool counting, int *d_flag, hipStream_t s, Route &route,
                 bool &nonneg)
 {
     nonneg = false;
-    const bool hops_fused = pick_fused_hops<T>(op.engine, n, rate, next, hops, whole);
-    if (op.engine == FWX_ENGINE_FUSED && !hops_fused && !fused_ok<T>(n, rate, hops))
-        return FWX_ERR_UNSUPPORTED;
+    (void)whole;
+    if (op.engine == FWX_ENGINE_FUSED && !fused_ok<T>(n, rate, hops)) return FWX_ERR_UNSUPPORTED;
     if (op.engine == FWX_ENGINE_AUTO && n <= FWX_SMALL_N) { route = ROUTE_SMALL; return FWX_OK; }
-    if (!hops_fused && !pick_fused<T>(op.engine, n, rate, hops)) { route = ROUTE_PERK; return FWX_OK; }
+    if (!pick_fused<T>(op.engine, n, rate, hops)) { route = ROUTE_PERK; return FWX_OK; }
     // The fused kernels take next[i][k] as the head of ikPath ++ kjPath (Algorithms.hs:55), which
     // is the reference's list head only while a winning product never has an empty ikPath -- true
     // on the reference's own domain, checked here.  Outside it the per-k engine, which reads the
@@ -189,83 +187,7 @@ int route_solve(const Opts &op, int n, bool whole, const T *rate, const int32_t 
     }
     if (next && bits != 3) { route = ROUTE_PERK; return FWX_OK; }
     nonneg = !counting && (next ? bits == 3 : (bits & 1) != 0);   // max-form kernels allowed
-    route = hops_fused ? ROUTE_FUSED_HOPS : ROUTE_FUSED;
-    return FWX_OK;
-}
-
-// ---- hops from the fused engine ------------------------------------------------------------------
-// The fused kernels carry no `hops` (= length _path).  They can keep the path trace, though, and the
-// lengths follow from it in O(n^2): with lcol[a][k] = hops of (a,k) at time k and lrow[k][b] = hops
-// of (k,b) at time k, an entry last improved by pivot q has hops = lcol[a][q] + lrow[q][b] -- the
-// very sum the per-k engine formed at step q (Algorithms.hs:55: path = ikPath ++ kjPath) -- and
-// lcol / lrow themselves obey the same rule through at_col / at_row, which only point at smaller
-// pivots: one tiny launch per pivot, in order.  Entries never improved keep their input hops.
-__global__ __launch_bounds__(256) void hops_dp_step(const int32_t *at_col, const int32_t *at_row,
-                                                    const int32_t *hops0, int32_t *lcol,
-                                                    int32_t *lrow, int n, int k)
-{
-    const int t = blockIdx.x * 256 + threadIdx.x;
-    if (t < n) {                                     // column k: entry (a, k) as of step k
-        const size_t off = (size_t)t * n + k;
-        const int q = at_col[off];
-        lcol[off] = q < 0 ? hops0[off]
-                          : (int32_t)((uint32_t)lcol[(size_t)t * n + q] + (uint32_t)lrow[(size_t)q * n + k]);
-    } else if (t < 2 * n) {                          // row k: entry (k, b) as of step k
-        const int b = t - n;
-        const size_t off = (size_t)k * n + b;
-        const int q = at_row[off];
-        lrow[off] = q < 0 ? hops0[off]
-                          : (int32_t)((uint32_t)lcol[(size_t)k * n + q] + (uint32_t)lrow[(size_t)q * n + b]);
-    }
-}
-
-__global__ __launch_bounds__(256) void hops_final(const int32_t *last, const int32_t *lcol,
-                                                  const int32_t *lrow, int32_t *hops, int n)
-{
-    const size_t nn = (size_t)n * n;
-    for (size_t off = (size_t)blockIdx.x * 256 + threadIdx.x; off < nn; off += (size_t)gridDim.x * 256) {
-        const int q = last[off];
-        if (q >= 0) {
-            const size_t a = off / n, b = off % n;
-            hops[off] = (int32_t)((uint32_t)lcol[a * n + q] + (uint32_t)lrow[(size_t)q * n + b]);
-        }
-    }
-}
-
-// Whole solve of a matrix WITH hops on the fused engine: order n, pivots [0, pivots) (pivots < n
-// only for a matrix padded by the host-buffer path).  plog: the caller's path trace if it keeps
-// one, else a temporary one is used.
-template <typename T>
-int fused_with_hops(T *rate, int32_t *next, int32_t *hops, int n, int pivots,
-                    unsigned long long *d_updates, hipStream_t s, fwx::PathLog plog)
-{
-    const size_t nn = (size_t)n * n;
-    DevBuf t_last, t_col, t_row, d_lcol, d_lrow, d_ws;
-    int rc;
-    if (!plog.last) {
-        if ((rc = t_last.alloc(nn * 4)) || (rc = t_col.alloc(nn * 4)) || (rc = t_row.alloc(nn * 4))) return rc;
-        plog.last = (int32_t *)t_last.p; plog.at_col = (int32_t *)t_col.p; plog.at_row = (int32_t *)t_row.p;
-        FWX_HIP(hipMemsetAsync(plog.last, 0xFF, nn * 4, s));
-        FWX_HIP(hipMemsetAsync(plog.at_col, 0xFF, nn * 4, s));
-        FWX_HIP(hipMemsetAsync(plog.at_row, 0xFF, nn * 4, s));
-    }
-    if ((rc = d_lcol.alloc(nn * 4)) || (rc = d_lrow.alloc(nn * 4)) ||
-        (rc = d_ws.alloc(fused_ws_bytes(n, sizeof(T)))))
-        return rc;
-    // (the caller routed here only inside the domain; counting keeps the compare form)
-    if ((rc = fused_range<T>(rate, next, n, 0, pivots, d_ws.p, d_updates, s, plog, d_updates == nullptr)))
-        return rc;
-    const dim3 grid((unsigned)((2 * (size_t)n + 255) / 256)), block(256);
-    for (int k = 0; k < pivots; ++k)
-        hipLaunchKernelGGL(hops_dp_step, grid, block, 0, s, plog.at_col, plog.at_row, hops,
-                           (int32_t *)d_lcol.p, (int32_t *)d_lrow.p, n, k);
-    FWX_HIP(hipGetLastError());
-    size_t blocks = (nn + 255) / 256;
-    if (blocks > 65536) blocks = 65536;
-    hipLaunchKernelGGL(hops_final, dim3((unsigned)blocks), block, 0, s, plog.last, (int32_t *)d_lcol.p,
-                       (int32_t *)d_lrow.p, hops, n);
-    FWX_HIP(hipGetLastError());
-    FWX_HIP(hipStreamSynchronize(s));      // the scratch is released at scope exit
+    route = ROUTE_FUSED;
     return FWX_OK;
 }
 
@@ -289,9 +211,7 @@ int solve_host(int32_t n, T *rate, int32_t *next, int32_t *hops, const fwx_opts 
     // (0 < +-0 and 0 < NaN are false), so U is unchanged too.  The caller's arrays stay n x n.
     constexpr int VW = 16 / (int)sizeof(T);
     const bool whole = op.k_begin == 0 && op.k_end == n;
-    const bool to_fused = (!hops || (next && whole)) &&
-                          (op.engine == FWX_ENGINE_FUSED ||
-                           (op.engine == FWX_ENGINE_AUTO && n >= (hops ? 3072 : 256)));
+    const bool to_fused = op.engine == FWX_ENGINE_FUSED || (op.engine == FWX_ENGINE_AUTO && n >= 256);
     const int nd = (to_fused && n % VW) ? (n + VW - 1) / VW * VW : n;
     const size_t nn = (size_t)nd * (size_t)nd;
     DevBuf d_rate, d_next, d_hops, d_upd;
@@ -339,12 +259,10 @@ int solve_host(int32_t n, T *rate, int32_t *next, int32_t *hops, const fwx_opts 
     if (route == ROUTE_SMALL) {
         // the reference's own regime: the whole solve in one single-workgroup launch
         FWX_HIP(fwx::launch_small_solve<T>(dr, dn, dh, n, op.k_begin, op.k_end, upd, fwx::PathLog(), s));
-    } else if (route == ROUTE_FUSED_HOPS) {
-        if ((rc = fused_with_hops<T>(dr, dn, dh, nd, n, upd, s, fwx::PathLog()))) return rc;
     } else if (route == ROUTE_FUSED) {
         DevBuf d_ws;
-        if ((rc = d_ws.alloc(fused_ws_bytes(nd, sizeof(T))))) return rc;
-        rc = fused_range<T>(dr, dn, nd, op.k_begin, op.k_end, d_ws.p, upd, s, fwx::PathLog(), nonneg);
+        if ((rc = d_ws.alloc(fused_ws_bytes(nd, sizeof(T), dh != nullptr)))) return rc;
+        rc = fused_range<T>(dr, dn, dh, nd, op.k_begin, op.k_end, d_ws.p, upd, s, fwx::PathLog(), nonneg);
         if (rc) return rc;
         FWX_HIP(hipStreamSynchronize(s));   // d_ws is released at scope exit
     } else {
@@ -477,10 +395,9 @@ int matrix_solve_typed(fwx_matrix *m, const Opts &op, unsigned long long *upd, h
                                            m->plog, s));
         return FWX_OK;
     }
-    if (route == ROUTE_FUSED_HOPS) return fused_with_hops<T>(r, m->next, m->hops, n, n, upd, s, m->plog);
     if (route == ROUTE_FUSED) {
         // a handle keeps its workspace and look-ahead stream across solves; a view allocates per call
-        const size_t need = fused_ws_bytes(n, sizeof(T));
+        const size_t need = fused_ws_bytes(n, sizeof(T), m->hops != nullptr);
         DevBuf tmp_ws;
         void *ws = nullptr;
         SideStream *side = nullptr;
@@ -500,7 +417,7 @@ int matrix_solve_typed(fwx_matrix *m, const Opts &op, unsigned long long *upd, h
             if ((rc = tmp_ws.alloc(need))) return rc;
             ws = tmp_ws.p;
         }
-        rc = fused_range<T>(r, m->next, n, op.k_begin, op.k_end, ws, upd, s, m->plog, nonneg, side);
+        rc = fused_range<T>(r, m->next, m->hops, n, op.k_begin, op.k_end, ws, upd, s, m->plog, nonneg, side);
         if (rc) return rc;
         FWX_HIP(hipStreamSynchronize(s));
         return FWX_OK;
@@ -733,7 +650,7 @@ int fwx_matrix_upload(fwx_matrix *m, const void *rate, const int32_t *next, cons
     if (!m) return FWX_ERR_INVALID;
     if (m->n == 0) return FWX_OK;
     if (!rate || (m->next && !next) || (m->hops && !hops)) return FWX_ERR_INVALID;
-    if (m->multi) return multi_upload(m, rate, next);
+    if (m->multi) return multi_upload(m, rate, next, hops);
     DeviceGuard g;
     int rc = g.enter(m->device);
     if (rc) return rc;
@@ -858,7 +775,7 @@ int fwx_matrix_download(fwx_matrix *m, void *rate, int32_t *next, int32_t *hops)
     if (!m) return FWX_ERR_INVALID;
     if (m->n == 0) return FWX_OK;
     if ((next && !m->next) || (hops && !m->hops)) return FWX_ERR_INVALID;
-    if (m->multi) return multi_download(m, rate, next);
+    if (m->multi) return multi_download(m, rate, next, hops);
     DeviceGuard g;
     int rc = g.enter(m->device);
     if (rc) return rc;
@@ -1031,25 +948,24 @@ int fwx_dev_follow_paths(int32_t n, const int32_t *next, int32_t count, const in
     return FWX_OK;
 }
 
-size_t fwx_fused_diag_ws_bytes(int32_t dtype)
-{
-    return (size_t)2 * FWX_FUSED_B * FWX_FUSED_B * (dtype == FWX_F64 ? 8 : 4);
-}
-
-int fwx_dev_panel_snap(const fwx_slab *block, void *w_rate, void *diag_ws, void *stream)
+int fwx_dev_panel_snap(const fwx_slab *block, void *w_rate, int32_t *w_hops, const fwx_trace *trace,
+                       void *stream)
 {
     int rc = check_slab(block);
     if (rc) return rc;
     if (block->rows == 0 || block->n == 0) return FWX_OK;
-    if (!w_rate || !diag_ws || block->rows > FWX_FUSED_B) return FWX_ERR_INVALID;
+    if (!w_rate || block->rows > FWX_FUSED_B || (block->hops && !w_hops)) return FWX_ERR_INVALID;
+    if (trace && (!trace->last || !trace->at_row || !block->next)) return FWX_ERR_INVALID;
     if (device_count() <= 0) return FWX_ERR_NO_DEVICE;
     hipStream_t s = (hipStream_t)stream;
+    fwx::PathLog pl = fwx::PathLog();
+    if (trace) { pl.last = trace->last; pl.at_col = trace->at_col; pl.at_row = trace->at_row; }
     if (block->dtype == FWX_F64)
         FWX_HIP(fwx::launch_fused_panel<double>((const double *)block->rate, block->n, block->row0,
-                                                block->rows, (double *)w_rate, (double *)diag_ws, s));
+                                                block->rows, (double *)w_rate, s, pl, block->hops, w_hops));
     else
         FWX_HIP(fwx::launch_fused_panel<float>((const float *)block->rate, block->n, block->row0,
-                                               block->rows, (float *)w_rate, (float *)diag_ws, s));
+                                               block->rows, (float *)w_rate, s, pl, block->hops, w_hops));
     return FWX_OK;
 }
 
@@ -1069,16 +985,17 @@ int fwx_dev_check_nonneg(const fwx_slab *slab, int32_t *d_flag, void *stream)
     return FWX_OK;
 }
 
-int fwx_dev_relax_fused(const fwx_slab *slab, const fwx_pivots *piv, void *col_rate,
-                        int32_t *col_next, unsigned long long *d_updates, int32_t flags,
+int fwx_dev_relax_fused(const fwx_slab *slab, const fwx_pivots *piv, const fwx_fused_scratch *scratch,
+                        const fwx_trace *trace, unsigned long long *d_updates, int32_t flags,
                         void *stream)
 {
-    return fwx_dev_relax_fused_skip(slab, piv, col_rate, col_next, d_updates, flags, 0, 0, stream);
+    return fwx_dev_relax_fused_skip(slab, piv, scratch, trace, d_updates, flags, 0, 0, stream);
 }
 
-int fwx_dev_relax_fused_skip(const fwx_slab *slab, const fwx_pivots *piv, void *col_rate,
-                             int32_t *col_next, unsigned long long *d_updates, int32_t flags,
-                             int32_t skip_lo, int32_t skip_hi, void *stream)
+int fwx_dev_relax_fused_skip(const fwx_slab *slab, const fwx_pivots *piv,
+                             const fwx_fused_scratch *scratch, const fwx_trace *trace,
+                             unsigned long long *d_updates, int32_t flags, int32_t skip_lo,
+                             int32_t skip_hi, void *stream)
 {
     int rc = check_slab(slab);
     if (rc) return rc;
@@ -1086,23 +1003,21 @@ int fwx_dev_relax_fused_skip(const fwx_slab *slab, const fwx_pivots *piv, void *
         piv->k_end - piv->k_begin > FWX_FUSED_B)
         return FWX_ERR_INVALID;
     if (slab->rows == 0 || slab->n == 0 || piv->k_end == piv->k_begin) return FWX_OK;
-    if (slab->hops) return FWX_ERR_UNSUPPORTED;
-    if (!piv->rate || piv->stride != slab->n || !col_rate || (slab->next && !col_next))
+    if (!piv->rate || piv->stride != slab->n || !scratch || !scratch->col_rate ||
+        (slab->next && !scratch->col_next) || (slab->hops && (!scratch->col_hops || !piv->hops)))
         return FWX_ERR_INVALID;
+    if (trace && (!slab->next || !trace->last || !trace->at_col)) return FWX_ERR_INVALID;
     if (skip_lo < 0 || skip_hi < skip_lo || skip_hi > slab->rows ||
         (skip_hi > skip_lo && (skip_lo % 8 || skip_hi % 8)))
         return FWX_ERR_INVALID;
     if (device_count() <= 0) return FWX_ERR_NO_DEVICE;
     hipStream_t s = (hipStream_t)stream;
+    const bool nonneg = (flags & FWX_FLAG_NONNEG) != 0;
     if (slab->dtype == FWX_F64)
-        return fused_block<double>((double *)slab->rate, slab->next, slab->rows, slab->n, slab->row0,
-                                   piv->k_begin, piv->k_end - piv->k_begin, (const double *)piv->rate,
-                                   (double *)col_rate, col_next, d_updates,
-                                   (flags & FWX_FLAG_NONNEG) != 0, s, skip_lo, skip_hi);
-    return fused_block<float>((float *)slab->rate, slab->next, slab->rows, slab->n, slab->row0,
-                              piv->k_begin, piv->k_end - piv->k_begin, (const float *)piv->rate,
-                              (float *)col_rate, col_next, d_updates, (flags & FWX_FLAG_NONNEG) != 0,
-                              s, skip_lo, skip_hi);
+        return fused_block<double>(slab, piv->k_begin, piv->k_end - piv->k_begin, (const double *)piv->rate,
+                                   piv->hops, scratch, trace, d_updates, nonneg, s, skip_lo, skip_hi);
+    return fused_block<float>(slab, piv->k_begin, piv->k_end - piv->k_begin, (const float *)piv->rate,
+                              piv->hops, scratch, trace, d_updates, nonneg, s, skip_lo, skip_hi);
 }
 
 }  // extern "C"

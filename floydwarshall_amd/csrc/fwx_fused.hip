@@ -42,7 +42,16 @@ template <> __device__ __forceinline__ float qnan<float>() { return __builtin_na
 template <> __device__ __forceinline__ double qnan<double>() { return __builtin_nan(""); }
 
 __device__ __forceinline__ float fmax_t(float a, float b) { return __builtin_fmaxf(a, b); }
-__device__ __forceinline__ double fmax_t(double a, double b) { return __builtin_fmax(a, b); }
+// ONE v_max_f64.  __builtin_fmax makes the compiler quiet a possible signalling NaN first -- a second
+// `v_max_f64 x, x, x` per relaxation, i.e. three 4.35-cycle f64 instructions where two suffice (the
+// f64 fused solve at N = 16384: 513 ms with the builtin).  The instruction itself already is IEEE
+// maxNum: max(x, qNaN) = x, and the only NaNs here are the quiet products inf * 0.
+__device__ __forceinline__ double fmax_t(double a, double b)
+{
+    double d;
+    asm("v_max_f64 %0, %1, %2" : "=v"(d) : "v"(a), "v"(b));
+    return d;
+}
 
 template <typename T> struct Vec16;
 template <> struct Vec16<float> {
@@ -116,6 +125,14 @@ template <int LANE> __device__ __forceinline__ double writelane(double dst, doub
     const int hi = writelane_b32<LANE>((int)(bd >> 32), (int)(bv >> 32));
     return __builtin_bit_cast(double, ((long long)hi << 32) | (unsigned int)lo);
 }
+template <> __device__ __forceinline__ int readlane<int>(int v, int lane)
+{
+    return __builtin_amdgcn_readlane(v, lane);
+}
+template <int LANE> __device__ __forceinline__ int writelane(int dst, int v)
+{
+    return writelane_b32<LANE>(dst, v);
+}
 // cv[q] = lane `src_lane` of p[q] for q = 0..SB-1, gathered into one register (lane q <- cv[q])
 template <int Q, typename T>
 __device__ __forceinline__ void gather_column(const T (&p)[SB], int src_lane, T (&cv)[SB], T &cdv)
@@ -134,22 +151,30 @@ __device__ __forceinline__ void gather_column(const T (&p)[SB], int src_lane, T 
 // HAS_LAST: also keeps the path trace of the pivot rows (PathLog): `last` of each entry is carried
 // through the 64 pivots beside its rate, and at_row[k0+t][j] = last of (k0+t, j) at time k0+t is
 // exported with the snapshot.  last_rows / at_rows point at row k0 of the n x n matrices.
-template <typename T, bool HAS_LAST>
+// HAS_HOPS: also carries `hops` (= length _path) of the pivot rows: hops' = hops[i][k] + hops[k][j]
+// on every successful relaxation (Algorithms.hs:55), and exports wh_out[t][j] = hops of (k0+t, j) at
+// time k0+t beside the rate snapshot.  hops_rows points at row k0 of the hops matrix.
+template <typename T, bool HAS_LAST, bool HAS_HOPS>
 __global__ __launch_bounds__(PANEL_THREADS) void fused_rowpanel(const T *rows, int n, int k0, int bt,
                                                       T *w_out, const int32_t *last_rows,
-                                                      int32_t *at_rows)
+                                                      int32_t *at_rows, const int32_t *hops_rows,
+                                                      int32_t *wh_out)
 {
     __shared__ T s_line[B][64];                    // published pivot rows (time-t), per phase
     __shared__ T s_cd[B][B];                       // s_cd[t][r] = D_t[k0+r][k0+t]
+    __shared__ int32_t s_hline[HAS_HOPS ? B : 1][64];   // hops of the published pivot rows
+    __shared__ int32_t s_cdh[HAS_HOPS ? B : 1][B];      // hops of D_t[k0+r][k0+t]
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
 
     T p[SB];
+    int32_t hp[SB];                                // hops of this wave's lines (dead without HAS_HOPS)
     // ---------------- phase 0: the diagonal block, lanes = block columns -------------------------
 #pragma unroll
     for (int q = 0; q < SB; ++q) {
         const int r = wave * SB + q;
         p[q] = (r < bt && lane < bt) ? rows[(size_t)r * n + k0 + lane] : qnan<T>();
+        hp[q] = (HAS_HOPS && r < bt && lane < bt) ? hops_rows[(size_t)r * n + k0 + lane] : 0;
     }
 #pragma unroll 1                                   // code size: keep the panel inside the I-cache
     for (int b = 0; b < B / SB; ++b) {
@@ -161,17 +186,27 @@ __global__ __launch_bounds__(PANEL_THREADS) void fused_rowpanel(const T *rows, i
                 T w = p[tq];
                 if (lane == t) w = qnan<T>();      // skip j == k (also hides the stale diagonal)
                 s_line[t][lane] = w;
+                const int32_t hw = HAS_HOPS ? hp[tq] : 0;
+                if (HAS_HOPS) s_hline[t][lane] = hw;
                 // column t of this wave's rows: 16 independent cross-lane reads first, gathered
                 // into one register (lane q <- row q) and published with ONE LDS store
                 T cv[SB];
                 T cdv = T(0);
                 gather_column<0, T>(p, t, cv, cdv);
                 if (lane < SB) s_cd[t][b * SB + lane] = cdv;
+                int32_t chv[SB];
+                if (HAS_HOPS) {
+                    int32_t cdh = 0;
+                    gather_column<0, int32_t>(hp, t, chv, cdh);
+                    if (lane < SB) s_cdh[t][b * SB + lane] = cdh;
+                }
 #pragma unroll
                 for (int q = 0; q < SB; ++q) {
                     if (q == tq) continue;         // skip i == k
                     const T cand = cv[q] * w;
-                    p[q] = (p[q] < cand) ? cand : p[q];
+                    const bool up = p[q] < cand;
+                    p[q] = up ? cand : p[q];
+                    if (HAS_HOPS) hp[q] = up ? (int32_t)((uint32_t)chv[q] + (uint32_t)hw) : hp[q];
                 }
             }
         }
@@ -182,14 +217,23 @@ __global__ __launch_bounds__(PANEL_THREADS) void fused_rowpanel(const T *rows, i
                 const int t = b * SB + tq;
                 if (t >= bt) continue;
                 const T w = s_line[t][lane];
+                const int32_t hw = HAS_HOPS ? s_hline[t][lane] : 0;
                 T cv[SB];
                 T cdv = T(0);
                 gather_column<0, T>(p, t, cv, cdv);
                 if (lane < SB) s_cd[t][wave * SB + lane] = cdv;
+                int32_t chv[SB];
+                if (HAS_HOPS) {
+                    int32_t cdh = 0;
+                    gather_column<0, int32_t>(hp, t, chv, cdh);
+                    if (lane < SB) s_cdh[t][wave * SB + lane] = cdh;
+                }
 #pragma unroll
                 for (int q = 0; q < SB; ++q) {
                     const T cand = cv[q] * w;
-                    p[q] = (p[q] < cand) ? cand : p[q];
+                    const bool up = p[q] < cand;
+                    p[q] = up ? cand : p[q];
+                    if (HAS_HOPS) hp[q] = up ? (int32_t)((uint32_t)chv[q] + (uint32_t)hw) : hp[q];
                 }
             }
         }
@@ -206,10 +250,12 @@ __global__ __launch_bounds__(PANEL_THREADS) void fused_rowpanel(const T *rows, i
         const int r = wave * SB + q;
         p[q] = r < bt ? rows[(size_t)r * n + jc] : qnan<T>();
         if (HAS_LAST) lp[q] = r < bt ? last_rows[(size_t)r * n + jc] : -1;
+        if (HAS_HOPS) hp[q] = r < bt ? hops_rows[(size_t)r * n + jc] : 0;
     }
     // a column inside the block carries one diagonal entry: published from memory, untouched
     const bool in_blk = valid && j >= k0 && j < k0 + bt;
     const T dorig = in_blk ? rows[(size_t)(j - k0) * n + j] : T(0);
+    const int32_t hdorig = (HAS_HOPS && in_blk) ? hops_rows[(size_t)(j - k0) * n + j] : 0;
 
 #pragma unroll 1
     for (int b = 0; b < B / SB; ++b) {
@@ -223,8 +269,11 @@ __global__ __launch_bounds__(PANEL_THREADS) void fused_rowpanel(const T *rows, i
                 if (j == k0 + t) w = dorig;
                 if (valid) w_out[(size_t)t * n + j] = w;          // the snapshot
                 if (HAS_LAST && valid) at_rows[(size_t)t * n + j] = j == k0 + t ? -1 : lp[tq];
+                const int32_t hw = HAS_HOPS ? (j == k0 + t ? hdorig : hp[tq]) : 0;
+                if (HAS_HOPS && valid) wh_out[(size_t)t * n + j] = hw;
                 if (j == k0 + t) w = qnan<T>();                   // skip j == k
                 s_line[t][lane] = w;
+                if (HAS_HOPS) s_hline[t][lane] = hw;
 #pragma unroll
                 for (int q = 0; q < SB; ++q) {
                     if (q == tq) continue;                        // skip i == k
@@ -232,6 +281,7 @@ __global__ __launch_bounds__(PANEL_THREADS) void fused_rowpanel(const T *rows, i
                     const bool up = p[q] < cand;
                     p[q] = up ? cand : p[q];
                     if (HAS_LAST) lp[q] = up ? k0 + t : lp[q];
+                    if (HAS_HOPS) hp[q] = up ? (int32_t)((uint32_t)s_cdh[t][b * SB + q] + (uint32_t)hw) : hp[q];
                 }
             }
         }
@@ -242,12 +292,14 @@ __global__ __launch_bounds__(PANEL_THREADS) void fused_rowpanel(const T *rows, i
                 const int t = b * SB + tq;
                 if (t >= bt) continue;
                 const T w = s_line[t][lane];
+                const int32_t hw = HAS_HOPS ? s_hline[t][lane] : 0;
 #pragma unroll
                 for (int q = 0; q < SB; ++q) {
                     const T cand = s_cd[t][wave * SB + q] * w;
                     const bool up = p[q] < cand;
                     p[q] = up ? cand : p[q];
                     if (HAS_LAST) lp[q] = up ? k0 + t : lp[q];
+                    if (HAS_HOPS) hp[q] = up ? (int32_t)((uint32_t)s_cdh[t][wave * SB + q] + (uint32_t)hw) : hp[q];
                 }
             }
         }
@@ -259,15 +311,22 @@ __global__ __launch_bounds__(PANEL_THREADS) void fused_rowpanel(const T *rows, i
 // HAS_LAST: the path trace of the pivot columns (PathLog): `last` of each block entry is carried
 // beside its rate, and at_col[i][k0+t] = last of (i, k0+t) at time k0+t is stored directly into the
 // n x n matrix (single-GPU solves only: rows are global rows).
-template <typename T, bool HAS_NEXT, bool HAS_LAST>
+// HAS_HOPS: `hops` of the block columns are carried beside their rates (hops' = hops[i][k] +
+// hops[k][j], the second operand from the hops panel wh of the pivot rows), and cht[t][i] = hops
+// of (i, k0+t) at time k0+t is exported for the main kernel.
+template <typename T, bool HAS_NEXT, bool HAS_LAST, bool HAS_HOPS>
 __global__ __launch_bounds__(PANEL_THREADS) void fused_colpanel(const T *rate, const int32_t *next, int rows,
                                                       int n, int row0, int k0, int bt, const T *w,
                                                       T *ct, int32_t *cnt, int ct_ld,
-                                                      const int32_t *last, int32_t *at_col)
+                                                      const int32_t *last, int32_t *at_col,
+                                                      const int32_t *hops, const int32_t *wh,
+                                                      int32_t *cht)
 {
     __shared__ T s_line[B][64];                    // published pivot columns (time-t, NaN at i==k)
     __shared__ int32_t s_nline[HAS_NEXT ? B : 1][64];
     __shared__ T s_wd[B][B];                       // s_wd[t][c] = D_t[k0+t][k0+c]
+    __shared__ int32_t s_hline[HAS_HOPS ? B : 1][64];   // hops of the published pivot columns
+    __shared__ int32_t s_wdh[HAS_HOPS ? B : 1][B];      // hops of D_t[k0+t][k0+c]
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int il = blockIdx.x * 64 + lane;
@@ -278,10 +337,11 @@ __global__ __launch_bounds__(PANEL_THREADS) void fused_colpanel(const T *rate, c
     for (int idx = threadIdx.x; idx < B * B; idx += PANEL_THREADS) {
         const int t = idx / B, c = idx % B;
         s_wd[t][c] = (t < bt && c < bt) ? w[(size_t)t * n + k0 + c] : qnan<T>();
+        if (HAS_HOPS) s_wdh[t][c] = (t < bt && c < bt) ? wh[(size_t)t * n + k0 + c] : 0;
     }
 
     T d[SB];
-    int32_t nx[SB], lp[HAS_LAST ? SB : 1];
+    int32_t nx[SB], lp[HAS_LAST ? SB : 1], hd[SB];
 #pragma unroll
     for (int q = 0; q < SB; ++q) {
         const int c = wave * SB + q;
@@ -289,6 +349,7 @@ __global__ __launch_bounds__(PANEL_THREADS) void fused_colpanel(const T *rate, c
         d[q] = c < bt ? rate[off] : qnan<T>();
         nx[q] = (HAS_NEXT && c < bt) ? next[off] : -1;
         if (HAS_LAST) lp[q] = c < bt ? last[off] : -1;
+        hd[q] = (HAS_HOPS && c < bt) ? hops[off] : 0;
     }
     __syncthreads();
 
@@ -302,13 +363,16 @@ __global__ __launch_bounds__(PANEL_THREADS) void fused_colpanel(const T *rate, c
                 if (t >= bt) continue;
                 T c = d[tq];
                 const int32_t cn = nx[tq];
+                const int32_t hc = hd[tq];
                 if (gi == k0 + t) c = qnan<T>();                  // skip i == k
                 s_line[t][lane] = c;
                 if (HAS_NEXT) s_nline[t][lane] = cn;
+                if (HAS_HOPS) s_hline[t][lane] = hc;
                 if (valid) {
                     ct[(size_t)t * ct_ld + il] = c;
                     if (HAS_NEXT) cnt[(size_t)t * ct_ld + il] = cn;
                     if (HAS_LAST) at_col[(size_t)il * n + k0 + t] = gi == k0 + t ? -1 : lp[tq];
+                    if (HAS_HOPS) cht[(size_t)t * ct_ld + il] = hc;
                 }
 #pragma unroll
                 for (int q = 0; q < SB; ++q) {
@@ -318,6 +382,7 @@ __global__ __launch_bounds__(PANEL_THREADS) void fused_colpanel(const T *rate, c
                     d[q] = up ? cand : d[q];
                     if (HAS_NEXT) nx[q] = up ? cn : nx[q];
                     if (HAS_LAST) lp[q] = up ? k0 + t : lp[q];
+                    if (HAS_HOPS) hd[q] = up ? (int32_t)((uint32_t)hc + (uint32_t)s_wdh[t][b * SB + q]) : hd[q];
                 }
             }
         }
@@ -329,6 +394,7 @@ __global__ __launch_bounds__(PANEL_THREADS) void fused_colpanel(const T *rate, c
                 if (t >= bt) continue;
                 const T c = s_line[t][lane];
                 const int32_t cn = HAS_NEXT ? s_nline[t][lane] : 0;
+                const int32_t hc = HAS_HOPS ? s_hline[t][lane] : 0;
 #pragma unroll
                 for (int q = 0; q < SB; ++q) {
                     const T cand = c * s_wd[t][wave * SB + q];
@@ -336,6 +402,7 @@ __global__ __launch_bounds__(PANEL_THREADS) void fused_colpanel(const T *rate, c
                     d[q] = up ? cand : d[q];
                     if (HAS_NEXT) nx[q] = up ? cn : nx[q];
                     if (HAS_LAST) lp[q] = up ? k0 + t : lp[q];
+                    if (HAS_HOPS) hd[q] = up ? (int32_t)((uint32_t)hc + (uint32_t)s_wdh[t][wave * SB + q]) : hd[q];
                 }
             }
         }
@@ -347,15 +414,22 @@ __global__ __launch_bounds__(PANEL_THREADS) void fused_colpanel(const T *rate, c
 // workgroup at 32 KiB of LDS and <= 128 VGPRs: 4 workgroups = 16 waves per CU.  The loop is pure
 // VALU (v_pk_mul_f32 + v_cmp + v_cndmask per pair of relaxations) and one wave alone issues at
 // half rate on a SIMD-32, so occupancy, not bytes, is what this kernel needs.
+// TRACK: per entry, the pivot of its newest update in this pass is kept in a register tile; the
+// write-back uses it for the path trace (last != nullptr) and for hops (hops != nullptr:
+// hops = cht[t*][i] + wh[t*][j], the lengths of the two halves Algorithms.hs:55 concatenates, as
+// exported by the column / row panels).
 template <typename T, bool HAS_NEXT, bool COUNT, int BS, int MINW, int NH, int RI, bool MAXF = false,
-          bool HAS_LAST = false>
+          bool TRACK = false>
 __global__ __launch_bounds__(256, MINW) void fused_main(T *rate, int32_t *next, int rows, int n,
                                                         int row0, int k0, int bt, const T *w,
                                                         const T *ct, const int32_t *cnt, int ct_ld,
                                                         int skip_lo, int skip_hi,
-                                                        unsigned long long *updates, int32_t *last)
+                                                        unsigned long long *updates, int32_t *last,
+                                                        int32_t *hops, const int32_t *cht,
+                                                        const int32_t *wh)
 {
-    static_assert(!HAS_LAST || HAS_NEXT, "the path trace rides on the next-hop variant");
+    constexpr bool HAS_LAST = TRACK;
+    static_assert(!HAS_LAST || HAS_NEXT, "the path trace and hops ride on the next-hop variant");
     using V = typename Vec16<T>::type;
     using IV = typename IVec<Vec16<T>::W>::type;
     constexpr int VW = Vec16<T>::W;
@@ -514,7 +588,16 @@ __global__ __launch_bounds__(256, MINW) void fused_main(T *rate, int32_t *next, 
                         if (nx[r][h][e] == -2) nx[r][h][e] = old[e];
                     *reinterpret_cast<IV *>(next + off) = nx[r][h];
                     *reinterpret_cast<V *>(rate + off) = x[r][h];
-                    if (HAS_LAST) {      // same vectors, same components: changed <=> lp != -2
+                    if (HAS_LAST && hops) {   // lengths of the two halves at the winning pivot
+#pragma unroll
+                        for (int e = 0; e < VW; ++e)
+                            if (lp[r][h][e] != -2) {
+                                const int t = lp[r][h][e] - k0;
+                                hops[off + e] = (int32_t)((uint32_t)cht[(size_t)t * ct_ld + i] +
+                                                          (uint32_t)wh[(size_t)t * n + jcol[h] + e]);
+                            }
+                    }
+                    if (HAS_LAST && last) {   // same vectors, same components: changed <=> lp != -2
                         const IV oldl = *reinterpret_cast<const IV *>(last + off);
 #pragma unroll
                         for (int e = 0; e < VW; ++e)
@@ -728,6 +811,158 @@ __global__ __launch_bounds__(256, MINW) void fused_main_max(float *rate, int row
 }
 
 // ------------------------------------------------------------------------------------------------
+// fused_main_max_f64: the rates-only main kernel at the REFERENCE'S precision (Types.hs:26,
+// `_bestRate :: Double`), on the max-form domain (see fused_main_max: there the strict fold equals
+// max bit for bit).  f64 has neither packed nor three-operand forms: a relaxation is one v_mul_f64
+// and one v_max_f64, 8.7 measured issue cycles, and ONE wave per SIMD already saturates the f64
+// pipe -- so this kernel spends its registers on the tile instead of on occupancy: 128 x 128
+// entries per workgroup, 8 x 8 doubles per thread (128 VGPRs), which brings the LDS operand
+// traffic down to 2 B per relaxation (the generic 8 x 4 tile reads 3 B, and at 4 waves per SIMD
+// the LDS pipe, not the VALU, was the limit: 59 % of the issue bound).  8 pivots per LDS stage,
+// two stages resident, the next stage prefetched into registers during the fold, and the operands
+// of pivot t+1 read from LDS while pivot t is folded.
+// ------------------------------------------------------------------------------------------------
+template <int MINW>
+__global__ __launch_bounds__(256, MINW) void fused_main_max_f64(double *rate, int rows, int n, int row0,
+                                                                int k0, int bt, const double *w,
+                                                                const double *ct, int ct_ld, int ct_vec,
+                                                                int skip_lo, int skip_hi)
+{
+    typedef double V2 __attribute__((ext_vector_type(2)));
+    constexpr int RI = 8, NH = 4, TI = 128, TJ = 128, HJ = 32, BS = 8;
+    __shared__ __attribute__((aligned(16))) double sW[2][BS][TJ];
+    __shared__ __attribute__((aligned(16))) double sC[2][BS][TI];
+
+    const int tid = threadIdx.x;
+    const int i_base = blockIdx.y * TI;
+    const int j_base = blockIdx.x * TJ;
+    const int ti = tid >> 4, tj = tid & 15;
+    const int i0 = i_base + ti * RI;
+    const bool skip = i0 >= skip_lo && i0 < skip_hi;
+    const double nanv = qnan<double>();
+
+    // staging role: pivot sp (0..7) of the stage, 4 consecutive doubles of W and of C at sv * 4
+    const int sp = tid >> 5, sv = tid & 31;
+    const int sj = j_base + sv * 4, si = i_base + sv * 4;
+    V2 pw[2], pc[2];
+    auto prefetch = [&](int s0) {
+        const int t = s0 + sp;
+        const bool t_ok = t < bt;
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int j = sj + 2 * u, i = si + 2 * u;
+            pw[u] = (t_ok && j < n) ? *reinterpret_cast<const V2 *>(w + (size_t)t * n + j) : V2{nanv, nanv};
+            if (t_ok && ct_vec && i + 2 <= rows) {
+                pc[u] = *reinterpret_cast<const V2 *>(ct + (size_t)t * ct_ld + i);
+            } else {
+                pc[u][0] = (t_ok && i < rows) ? ct[(size_t)t * ct_ld + i] : nanv;
+                pc[u][1] = (t_ok && i + 1 < rows) ? ct[(size_t)t * ct_ld + i + 1] : nanv;
+            }
+            const int kcol = k0 + t - j;                 // skip j == k: the pivot's own column
+            if (kcol >= 0 && kcol < 2) pw[u][kcol] = nanv;
+        }
+    };
+    auto commit = [&](int buf) {
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            *reinterpret_cast<V2 *>(&sW[buf][sp][sv * 4 + 2 * u]) = pw[u];
+            *reinterpret_cast<V2 *>(&sC[buf][sp][sv * 4 + 2 * u]) = pc[u];
+        }
+    };
+    prefetch(0);
+
+    int jcol[NH];
+    bool jok[NH];
+#pragma unroll
+    for (int h = 0; h < NH; ++h) {
+        const int j = j_base + h * HJ + tj * 2;
+        jok[h] = j < n;
+        jcol[h] = jok[h] ? j : n - 2;
+    }
+    V2 x[RI][NH];
+#pragma unroll
+    for (int r = 0; r < RI; ++r) {
+        const int i = min(i0 + r, rows - 1);
+#pragma unroll
+        for (int h = 0; h < NH; ++h)
+            x[r][h] = *reinterpret_cast<const V2 *>(rate + (size_t)i * n + jcol[h]);
+    }
+    const int gi_lo = row0 + i_base;
+    const bool diag_tile = gi_lo < j_base + TJ && j_base < gi_lo + TI;
+
+    commit(0);
+    __syncthreads();
+
+    int buf = 0;
+    for (int s0 = 0; s0 < bt; s0 += BS, buf ^= 1) {
+        const bool more = s0 + BS < bt;
+        if (more) prefetch(s0 + BS);
+        const int np = skip ? 0 : min(BS, bt - s0);
+        auto load_ops = [&](int t, double (&c)[RI], double (&wv)[NH][2]) {
+#pragma unroll
+            for (int q = 0; q < RI / 2; ++q) {
+                const V2 cv = *reinterpret_cast<const V2 *>(&sC[buf][t][ti * RI + q * 2]);
+                c[q * 2] = cv[0];
+                c[q * 2 + 1] = cv[1];
+            }
+#pragma unroll
+            for (int h = 0; h < NH; ++h) {
+                const V2 wq = *reinterpret_cast<const V2 *>(&sW[buf][t][h * HJ + tj * 2]);
+                wv[h][0] = wq[0];
+                wv[h][1] = wq[1];
+            }
+        };
+        auto fold = [&](const double (&c)[RI], const double (&wv)[NH][2]) {
+#pragma unroll
+            for (int r = 0; r < RI; ++r) {
+                double p[NH][2];                 // the 8 products of the row first, then the 8 folds
+#pragma unroll
+                for (int h = 0; h < NH; ++h) {
+                    p[h][0] = c[r] * wv[h][0];
+                    p[h][1] = c[r] * wv[h][1];
+                }
+#pragma unroll
+                for (int h = 0; h < NH; ++h) {
+                    x[r][h][0] = fmax_t(x[r][h][0], p[h][0]);
+                    x[r][h][1] = fmax_t(x[r][h][1], p[h][1]);
+                }
+            }
+        };
+        double cA[RI], wA[NH][2], cB[RI], wB[NH][2];
+        if (np > 0) load_ops(0, cA, wA);
+#pragma unroll 1
+        for (int t = 0; t < np; t += 2) {
+            if (t + 1 < np) load_ops(t + 1, cB, wB);
+            fold(cA, wA);
+            if (t + 1 < np) {
+                if (t + 2 < np) load_ops(t + 2, cA, wA);
+                fold(cB, wB);
+            }
+        }
+        if (more) {
+            commit(buf ^ 1);
+            __syncthreads();
+        }
+    }
+
+#pragma unroll
+    for (int r = 0; r < RI; ++r) {
+        const int i = i0 + r;
+        if (i >= rows || skip) continue;
+#pragma unroll
+        for (int h = 0; h < NH; ++h) {
+            if (!jok[h]) continue;
+            const size_t off = (size_t)i * n + jcol[h];
+            if (diag_tile) {
+                const int gi = row0 + i;
+                if (gi >= jcol[h] && gi < jcol[h] + 2) x[r][h][gi - jcol[h]] = rate[off + gi - jcol[h]];
+            }
+            *reinterpret_cast<V2 *>(rate + off) = x[r][h];
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // fused_main_arg: rates + next-hops (+ path trace) for f32 matrices INSIDE THE DOMAIN (fwx.h
 // "Domain": every rate >= +0 and not NaN, and a non-zero rate always has a path).
 //
@@ -737,30 +972,85 @@ __global__ __launch_bounds__(256, MINW) void fused_main_max(float *rate, int row
 // maximum -- the fold only moves on a strictly greater product, so it reaches its final value at
 // the first pivot that attains it and never moves again -- and it exists iff the maximum exceeds
 // the incoming value.  So instead of a compare and two selects per relaxation (12.1 issue cycles):
-//   1. fold the 64 pivots two at a time with v_max3_f32, exactly as fused_main_max does (4.0);
-//   2. every entry whose value changed becomes an ITEM (entry id, new value) in a per-wave list in
-//      LDS (ballot + mbcnt compaction: all 64 lanes of the re-scan below do useful work);
-//   3. one lane per item re-multiplies the 64 operand pairs -- all 64 pivots of the tile's C and W
-//      strips stay resident in LDS for this -- finds t* by equality, and writes
+//   1. fold the 64 pivots two at a time with v_max3_f32, exactly as fused_main_max does (4.0), in
+//      four stages of 16 pivots that ping-pong between two register tiles: comparing the tiles at
+//      the end of a stage tells, per entry, the last stage `sid` in which it moved (one compare and
+//      one select per 16 relaxations) -- and t* lies in that stage;
+//   2. every entry that moved becomes an ITEM (entry id, sid, new value) in a per-wave list in LDS
+//      (ballot + mbcnt compaction: all 64 lanes of the re-scan below do useful work);
+//   3. one lane per item re-multiplies the 16 operand pairs of stage sid -- all 64 pivots of the
+//      tile's C and W strips stay resident in LDS for this -- finds t* by equality, and writes
 //      next = CN[t*][i] (and last = k0 + t* for the path trace).
-// About 11 % of the entries change in an average pass of the N = 16384 benchmark solve (60 % in the
-// first sixteenth, 3.5 % in the last), and an item costs 64 x (2 LDS reads + mul + compare + select).
-// Bit-identical to the compare form: same products (one v_mul_f32 each), same winner, same t*.
-// No update counting (U is the number of strict increases along the fold: compare form only).
+// About 11 % of the entries move in an average pass of the N = 16384 benchmark solve (60 % in the
+// first sixteenth, 3.5 % in the last).  Bit-identical to the compare form: same products (one
+// v_mul_f32 each), same winner, same t*.  No update counting (U is the number of strict increases
+// along the fold: compare form only).
 // ------------------------------------------------------------------------------------------------
-template <int MINW, int RI, bool HAS_LAST>
+typedef __attribute__((address_space(3))) float lds_f32;
+typedef __attribute__((address_space(3))) unsigned int lds_u32;
+
+// Re-scan of the items [0, count) of one wave's list, in batches of 64 (one lane per item).  Full
+// batches only unless `all`; the remainder (< 64 items) is moved to the front of the list and its
+// length returned.  Out of line: it is reached from 33 places of the unrolled compaction below.
+// (where the re-scan writes travels as plain scalar arguments, in registers: a struct would be
+// passed through scratch memory; last / hops: nullptr = not kept)
+__device__ __attribute__((noinline)) int arg_rescan(lds_u32 *ids, lds_f32 *vals, int count, bool all,
+                                                    const lds_f32 *sC, const lds_f32 *sW, int ti_ld,
+                                                    int tj_ld, int32_t *o_next, int32_t *o_last,
+                                                    int32_t *o_hops, const int32_t *o_cnt,
+                                                    const int32_t *o_cht, const int32_t *o_wh, int o_n,
+                                                    int o_ct_ld, int o_i_base, int o_j_base, int o_k0)
+{
+    const int lane = (int)(threadIdx.x & 63);
+    int base = 0;
+    for (; base + 64 <= count || (all && base < count); base += 64) {
+        const int it = base + lane;
+        const bool act = it < count;
+        const unsigned int id = ids[act ? it : 0];
+        const float v = act ? vals[it] : __builtin_nanf("");        // NaN never matches
+        const int il = (int)((id >> 8) & 255u), jl = (int)(id & 255u), t0 = (int)(id >> 16) * 16;
+        const lds_f32 *pc = sC + t0 * ti_ld + il;
+        const lds_f32 *pw = sW + t0 * tj_ld + jl;
+        int found = -1;
+#pragma unroll
+        for (int u = 15; u >= 0; --u) {              // descending: the smallest matching pivot wins
+            const float p = pc[u * ti_ld] * pw[u * tj_ld];
+            found = (p == v) ? t0 + u : found;
+        }
+        if (act && found >= 0) {
+            const int i = o_i_base + il, j = o_j_base + jl;
+            const size_t off = (size_t)i * o_n + j;
+            o_next[off] = o_cnt[(size_t)found * o_ct_ld + i];
+            if (o_last) o_last[off] = o_k0 + found;
+            if (o_hops)    // lengths of the two halves at the winning pivot (Algorithms.hs:55)
+                o_hops[off] = (int32_t)((uint32_t)o_cht[(size_t)found * o_ct_ld + i] +
+                                        (uint32_t)o_wh[(size_t)found * o_n + j]);
+        }
+    }
+    const int rest = count - base;                   // < 64 (0 if all)
+    if (rest > 0 && base > 0) {
+        const unsigned int id = ids[base + (lane < rest ? lane : 0)];
+        const float v = vals[base + (lane < rest ? lane : 0)];
+        __builtin_amdgcn_wave_barrier();
+        if (lane < rest) { ids[lane] = id; vals[lane] = v; }
+    }
+    return rest > 0 ? rest : 0;
+}
+
+template <int MINW, int RI>
 __global__ __launch_bounds__(256, MINW) void fused_main_arg(float *rate, int32_t *next, int rows, int n,
                                                             int row0, int k0, int bt, const float *w,
                                                             const float *ct, const int32_t *cnt,
                                                             int ct_ld, int ct_vec, int skip_lo,
-                                                            int skip_hi, int32_t *last)
+                                                            int skip_hi, int32_t *last, int32_t *hops,
+                                                            const int32_t *cht, const int32_t *wh)
 {
     typedef float V4 __attribute__((ext_vector_type(4)));
-    constexpr int TI = 16 * RI, TJ = 64, NP = B / 2, LCAP = 128;
-    // all 64 pivots of the tile's operand strips, as (t, t+1) pairs like fused_main_max
-    __shared__ __attribute__((aligned(16))) float sW[NP][2][TJ];
-    __shared__ __attribute__((aligned(16))) float sC[NP][2][TI];
-    __shared__ unsigned int l_id[4][LCAP];      // per-wave item lists: (row in tile) << 8 | column in tile
+    constexpr int TI = 16 * RI, TJ = 64, LCAP = 128;
+    // all 64 pivots of the tile's operand strips: s?[t][.], pivot t = 2 * pair + u
+    __shared__ __attribute__((aligned(16))) float sW[B][TJ];
+    __shared__ __attribute__((aligned(16))) float sC[B][TI];
+    __shared__ unsigned int l_id[4][LCAP];      // per-wave item lists: sid << 16 | row << 8 | column
     __shared__ float l_val[4][LCAP];            //                      the entry's new value
 
     const int tid = threadIdx.x;
@@ -783,7 +1073,7 @@ __global__ __launch_bounds__(256, MINW) void fused_main_arg(float *rate, int32_t
             const int kcol = k0 + t - j;
             if (kcol >= 0 && kcol < 4) val[kcol] = nanv;
         }
-        *reinterpret_cast<V4 *>(&sW[t >> 1][t & 1][v * 4]) = val;
+        *reinterpret_cast<V4 *>(&sW[t][v * 4]) = val;
     }
     for (int idx = tid; idx < B * (TI / 4); idx += 256) {
         const int t = idx / (TI / 4), v = idx % (TI / 4);
@@ -798,35 +1088,36 @@ __global__ __launch_bounds__(256, MINW) void fused_main_arg(float *rate, int32_t
                     if (i + e < rows) val[e] = ct[(size_t)t * ct_ld + i + e];
             }
         }
-        *reinterpret_cast<V4 *>(&sC[t >> 1][t & 1][v * 4]) = val;
+        *reinterpret_cast<V4 *>(&sC[t][v * 4]) = val;
     }
 
     const int jcol = j_base + tj * 4;
     const bool jok = jcol < n;
     const int jc = jok ? jcol : n - 4;
-    V4 x[RI], xin[RI];
+    V4 xa[RI], xb[RI];
+    int sid[RI][4];
 #pragma unroll
     for (int r = 0; r < RI; ++r) {
         const int i = min(i0 + r, rows - 1);
-        x[r] = *reinterpret_cast<const V4 *>(rate + (size_t)i * n + jc);
-        xin[r] = x[r];
+        xa[r] = *reinterpret_cast<const V4 *>(rate + (size_t)i * n + jc);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) sid[r][e] = -1;
     }
     __syncthreads();
 
-    // ---- 1. the fold: two pivots per v_max3_f32 --------------------------------------------------
-    const int np = skip ? 0 : (bt + 1) / 2;
-#pragma unroll 1
-    for (int tp = 0; tp < np; ++tp) {
+    // ---- 1. the fold: two pivots per v_max3_f32, four stages that ping-pong xa <-> xb -----------
+    const int npairs = skip ? 0 : (bt + 1) / 2;
+    auto pair_step = [&](int tp, const V4 (&in)[RI], V4 (&out)[RI]) {
         float c[RI][2], wv[4][2];
 #pragma unroll
         for (int u = 0; u < 2; ++u) {
 #pragma unroll
             for (int q = 0; q < RI / 4; ++q) {
-                const V4 cv = *reinterpret_cast<const V4 *>(&sC[tp][u][ti * RI + q * 4]);
+                const V4 cv = *reinterpret_cast<const V4 *>(&sC[2 * tp + u][ti * RI + q * 4]);
 #pragma unroll
                 for (int e = 0; e < 4; ++e) c[q * 4 + e][u] = cv[e];
             }
-            const V4 wq = *reinterpret_cast<const V4 *>(&sW[tp][u][tj * 4]);
+            const V4 wq = *reinterpret_cast<const V4 *>(&sW[2 * tp + u][tj * 4]);
 #pragma unroll
             for (int e = 0; e < 4; ++e) wv[e][u] = wq[e];
         }
@@ -840,39 +1131,37 @@ __global__ __launch_bounds__(256, MINW) void fused_main_arg(float *rate, int32_t
             }
 #pragma unroll
             for (int e = 0; e < 4; ++e)
-                x[r][e] = __builtin_fmaxf(__builtin_fmaxf(x[r][e], p0[e]), p1[e]);
+                out[r][e] = __builtin_fmaxf(__builtin_fmaxf(in[r][e], p0[e]), p1[e]);
+        }
+    };
+    int stages = 0;                                  // stages executed (wave-uniform)
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+        if (s * 8 < npairs) {
+            const V4 (&src)[RI] = (s & 1) ? xb : xa;
+            V4 (&dst)[RI] = (s & 1) ? xa : xb;
+            const int p_hi = min(s * 8 + 8, npairs);
+            pair_step(s * 8, src, dst);
+#pragma unroll 1
+            for (int tp = s * 8 + 1; tp < p_hi; ++tp) pair_step(tp, dst, dst);
+#pragma unroll
+            for (int r = 0; r < RI; ++r)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) sid[r][e] = (dst[r][e] != src[r][e]) ? s : sid[r][e];
+            stages = s + 1;
         }
     }
+    if (stages & 1) {                                // the result sits in xb: bring it to xa
+#pragma unroll
+        for (int r = 0; r < RI; ++r) xa[r] = xb[r];
+    }
 
-    // ---- 2. + 3. changed entries -> items -> t* -> next (and last) -------------------------------
+    // ---- 2. + 3. moved entries -> items -> t* -> next (and last) ---------------------------------
     const int gi_lo = row0 + i_base;
     const bool diag_tile = gi_lo < j_base + TJ && j_base < gi_lo + TI;
+    lds_u32 *ids = (lds_u32 *)&l_id[wave][0];
+    lds_f32 *vals = (lds_f32 *)&l_val[wave][0];
     int count = 0;                                   // items in this wave's list (wave-uniform)
-    auto flush = [&]() {
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        for (int base = 0; base < count; base += 64) {
-            const int it = base + lane;
-            const bool act = it < count;
-            const unsigned int id = l_id[wave][act ? it : 0];
-            const float v = act ? l_val[wave][it] : nanv;       // NaN never matches
-            const int il = (int)(id >> 8), jl = (int)(id & 255u);
-            int found = -1;
-#pragma unroll 8
-            for (int t = B - 1; t >= 0; --t) {       // descending: the smallest matching t wins
-                const float p = sC[t >> 1][t & 1][il] * sW[t >> 1][t & 1][jl];
-                found = (p == v) ? t : found;
-            }
-            if (act && found >= 0) {
-                const int i = i_base + il;
-                const size_t off = (size_t)i * n + j_base + jl;
-                next[off] = cnt[(size_t)found * ct_ld + i];
-                if (HAS_LAST) last[off] = k0 + found;
-            }
-        }
-        __builtin_amdgcn_wave_barrier();
-        count = 0;
-    };
 #pragma unroll
     for (int r = 0; r < RI; ++r) {
         const int i = i0 + r;
@@ -881,13 +1170,15 @@ __global__ __launch_bounds__(256, MINW) void fused_main_arg(float *rate, int32_t
         bool any = false;
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
+            ch[e] = row_ok && sid[r][e] >= 0;
             // j == i is never touched (Algorithms.hs:54): the diagonal entry keeps its value
-            const bool is_diag = diag_tile && (row0 + i == jc + e);
-            if (is_diag) x[r][e] = xin[r][e];
-            ch[e] = row_ok && (x[r][e] != xin[r][e]);
+            if (diag_tile && row0 + i == jc + e) {
+                if (ch[e]) xa[r][e] = rate[(size_t)i * n + jc + e];
+                ch[e] = false;
+            }
             any |= ch[e];
         }
-        if (any) *reinterpret_cast<V4 *>(rate + (size_t)i * n + jc) = x[r];
+        if (any) *reinterpret_cast<V4 *>(rate + (size_t)i * n + jc) = xa[r];
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
             const unsigned long long mask = __ballot(ch[e]);
@@ -895,15 +1186,25 @@ __global__ __launch_bounds__(256, MINW) void fused_main_arg(float *rate, int32_t
                 const int pos = count + (int)__builtin_amdgcn_mbcnt_hi((unsigned int)(mask >> 32),
                                              __builtin_amdgcn_mbcnt_lo((unsigned int)mask, 0u));
                 if (ch[e]) {
-                    l_id[wave][pos] = ((unsigned int)(ti * RI + r) << 8) | (unsigned int)(tj * 4 + e);
-                    l_val[wave][pos] = x[r][e];
+                    ids[pos] = ((unsigned int)sid[r][e] << 16) | ((unsigned int)(ti * RI + r) << 8) |
+                               (unsigned int)(tj * 4 + e);
+                    vals[pos] = xa[r][e];
                 }
                 count += __builtin_popcountll(mask);
-                if (count > LCAP - 64) flush();
+                if (count >= 64) {
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                    count = arg_rescan(ids, vals, count, false, (const lds_f32 *)&sC[0][0],
+                                       (const lds_f32 *)&sW[0][0], TI, TJ, next, last, hops, cnt, cht, wh,
+                                       n, ct_ld, i_base, j_base, k0);
+                }
             }
         }
     }
-    if (count > 0) flush();
+    if (count > 0) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        arg_rescan(ids, vals, count, true, (const lds_f32 *)&sC[0][0], (const lds_f32 *)&sW[0][0], TI, TJ,
+                   next, last, hops, cnt, cht, wh, n, ct_ld, i_base, j_base, k0);
+    }
 }
 
 // Domain check (fwx.h "Domain"): clears bit 0 of *flag if any rate has its sign bit set or is NaN,
@@ -987,27 +1288,17 @@ static bool launch_max_form(const FusedArgs<float> &a, dim3 grid, dim3 block, in
     if (!a.nonneg || a.updates) return false;
     const int ct_vec = ((uintptr_t)a.ct % 16 == 0 && a.ct_ld % 4 == 0) ? 1 : 0;
     if (a.next) {
-        // rates + next-hops (+ trace): max-form fold, then arg re-scan of the changed entries
+        // rates + next-hops (+ trace, + hops): max-form fold, then arg re-scan of the moved entries
         if (small_tiles(a.n, a.rows)) {
             const dim3 g((unsigned)((a.n + 63) / 64), (unsigned)((a.rows + 63) / 64));
-            if (last)
-                hipLaunchKernelGGL((fused_main_arg<3, 4, true>), g, block, 0, s, a.rate, a.next, a.rows,
-                                   a.n, a.row0, a.k0, a.bt, a.w, a.ct, a.cnt, a.ct_ld, ct_vec, skip_lo,
-                                   skip_hi, last);
-            else
-                hipLaunchKernelGGL((fused_main_arg<3, 4, false>), g, block, 0, s, a.rate, a.next, a.rows,
-                                   a.n, a.row0, a.k0, a.bt, a.w, a.ct, a.cnt, a.ct_ld, ct_vec, skip_lo,
-                                   skip_hi, last);
+            hipLaunchKernelGGL((fused_main_arg<3, 4>), g, block, 0, s, a.rate, a.next, a.rows, a.n, a.row0,
+                               a.k0, a.bt, a.w, a.ct, a.cnt, a.ct_ld, ct_vec, skip_lo, skip_hi, last,
+                               a.hops, a.cht, a.wh);
         } else {
             const dim3 g((unsigned)((a.n + 63) / 64), (unsigned)((a.rows + 127) / 128));
-            if (last)
-                hipLaunchKernelGGL((fused_main_arg<3, 8, true>), g, block, 0, s, a.rate, a.next, a.rows,
-                                   a.n, a.row0, a.k0, a.bt, a.w, a.ct, a.cnt, a.ct_ld, ct_vec, skip_lo,
-                                   skip_hi, last);
-            else
-                hipLaunchKernelGGL((fused_main_arg<3, 8, false>), g, block, 0, s, a.rate, a.next, a.rows,
-                                   a.n, a.row0, a.k0, a.bt, a.w, a.ct, a.cnt, a.ct_ld, ct_vec, skip_lo,
-                                   skip_hi, last);
+            hipLaunchKernelGGL((fused_main_arg<3, 8>), g, block, 0, s, a.rate, a.next, a.rows, a.n, a.row0,
+                               a.k0, a.bt, a.w, a.ct, a.cnt, a.ct_ld, ct_vec, skip_lo, skip_hi, last,
+                               a.hops, a.cht, a.wh);
         }
         return true;
     }
@@ -1038,16 +1329,25 @@ static bool launch_max_form(const FusedArgs<double> &a, dim3 grid, dim3 block, i
                             int skip_hi, hipStream_t s, int32_t *)
 {
     if (!a.nonneg || a.next || a.updates) return false;
+    static const int variant = getenv("FWX_MAXF64_VARIANT") ? atoi(getenv("FWX_MAXF64_VARIANT")) : 0;
+    if (!small_tiles(a.n, a.rows) && variant != 9) {
+        const int ct_vec = ((uintptr_t)a.ct % 16 == 0 && a.ct_ld % 2 == 0) ? 1 : 0;
+        const dim3 g((unsigned)((a.n + 127) / 128), (unsigned)((a.rows + 127) / 128));
+        hipLaunchKernelGGL((fused_main_max_f64<2>), g, block, 0, s, a.rate, a.rows, a.n, a.row0, a.k0,
+                           a.bt, a.w, a.ct, a.ct_ld, ct_vec, skip_lo, skip_hi);
+        return true;
+    }
     if (small_tiles(a.n, a.rows))
         hipLaunchKernelGGL((fused_main<double, false, false, 16, 2, 1, 4, true>), grid, block, 0, s,
                            a.rate, a.next, a.rows, a.n, a.row0, a.k0, a.bt, a.w, a.ct, a.cnt,
-                           a.ct_ld, skip_lo, skip_hi, a.updates, nullptr);
+                           a.ct_ld, skip_lo, skip_hi, a.updates, nullptr, nullptr, nullptr, nullptr);
     else
         hipLaunchKernelGGL((fused_main<double, false, false, FusedCfg<double, false>::BS,
                                        FusedCfg<double, false>::MINW, FusedCfg<double, false>::NH, 8,
                                        true>),
                            grid, block, 0, s, a.rate, a.next, a.rows, a.n, a.row0, a.k0, a.bt, a.w,
-                           a.ct, a.cnt, a.ct_ld, skip_lo, skip_hi, a.updates, nullptr);
+                           a.ct, a.cnt, a.ct_ld, skip_lo, skip_hi, a.updates, nullptr, nullptr, nullptr,
+                           nullptr);
     return true;
 }
 
@@ -1099,16 +1399,19 @@ template <typename T> hipError_t launch_fused_colpanel(const FusedArgs<T> &a, hi
     const dim3 cgrid((unsigned)((a.rows + 63) / 64)), block(PANEL_THREADS);
     // (the trace matrices of a slab are indexed by LOCAL row, like its rate / next)
     if (a.plog.last && !a.next) return hipErrorInvalidValue;
-    if (a.plog.last)
-        hipLaunchKernelGGL((fused_colpanel<T, true, true>), cgrid, block, 0, s, a.rate, a.next, a.rows,
-                           a.n, a.row0, a.k0, a.bt, a.w, a.ct, a.cnt, a.ct_ld, a.plog.last,
-                           a.plog.at_col);
-    else if (a.next)
-        hipLaunchKernelGGL((fused_colpanel<T, true, false>), cgrid, block, 0, s, a.rate, a.next, a.rows,
-                           a.n, a.row0, a.k0, a.bt, a.w, a.ct, a.cnt, a.ct_ld, nullptr, nullptr);
-    else
-        hipLaunchKernelGGL((fused_colpanel<T, false, false>), cgrid, block, 0, s, a.rate, a.next, a.rows,
-                           a.n, a.row0, a.k0, a.bt, a.w, a.ct, a.cnt, a.ct_ld, nullptr, nullptr);
+    if (a.hops && (!a.next || !a.wh || !a.cht)) return hipErrorInvalidValue;
+#define FWX_COLPANEL(HN, HL, HH)                                                                   \
+    hipLaunchKernelGGL((fused_colpanel<T, HN, HL, HH>), cgrid, block, 0, s, a.rate, a.next, a.rows, a.n, \
+                       a.row0, a.k0, a.bt, a.w, a.ct, a.cnt, a.ct_ld, a.plog.last, a.plog.at_col,  \
+                       a.hops, a.wh, a.cht)
+    if (a.plog.last) {
+        if (a.hops) FWX_COLPANEL(true, true, true); else FWX_COLPANEL(true, true, false);
+    } else if (a.next) {
+        if (a.hops) FWX_COLPANEL(true, false, true); else FWX_COLPANEL(true, false, false);
+    } else {
+        FWX_COLPANEL(false, false, false);
+    }
+#undef FWX_COLPANEL
     return hipGetLastError();
 }
 
@@ -1135,7 +1438,10 @@ hipError_t launch_fused_main(const FusedArgs<T> &full, int r_lo, int r_hi, hipSt
     a.ct = full.ct + r_lo;
     a.cnt = full.cnt ? full.cnt + r_lo : nullptr;
     int32_t *last = full.plog.last ? full.plog.last + (size_t)r_lo * full.n : nullptr;
-    if (last && !a.next) return hipErrorInvalidValue;
+    if ((last || full.hops) && !a.next) return hipErrorInvalidValue;
+    a.hops = full.hops ? full.hops + (size_t)r_lo * full.n : nullptr;
+    a.cht = full.cht ? full.cht + r_lo : nullptr;
+    const bool track = last || a.hops;
     const dim3 block(256);
     const bool small = small_tiles(a.n, a.rows);
     const int tj = 16 * VW * (small ? 1 : (a.next ? FusedCfg<T, true>::NH : FusedCfg<T, false>::NH));
@@ -1147,16 +1453,17 @@ hipError_t launch_fused_main(const FusedArgs<T> &full, int r_lo, int r_hi, hipSt
         if (small)                                                                                 \
             hipLaunchKernelGGL((fused_main<T, HN, CN, 16, 2, 1, 4, false, HL>), grid, block, 0, s, \
                                a.rate, a.next, a.rows, a.n, a.row0, a.k0, a.bt, a.w, a.ct, a.cnt,  \
-                               a.ct_ld, skip_lo, skip_hi, a.updates, last);                        \
+                               a.ct_ld, skip_lo, skip_hi, a.updates, last, a.hops, a.cht, a.wh);   \
         else                                                                                       \
             hipLaunchKernelGGL((fused_main<T, HN, CN, FusedCfg<T, HN>::BS,                         \
                                            HL ? (CN ? 2 : (FusedCfg<T, HN>::MINW > 3 ? 3 : FusedCfg<T, HN>::MINW)) \
                                               : FusedCfg<T, HN>::MINW,                             \
                                            FusedCfg<T, HN>::NH, 8, false, HL>),                    \
                                grid, block, 0, s, a.rate, a.next, a.rows, a.n, a.row0, a.k0, a.bt, \
-                               a.w, a.ct, a.cnt, a.ct_ld, skip_lo, skip_hi, a.updates, last);      \
+                               a.w, a.ct, a.cnt, a.ct_ld, skip_lo, skip_hi, a.updates, last,       \
+                               a.hops, a.cht, a.wh);                                               \
     } while (0)
-    if (last) {
+    if (track) {
         if (a.updates) FWX_FUSED_LAUNCH(true, true, true); else FWX_FUSED_LAUNCH(true, false, true);
     } else if (a.next) {
         if (a.updates) FWX_FUSED_LAUNCH(true, true, false); else FWX_FUSED_LAUNCH(true, false, false);
@@ -1176,19 +1483,22 @@ hipError_t launch_fused_relax(const FusedArgs<T> &a, hipStream_t s, int skip_lo,
 }
 
 template <typename T>
-hipError_t launch_fused_panel(const T *rows_base, int n, int k0, int bt, T *w, T *diag_ws,
-                              hipStream_t s, PathLog plog)
+hipError_t launch_fused_panel(const T *rows_base, int n, int k0, int bt, T *w, hipStream_t s, PathLog plog,
+                              const int32_t *hops_rows, int32_t *wh)
 {
-    (void)diag_ws;   // kept in the ABI: the diagonal block is now evolved inside fused_rowpanel
     if (n <= 0 || bt <= 0) return hipSuccess;
-    if (bt > B) return hipErrorInvalidValue;
+    if (bt > B || (hops_rows && !wh)) return hipErrorInvalidValue;
     const dim3 grid((unsigned)((n + 63) / 64)), block(PANEL_THREADS);
-    if (plog.last)   // plog points at the SAME rows as rows_base (pivot row k0 of the trace matrices)
-        hipLaunchKernelGGL((fused_rowpanel<T, true>), grid, block, 0, s, rows_base, n, k0, bt, w,
-                           plog.last, plog.at_row);
-    else
-        hipLaunchKernelGGL((fused_rowpanel<T, false>), grid, block, 0, s, rows_base, n, k0, bt, w,
-                           nullptr, nullptr);
+    // plog / hops_rows point at the SAME rows as rows_base (pivot row k0 of those matrices)
+#define FWX_ROWPANEL(HL, HH)                                                                       \
+    hipLaunchKernelGGL((fused_rowpanel<T, HL, HH>), grid, block, 0, s, rows_base, n, k0, bt, w, plog.last, \
+                       plog.at_row, hops_rows, wh)
+    if (plog.last) {
+        if (hops_rows) FWX_ROWPANEL(true, true); else FWX_ROWPANEL(true, false);
+    } else {
+        if (hops_rows) FWX_ROWPANEL(false, true); else FWX_ROWPANEL(false, false);
+    }
+#undef FWX_ROWPANEL
     return hipGetLastError();
 }
 
@@ -1200,9 +1510,9 @@ template hipError_t launch_fused_main<float>(const FusedArgs<float> &, int, int,
                                              int);
 template hipError_t launch_fused_main<double>(const FusedArgs<double> &, int, int, hipStream_t, int,
                                               int);
-template hipError_t launch_fused_panel<float>(const float *, int, int, int, float *, float *,
-                                              hipStream_t, PathLog);
-template hipError_t launch_fused_panel<double>(const double *, int, int, int, double *, double *,
-                                               hipStream_t, PathLog);
+template hipError_t launch_fused_panel<float>(const float *, int, int, int, float *, hipStream_t, PathLog,
+                                              const int32_t *, int32_t *);
+template hipError_t launch_fused_panel<double>(const double *, int, int, int, double *, hipStream_t,
+                                               PathLog, const int32_t *, int32_t *);
 
 }  // namespace fwx

@@ -179,13 +179,13 @@ struct SideStream {
 };
 
 
-inline size_t fused_ws_bytes(int n, size_t es)
+inline size_t fused_ws_bytes(int n, size_t es, bool with_hops)
 {
     const size_t ld = ((size_t)n + 3) & ~(size_t)3;
-    return (size_t)FWX_FUSED_B * n * 2 * es + (size_t)FWX_FUSED_B * ld * (es + 4) +
-           (size_t)2 * FWX_FUSED_B * FWX_FUSED_B * es + 256;
+    size_t b = (size_t)FWX_FUSED_B * n * 2 * es + (size_t)FWX_FUSED_B * ld * (es + 4) + 256;
+    if (with_hops) b += (size_t)FWX_FUSED_B * n * 2 * 4 + (size_t)FWX_FUSED_B * ld * 4;
+    return b;
 }
-
 
 // One read of the matrix (fwx.h "Domain"): bit 0 = every rate is >= +0.0 and not NaN; bit 1 = no
 // entry has a non-zero rate and next < 0.  d_flag: a device int the caller owns.
@@ -240,8 +240,8 @@ struct fwx_matrix {
 
 // fwx_multi.hip: what the handle entry points of fwx_api.hip call for a handle with m->multi
 namespace fwxi {
-int multi_upload(fwx_matrix *m, const void *rate, const int32_t *next);
-int multi_download(fwx_matrix *m, void *rate, int32_t *next);
+int multi_upload(fwx_matrix *m, const void *rate, const int32_t *next, const int32_t *hops);
+int multi_download(fwx_matrix *m, void *rate, int32_t *next, int32_t *hops);
 int multi_solve(fwx_matrix *m, const Opts &op);
 int multi_enable_path_log(fwx_matrix *m);
 int multi_query(fwx_matrix *m, int32_t src, int32_t dst, double *rate_out, int32_t *path_out, int32_t cap);

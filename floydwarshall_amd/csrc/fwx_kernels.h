@@ -22,9 +22,9 @@ struct PathLog {
     // (i,q) before step q = at_col[i][q], path_q(q,j) needs at_row[q][j]; the recursion only ever asks
     // for an entry "as of the step named by one of its own indices", so these three suffice.
     // Column k and row k of `last` are not modified during step k: the snapshots are plain copies.
-    int32_t *last;
-    int32_t *at_col;
-    int32_t *at_row;
+    int32_t *last = nullptr;       // (null by default: a PathLog that was never filled in means "no trace")
+    int32_t *at_col = nullptr;
+    int32_t *at_row = nullptr;
 };
 
 template <typename T> struct RelaxArgs {
@@ -70,6 +70,9 @@ template <typename T> struct FusedArgs {
     const T *w;            // snapshot panel: w[t*n + j] = row k0+t at time k0+t
     T *ct;                 // scratch bt x rows: ct[t*rows + i] = column k0+t at time k0+t (NaN if i==k)
     int32_t *cnt;          // scratch bt x rows (iff next)
+    int32_t *hops = nullptr;      // slab rows x n, or nullptr (needs next): hops' = hops[i][k] + hops[k][j]
+    const int32_t *wh = nullptr;  // hops panel: wh[t*n + j] = hops of row k0+t at time k0+t (iff hops)
+    int32_t *cht = nullptr;       // scratch bt x rows (iff hops): hops of column k0+t at time k0+t
     int ct_ld;             // leading dimension of ct / cnt (>= rows; a multiple of 4 keeps the
                            // staging loads 16-byte aligned)
     unsigned long long *updates;
@@ -98,11 +101,13 @@ hipError_t launch_fused_main(const FusedArgs<T> &a, int r_lo, int r_hi, hipStrea
                              int skip_lo = 0, int skip_hi = 0);
 
 // diag + rowpanel: snapshot panel of the pivot rows `rows_base` (bt x n, at time k0); the matrix
-// is not modified.  diag_ws: unused (kept for the ABI).  plog: the path trace AT THE SAME ROWS as
-// rows_base (plog.last / plog.at_row point at pivot row k0; at_col is not touched).
+// is not modified.  plog: the path trace AT THE SAME ROWS as rows_base (plog.last / plog.at_row
+// point at pivot row k0; at_col is not touched).  hops_rows (same rows again) / wh: the hops of the
+// pivot rows are carried through the panel and their time-k snapshots exported to wh (bt x n).
 template <typename T>
-hipError_t launch_fused_panel(const T *rows_base, int n, int k0, int bt, T *w, T *diag_ws,
-                              hipStream_t s, PathLog plog = PathLog());
+hipError_t launch_fused_panel(const T *rows_base, int n, int k0, int bt, T *w, hipStream_t s,
+                              PathLog plog = PathLog(), const int32_t *hops_rows = nullptr,
+                              int32_t *wh = nullptr);
 
 }  // namespace fwx
 #endif

@@ -441,7 +441,7 @@ template <typename T> hipError_t launch_relax(const RelaxArgs<T> &a, hipStream_t
     const bool vec_ok = (a.n % WV == 0) && ((uintptr_t)a.rate % 16 == 0) &&
                         ((uintptr_t)a.prow % 16 == 0);
     if (a.hops && !a.next) return hipErrorInvalidValue;  // hops ride on the next-hop path
-    // Launch geometry from the sweep in tools/tune_relax.hip (profiles/r01_tune_relax.txt):
+    // Launch geometry from the sweep in tools/tune_relax.hip (profiles/r01_tune_relax_sweep1.txt ... _sweep3.txt):
     // one 16-byte vector per thread (strip = 1024 f32 / 512 f64 columns), 4 rows per workgroup,
     // 4 loads in flight per thread.  Many small workgroups beat fewer large ones by 10-15 % at
     // N = 16384: the resident set then covers a compact band of rows (DRAM page locality) and

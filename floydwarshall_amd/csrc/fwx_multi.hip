@@ -68,12 +68,13 @@ static RcclApi &rccl()
 struct Part {
     int device = 0, row0 = 0, rows = 0;    // rows [row0, row0 + rows) of the nd x nd device matrix
     void *rate = nullptr;
-    int32_t *next = nullptr;
+    int32_t *next = nullptr, *hops = nullptr;
     fwx::PathLog plog;                      // slab-local trace matrices (rows x nd), or null
     int32_t *next0 = nullptr;
     void *w[2] = {nullptr, nullptr};        // snapshot panels, 64 x nd
+    int32_t *wh[2] = {nullptr, nullptr};    // their hops (iff hops)
     void *ct = nullptr;                     // pivot-column snapshots, 64 x ct_ld
-    int32_t *cnt = nullptr;
+    int32_t *cnt = nullptr, *cht = nullptr; // their next-hops / hops
     int ct_ld = 0;
     unsigned long long *upd = nullptr;
     int *flag = nullptr;
@@ -207,8 +208,8 @@ static void multi_free(MultiState *M)
     for (int p = 0; p < M->parts; ++p) {
         Part &q = M->part[p];
         if (hipSetDevice(q.device) != hipSuccess) continue;
-        void *bufs[] = {q.rate, q.next, q.plog.last, q.plog.at_col, q.plog.at_row, q.next0, q.w[0], q.w[1],
-                        q.ct, q.cnt, q.upd, q.flag};
+        void *bufs[] = {q.rate, q.next, q.hops, q.plog.last, q.plog.at_col, q.plog.at_row, q.next0, q.w[0],
+                        q.w[1], q.wh[0], q.wh[1], q.ct, q.cnt, q.cht, q.upd, q.flag};
         for (void *b : bufs)
             if (b) (void)hipFree(b);
         hipEvent_t evs[] = {q.rows_done, q.w_ready[0], q.w_ready[1], q.main_free[0], q.main_free[1]};
@@ -253,6 +254,12 @@ static int multi_alloc(fwx_matrix *m, int n_parts, const int32_t *devices, int e
         FWX_HIP(hipMalloc(&q.w[1], (size_t)FWX_FUSED_BLOCK * nd * es));
         FWX_HIP(hipMalloc(&q.ct, (size_t)FWX_FUSED_BLOCK * (q.ct_ld ? q.ct_ld : 4) * es));
         if (m->next) FWX_HIP(hipMalloc((void **)&q.cnt, (size_t)FWX_FUSED_BLOCK * (q.ct_ld ? q.ct_ld : 4) * 4));
+        if (m->hops) {
+            FWX_HIP(hipMalloc((void **)&q.hops, cells * 4 ? cells * 4 : 16));
+            FWX_HIP(hipMalloc((void **)&q.wh[0], (size_t)FWX_FUSED_BLOCK * nd * 4));
+            FWX_HIP(hipMalloc((void **)&q.wh[1], (size_t)FWX_FUSED_BLOCK * nd * 4));
+            FWX_HIP(hipMalloc((void **)&q.cht, (size_t)FWX_FUSED_BLOCK * (q.ct_ld ? q.ct_ld : 4) * 4));
+        }
         FWX_HIP(hipMalloc((void **)&q.upd, FWX_UPDATE_SHARDS * 8));
         FWX_HIP(hipMalloc((void **)&q.flag, 16));
         FWX_HIP(hipStreamCreateWithFlags(&q.main, hipStreamNonBlocking));
@@ -287,7 +294,8 @@ static int multi_alloc(fwx_matrix *m, int n_parts, const int32_t *devices, int e
 }
 
 // The arrays of partition p hold rows [row0, row0 + rows) at pitch nd; the caller's are n x n.
-static int multi_copy(fwx_matrix *m, void *host_rate, int32_t *host_next, bool to_device)
+static int multi_copy(fwx_matrix *m, void *host_rate, int32_t *host_next, int32_t *host_hops,
+                      bool to_device)
 {
     MultiState &M = *m->multi;
     const size_t es = m->dtype == FWX_F64 ? 8 : 4;
@@ -300,6 +308,7 @@ static int multi_copy(fwx_matrix *m, void *host_rate, int32_t *host_next, bool t
         if (to_device && nd != n) {
             FWX_HIP(hipMemsetAsync(q.rate, 0, (size_t)q.rows * nd * es, q.main));              // +0.0
             if (q.next) FWX_HIP(hipMemsetAsync(q.next, 0xFF, (size_t)q.rows * nd * 4, q.main));   // -1
+            if (q.hops) FWX_HIP(hipMemsetAsync(q.hops, 0, (size_t)q.rows * nd * 4, q.main));
         }
         if (real <= 0) continue;
         auto copy = [&](void *dev, char *host, size_t e) -> int {
@@ -315,6 +324,7 @@ static int multi_copy(fwx_matrix *m, void *host_rate, int32_t *host_next, bool t
         };
         if ((rc = copy(q.rate, (char *)host_rate, es))) return rc;
         if (q.next && (rc = copy(q.next, (char *)host_next, 4))) return rc;
+        if (q.hops && (rc = copy(q.hops, (char *)host_hops, 4))) return rc;
         if (to_device && q.plog.last)
             FWX_HIP(hipMemcpyAsync(q.next0, q.next, (size_t)q.rows * nd * 4, hipMemcpyDeviceToDevice, q.main));
     }
@@ -335,6 +345,7 @@ template <typename T> static fwx::FusedArgs<T> part_args(const MultiState &M, co
     a.rate = (T *)q.rate; a.next = q.next; a.rows = q.rows; a.n = M.nd; a.row0 = q.row0;
     a.ct = (T *)q.ct; a.cnt = q.next ? q.cnt : nullptr; a.ct_ld = q.ct_ld;
     a.updates = counting ? q.upd : nullptr; a.nonneg = nonneg; a.plog = q.plog;
+    a.hops = q.hops; a.cht = q.cht;
     return a;
 }
 
@@ -353,8 +364,10 @@ template <typename T> static int issue_panel(MultiState &M, const Block &blk, in
         for (int r = 0; r < M.parts; ++r)      // nobody is still copying the previous panel out of this slot
             if (r != blk.owner) FWX_HIP(hipStreamWaitEvent(o.side, M.part[r].w_ready[slot], 0));
     const size_t row_off = (size_t)(blk.k0 - o.row0) * M.nd;
+    const size_t hbytes = (size_t)blk.bt * M.nd * sizeof(int32_t);
     FWX_HIP(fwx::launch_fused_panel<T>((const T *)o.rate + row_off, M.nd, blk.k0, blk.bt, (T *)o.w[slot],
-                                       nullptr, o.side, plog_rows(o.plog, row_off)));
+                                       o.side, plog_rows(o.plog, row_off),
+                                       o.hops ? o.hops + row_off : nullptr, o.wh[slot]));
     FWX_HIP(hipEventRecord(o.w_ready[slot], o.side));
     if (M.exchange == FWX_XCHG_PEER) {
         for (int r = 0; r < M.parts; ++r) {
@@ -363,10 +376,15 @@ template <typename T> static int issue_panel(MultiState &M, const Block &blk, in
             if ((rc = set_dev(q.device))) return rc;
             FWX_HIP(hipStreamWaitEvent(q.side, q.main_free[slot], 0));
             FWX_HIP(hipStreamWaitEvent(q.side, o.w_ready[slot], 0));
-            if (q.device == o.device)
+            if (q.device == o.device) {
                 FWX_HIP(hipMemcpyAsync(q.w[slot], o.w[slot], bytes, hipMemcpyDeviceToDevice, q.side));
-            else
+                if (o.hops)
+                    FWX_HIP(hipMemcpyAsync(q.wh[slot], o.wh[slot], hbytes, hipMemcpyDeviceToDevice, q.side));
+            } else {
                 FWX_HIP(hipMemcpyPeerAsync(q.w[slot], q.device, o.w[slot], o.device, bytes, q.side));
+                if (o.hops)
+                    FWX_HIP(hipMemcpyPeerAsync(q.wh[slot], q.device, o.wh[slot], o.device, hbytes, q.side));
+            }
             FWX_HIP(hipEventRecord(q.w_ready[slot], q.side));
         }
     } else {
@@ -382,6 +400,9 @@ template <typename T> static int issue_panel(MultiState &M, const Block &blk, in
             if ((rc = set_dev(q.device))) return rc;
             FWX_NCCL(api.Broadcast(q.w[slot], q.w[slot], (size_t)blk.bt * M.nd,
                                    sizeof(T) == 8 ? ncclFloat64 : ncclFloat32, blk.owner, M.comm[r], q.side));
+            if (q.hops)     // the hops of the pivot rows travel with their rates
+                FWX_NCCL(api.Broadcast(q.wh[slot], q.wh[slot], (size_t)blk.bt * M.nd, ncclInt32, blk.owner,
+                                       M.comm[r], q.side));
         }
         FWX_NCCL(api.GroupEnd());
         for (int r = 0; r < M.parts; ++r) {
@@ -454,7 +475,7 @@ template <typename T> static int multi_solve_typed(fwx_matrix *m, const Opts &op
             if ((rc = set_dev(q.device))) return rc;
             FWX_HIP(hipStreamWaitEvent(q.main, q.w_ready[slot], 0));
             fwx::FusedArgs<T> a = part_args<T>(M, q, nonneg, counting);
-            a.k0 = blk.k0; a.bt = blk.bt; a.w = (const T *)q.w[slot];
+            a.k0 = blk.k0; a.bt = blk.bt; a.w = (const T *)q.w[slot]; a.wh = q.wh[slot];
             FWX_HIP(fwx::launch_fused_colpanel<T>(a, q.main));
         }
         int la_lo = 0, la_hi = 0, la_owner = -1;
@@ -465,7 +486,7 @@ template <typename T> static int multi_solve_typed(fwx_matrix *m, const Opts &op
             la_owner = nb.owner; la_lo = nb.k0 - o.row0; la_hi = la_lo + nb.bt;
             if ((rc = set_dev(o.device))) return rc;
             fwx::FusedArgs<T> a = part_args<T>(M, o, nonneg, counting);
-            a.k0 = blk.k0; a.bt = blk.bt; a.w = (const T *)o.w[slot];
+            a.k0 = blk.k0; a.bt = blk.bt; a.w = (const T *)o.w[slot]; a.wh = o.wh[slot];
             FWX_HIP(fwx::launch_fused_main<T>(a, la_lo, la_hi, o.main));
             FWX_HIP(hipEventRecord(o.rows_done, o.main));
             if ((rc = issue_panel<T>(M, nb, slot ^ 1))) return rc;
@@ -475,7 +496,7 @@ template <typename T> static int multi_solve_typed(fwx_matrix *m, const Opts &op
             if ((rc = set_dev(q.device))) return rc;
             if (q.rows > 0) {
                 fwx::FusedArgs<T> a = part_args<T>(M, q, nonneg, counting);
-                a.k0 = blk.k0; a.bt = blk.bt; a.w = (const T *)q.w[slot];
+                a.k0 = blk.k0; a.bt = blk.bt; a.w = (const T *)q.w[slot]; a.wh = q.wh[slot];
                 if (p != la_owner) {
                     FWX_HIP(fwx::launch_fused_main<T>(a, 0, q.rows, q.main));
                 } else if (la_lo % 8 == 0 && la_hi % 8 == 0) {
@@ -508,20 +529,21 @@ template <typename T> static int multi_solve_typed(fwx_matrix *m, const Opts &op
 }
 
 // ---- entry points used by fwx_api.hip for handles with m->multi -----------------------------------
-int multi_upload(fwx_matrix *m, const void *rate, const int32_t *next)
+int multi_upload(fwx_matrix *m, const void *rate, const int32_t *next, const int32_t *hops)
 {
     DevRestore keep;
-    const int rc = multi_copy(m, const_cast<void *>(rate), const_cast<int32_t *>(next), true);
+    const int rc = multi_copy(m, const_cast<void *>(rate), const_cast<int32_t *>(next),
+                              const_cast<int32_t *>(hops), true);
     if (rc) return rc;
     if (m->plog.last) m->rec_ready = 0;
     m->fresh = 1;
     return FWX_OK;
 }
 
-int multi_download(fwx_matrix *m, void *rate, int32_t *next)
+int multi_download(fwx_matrix *m, void *rate, int32_t *next, int32_t *hops)
 {
     DevRestore keep;
-    return multi_copy(m, rate, next, false);
+    return multi_copy(m, rate, next, hops, false);
 }
 
 int multi_solve(fwx_matrix *m, const Opts &op)
@@ -672,7 +694,7 @@ int fwx_matrix_create_multi(fwx_matrix **out, int32_t n, int32_t dtype, int32_t 
         (exchange != FWX_XCHG_AUTO && exchange != FWX_XCHG_PEER && exchange != FWX_XCHG_RCCL))
         return FWX_ERR_INVALID;
     *out = nullptr;
-    if (with_hops) return FWX_ERR_UNSUPPORTED;
+    if (with_hops && !with_next) return FWX_ERR_INVALID;
     const int cnt = device_count();
     if (cnt <= 0) return FWX_ERR_NO_DEVICE;
     for (int p = 0; p < n_parts; ++p)
@@ -681,7 +703,8 @@ int fwx_matrix_create_multi(fwx_matrix **out, int32_t n, int32_t dtype, int32_t 
     if (!m) return FWX_ERR_OOM;
     memset(m, 0, sizeof(*m));
     m->n = n; m->dtype = dtype; m->device = devices[0];
-    m->next = with_next ? (int32_t *)(uintptr_t)16 : nullptr;   // marker only: the slabs own the arrays
+    m->next = with_next ? (int32_t *)(uintptr_t)16 : nullptr;   // markers only: the slabs own the arrays
+    m->hops = with_hops ? (int32_t *)(uintptr_t)16 : nullptr;
     DevRestore keep;
     const int rc = multi_alloc(m, n_parts, devices, exchange);
     if (rc) {
@@ -706,15 +729,16 @@ static int solve_multi_host(int32_t n, int dtype, void *rate, int32_t *next, int
     if (n < 0) return FWX_ERR_INVALID;
     if (n == 0) return FWX_OK;
     if (!rate || (hops && !next)) return FWX_ERR_INVALID;
-    if (hops) return FWX_ERR_UNSUPPORTED;
     Opts op;
     int rc = read_opts(opts, n, op);
     if (rc) return rc;
     fwx_matrix *m = nullptr;
-    if ((rc = fwx_matrix_create_multi(&m, n, dtype, next != nullptr, 0, n_parts, devices, exchange))) return rc;
-    rc = multi_upload(m, rate, next);
+    if ((rc = fwx_matrix_create_multi(&m, n, dtype, next != nullptr, hops != nullptr, n_parts, devices,
+                                      exchange)))
+        return rc;
+    rc = multi_upload(m, rate, next, hops);
     if (!rc) rc = multi_solve(m, op);
-    if (!rc) rc = multi_download(m, rate, next);
+    if (!rc) rc = multi_download(m, rate, next, hops);
     fwx_matrix_destroy(m);
     return rc;
 }

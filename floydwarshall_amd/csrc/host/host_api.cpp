@@ -60,6 +60,16 @@ int fwxh_session_destroy(fwxh_session *s)
     return FWX_OK;
 }
 
+int fwxh_session_set_devices(fwxh_session *s, int32_t n_parts, const int32_t *devices, int32_t min_vertices)
+{
+    if (!s || n_parts < 0 || n_parts > FWX_MAX_PARTS || (n_parts > 0 && !devices) || min_vertices < 0)
+        return FWX_ERR_INVALID;
+    s->impl.set_devices(std::vector<int32_t>(devices, devices + n_parts), min_vertices);
+    return FWX_OK;
+}
+
+int32_t fwxh_session_parts(const fwxh_session *s) { return s ? s->impl.parts() : -1; }
+
 int fwxh_session_state(const fwxh_session *s) { return s ? s->impl.state() : FWX_ERR_INVALID; }
 
 int64_t fwxh_session_solves(const fwxh_session *s) { return s ? s->impl.solves() : -1; }

@@ -81,6 +81,9 @@ public:
     Session(const Session &) = delete;
     Session &operator=(const Session &) = delete;
 
+    // Row-partitioned solves over `devices` from min_vertices vertices on (fwx_matrix_create_multi)
+    void set_devices(const std::vector<int32_t> &devices, int32_t min_vertices);
+    int parts() const;          // partitions of the resident matrix, 0 if there is none
     int state() const { return in_sync_ ? 1 : 0; }
     int64_t solves() const { return solves_; }
     const ExchRateTimes &rates() const { return rates_; }
@@ -99,6 +102,9 @@ private:
     void drop_device();
 
     int device_;
+    std::vector<int32_t> devices_;   // non-empty: partition the matrix over these from multi_from_ on
+    int32_t multi_from_ = 0;
+    bool dev_multi_ = false;         // dev_ is a partitioned handle
     ExchRateTimes rates_;
     bool in_sync_ = false;      // what the reference's AppState would be
     uint64_t version_ = 0;      // bumped by every accepted update that changes buildMatrix's output

@@ -21,6 +21,16 @@ Session::Session(int device) : device_(device) {}
 
 Session::~Session() { drop_device(); }
 
+void Session::set_devices(const std::vector<int32_t> &devices, int32_t min_vertices)
+{
+    devices_ = devices;
+    multi_from_ = min_vertices;
+    drop_device();               // the next query re-creates the handle where it now belongs
+    solved_version_ = ~0ull;
+}
+
+int Session::parts() const { return dev_ ? fwx_matrix_parts(dev_, nullptr) : 0; }
+
 void Session::drop_device()
 {
     if (dev_) {
@@ -59,7 +69,8 @@ int Session::ensure_solved()
     build_matrix_into(rates_, m);
     // The device handle (matrix, pristine copies, log arrays) is kept while the vertex count stays
     // the same -- a rate update between known vertices, the common case -- and only re-uploaded.
-    if (dev_ && dev_n_ != m.n()) drop_device();
+    const bool want_multi = !devices_.empty() && m.n() >= multi_from_;
+    if (dev_ && (dev_n_ != m.n() || dev_multi_ != want_multi)) drop_device();
     vertices_ = m.vertices;
     if (m.n() > 0) {
         // The solve keeps the path trace (fwx_matrix_enable_path_log), from which
@@ -71,7 +82,15 @@ int Session::ensure_solved()
         int rc = FWX_OK;
         dev_hops_ = m.n() < kFusedFrom;
         if (!dev_) {
-            if ((rc = fwx_matrix_create(&dev_, m.n(), FWX_F64, 1, dev_hops_ ? 1 : 0, device_))) return rc;
+            // one floydWarshall call, the whole node behind it: a partitioned handle is an
+            // ordinary fwx_matrix (same upload / solve / query_exact below)
+            rc = want_multi ? fwx_matrix_create_multi(&dev_, m.n(), FWX_F64, 1, dev_hops_ ? 1 : 0,
+                                                      (int32_t)devices_.size(), devices_.data(),
+                                                      FWX_XCHG_AUTO)
+                            : fwx_matrix_create(&dev_, m.n(), FWX_F64, 1, dev_hops_ ? 1 : 0,
+                                                devices_.empty() ? device_ : devices_[0]);
+            if (rc) return rc;
+            dev_multi_ = want_multi;
             dev_n_ = m.n();
             if ((rc = fwx_matrix_enable_path_log(dev_))) { drop_device(); return rc; }
         }

@@ -47,11 +47,29 @@ def pivot_blocks(n, world, block):
     return out
 
 
+class Slab:
+    """The arrays one rank holds for its rows: rate, optional next / hops (torch tensors, rows x n)
+    and an optional engine.Trace.  rows(lo, hi) slices all of them alike."""
+
+    def __init__(self, rate, nxt=None, hops=None, trace=None):
+        self.rate, self.nxt, self.hops, self.trace = rate, nxt, hops, trace
+
+    @property
+    def nrows(self):
+        return self.rate.shape[0]
+
+    def rows(self, lo, hi):
+        cut = lambda t: None if t is None else t[lo:hi]  # noqa: E731
+        return Slab(self.rate[lo:hi], cut(self.nxt), cut(self.hops),
+                    None if self.trace is None else self.trace.rows(lo, hi))
+
+
 class HipBackend:
     """The product backend: libfwx kernels on torch-owned device memory, current stream.
 
-    engine "fused": fwx_dev_relax_fused (64 pivots per pass); "perk": fwx_dev_relax (one launch per
-    pivot).  Both consume the same snapshot panel and give the same bits."""
+    engine "fused": fwx_dev_relax_fused (64 pivots per pass; carries next, hops and the path
+    trace); "perk": fwx_dev_relax (one launch per pivot; next and hops, no trace on slabs).  Both
+    consume the same snapshot panels and give the same bits."""
 
     def __init__(self, engine_name="fused"):
         assert engine_name in ("fused", "perk")
@@ -59,66 +77,73 @@ class HipBackend:
         self.ws = None
         self.nonneg = False
 
-    def check_domain(self, slab_rate, n, row0, slab_next):
+    def check_domain(self, slab, n, row0):
         """Domain bits of this slab (fwx.h "Domain"): bit 0 = every rate >= +0 and not NaN, bit 1 =
         no positive rate without a path.  solve_partitioned combines the answers of all ranks (the
         domain must hold globally)."""
-        if slab_rate.shape[0] == 0:
+        if slab.nrows == 0:
             return 3
-        return engine.dev_domain_bits(slab_rate, n, row0, slab_next)
+        return engine.dev_domain_bits(slab.rate, n, row0, slab.nxt)
 
-    def prepare(self, n, rows, dtype, device, with_next):
-        self.ws = engine.FusedWorkspace(n, rows, dtype, device, with_next=with_next)
+    def prepare(self, n, rows, dtype, device, with_next, with_hops=False):
+        self.ws = engine.FusedWorkspace(n, rows, dtype, device, with_next=with_next, with_hops=with_hops)
 
-    def panel(self, block_rate, n, k0, w):
-        """Snapshot panel of the pivot rows (the matrix is not modified)."""
-        engine.dev_panel_snap(block_rate, n, k0, w, self.ws.diag)
+    def panel(self, block, n, k0, w, wh=None):
+        """Snapshot panel of the pivot rows `block` (the matrix is not modified); wh: their hops."""
+        engine.dev_panel_snap(block.rate, n, k0, w, block_next_t=block.nxt, block_hops_t=block.hops,
+                              w_hops_t=wh, trace=block.trace)
 
-    def relax(self, slab_rate, n, row0, k0, k1, w, slab_next=None):
-        if slab_rate.shape[0] == 0:
+    def _fused(self, slab, n, row0, k0, k1, w, wh, skip=None):
+        engine.dev_relax_fused(slab.rate, n, row0, k0, k1, w, self.ws, next_t=slab.nxt, hops_t=slab.hops,
+                               wh_t=wh, trace=slab.trace, nonneg=self.nonneg, skip=skip)
+
+    def _perk(self, slab, n, row0, k0, k1, w, wh, skip=None):
+        assert slab.trace is None, "the per-k engine keeps no path trace on slabs: use the fused engine"
+        engine.dev_relax(slab.rate, n, row0, k0, k1, pivots_t=w, pivot_hops_t=wh, next_t=slab.nxt,
+                         hops_t=slab.hops, skip=skip)
+
+    def relax(self, slab, n, row0, k0, k1, w, wh=None):
+        if slab.nrows == 0:
             return
-        if self.engine_name == "fused":
-            engine.dev_relax_fused(slab_rate, n, row0, k0, k1, w, self.ws.ct, next_t=slab_next,
-                                   cnt_t=self.ws.cnt, nonneg=self.nonneg)
-        else:
-            engine.dev_relax(slab_rate, n, row0, k0, k1, pivots_t=w, next_t=slab_next)
+        (self._fused if self.engine_name == "fused" else self._perk)(slab, n, row0, k0, k1, w, wh)
 
-    def relax_skipping(self, slab_rate, n, row0, k0, k1, w, slab_next, skip):
+    def relax_skipping(self, slab, n, row0, k0, k1, w, wh, skip):
         """The whole slab except the rows skip = (lo, hi) in ONE launch per pivot; False if this
         backend / alignment cannot do it (the caller then relaxes above and below separately)."""
         lo, hi = skip
         if self.engine_name == "fused":
             if lo % 8 or hi % 8:
                 return False
-            engine.dev_relax_fused(slab_rate, n, row0, k0, k1, w, self.ws.ct, next_t=slab_next,
-                                   cnt_t=self.ws.cnt, nonneg=self.nonneg, skip=skip)
+            self._fused(slab, n, row0, k0, k1, w, wh, skip=skip)
             return True
         if lo % 4 or hi % 4:
             return False
-        engine.dev_relax(slab_rate, n, row0, k0, k1, pivots_t=w, next_t=slab_next, skip=skip)
+        self._perk(slab, n, row0, k0, k1, w, wh, skip=skip)
         return True
 
-    def relax_lookahead(self, slab_rate, n, row0, k0, k1, w, slab_next=None):
+    def relax_lookahead(self, slab, n, row0, k0, k1, w, wh=None):
         """The few rows the next panel is made of.  They sit on the owner's critical path, so
         they always take the one-launch fused kernel (bit-identical to 64 per-k launches)."""
-        if slab_rate.shape[0] == 0:
+        if slab.nrows == 0:
             return
-        if n % (16 // slab_rate.element_size()) == 0:
-            engine.dev_relax_fused(slab_rate, n, row0, k0, k1, w, self.ws.ct, next_t=slab_next,
-                                   cnt_t=self.ws.cnt, nonneg=self.nonneg)
+        if n % (16 // slab.rate.element_size()) == 0:
+            self._fused(slab, n, row0, k0, k1, w, wh)
         else:
-            self.relax(slab_rate, n, row0, k0, k1, w, slab_next)
+            self.relax(slab, n, row0, k0, k1, w, wh)
 
 
-def solve_partitioned(rate, n, rank, world, *, nxt=None, block=64, backend=None, group=None,
-                      lookahead=True, force_collectives=False, skip_launch=True):
-    """In-place solve of this rank's slab `rate` (rows row_bounds(n, world)[rank]...).
+def solve_partitioned(rate, n, rank, world, *, nxt=None, hops=None, trace=None, block=64, backend=None,
+                      group=None, lookahead=True, force_collectives=False, skip_launch=True):
+    """In-place solve of this rank's slab `rate` (rows row_bounds(n, world)[rank]...), with its
+    next-hops `nxt`, path lengths `hops` (needs nxt) and path trace `trace` (an engine.Trace of the
+    slab, all -1; needs nxt) if given.
 
     All ranks must call this with the same n / world / block / lookahead.  Works on any device the
     backend and the process group support (HIP + RCCL in production; the tests drive it on
     CPU + gloo with an oracle-backed backend to check the schedule).
 
-    Schedule per panel b (pivots [k0, k0+B), snapshots W_b).  A panel is a pure SNAPSHOT of the
+    Schedule per panel b (pivots [k0, k0+B), snapshots W_b; with hops also WH_b, the hops of the
+    pivot rows at the same times, which travel with them).  A panel is a pure SNAPSHOT of the
     pivot rows (they are not modified by it), so every rank relaxes ALL its rows with W_b:
         wait for W_b
         owner of panel b+1: relax ONLY the rows of panel b+1 with W_b, then snapshot them
@@ -130,16 +155,18 @@ def solve_partitioned(rate, n, rank, world, *, nxt=None, block=64, backend=None,
     backend = backend or HipBackend()
     collectives = world > 1 or force_collectives   # force: rehearse the RCCL calls on one rank
     assert 1 <= block <= engine.FWX_FUSED_BLOCK
+    assert (hops is None and trace is None) or nxt is not None
     bounds = row_bounds(n, world)
     row0, rows = bounds[rank], bounds[rank + 1] - bounds[rank]
     assert tuple(rate.shape) == (rows, n)
+    slab = Slab(rate, nxt, hops, trace)
     blocks = pivot_blocks(n, world, block)
     if not blocks:
         return
     if hasattr(backend, "prepare"):
-        backend.prepare(n, rows, rate.dtype, rate.device, nxt is not None)
+        backend.prepare(n, rows, rate.dtype, rate.device, nxt is not None, hops is not None)
     if hasattr(backend, "check_domain"):
-        bits = backend.check_domain(rate, n, row0, nxt)
+        bits = backend.check_domain(slab, n, row0)
         ok = torch.tensor([bits & 1, (bits >> 1) & 1], dtype=torch.int32, device=rate.device)
         if collectives:
             dist.all_reduce(ok, op=dist.ReduceOp.MIN, group=group)
@@ -151,43 +178,45 @@ def solve_partitioned(rate, n, rank, world, *, nxt=None, block=64, backend=None,
             raise engine.FwxError(_lib_unsupported(), "solve_partitioned: matrix outside the "
                                   "reference's domain (negative/NaN rate or a positive rate without "
                                   "a path) with next-hops")
-        # max form: rates only, fused engine, every entry >= +0 and not NaN on every rank
-        backend.nonneg = bool(d1) and nxt is None and getattr(backend, "engine_name", "") == "fused"
+        # max-form kernels: fused engine, every entry >= +0 and not NaN on every rank (and D2 with next)
+        backend.nonneg = bool(d1) and (nxt is None or bool(d2)) and \
+            getattr(backend, "engine_name", "") == "fused"
     bufs = [torch.empty((block, n), dtype=rate.dtype, device=rate.device) for _ in range(2)]
+    hbufs = [torch.empty((block, n), dtype=torch.int32, device=rate.device) for _ in range(2)] \
+        if hops is not None else [None, None]
     # On a GPU the panel phase and the broadcast run on a SIDE stream, so that on the owner they
     # overlap the bulk relax of the previous panel instead of queueing behind it.
     on_gpu = rate.is_cuda
     main = torch.cuda.current_stream(rate.device) if on_gpu else None
     side = torch.cuda.Stream(device=rate.device) if on_gpu else None
 
-    def sub(t, lo, hi):
-        return None if t is None else t[lo:hi]
-
     def panel_and_broadcast(idx):
-        """Snapshot panel idx (owner) + its broadcast; returns (w, wait) where wait() orders the
-        current stream behind both."""
+        """Snapshot panel idx (owner) + its broadcast; returns (w, wh, wait) where wait() orders
+        the current stream behind both."""
         k0, b, owner = blocks[idx]
         w = bufs[idx & 1][:b]
-        work = None
+        wh = hbufs[idx & 1][:b] if hops is not None else None
+        works = []
+
+        def issue():
+            if rank == owner:
+                lo = k0 - row0
+                backend.panel(slab.rows(lo, lo + b), n, k0, w, wh)
+            if collectives:
+                src = owner if group is None else dist.get_global_rank(group, owner)
+                works.append(dist.broadcast(w, src=src, group=group, async_op=True))
+                if wh is not None:
+                    works.append(dist.broadcast(wh, src=src, group=group, async_op=True))
+
         if on_gpu:
             side.wait_stream(main)                 # everything queued so far precedes the panel
             with torch.cuda.stream(side):
-                if rank == owner:
-                    lo = k0 - row0
-                    backend.panel(rate[lo:lo + b], n, k0, w)
-                if collectives:
-                    src = owner if group is None else dist.get_global_rank(group, owner)
-                    work = dist.broadcast(w, src=src, group=group, async_op=True)
+                issue()
         else:
-            if rank == owner:
-                lo = k0 - row0
-                backend.panel(rate[lo:lo + b], n, k0, w)
-            if collectives:
-                src = owner if group is None else dist.get_global_rank(group, owner)
-                work = dist.broadcast(w, src=src, group=group, async_op=True)
+            issue()
 
         def wait():
-            if work is not None:
+            for work in works:
                 if on_gpu:
                     with torch.cuda.stream(side):
                         work.wait()                # side stream behind the collective
@@ -195,37 +224,38 @@ def solve_partitioned(rate, n, rank, world, *, nxt=None, block=64, backend=None,
                     work.wait()
             if on_gpu:
                 main.wait_stream(side)
-        return w, wait
+        return w, wh, wait
 
-    def relax_rows_except(skips, k0, k1, w):
+    def relax_rows_except(skips, k0, k1, w, wh):
         if skip_launch and len(skips) == 1 and hasattr(backend, "relax_skipping") and \
-                backend.relax_skipping(rate, n, row0, k0, k1, w, nxt, skips[0]):
+                backend.relax_skipping(slab, n, row0, k0, k1, w, wh, skips[0]):
             return
         pos = 0
         for lo, hi in sorted(skips) + [(rows, rows)]:
             if lo > pos:
-                backend.relax(rate[pos:lo], n, row0 + pos, k0, k1, w, sub(nxt, pos, lo))
+                backend.relax(slab.rows(pos, lo), n, row0 + pos, k0, k1, w, wh)
             pos = max(pos, hi)
 
-    w, wait = panel_and_broadcast(0)
+    w, wh, wait = panel_and_broadcast(0)
     for idx, (k0, b, owner) in enumerate(blocks):
         wait()
         k1 = k0 + b
         skips = []
-        nxt_w = nxt_wait = None
+        nxt_panel = None
         if idx + 1 < len(blocks) and lookahead:
             nk0, nb, nowner = blocks[idx + 1]
             if rank == nowner:
                 nlo = nk0 - row0
                 getattr(backend, "relax_lookahead", backend.relax)(
-                    rate[nlo:nlo + nb], n, nk0, k0, k1, w, sub(nxt, nlo, nlo + nb))
+                    slab.rows(nlo, nlo + nb), n, nk0, k0, k1, w, wh)
                 skips.append((nlo, nlo + nb))
-            nxt_w, nxt_wait = panel_and_broadcast(idx + 1)
-            relax_rows_except(skips, k0, k1, w)
+            nxt_panel = panel_and_broadcast(idx + 1)
+            relax_rows_except(skips, k0, k1, w, wh)
         else:
-            relax_rows_except(skips, k0, k1, w)
+            relax_rows_except(skips, k0, k1, w, wh)
             if idx + 1 < len(blocks):
-                nxt_w, nxt_wait = panel_and_broadcast(idx + 1)
-        w, wait = nxt_w, nxt_wait
+                nxt_panel = panel_and_broadcast(idx + 1)
+        if nxt_panel is not None:
+            w, wh, wait = nxt_panel
     if on_gpu:
         main.wait_stream(side)

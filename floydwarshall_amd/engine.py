@@ -16,7 +16,7 @@ from ._lib import (FWX_ENGINE_AUTO, FWX_ENGINE_FUSED, FWX_ENGINE_PERK, FWX_F32, 
 
 __all__ = ["solve", "follow_path", "dev_follow_paths", "dev_check_nonneg", "dev_domain_bits", "dev_solve_fused",
            "dev_solve", "DeviceMatrix", "dev_relax", "dev_panel", "dev_panel_snap",
-           "dev_relax_fused", "FusedWorkspace", "FWX_FUSED_BLOCK", "device_count",
+           "dev_relax_fused", "FusedWorkspace", "Trace", "FWX_FUSED_BLOCK", "device_count",
            "FwxError", "FWX_ENGINE_AUTO", "FWX_ENGINE_PERK", "FWX_ENGINE_FUSED",
            "FWX_UPDATE_SHARDS", "solve_multi", "FWX_XCHG_AUTO", "FWX_XCHG_PEER", "FWX_XCHG_RCCL"]
 
@@ -297,28 +297,60 @@ def dev_panel(block_rate_t, n, k0, w_rate_t, *, next_t=None, hops_t=None, w_hops
 
 class FusedWorkspace:
     """Device scratch of the fused engine for slabs of up to `rows` rows: snapshot panels W (two,
-    for look-ahead), pivot-column snapshots Ct / CNt, and the diagonal-block scratch."""
+    for look-ahead; with hops also their hops panels WH), pivot-column snapshots Ct / CNt / CHt."""
 
-    def __init__(self, n, rows, dtype, device, with_next=False):
+    def __init__(self, n, rows, dtype, device, with_next=False, with_hops=False):
         import torch
         B = FWX_FUSED_BLOCK
         self.w = [torch.empty((B, n), dtype=dtype, device=device) for _ in range(2)]
+        self.wh = [torch.empty((B, n), dtype=torch.int32, device=device) for _ in range(2)] \
+            if with_hops else [None, None]
         ld = (max(rows, 1) + 3) & ~3
+        self.ld = ld
         self.ct = torch.empty((B, ld), dtype=dtype, device=device)
         self.cnt = torch.empty((B, ld), dtype=torch.int32, device=device) if with_next else None
-        code = FWX_F64 if dtype == torch.float64 else FWX_F32
-        self.diag = torch.empty(lib().fwx_fused_diag_ws_bytes(code), dtype=torch.uint8, device=device)
+        self.cht = torch.empty((B, ld), dtype=torch.int32, device=device) if with_hops else None
 
 
-def dev_panel_snap(block_rate_t, n, k0, w_rate_t, diag_ws_t):
-    """Snapshot panel of pivot rows [k0, k0+B) (B <= 64): w[t] = row k0+t at time k0+t.
-    The matrix is NOT modified (contrast dev_panel)."""
-    s = _slab(block_rate_t, None, None, n, k0)
+class Trace:
+    """Path trace of a slab (fwx.h fwx_trace): three rows x n int32 device arrays, LOCAL rows, all
+    -1 before a solve.  rows(lo, hi) gives the views a panel of pivot rows needs."""
+
+    def __init__(self, rows, n, device=None, _views=None):
+        import torch
+        if _views is not None:
+            self.last, self.at_col, self.at_row = _views
+        else:
+            self.last, self.at_col, self.at_row = (torch.full((rows, n), -1, dtype=torch.int32, device=device)
+                                                   for _ in range(3))
+
+    def rows(self, lo, hi):
+        return Trace(0, 0, _views=(self.last[lo:hi], self.at_col[lo:hi], self.at_row[lo:hi]))
+
+    def c_struct(self):
+        t = _lib.FwxTrace()
+        t.last, t.at_col, t.at_row = self.last.data_ptr(), self.at_col.data_ptr(), self.at_row.data_ptr()
+        return t
+
+
+def _trace_ref(trace):
+    return ctypes.byref(trace.c_struct()) if trace is not None else None
+
+
+def dev_panel_snap(block_rate_t, n, k0, w_rate_t, *, block_next_t=None, block_hops_t=None, w_hops_t=None,
+                   trace=None):
+    """Snapshot panel of pivot rows [k0, k0+B) (B <= 64): w[t] = row k0+t at time k0+t (and w_hops
+    its hops row, if the block carries hops).  The matrix is NOT modified (contrast dev_panel).
+    trace: the Trace views OF THE SAME ROWS (Trace.rows); its at_row rows are written."""
+    s = _slab(block_rate_t, block_next_t, block_hops_t, n, k0)
     assert w_rate_t.is_cuda and w_rate_t.is_contiguous()
     assert tuple(w_rate_t.shape) == tuple(block_rate_t.shape) and w_rate_t.dtype == block_rate_t.dtype
-    check(lib().fwx_dev_panel_snap(ctypes.byref(s), ctypes.c_void_p(w_rate_t.data_ptr()),
-                                   ctypes.c_void_p(diag_ws_t.data_ptr()), _stream_ptr()),
-          "fwx_dev_panel_snap")
+    wh = None
+    if block_hops_t is not None:
+        assert w_hops_t is not None and tuple(w_hops_t.shape) == tuple(block_rate_t.shape)
+        wh = ctypes.c_void_p(w_hops_t.data_ptr())
+    check(lib().fwx_dev_panel_snap(ctypes.byref(s), ctypes.c_void_p(w_rate_t.data_ptr()), wh,
+                                   _trace_ref(trace), _stream_ptr()), "fwx_dev_panel_snap")
 
 
 def dev_domain_bits(rate_t, n, row0=0, next_t=None):
@@ -337,48 +369,60 @@ def dev_check_nonneg(rate_t, n, row0=0):
     return bool(dev_domain_bits(rate_t, n, row0) & 1)
 
 
-def dev_relax_fused(rate_t, n, row0, k0, k1, w_t, ct_t, *, next_t=None, cnt_t=None, updates_t=None,
-                    nonneg=False, skip=None):
+def dev_relax_fused(rate_t, n, row0, k0, k1, w_t, ws, *, next_t=None, hops_t=None, wh_t=None, trace=None,
+                    updates_t=None, nonneg=False, skip=None):
     """Apply pivots [k0,k1) (at most 64) to EVERY row of the slab in one pass, from the snapshot
-    panel w_t ((k1-k0) x n).  ct_t / cnt_t: scratch of at least 64*rows elements.  skip = (lo, hi):
-    slab rows [lo, hi) (multiples of 8) are left to an earlier look-ahead step."""
-    s = _slab(rate_t, next_t, None, n, row0)
+    panel w_t ((k1-k0) x n; wh_t: its hops panel, iff hops_t).  ws: a FusedWorkspace sized for this
+    slab.  trace: the slab's Trace.  skip = (lo, hi): slab rows [lo, hi) (multiples of 8) are left
+    to an earlier look-ahead step."""
+    s = _slab(rate_t, next_t, hops_t, n, row0)
     p = FwxPivots()
     p.k_begin, p.k_end = k0, k1
     assert w_t.is_cuda and w_t.is_contiguous() and w_t.dtype == rate_t.dtype
     assert tuple(w_t.shape) == (k1 - k0, n)
     ld = (rate_t.shape[0] + 3) & ~3
-    assert ct_t.numel() >= FWX_FUSED_BLOCK * ld and ct_t.dtype == rate_t.dtype
+    assert ws.ct.numel() >= FWX_FUSED_BLOCK * ld and ws.ct.dtype == rate_t.dtype
     p.rate, p.hops, p.stride = w_t.data_ptr(), None, n
-    upd = ctypes.c_void_p(updates_t.data_ptr()) if updates_t is not None else None
-    cn = None
+    sc = _lib.FwxFusedScratch()
+    sc.col_rate = ws.ct.data_ptr()
     if next_t is not None:
-        assert cnt_t is not None and cnt_t.numel() >= FWX_FUSED_BLOCK * ld
-        cn = ctypes.c_void_p(cnt_t.data_ptr())
+        assert ws.cnt is not None and ws.cnt.numel() >= FWX_FUSED_BLOCK * ld
+        sc.col_next = ws.cnt.data_ptr()
+    if hops_t is not None:
+        assert wh_t is not None and tuple(wh_t.shape) == (k1 - k0, n) and ws.cht is not None
+        p.hops = wh_t.data_ptr()
+        sc.col_hops = ws.cht.data_ptr()
+    upd = ctypes.c_void_p(updates_t.data_ptr()) if updates_t is not None else None
     lo, hi = skip if skip else (0, 0)
-    check(lib().fwx_dev_relax_fused_skip(ctypes.byref(s), ctypes.byref(p),
-                                         ctypes.c_void_p(ct_t.data_ptr()), cn, upd,
+    check(lib().fwx_dev_relax_fused_skip(ctypes.byref(s), ctypes.byref(p), ctypes.byref(sc),
+                                         _trace_ref(trace), upd,
                                          _lib.FWX_FLAG_NONNEG if nonneg else 0, int(lo), int(hi),
                                          _stream_ptr()),
           "fwx_dev_relax_fused_skip")
 
 
-def dev_solve_fused(rate_t, n, k_begin=0, k_end=None, *, next_t=None, ws=None, updates_t=None,
-                    nonneg=None):
+def dev_solve_fused(rate_t, n, k_begin=0, k_end=None, *, next_t=None, hops_t=None, trace=None, ws=None,
+                    updates_t=None, nonneg=None):
     """Single-GPU solve of pivots [k_begin,k_end) with the fused engine on a torch tensor holding
-    the whole n x n matrix; asynchronous on the current stream (after one small synchronising
-    domain check when the max-form kernel could apply and `nonneg` is not given)."""
-    import torch
+    the whole n x n matrix, one panel + one pass at a time (no look-ahead: fwx_dev_solve has it);
+    asynchronous on the current stream (after one small synchronising domain check when `nonneg`
+    is not given)."""
     k_end = n if k_end is None else k_end
     if nonneg is None:
-        nonneg = next_t is None and updates_t is None and dev_check_nonneg(rate_t, n)
-    ws = ws or FusedWorkspace(n, n, rate_t.dtype, rate_t.device, with_next=next_t is not None)
+        bits = dev_domain_bits(rate_t, n, 0, next_t)
+        nonneg = updates_t is None and (bits == 3 if next_t is not None else bool(bits & 1))
+    ws = ws or FusedWorkspace(n, n, rate_t.dtype, rate_t.device, with_next=next_t is not None,
+                              with_hops=hops_t is not None)
     B = FWX_FUSED_BLOCK
     for k0 in range(k_begin, k_end, B):
         k1 = min(k_end, k0 + B)
         w = ws.w[0][:k1 - k0]
-        dev_panel_snap(rate_t[k0:k1], n, k0, w, ws.diag)
-        dev_relax_fused(rate_t, n, 0, k0, k1, w, ws.ct, next_t=next_t, cnt_t=ws.cnt,
+        wh = ws.wh[0][:k1 - k0] if hops_t is not None else None
+        dev_panel_snap(rate_t[k0:k1], n, k0, w,
+                       block_next_t=next_t[k0:k1] if next_t is not None else None,
+                       block_hops_t=hops_t[k0:k1] if hops_t is not None else None, w_hops_t=wh,
+                       trace=trace.rows(k0, k1) if trace is not None else None)
+        dev_relax_fused(rate_t, n, 0, k0, k1, w, ws, next_t=next_t, hops_t=hops_t, wh_t=wh, trace=trace,
                         updates_t=updates_t, nonneg=nonneg)
     return ws
 

@@ -18,6 +18,8 @@ c_cp, c_dp = ctypes.c_char_p, ctypes.POINTER(ctypes.c_double)
 
 HOST_SIGNATURES = {
     "fwxh_session_create": (ctypes.c_int, [ctypes.POINTER(c_vp), c_i32]),
+    "fwxh_session_set_devices": (ctypes.c_int, [c_vp, c_i32, ctypes.POINTER(c_i32), c_i32]),
+    "fwxh_session_parts": (c_i32, [c_vp]),
     "fwxh_session_destroy": (ctypes.c_int, [c_vp]),
     "fwxh_session_state": (ctypes.c_int, [c_vp]),
     "fwxh_session_solves": (c_i64, [c_vp]),
@@ -138,6 +140,16 @@ class Session:
         h = c_vp()
         check(hlib().fwxh_session_create(ctypes.byref(h), device), "fwxh_session_create")
         self._h = h
+
+    def set_devices(self, devices, min_vertices=0):
+        """Row-partition the solved matrix over `devices` (repeats allowed) from min_vertices on."""
+        arr = (c_i32 * len(devices))(*devices)
+        check(hlib().fwxh_session_set_devices(self._h, len(devices), arr, int(min_vertices)),
+              "fwxh_session_set_devices")
+
+    @property
+    def parts(self):
+        return hlib().fwxh_session_parts(self._h)
 
     @property
     def state(self):

@@ -73,9 +73,8 @@ typedef enum fwx_status {
 typedef enum fwx_dtype { FWX_F32 = 0, FWX_F64 = 1 } fwx_dtype;
 
 /* Which relaxation engine runs the pivots.  All are bit-exact with the reference loop.
- * AUTO: n <= 128 -> the whole solve in one single-workgroup launch; n >= 256 -> FUSED (a matrix
- * with hops: from n = 3072 and for the whole pivot range only -- the lengths are rebuilt from the
- * path trace the fused kernels keep, which costs 5 n^2 int32 of scratch); otherwise PERK.  The fused kernels need rows that are a multiple of 16 bytes: fwx_solve_f32/f64
+ * AUTO: n <= 128 -> the whole solve in one single-workgroup launch; n >= 256 -> FUSED; otherwise
+ * PERK.  The fused kernels need rows that are a multiple of 16 bytes: fwx_solve_f32/f64
  * (host buffers) pad an odd-sized matrix on the device, the entry points that work on device
  * memory they do not own (fwx_matrix_*, fwx_dev_*) fall back to PERK under AUTO and refuse an
  * explicit FUSED (FWX_ERR_UNSUPPORTED).                                                          */
@@ -186,10 +185,11 @@ int fwx_matrix_query_exact_batch(fwx_matrix *m, int32_t count, const int32_t *sr
  * A multi handle is an fwx_matrix: upload / solve / download / query / enable_path_log /
  * query_exact[_batch] / path_log_count / destroy work on it unchanged (whole pivot range only;
  * fwx_opts.engine AUTO or FUSED; fwx_opts.device / stream are ignored).  Any n: rows are padded on
- * the device to a multiple of 16 bytes.  Not (yet) carried through slabs: `hops` (with_hops != 0 is
- * FWX_ERR_UNSUPPORTED) and matrices outside the reference's domain WITH next-hops (see "Domain":
- * the slab kernels take next[i][k]; such a matrix returns FWX_ERR_UNSUPPORTED from solve and is
- * solved on one device by fwx_solve_* / fwx_matrix_create).                                       */
+ * the device to a multiple of 16 bytes.  rate, next, hops and the path trace are all carried
+ * through the slabs (the hops of the pivot rows travel with their rates).  Not carried: matrices
+ * outside the reference's domain WITH next-hops (see "Domain": the slab kernels take next[i][k];
+ * such a matrix returns FWX_ERR_UNSUPPORTED from solve and is solved on one device by
+ * fwx_solve_* / fwx_matrix_create).                                                               */
 #define FWX_XCHG_AUTO 0
 #define FWX_XCHG_PEER 1
 #define FWX_XCHG_RCCL 2
@@ -280,36 +280,49 @@ int fwx_dev_follow_paths(int32_t n, const int32_t *next, int32_t count, const in
 /* ---- fused engine (FWX_FUSED_BLOCK pivots per pass; bit-identical to the per-k engine) --------
  * fwx_dev_panel_snap: snapshot panel of the pivot rows in `block` (rows [row0,row0+rows), rows <=
  *   FWX_FUSED_BLOCK, at time row0): writes the time-k snapshot of each pivot row to w_rate
- *   (rows x n).  UNLIKE fwx_dev_panel THE MATRIX IS NOT MODIFIED: the pivot rows are then relaxed
- *   like any other row.  diag_ws: device scratch, fwx_fused_diag_ws_bytes(dtype) bytes (reserved:
- *   the current kernels evolve the diagonal block in LDS and do not touch it).
+ *   (rows x n) and, if the block carries hops, of its hops row to w_hops.  UNLIKE fwx_dev_panel THE
+ *   MATRIX IS NOT MODIFIED: the pivot rows are then relaxed like any other row.  trace (optional):
+ *   the path trace OF THE SAME ROWS (views of rows [row0, row0+rows) of the trace arrays); its
+ *   at_row rows are written.
  * fwx_dev_relax_fused: applies the pivots [piv->k_begin, piv->k_end) (at most FWX_FUSED_BLOCK,
- *   piv->rate = snapshot panel, stride n) to EVERY row of the slab in one pass.  col_rate /
- *   col_next: device scratch of FWX_FUSED_BLOCK * ((slab->rows + 3) & ~3) elements (col_next only
- *   if the slab carries next).  Slabs with hops are not supported (FWX_ERR_UNSUPPORTED); n must be a multiple
- *   of 16 bytes worth of elements.
+ *   piv->rate = snapshot panel, piv->hops = hops panel, stride n) to EVERY row of the slab in one
+ *   pass.  scratch: device scratch of FWX_FUSED_BLOCK * ((slab->rows + 3) & ~3) elements per array
+ *   (col_next only if the slab carries next, col_hops only if it carries hops).  trace
+ *   (optional): the slab's path trace, rows x n like rate / next (LOCAL rows).  n must be a
+ *   multiple of 16 bytes worth of elements.
  * The snapshot panel also feeds fwx_dev_relax (per-k engine), so fwx_dev_panel_snap +
  * fwx_dev_relax over all rows is a valid (slower) combination.
  *
  * flags: FWX_FLAG_NONNEG = the caller has verified (fwx_dev_check_nonneg on EVERY slab of the
  *   matrix, all ranks) that every entry is >= +0.0 and not NaN -- what the reference's parser
- *   guarantees (rates > 0, Parsers.hs:40; "no route" = +0.0).  On that domain the strict fold
- *   equals max() bit for bit, and rates-only f32 slabs take a kernel that folds two pivots per
- *   v_max3_f32.  Without the flag nothing is assumed about the rates.
- *   A slab WITH next must be inside the domain (D1 and D2, both bits of fwx_dev_check_nonneg on
- *   every slab): the fused kernels take next[i][k] as the head of the concatenated path.  The
- *   whole-matrix entry points check this themselves; here it is the caller's duty.              */
+ *   guarantees (rates > 0, Parsers.hs:40; "no route" = +0.0) -- and, if next is carried, that no
+ *   non-zero rate lacks a path (both bits).  On that domain the strict fold equals max() bit for
+ *   bit, and f32 slabs take the kernels that fold two pivots per v_max3_f32 (rates only, or
+ *   rates + next + trace + hops through the arg re-scan).  Without the flag nothing is assumed
+ *   about the rates.
+ *   A slab WITH next must be inside the domain in any case (D1 and D2 on every slab): the fused
+ *   kernels take next[i][k] as the head of the concatenated path.  The whole-matrix entry points
+ *   check this themselves; here it is the caller's duty.                                        */
 #define FWX_FUSED_BLOCK 64
 #define FWX_FLAG_NONNEG 1
-size_t fwx_fused_diag_ws_bytes(int32_t dtype);
-int fwx_dev_panel_snap(const fwx_slab *block, void *w_rate, void *diag_ws, void *stream);
-int fwx_dev_relax_fused(const fwx_slab *slab, const fwx_pivots *piv, void *col_rate,
-                        int32_t *col_next, unsigned long long *d_updates, int32_t flags,
+typedef struct fwx_trace {      /* path trace of a slab (or of a block of pivot rows): rows x n each */
+    int32_t *last, *at_col, *at_row;
+} fwx_trace;
+typedef struct fwx_fused_scratch {
+    void *col_rate;             /* pivot-column snapshots of the slab's rows                       */
+    int32_t *col_next;          /* ... their next-hops (iff slab->next)                            */
+    int32_t *col_hops;          /* ... their hops      (iff slab->hops)                            */
+} fwx_fused_scratch;
+int fwx_dev_panel_snap(const fwx_slab *block, void *w_rate, int32_t *w_hops, const fwx_trace *trace,
+                       void *stream);
+int fwx_dev_relax_fused(const fwx_slab *slab, const fwx_pivots *piv, const fwx_fused_scratch *scratch,
+                        const fwx_trace *trace, unsigned long long *d_updates, int32_t flags,
                         void *stream);
 /* Same, leaving the slab rows [skip_lo, skip_hi) (multiples of 8) to an earlier look-ahead step. */
-int fwx_dev_relax_fused_skip(const fwx_slab *slab, const fwx_pivots *piv, void *col_rate,
-                             int32_t *col_next, unsigned long long *d_updates, int32_t flags,
-                             int32_t skip_lo, int32_t skip_hi, void *stream);
+int fwx_dev_relax_fused_skip(const fwx_slab *slab, const fwx_pivots *piv,
+                             const fwx_fused_scratch *scratch, const fwx_trace *trace,
+                             unsigned long long *d_updates, int32_t flags, int32_t skip_lo,
+                             int32_t skip_hi, void *stream);
 /* Domain check of one slab (see "Domain").  *d_flag is a device int32 the caller has set to 3 (or
  * to 1 for a rates-only slab): bit 0 is cleared if any rate of the slab is negative, -0.0 or NaN,
  * bit 1 if the slab carries next and some entry has a non-zero rate with next < 0.  A partitioned

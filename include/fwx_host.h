@@ -45,6 +45,14 @@ typedef struct fwxh_session fwxh_session;
  * Creating a session needs no GPU; only a best-rate query that must solve does. */
 int fwxh_session_create(fwxh_session **out, int32_t device);
 int fwxh_session_destroy(fwxh_session *s);
+/* Put the whole node behind the session's one floydWarshall call (ProcessRequests.hs:82-84): from
+ * min_vertices vertices on, the solved matrix is a ROW-PARTITIONED handle over `devices`
+ * (fwx_matrix_create_multi in fwx.h: one partition per entry, a device may repeat, panels
+ * exchanged on RCCL or by peer copy); smaller matrices stay on devices[0].  n_parts == 0 returns
+ * to the single device given at creation.  Answers are bit-identical either way.              */
+int fwxh_session_set_devices(fwxh_session *s, int32_t n_parts, const int32_t *devices,
+                             int32_t min_vertices);
+int32_t fwxh_session_parts(const fwxh_session *s);   /* partitions of the resident matrix (0: none yet) */
 int fwxh_session_state(const fwxh_session *s);        /* FWXH_STATE_* as the reference would hold */
 int64_t fwxh_session_solves(const fwxh_session *s);   /* floydWarshall runs so far (GPU solves)   */
 int32_t fwxh_session_rate_count(const fwxh_session *s);

@@ -21,10 +21,10 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 class OracleBackend:
     """relax / panel restated with numpy for slabs with an explicit snapshot panel.
     Step k on a slab (Algorithms.hs:42-61): c = r[i][k] * w_k[j]; update iff r[i][j] < c;
-    skip i == k (:50) and j in {i, k} (:54)."""
+    skip i == k (:50) and j in {i, k} (:54); next' = next[i][k], hops' = hops[i][k] + hops[k][j]."""
 
     @staticmethod
-    def _apply(rate, nxt, n, row0, k, wk):
+    def _apply(rate, nxt, hops, n, row0, k, wk, whk):
         rows = rate.shape[0]
         with np.errstate(all="ignore"):
             c = rate[:, k:k + 1] * wk[None, :]
@@ -37,32 +37,41 @@ class OracleBackend:
         if nxt is not None:
             nk = nxt[:, k].copy()
             nxt[mask] = np.broadcast_to(nk[:, None], mask.shape)[mask]
+        if hops is not None:
+            hsum = hops[:, k:k + 1] + whk[None, :]
+            hops[mask] = hsum[mask]
         rate[mask] = c[mask]
 
-    def relax(self, slab_rate, n, row0, k0, k1, w, slab_next=None):
-        r = slab_rate.numpy()
-        nx = None if slab_next is None else slab_next.numpy()
-        wn = w.numpy()
-        for k in range(k0, k1):
-            self._apply(r, nx, n, row0, k, wn[k - k0])
+    @staticmethod
+    def _np(t):
+        return None if t is None else t.numpy()
 
-    def relax_skipping(self, slab_rate, n, row0, k0, k1, w, slab_next, skip):
+    def relax(self, slab, n, row0, k0, k1, w, wh=None):
+        r, nx, hp = slab.rate.numpy(), self._np(slab.nxt), self._np(slab.hops)
+        wn, whn = w.numpy(), self._np(wh)
+        for k in range(k0, k1):
+            self._apply(r, nx, hp, n, row0, k, wn[k - k0], None if whn is None else whn[k - k0])
+
+    def relax_skipping(self, slab, n, row0, k0, k1, w, wh, skip):
         """One call for the whole slab minus the rows skip = (lo, hi) -- what the HIP backend does
         in a single launch per pivot; here simply the two parts.  Multiples of 4 only (as HIP)."""
         lo, hi = skip
         if lo % 4 or hi % 4:
             return False
         self.skip_calls = getattr(self, "skip_calls", 0) + 1
-        self.relax(slab_rate[:lo], n, row0, k0, k1, w, None if slab_next is None else slab_next[:lo])
-        self.relax(slab_rate[hi:], n, row0 + hi, k0, k1, w, None if slab_next is None else slab_next[hi:])
+        self.relax(slab.rows(0, lo), n, row0, k0, k1, w, wh)
+        self.relax(slab.rows(hi, slab.nrows), n, row0 + hi, k0, k1, w, wh)
         return True
 
-    def panel(self, block_rate, n, k0, w):
-        r = block_rate.numpy().copy()         # snapshot only: the matrix itself is not modified
-        wn = w.numpy()
+    def panel(self, block, n, k0, w, wh=None):
+        r = block.rate.numpy().copy()         # snapshot only: the matrix itself is not modified
+        hp = None if block.hops is None else block.hops.numpy().copy()
+        wn, whn = w.numpy(), self._np(wh)
         for t in range(r.shape[0]):
             wn[t] = r[t]                      # time-k snapshot of pivot row k0+t
-            self._apply(r, None, n, k0, k0 + t, wn[t])
+            if hp is not None:
+                whn[t] = hp[t]
+            self._apply(r, None, hp, n, k0, k0 + t, wn[t], None if hp is None else whn[t])
 
 
 def _worker(rank, world, port, n, block, lookahead, kind, with_next, outdir):
@@ -71,15 +80,17 @@ def _worker(rank, world, port, n, block, lookahead, kind, with_next, outdir):
     dist.init_process_group("gloo", rank=rank, world_size=world)
     from floydwarshall_amd import dist as fwdist
     from floydwarshall_amd import synth
-    rate, nxt, _ = synth.make(kind, n, np.float32, seed=4242)
+    rate, nxt, hops = synth.make(kind, n, np.float32, seed=4242)
     b = fwdist.row_bounds(n, world)
     slab = torch.from_numpy(rate[b[rank]:b[rank + 1]].copy())
     nslab = torch.from_numpy(nxt[b[rank]:b[rank + 1]].copy()) if with_next else None
-    fwdist.solve_partitioned(slab, n, rank, world, nxt=nslab, block=block,
+    hslab = torch.from_numpy(hops[b[rank]:b[rank + 1]].copy()) if with_next else None
+    fwdist.solve_partitioned(slab, n, rank, world, nxt=nslab, hops=hslab, block=block,
                              backend=OracleBackend(), lookahead=lookahead)
     np.save(os.path.join(outdir, "rate_%d.npy" % rank), slab.numpy())
     if with_next:
         np.save(os.path.join(outdir, "next_%d.npy" % rank), nslab.numpy())
+        np.save(os.path.join(outdir, "hops_%d.npy" % rank), hslab.numpy())
     dist.barrier()
     dist.destroy_process_group()
 
@@ -106,12 +117,14 @@ def test_partitioned_solve_equals_single_process_oracle(tmp_path, world, n, bloc
     from helpers import assert_bits_equal
     mp.spawn(_worker, args=(world, _free_port(), n, block, lookahead, kind, True, str(tmp_path)),
              nprocs=world, join=True)
-    rate, nxt, _ = synth.make(kind, n, np.float32, seed=4242)
-    oracle.relax(rate, nxt)
+    rate, nxt, hops = synth.make(kind, n, np.float32, seed=4242)
+    oracle.relax(rate, nxt, hops)
     got_r = np.concatenate([np.load(tmp_path / ("rate_%d.npy" % r)) for r in range(world)])
     got_n = np.concatenate([np.load(tmp_path / ("next_%d.npy" % r)) for r in range(world)])
+    got_h = np.concatenate([np.load(tmp_path / ("hops_%d.npy" % r)) for r in range(world)])
     assert_bits_equal(got_r, rate, "partitioned rate")
     assert_bits_equal(got_n, nxt, "partitioned next")
+    assert_bits_equal(got_h, hops, "partitioned hops (they travel with the panels)")
 
 
 def test_partition_helpers():

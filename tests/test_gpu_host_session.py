@@ -33,6 +33,53 @@ def test_readme_session_replays_byte_for_byte():
     assert s.state == host.INSYNC
 
 
+def test_partitioned_session_gives_the_same_transcript_and_paths():
+    """The session's one floydWarshall call with the whole node behind it (fwxh_session_set_devices ->
+    fwx_matrix_create_multi; here three LOGICAL partitions of device 0): the README session replays
+    byte for byte, and on a tie-heavy market every sampled answer -- rate and the reference's exact
+    `_path` -- equals the single-device session's."""
+    g = load_golden("readme_session.json")
+    s = host.Session(device=0)
+    s.set_devices([0, 0, 0], min_vertices=0)
+    for turn in g["turns"]:
+        assert s.serve_line(turn["in"]) == turn["out"], turn["in"]
+    assert s.parts == 3 and s.solves == 2
+    rnd = np.random.default_rng(77)
+    ccys = ["C%02d" % i for i in range(10)]
+    price = dict(zip(ccys, 0.5 + 1.5 * rnd.random(len(ccys))))
+    one, many = host.Session(device=0), host.Session(device=0)
+    many.set_devices([0, 0, 0, 0], min_vertices=200)
+    vertices = set()
+    for e in range(30):
+        exch = "E%02d" % e
+        for i in range(len(ccys)):
+            for j in range(i + 1, len(ccys)):
+                if rnd.random() < 0.5:
+                    a, b = ccys[i], ccys[j]
+                    fwd = price[b] / price[a] * (0.97 + 0.03 * rnd.random())
+                    bkd = price[a] / price[b] * (0.97 + 0.03 * rnd.random())
+                    for sess in (one, many):
+                        assert sess.update_rates(1000 + e, exch, a, b, fwd, bkd)
+                    vertices.update([(exch, a), (exch, b)])
+    vertices = sorted(vertices)
+    assert len(vertices) >= 256
+    for _ in range(150):
+        a, b = (vertices[int(x)] for x in rnd.integers(0, len(vertices), 2))
+        try:
+            want = one.find_best_rate(a, b)
+        except host.AlgoError as e:
+            with pytest.raises(host.AlgoError) as e2:
+                many.find_best_rate(a, b)
+            assert str(e2.value) == str(e)
+            continue
+        assert many.find_best_rate(a, b) == want
+    assert one.parts == 1 and many.parts == 4 and one.solves == many.solves == 1
+    r1, n1, h1 = one.solved_matrix()
+    r2, n2, h2 = many.solved_matrix()
+    assert_bits_equal(r1, r2, "rate")
+    assert np.array_equal(n1, n2) and np.array_equal(h1, h2)
+
+
 def test_floyd_warshall_golden_through_the_session():
     # AlgorithmsTest.hs:66-77 via updateRates -> floydWarshall (GPU) -> download
     g = load_golden("algorithms_4x4.json")

@@ -108,12 +108,28 @@ def test_partitioned_handle_queries_and_exact_paths():
             dm.solve()
 
 
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+def test_hops_travel_with_the_panels(dtype):
+    """rate + next + hops through P logical partitions (config 5's fields): hops' = hops[i][k] +
+    hops[k][j] needs the hops of pivot row k at time k, which the owner exports beside the rate
+    snapshot and which is exchanged with it.  f32 takes the max-form + arg re-scan kernel, f64 and
+    counted solves the compare form."""
+    for kind, n, parts in (("t1", 384, 3), ("d2", 1000, 2), ("t2", 200, 8)):
+        rate, nxt, hops = synth.make(kind, n, dtype, seed=n)
+        er, en, eh = rate.copy(), nxt.copy(), hops.copy()
+        eu = oracle.relax(er, en, eh)
+        for count in (False, True):
+            gr, gn, gh = rate.copy(), nxt.copy(), hops.copy()
+            u = engine.solve_multi(gr, gn, gh, devices=[0] * parts, count_updates=count)
+            assert_bits_equal(gr, er, "rate %s" % kind)
+            assert_bits_equal(gn, en, "next %s" % kind)
+            assert_bits_equal(gh, eh, "hops %s" % kind)
+            assert not count or u == eu
+
+
 def test_unsupported_combinations_say_so():
     n = 128
     rate, nxt, hops = synth.make("d1", n, np.float32, seed=1)
-    with pytest.raises(engine.FwxError) as e:
-        engine.solve_multi(rate.copy(), nxt.copy(), hops.copy(), devices=[0, 0])
-    assert e.value.status == FWX_ERR_UNSUPPORTED                   # hops are not carried through slabs
     bad = rate.copy()
     bad[3, 5] = -1.0                                               # outside the reference's domain
     with pytest.raises(engine.FwxError) as e:

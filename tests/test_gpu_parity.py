@@ -280,12 +280,9 @@ def test_fused_engine_golden_4x4():
 def test_fused_engine_k_range_and_unsupported():
     rate, nxt, hops = synth.make("d2", 300, np.float64, seed=22)
     _solve_and_compare(rate, nxt, None, engine=engine.FWX_ENGINE_FUSED, k_begin=37, k_end=211)
-    # hops on the fused engine come from the path trace, which needs the WHOLE pivot range
+    # hops ride through the fused engine's panels: whole range and pivot ranges alike
     _solve_and_compare(rate, nxt, hops, engine=engine.FWX_ENGINE_FUSED)
-    with pytest.raises(engine.FwxError) as e:
-        engine.solve(rate.copy(), nxt.copy(), hops.copy(), engine=engine.FWX_ENGINE_FUSED,
-                     k_begin=37, k_end=211)
-    assert e.value.status == -7
+    _solve_and_compare(rate, nxt, hops, engine=engine.FWX_ENGINE_FUSED, k_begin=37, k_end=211)
     # n not a multiple of the 16-byte vector width: the device-pointer API refuses the fused engine
     # (it cannot pad memory it does not own) ...
     import torch
@@ -331,37 +328,80 @@ def test_config3_n8192_fp32_fused_vs_perk_and_oracle_slices():
     _solve_and_compare(rate0, nxt0, None, engine=engine.FWX_ENGINE_FUSED, k_begin=0, k_end=2)
 
 
-def test_fused_device_api_partition_emulation():
-    """fwx_dev_panel_snap + fwx_dev_relax_fused on P logical partitions of one GPU."""
+@pytest.mark.parametrize("with_extras", [False, True])
+def test_fused_device_api_partition_emulation(with_extras):
+    """fwx_dev_panel_snap + fwx_dev_relax_fused on P logical partitions of one GPU: rate + next, and
+    (with_extras) hops -- which travel with the panel -- and the path trace, kept slab-local."""
     import torch
     n, P = 640, 3
-    rate, nxt, _ = synth.make("t1", n, np.float32, seed=33)
-    er, en = rate.copy(), nxt.copy()
-    eu = oracle.relax(er, en)
+    rate, nxt, hops = synth.make("t1", n, np.float32, seed=33)
+    er, en, eh = rate.copy(), nxt.copy(), hops.copy()
+    eu = oracle.relax(er, en, eh)
     dev = torch.device("cuda:0")
     bounds = [n * p // P for p in range(P + 1)]
-    slabs = [torch.from_numpy(rate[bounds[p]:bounds[p + 1]].copy()).to(dev) for p in range(P)]
-    nslabs = [torch.from_numpy(nxt[bounds[p]:bounds[p + 1]].copy()).to(dev) for p in range(P)]
-    wss = [engine.FusedWorkspace(n, bounds[p + 1] - bounds[p], torch.float32, dev, with_next=True)
-           for p in range(P)]
+    cut = lambda a, p: torch.from_numpy(a[bounds[p]:bounds[p + 1]].copy()).to(dev)  # noqa: E731
+    slabs = [cut(rate, p) for p in range(P)]
+    nslabs = [cut(nxt, p) for p in range(P)]
+    hslabs = [cut(hops, p) if with_extras else None for p in range(P)]
+    traces = [engine.Trace(bounds[p + 1] - bounds[p], n, dev) if with_extras else None for p in range(P)]
+    wss = [engine.FusedWorkspace(n, bounds[p + 1] - bounds[p], torch.float32, dev, with_next=True,
+                                 with_hops=with_extras) for p in range(P)]
     upd = torch.zeros(engine.FWX_UPDATE_SHARDS, dtype=torch.int64, device=dev)
     B = engine.FWX_FUSED_BLOCK
     for owner in range(P):
         k0 = bounds[owner]
         while k0 < bounds[owner + 1]:
             k1 = min(k0 + B, bounds[owner + 1])
-            lo = k0 - bounds[owner]
+            lo, hi = k0 - bounds[owner], k1 - bounds[owner]
             w = wss[owner].w[0][:k1 - k0]
-            engine.dev_panel_snap(slabs[owner][lo:lo + k1 - k0], n, k0, w, wss[owner].diag)
+            wh = wss[owner].wh[0][:k1 - k0] if with_extras else None
+            engine.dev_panel_snap(slabs[owner][lo:hi], n, k0, w, block_next_t=nslabs[owner][lo:hi],
+                                  block_hops_t=hslabs[owner][lo:hi] if with_extras else None, w_hops_t=wh,
+                                  trace=traces[owner].rows(lo, hi) if with_extras else None)
             for p in range(P):
                 wp = w.clone()                           # stands in for the broadcast
-                engine.dev_relax_fused(slabs[p], n, bounds[p], k0, k1, wp, wss[p].ct,
-                                       next_t=nslabs[p], cnt_t=wss[p].cnt, updates_t=upd)
+                whp = wh.clone() if with_extras else None
+                # counting keeps the compare-form kernel; the uncounted variant below takes the
+                # max-form + arg re-scan kernel
+                engine.dev_relax_fused(slabs[p], n, bounds[p], k0, k1, wp, wss[p], next_t=nslabs[p],
+                                       hops_t=hslabs[p], wh_t=whp, trace=traces[p], updates_t=upd)
             k0 = k1
     torch.cuda.synchronize()
     assert_bits_equal(torch.cat(slabs).cpu().numpy(), er, "partitioned fused rate")
     assert_bits_equal(torch.cat(nslabs).cpu().numpy(), en, "partitioned fused next")
     assert int(upd.sum().item()) == eu
+    if with_extras:
+        assert_bits_equal(torch.cat(hslabs).cpu().numpy(), eh, "partitioned fused hops")
+        # the slab-local traces, stacked, are the single-device trace: check `last` against a
+        # single-device traced solve of the same input
+        with engine.DeviceMatrix(n, np.float32, with_next=True) as dm:
+            dm.enable_path_log()
+            dm.upload(rate, nxt)
+            dm.solve(engine=engine.FWX_ENGINE_FUSED)
+            src = np.arange(0, n, 7, dtype=np.int32)
+            dst = ((src * 13 + 5) % n).astype(np.int32)
+            want = dm.query_exact_batch(src, dst)
+        last, at_col, at_row = (torch.cat([getattr(t, f) for t in traces]).cpu().numpy()
+                                for f in ("last", "at_col", "at_row"))
+        for q in range(len(src)):
+            assert _path_from_trace(last, at_col, at_row, nxt, int(src[q]), int(dst[q])) == want[q]
+
+
+def _path_from_trace(last, at_col, at_row, next0, a, b):
+    """Host restatement of exact_path_kernel: path(a,b) = path_q(a,q) ++ path_q(q,b), q = newest
+    pivot of (a,b) -- `last` for the query, at_col / at_row for the two halves."""
+    out = []
+    stack = [(a, b, 0)]
+    while stack:
+        x, y, kind = stack.pop()
+        q = (last, at_col, at_row)[kind][x, y]
+        if q < 0:
+            if next0[x, y] >= 0:
+                out.append(y)
+        else:
+            stack.append((int(q), y, 2))
+            stack.append((x, int(q), 1))
+    return out
 
 
 @pytest.mark.parametrize("engine_name", ["fused", "perk"])
@@ -383,6 +423,29 @@ def test_dist_driver_single_rank_on_gpu(engine_name, lookahead):
     torch.cuda.synchronize()
     assert_bits_equal(r.cpu().numpy(), er, "rate")
     assert_bits_equal(nx.cpu().numpy(), en, "next")
+    # with hops (both engines) and the path trace (fused engine): config 5's fields
+    rate, nxt, hops = synth.make("t1", n, np.float32, seed=43)
+    er, en, eh = rate.copy(), nxt.copy(), hops.copy()
+    oracle.relax(er, en, eh)
+    r, nx, hp = (torch.from_numpy(a.copy()).to(dev) for a in (rate, nxt, hops))
+    trace = engine.Trace(n, n, dev) if engine_name == "fused" else None
+    fwdist.solve_partitioned(r, n, 0, 1, nxt=nx, hops=hp, trace=trace, block=64, lookahead=lookahead,
+                             backend=fwdist.HipBackend(engine_name))
+    torch.cuda.synchronize()
+    assert_bits_equal(r.cpu().numpy(), er, "rate")
+    assert_bits_equal(nx.cpu().numpy(), en, "next")
+    assert_bits_equal(hp.cpu().numpy(), eh, "hops")
+    if trace is not None:
+        vertices = [("X", "C%03d" % i) for i in range(n)]
+        last, at_col, at_row = (t.cpu().numpy() for t in (trace.last, trace.at_col, trace.at_row))
+        rnd = np.random.default_rng(9)
+        with engine.DeviceMatrix(n, np.float32, with_next=True) as dm:
+            dm.enable_path_log()
+            dm.upload(rate, nxt)
+            dm.solve()
+            for _ in range(200):
+                a, b = int(rnd.integers(0, n)), int(rnd.integers(0, n))
+                assert _path_from_trace(last, at_col, at_row, nxt, a, b) == dm.query_exact(a, b)[1]
 
 
 def test_batch_path_follow_matches_host_walk():
@@ -669,6 +732,51 @@ def test_concurrent_solves_from_several_host_threads():
     assert len(results) == 6 and all(results.values())
 
 
+def test_solves_on_different_host_threads_overlap_on_the_device():
+    """Every handle runs on its own non-blocking stream (never the legacy null stream), so solves
+    issued from different host threads overlap on the device.  n = 128 solves are ONE single-
+    workgroup launch each (1 of 256 CUs busy): four threads with a handle each must get clearly more
+    solves per second than one thread alone -- on a shared blocking stream the launches would
+    queue behind one another and the aggregate rate could not rise."""
+    import threading
+    import time
+    n, reps = 128, 300
+    rate, nxt, hops = synth.make("d2", n, np.float64, seed=12)
+    er, en, eh = rate.copy(), nxt.copy(), hops.copy()
+    oracle.relax(er, en, eh)
+
+    def run(handle, out, idx):
+        ok = True
+        for _ in range(reps):
+            handle.upload(rate, nxt, hops)
+            handle.solve()
+        r, nx, hp = handle.download()
+        ok = ok and np.array_equal(r.view(np.uint64), er.view(np.uint64)) and np.array_equal(nx, en) \
+            and np.array_equal(hp, eh)
+        out[idx] = ok
+
+    handles = [engine.DeviceMatrix(n, np.float64, with_next=True, with_hops=True) for _ in range(4)]
+    try:
+        out = [None] * 4
+        run(handles[0], out, 0)                       # warm-up
+        t0 = time.perf_counter()
+        run(handles[0], out, 0)
+        t_one = time.perf_counter() - t0
+        ts = [threading.Thread(target=run, args=(handles[i], out, i)) for i in range(4)]
+        t0 = time.perf_counter()
+        for t in ts:
+            t.start()
+        for t in ts:
+            t.join()
+        t_four = time.perf_counter() - t0
+    finally:
+        for h in handles:
+            h.close()
+    assert all(out)
+    rate_one, rate_four = reps / t_one, 4 * reps / t_four
+    assert rate_four > 1.5 * rate_one, (rate_one, rate_four)
+
+
 def test_index_math_beyond_2_to_31_elements():
     """N = 49152: 2.4e9 entries (9 GiB of f32) -- every offset must be computed in 64 bits.
     Per-k engine vs the oracle on two pivots; fused engine (both forms) vs per-k on 64 pivots, all
@@ -911,7 +1019,7 @@ def test_per_k_relax_with_a_skipped_row_range(dtype):
     oracle.relax(want_r, want_n, None, k0, k1)
     r_t, n_t = torch.from_numpy(rate.copy()).cuda(), torch.from_numpy(nxt.copy()).cuda()
     w = torch.empty((k1 - k0, n), dtype=r_t.dtype, device="cuda")     # time-k snapshots of the pivots
-    engine.dev_panel_snap(r_t[k0:k1], n, k0, w, engine.FusedWorkspace(n, n, r_t.dtype, r_t.device).diag)
+    engine.dev_panel_snap(r_t[k0:k1], n, k0, w)
     engine.dev_relax(r_t, n, 0, k0, k1, pivots_t=w, next_t=n_t, skip=(lo, hi))
     torch.cuda.synchronize()
     got_r, got_n = r_t.cpu().numpy(), n_t.cpu().numpy()
@@ -968,10 +1076,12 @@ def test_path_trace_with_several_strips_and_chunks(dtype, n):
 @pytest.mark.parametrize("dtype", [np.float64, np.float32])
 @pytest.mark.parametrize("kind", ["d2", "t1", "t2", "t3"])
 def test_hops_from_the_fused_engine(kind, dtype):
-    """`hops` (= length _path) from the fused engine: lengths rebuilt from the path trace in pivot
-    order.  Same integers as the per-k engine forms step by step -- ties, unreachable pairs,
-    arbitrage blow-ups (wrapping sums) included -- through the host-buffer API (odd sizes padded)
-    and the handle API.  (AUTO takes this route from n = 3072: test_hops_auto_large.)"""
+    """`hops` (= length _path) from the fused engine: the panel kernels carry the hops of the pivot
+    rows / columns beside their rates and export their time-k snapshots; the main kernel forms
+    hops = hops[i][k] + hops[k][j] at the winning pivot.  Same integers as the per-k engine forms
+    step by step -- ties, unreachable pairs, arbitrage blow-ups (wrapping sums; t3 is outside the
+    domain and runs on the per-k engine) -- through the host-buffer API (odd sizes padded) and the
+    handle API."""
     for n in (300, 257):
         rate, nxt, hops = synth.make(kind, n, dtype, seed=400 + n)
         _solve_and_compare(rate, nxt, hops, engine=engine.FWX_ENGINE_FUSED)
@@ -989,9 +1099,9 @@ def test_hops_from_the_fused_engine(kind, dtype):
 
 @pytest.mark.parametrize("dtype", [np.float32, np.float64])
 def test_hops_auto_large(dtype):
-    """AUTO with hops at n = 3102 (> 3072, not a multiple of 4: padded; full-size tiles): fused
-    engine + path trace + length reconstruction must give the per-k engine's rate, next and hops
-    (the per-k engine itself is checked against the oracle throughout this file)."""
+    """AUTO with hops at n = 3102 (not a multiple of 4: padded; full-size tiles): the fused engine
+    must give the per-k engine's rate, next and hops (the per-k engine itself is checked against the
+    oracle throughout this file)."""
     rate, nxt, hops = synth.make("d2", 3102, dtype, seed=77)
     a = [rate.copy(), nxt.copy(), hops.copy()]
     b = [rate.copy(), nxt.copy(), hops.copy()]

@@ -29,7 +29,7 @@ def run(T, band_rows, kmax=2048):
     t0 = time.perf_counter()
     for k0 in range(0, kmax, T):
         w = ws.w[0][:T]
-        engine.dev_panel_snap(r[k0:k0 + T], n, k0, w, ws.diag)
+        engine.dev_panel_snap(r[k0:k0 + T], n, k0, w)
         for b0 in range(0, n, band_rows):
             engine.dev_relax(r[b0:b0 + band_rows], n, b0, k0, k0 + T, pivots_t=w)
     torch.cuda.synchronize()

@@ -85,7 +85,7 @@ int main(int argc, char **argv)
         CK(hipEventRecord(e0, 0));
         for (int p = 0; p < passes; ++p) {
             a.k0 = p * 64; a.bt = 64;
-            CK(fwx::launch_fused_panel<float>(d + (size_t)a.k0 * n, n, a.k0, 64, w, nullptr, 0));
+            CK(fwx::launch_fused_panel<float>(d + (size_t)a.k0 * n, n, a.k0, 64, w, 0));
             CK(fwx::launch_fused_relax<float>(a, 0));
             CK(hipDeviceSynchronize());
         }
