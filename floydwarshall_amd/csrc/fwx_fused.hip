@@ -632,10 +632,10 @@ __global__ __launch_bounds__(256, MINW) void fused_main(T *rate, int32_t *next, 
 //       x <- max3(x, C_t[i]*W_t[j], C_{t+1}[i]*W_{t+1}[j])
 // with the operands stored as (t, t+1) pairs in LDS: 8.0 issue cycles per pair of relaxations
 // (two 2-cycle v_mul_f32 + one 4-cycle v_max3_f32; tools/valu_rate.hip) instead of 24 for the
-// compare form.  The caller must have verified the domain
-// (fwx_dev_check_nonneg); the next-hop variant needs the compare and stays on fused_main.
+// compare form.  The caller must have verified the domain (fwx_dev_check_nonneg); with next-hops
+// the same fold runs in fused_main_arg, which recovers the winning pivot afterwards.
 // ------------------------------------------------------------------------------------------------
-template <int MINW, int UNR, int RI, int NH, bool PIPE = false>
+template <int MINW, int UNR, int RI, int NH>
 __global__ __launch_bounds__(256, MINW) void fused_main_max(float *rate, int rows, int n, int row0,
                                                             int k0, int bt, const float *w,
                                                             const float *ct, int ct_ld, int ct_vec,
@@ -764,28 +764,11 @@ __global__ __launch_bounds__(256, MINW) void fused_main_max(float *rate, int row
                         x[r][h][e] = __builtin_fmaxf(__builtin_fmaxf(x[r][h][e], p0[h][e]), p1[h][e]);
             }
         };
-        if (PIPE) {
-            // the operands of pair tp+1 are read from LDS while pair tp is folded: the ds_reads are
-            // in flight behind ~190 VALU instructions instead of in front of them (the waits then
-            // carry lgkmcnt(N > 0): LDS returns in order)
-            float cA[RI][2], wA[NH][4][2], cB[RI][2], wB[NH][4][2];
-            if (np > 0) load_ops(0, cA, wA);
-#pragma unroll 1
-            for (int tp = 0; tp < np; tp += 2) {
-                if (tp + 1 < np) load_ops(tp + 1, cB, wB);
-                fold_pair(cA, wA);
-                if (tp + 1 < np) {
-                    if (tp + 2 < np) load_ops(tp + 2, cA, wA);
-                    fold_pair(cB, wB);
-                }
-            }
-        } else {
 #pragma unroll UNR
-            for (int tp = 0; tp < np; ++tp) {
-                float c[RI][2], wv[NH][4][2];
-                load_ops(tp, c, wv);
-                fold_pair(c, wv);
-            }
+        for (int tp = 0; tp < np; ++tp) {
+            float c[RI][2], wv[NH][4][2];
+            load_ops(tp, c, wv);
+            fold_pair(c, wv);
         }
         if (more) {
             commit(buf ^ 1);                      // the other buffer: nobody reads it now
@@ -818,9 +801,8 @@ __global__ __launch_bounds__(256, MINW) void fused_main_max(float *rate, int row
 // pipe -- so this kernel spends its registers on the tile instead of on occupancy: 128 x 128
 // entries per workgroup, 8 x 8 doubles per thread (128 VGPRs), which brings the LDS operand
 // traffic down to 2 B per relaxation (the generic 8 x 4 tile reads 3 B, and at 4 waves per SIMD
-// the LDS pipe, not the VALU, was the limit: 59 % of the issue bound).  8 pivots per LDS stage,
-// two stages resident, the next stage prefetched into registers during the fold, and the operands
-// of pivot t+1 read from LDS while pivot t is folded.
+// the LDS pipe was the second limit after the canonicalising v_max, see fmax_t).  8 pivots per LDS
+// stage, two stages resident, the next stage prefetched into registers during the fold.
 // ------------------------------------------------------------------------------------------------
 template <int MINW>
 __global__ __launch_bounds__(256, MINW) void fused_main_max_f64(double *rate, int rows, int n, int row0,
@@ -830,6 +812,7 @@ __global__ __launch_bounds__(256, MINW) void fused_main_max_f64(double *rate, in
 {
     typedef double V2 __attribute__((ext_vector_type(2)));
     constexpr int RI = 8, NH = 4, TI = 128, TJ = 128, HJ = 32, BS = 8;
+    constexpr int NST = BS / 8;                  // staging rounds per stage (8 pivots per round)
     __shared__ __attribute__((aligned(16))) double sW[2][BS][TJ];
     __shared__ __attribute__((aligned(16))) double sC[2][BS][TI];
 
@@ -844,30 +827,35 @@ __global__ __launch_bounds__(256, MINW) void fused_main_max_f64(double *rate, in
     // staging role: pivot sp (0..7) of the stage, 4 consecutive doubles of W and of C at sv * 4
     const int sp = tid >> 5, sv = tid & 31;
     const int sj = j_base + sv * 4, si = i_base + sv * 4;
-    V2 pw[2], pc[2];
+    V2 pw[NST][2], pc[NST][2];
     auto prefetch = [&](int s0) {
-        const int t = s0 + sp;
-        const bool t_ok = t < bt;
 #pragma unroll
-        for (int u = 0; u < 2; ++u) {
-            const int j = sj + 2 * u, i = si + 2 * u;
-            pw[u] = (t_ok && j < n) ? *reinterpret_cast<const V2 *>(w + (size_t)t * n + j) : V2{nanv, nanv};
-            if (t_ok && ct_vec && i + 2 <= rows) {
-                pc[u] = *reinterpret_cast<const V2 *>(ct + (size_t)t * ct_ld + i);
-            } else {
-                pc[u][0] = (t_ok && i < rows) ? ct[(size_t)t * ct_ld + i] : nanv;
-                pc[u][1] = (t_ok && i + 1 < rows) ? ct[(size_t)t * ct_ld + i + 1] : nanv;
+        for (int g = 0; g < NST; ++g) {
+            const int t = s0 + g * 8 + sp;
+            const bool t_ok = t < bt;
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                const int j = sj + 2 * u, i = si + 2 * u;
+                pw[g][u] = (t_ok && j < n) ? *reinterpret_cast<const V2 *>(w + (size_t)t * n + j) : V2{nanv, nanv};
+                if (t_ok && ct_vec && i + 2 <= rows) {
+                    pc[g][u] = *reinterpret_cast<const V2 *>(ct + (size_t)t * ct_ld + i);
+                } else {
+                    pc[g][u][0] = (t_ok && i < rows) ? ct[(size_t)t * ct_ld + i] : nanv;
+                    pc[g][u][1] = (t_ok && i + 1 < rows) ? ct[(size_t)t * ct_ld + i + 1] : nanv;
+                }
+                const int kcol = k0 + t - j;             // skip j == k: the pivot's own column
+                if (kcol >= 0 && kcol < 2) pw[g][u][kcol] = nanv;
             }
-            const int kcol = k0 + t - j;                 // skip j == k: the pivot's own column
-            if (kcol >= 0 && kcol < 2) pw[u][kcol] = nanv;
         }
     };
     auto commit = [&](int buf) {
 #pragma unroll
-        for (int u = 0; u < 2; ++u) {
-            *reinterpret_cast<V2 *>(&sW[buf][sp][sv * 4 + 2 * u]) = pw[u];
-            *reinterpret_cast<V2 *>(&sC[buf][sp][sv * 4 + 2 * u]) = pc[u];
-        }
+        for (int g = 0; g < NST; ++g)
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                *reinterpret_cast<V2 *>(&sW[buf][g * 8 + sp][sv * 4 + 2 * u]) = pw[g][u];
+                *reinterpret_cast<V2 *>(&sC[buf][g * 8 + sp][sv * 4 + 2 * u]) = pc[g][u];
+            }
     };
     prefetch(0);
 
@@ -928,16 +916,13 @@ __global__ __launch_bounds__(256, MINW) void fused_main_max_f64(double *rate, in
                 }
             }
         };
-        double cA[RI], wA[NH][2], cB[RI], wB[NH][2];
-        if (np > 0) load_ops(0, cA, wA);
+        // (reading pivot t+1's operands while pivot t is folded was tried: 423 ms against 405 ms at
+        // N = 16384, and 16-pivot stages 466-490 ms: profiles/r02_experiments_not_adopted.txt)
 #pragma unroll 1
-        for (int t = 0; t < np; t += 2) {
-            if (t + 1 < np) load_ops(t + 1, cB, wB);
+        for (int t = 0; t < np; ++t) {
+            double cA[RI], wA[NH][2];
+            load_ops(t, cA, wA);
             fold(cA, wA);
-            if (t + 1 < np) {
-                if (t + 2 < np) load_ops(t + 2, cA, wA);
-                fold(cB, wB);
-            }
         }
         if (more) {
             commit(buf ^ 1);
@@ -1307,17 +1292,6 @@ static bool launch_max_form(const FusedArgs<float> &a, dim3 grid, dim3 block, in
         hipLaunchKernelGGL((fused_main_max<4, 1, 4, 1>), g, block, 0, s, a.rate, a.rows, a.n, a.row0,
                            a.k0, a.bt, a.w, a.ct, a.ct_ld, ct_vec, skip_lo, skip_hi);
     } else {
-        static const int variant = getenv("FWX_MAXF_VARIANT") ? atoi(getenv("FWX_MAXF_VARIANT")) : 0;
-        if (variant == 1)
-            hipLaunchKernelGGL((fused_main_max<2, 1, 8, 2, true>), grid, block, 0, s, a.rate, a.rows, a.n,
-                               a.row0, a.k0, a.bt, a.w, a.ct, a.ct_ld, ct_vec, skip_lo, skip_hi);
-        else if (variant == 2)
-            hipLaunchKernelGGL((fused_main_max<3, 1, 8, 2, true>), grid, block, 0, s, a.rate, a.rows, a.n,
-                               a.row0, a.k0, a.bt, a.w, a.ct, a.ct_ld, ct_vec, skip_lo, skip_hi);
-        else if (variant == 3)
-            hipLaunchKernelGGL((fused_main_max<2, 1, 8, 2, false>), grid, block, 0, s, a.rate, a.rows, a.n,
-                               a.row0, a.k0, a.bt, a.w, a.ct, a.ct_ld, ct_vec, skip_lo, skip_hi);
-        else
         hipLaunchKernelGGL((fused_main_max<3, 1, 8, 2>), grid, block, 0, s, a.rate, a.rows, a.n,
                            a.row0, a.k0, a.bt, a.w, a.ct, a.ct_ld, ct_vec, skip_lo, skip_hi);
     }
@@ -1329,8 +1303,7 @@ static bool launch_max_form(const FusedArgs<double> &a, dim3 grid, dim3 block, i
                             int skip_hi, hipStream_t s, int32_t *)
 {
     if (!a.nonneg || a.next || a.updates) return false;
-    static const int variant = getenv("FWX_MAXF64_VARIANT") ? atoi(getenv("FWX_MAXF64_VARIANT")) : 0;
-    if (!small_tiles(a.n, a.rows) && variant != 9) {
+    if (!small_tiles(a.n, a.rows)) {
         const int ct_vec = ((uintptr_t)a.ct % 16 == 0 && a.ct_ld % 2 == 0) ? 1 : 0;
         const dim3 g((unsigned)((a.n + 127) / 128), (unsigned)((a.rows + 127) / 128));
         hipLaunchKernelGGL((fused_main_max_f64<2>), g, block, 0, s, a.rate, a.rows, a.n, a.row0, a.k0,

@@ -57,6 +57,27 @@ __global__ __launch_bounds__(256) void stream(float *out, unsigned long long *cy
                 if (KIND == 17) asm volatile("v_max_f32 %0, %1, %2" : "=v"(a[i]) : "v"(b[i]), "v"(c[(i + 1) % REG]));
                 if (KIND == 18) asm volatile("v_and_b32 %0, %0, %1" : "+v"(a[i]) : "v"(b[i]));
                 if (KIND == 19) asm volatile("v_max_i32 %0, %0, %1" : "+v"(a[i]) : "v"(b[i]));
+                // f64 with three distinct register pairs, and the f64 max-form pair as the kernels issue it
+                if (KIND == 20 && !(i & 1))
+                    asm volatile("v_mul_f64 %0, %1, %2" : "=v"(*(double *)&a[i]) : "v"(*(double *)&b[i]), "v"(*(double *)&c[(i + 2) % REG]));
+                if (KIND == 21 && !(i & 1)) {
+                    double p;
+                    asm volatile("v_mul_f64 %0, %1, %2" : "=v"(p) : "v"(*(double *)&b[i]), "v"(*(double *)&c[(i + 2) % REG]));
+                    asm volatile("v_max_f64 %0, %0, %1" : "+v"(*(double *)&a[i]) : "v"(p));
+                }
+                if (KIND == 22 && !(i & 1)) {   // 4 products first, then 4 folds (distance between producer and consumer)
+                    if ((i & 7) == 0) {
+                        double p0, p1, p2, p3;
+                        asm volatile("v_mul_f64 %0, %1, %2" : "=v"(p0) : "v"(*(double *)&b[i]), "v"(*(double *)&c[i]));
+                        asm volatile("v_mul_f64 %0, %1, %2" : "=v"(p1) : "v"(*(double *)&b[i + 2]), "v"(*(double *)&c[i]));
+                        asm volatile("v_mul_f64 %0, %1, %2" : "=v"(p2) : "v"(*(double *)&b[i + 4]), "v"(*(double *)&c[i]));
+                        asm volatile("v_mul_f64 %0, %1, %2" : "=v"(p3) : "v"(*(double *)&b[i + 6]), "v"(*(double *)&c[i]));
+                        asm volatile("v_max_f64 %0, %0, %1" : "+v"(*(double *)&a[i]) : "v"(p0));
+                        asm volatile("v_max_f64 %0, %0, %1" : "+v"(*(double *)&a[i + 2]) : "v"(p1));
+                        asm volatile("v_max_f64 %0, %0, %1" : "+v"(*(double *)&a[i + 4]) : "v"(p2));
+                        asm volatile("v_max_f64 %0, %0, %1" : "+v"(*(double *)&a[i + 6]) : "v"(p3));
+                    }
+                }
             }
         }
     }
@@ -120,6 +141,10 @@ int main()
     run<15>("v_cmp_lt_f32", 1, out, cyc);
     run<16>("v_mul_f32 d,b,c (3 regs)", 1, out, cyc);
     run<17>("v_max_f32 d,b,c (3 regs)", 1, out, cyc);
+    // per_group below = f64 instructions per REG-sized group / REG (the loop body covers REG floats)
+    run<20>("v_mul_f64 d,b,c (3 pairs) [x0.5]", 1, out, cyc);
+    run<21>("v_mul_f64+v_max_f64 pair [x1.0]", 1, out, cyc);
+    run<22>("4 x mul_f64 then 4 x max_f64 [x1.0]", 1, out, cyc);
     run<0>("v_mul_f32 (v,v) again", 1, out, cyc);
     return 0;
 }
