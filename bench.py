@@ -356,18 +356,19 @@ def run_single(args):
         valu = None
         if es == 4 and not args.with_next:
             cyc = relax_per_step / 2.0 * 8.0 / 64.0 / 1024.0
-            # real-time form of the same bound: the triple (2 x v_mul_f32 + v_max3_f32) issues at
-            # 1.15 ns per instruction per SIMD as a saturated stream (profiles/r02_valu_issue_rates.txt)
-            stream_s = relax_per_step / 2.0 * 3 * 1.15e-9 / 64.0 / 1024.0
+            # real-time form of the same bound: the triple (2 x v_mul_f32 + v_max3_f32) SUSTAINS
+            # 1.104 ns per instruction per SIMD over a 0.3 s burst at 3 waves per SIMD, the chip holding
+            # 2.33 GHz (`build/valu_rate long`, profiles/r02_valu_sustained.txt)
+            stream_s = relax_per_step / 2.0 * 3 * 1.104e-9 / 64.0 / 1024.0
             valu = {"bound": "valu-issue", "cycles_per_pair_of_relaxations": 8.0,
-                    "at_measured_stream_rate": {"ns_per_instruction_per_simd": 1.15, "instructions_per_pair": 3,
+                    "at_measured_stream_rate": {"ns_per_instruction_per_simd": 1.104, "instructions_per_pair": 3,
                                                 "bound_ms_per_step": 1e3 * stream_s, "frac": stream_s / ft},
                     "at_round1_clock": {"clock_GHz": 1.92, "bound_ms_per_step": 1e3 * cyc / 1.92e9,
                                         "frac": cyc / 1.92e9 / ft},
                     "at_nominal_clock": {"clock_GHz": 2.4, "bound_ms_per_step": 1e3 * cyc / 2.4e9,
                                          "frac": cyc / 2.4e9 / ft},
-                    "source": "tools/valu_rate.hip: profiles/r01_valu_issue_rates.txt, "
-                              "profiles/r02_valu_issue_rates.txt; profiles/r02_clocks.txt; whole solve "
+                    "source": "tools/valu_rate.hip: profiles/r02_valu_sustained.txt (0.3 s bursts: 2.33 GHz "
+                              "held), profiles/r02_valu_issue_rates.txt, profiles/r02_clocks.txt; whole solve "
                               "(panels and look-ahead launches included), not the main kernel alone"}
         out["fused_engine"] = {"value": relax_per_step / ft, "unit": "edge-relaxations/s",
                                "ms_per_step": 1e3 * ft, "steps": 2, "valu_roofline": valu,
@@ -422,13 +423,13 @@ def f64_leg(engine, hip, rate64, n, stream):
         times.append(time.perf_counter() - t1)
     ft = min(times)
     same = bool(np.array_equal(h.download()[0].view(np.uint64), rate.numpy(stream).view(np.uint64)))
-    # f64 max form: v_mul_f64 + v_max_f64; as a saturated stream the pair issues at 1.88 ns per
-    # instruction per SIMD (profiles/r02_valu_issue_rates.txt), 8.7 cycles per relaxation
+    # f64 max form: v_mul_f64 + v_max_f64; the pair SUSTAINS 1.907 ns per instruction per SIMD over a
+    # 0.2 s burst at 2-3 waves per SIMD, 2.38 GHz held (profiles/r02_valu_sustained.txt)
     cyc = float(n) ** 3 * 8.7 / 64.0 / 1024.0
-    stream_s = float(n) ** 3 * 2 * 1.88e-9 / 64.0 / 1024.0
+    stream_s = float(n) ** 3 * 2 * 1.907e-9 / 64.0 / 1024.0
     res["fused"] = {"ms_per_step": 1e3 * ft, "value": float(n) ** 3 / ft,
                     "valu_roofline": {"cycles_per_relaxation": 8.7,
-                                      "at_measured_stream_rate": {"ns_per_instruction_per_simd": 1.88,
+                                      "at_measured_stream_rate": {"ns_per_instruction_per_simd": 1.907,
                                                                   "bound_ms_per_step": 1e3 * stream_s,
                                                                   "frac": stream_s / ft},
                                       "at_round1_clock": {"clock_GHz": 1.92, "frac": cyc / 1.92e9 / ft},

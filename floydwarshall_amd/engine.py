@@ -43,7 +43,9 @@ def _check_arrays(rate, nxt, hops):
 
 
 def _opts(device=-1, engine=FWX_ENGINE_AUTO, k_begin=0, k_end=0, block=0, serpentine=True,
-          want_updates=False):
+          want_updates=False, stream=None):
+    """fwx_opts.  stream: a hip.Stream / torch stream handle the (still blocking) call runs on instead
+    of a library-owned non-blocking stream."""
     o = FwxOpts()
     o.struct_size = ctypes.sizeof(FwxOpts)
     o.device, o.engine, o.k_begin, o.k_end, o.block = device, engine, k_begin, k_end, block
@@ -51,6 +53,9 @@ def _opts(device=-1, engine=FWX_ENGINE_AUTO, k_begin=0, k_end=0, block=0, serpen
     u = ctypes.c_uint64(0)
     if want_updates:
         o.updates_out = ctypes.pointer(u)
+    if stream is not None:
+        o.stream = _stream_ptr(stream)
+        o.use_stream = 1
     return o, u
 
 
@@ -455,15 +460,16 @@ def dev_follow_paths(next_t, src_t, dst_t, *, edge_rate_t=None, path_cap=0):
 
 
 def dev_solve(rate_t, *, next_t=None, hops_t=None, engine=FWX_ENGINE_AUTO, k_begin=0, k_end=0,
-              serpentine=True, count_updates=False):
+              serpentine=True, count_updates=False, stream=None):
     """fwx_dev_solve: whole solve (or a pivot range) on a torch tensor holding the entire n x n
     matrix, in place, BLOCKING.  The fused engine runs with look-ahead on an internal side stream.
     Work queued on torch's current stream must be finished first: this synchronises it."""
-    import torch
     n = rate_t.shape[0]
-    assert rate_t.shape == (n, n)
-    torch.cuda.current_stream().synchronize()
+    assert tuple(rate_t.shape) == (n, n)
+    if stream is None:
+        import torch
+        torch.cuda.current_stream().synchronize()
     s = _slab(rate_t, next_t, hops_t, n, 0)
-    o, u = _opts(-1, engine, k_begin, k_end, 0, serpentine, count_updates)
+    o, u = _opts(-1, engine, k_begin, k_end, 0, serpentine, count_updates, stream=stream)
     check(lib().fwx_dev_solve(ctypes.byref(s), ctypes.byref(o)), "fwx_dev_solve")
     return int(u.value) if count_updates else None

@@ -777,6 +777,43 @@ def test_solves_on_different_host_threads_overlap_on_the_device():
     assert rate_four > 1.5 * rate_one, (rate_one, rate_four)
 
 
+def test_caller_supplied_stream_and_v1_opts_struct():
+    """fwx_opts.stream (ABI v2): the blocking call runs on the caller's stream, so work queued on it
+    beforehand is ordered before the solve -- here the upload of the input itself, asynchronously on
+    that stream -- and a caller built against the v1 struct (no stream fields, struct_size = 40)
+    still works."""
+    import ctypes
+    from floydwarshall_amd import _lib, hip
+    n = 512
+    rate, nxt, _ = synth.make("d2", n, np.float32, seed=21)
+    er, en = rate.copy(), nxt.copy()
+    oracle.relax(er, en)
+    st = hip.Stream()
+    d_rate, d_next = hip.DeviceArray((n, n), np.float32), hip.DeviceArray((n, n), np.int32)
+    d_rate.copy_from_host(rate, st)                 # async on st; the solve below must wait for it
+    d_next.copy_from_host(nxt, st)
+    engine.dev_solve(d_rate, next_t=d_next, stream=st)
+    assert_bits_equal(d_rate.numpy(st), er, "rate on the caller's stream")
+    assert_bits_equal(d_next.numpy(st), en, "next on the caller's stream")
+
+    class OptsV1(ctypes.Structure):                 # fwx_opts as ABI version 1 declared it
+        _fields_ = [("struct_size", ctypes.c_uint32), ("device", ctypes.c_int32), ("engine", ctypes.c_int32),
+                    ("k_begin", ctypes.c_int32), ("k_end", ctypes.c_int32), ("block", ctypes.c_int32),
+                    ("serpentine", ctypes.c_int32), ("updates_out", ctypes.POINTER(ctypes.c_uint64))]
+    o = OptsV1()
+    o.struct_size, o.device = ctypes.sizeof(OptsV1), -1
+    assert ctypes.sizeof(OptsV1) == 40
+    r2, n2 = rate.copy(), nxt.copy()
+    fn = _lib.lib().fwx_solve_f32
+    rc = fn(n, r2.ctypes.data_as(ctypes.c_void_p), n2.ctypes.data_as(ctypes.c_void_p), None,
+            ctypes.cast(ctypes.byref(o), ctypes.POINTER(_lib.FwxOpts)))
+    assert rc == 0
+    assert_bits_equal(r2, er, "rate through the v1 options struct")
+    o.struct_size = 16                              # too small to be any version of the struct
+    assert fn(n, r2.ctypes.data_as(ctypes.c_void_p), None, None,
+              ctypes.cast(ctypes.byref(o), ctypes.POINTER(_lib.FwxOpts))) == _lib.FWX_ERR_INVALID
+
+
 def test_index_math_beyond_2_to_31_elements():
     """N = 49152: 2.4e9 entries (9 GiB of f32) -- every offset must be computed in 64 bits.
     Per-k engine vs the oracle on two pivots; fused engine (both forms) vs per-k on 64 pivots, all

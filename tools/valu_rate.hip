@@ -4,13 +4,14 @@
 #include <hip/hip_runtime.h>
 #include <stdio.h>
 #include <stdlib.h>
+#include <string.h>
 #include <vector>
 
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s line %d\n", hipGetErrorString(e_), __LINE__); exit(1); } } while (0)
 
 constexpr int REG = 16;      // independent accumulators per lane
 constexpr int INNER = 64;    // repetitions of the REG-instruction group per loop trip
-constexpr int TRIPS = 512;
+constexpr int TRIPS = 512;     // per launch; `valu_rate long` repeats launches back to back for ~0.3 s
 
 template <int KIND>
 __global__ __launch_bounds__(256) void stream(float *out, unsigned long long *cycles, float seed)
@@ -90,6 +91,32 @@ __global__ __launch_bounds__(256) void stream(float *out, unsigned long long *cy
     if (threadIdx.x == 0) { cycles[2 * blockIdx.x] = t1 - t0; cycles[2 * blockIdx.x + 1] = w1 - w0; }
 }
 
+// Sustained form: `reps` launches back to back (no gaps to speak of), 3 workgroups per CU like the
+// fused main kernels; the clock is read inside the LAST launch, the rate over all of them.
+template <int KIND> static void run_long(const char *name, int per_group, float *out, unsigned long long *cyc,
+                                         int wg_per_cu, int reps)
+{
+    const int blocks = 256 * wg_per_cu;
+    hipEvent_t e0, e1;
+    CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+    hipLaunchKernelGGL(stream<KIND>, dim3(blocks), dim3(256), 0, 0, out, cyc, 1.5f);
+    CK(hipDeviceSynchronize());
+    CK(hipEventRecord(e0, 0));
+    for (int r = 0; r < reps; ++r) hipLaunchKernelGGL(stream<KIND>, dim3(blocks), dim3(256), 0, 0, out, cyc, 1.5f);
+    CK(hipEventRecord(e1, 0));
+    CK(hipEventSynchronize(e1));
+    float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+    std::vector<unsigned long long> h(2 * blocks);
+    CK(hipMemcpy(h.data(), cyc, 2 * blocks * 8, hipMemcpyDeviceToHost));
+    double avg = 0, wall = 0;
+    for (int i = 0; i < blocks; ++i) { avg += (double)h[2 * i]; wall += (double)h[2 * i + 1]; }
+    const double ghz = avg / wall * 0.1;
+    const double instr = (double)TRIPS * INNER * REG * per_group * reps;
+    const double ns = ms * 1e6 / (instr * wg_per_cu);
+    printf("%-34s %d wave/SIMD, %3d launches = %.1f ms: %.3f ns per instruction per SIMD = %.2f cycles at %.3f GHz (clock of the last launch)\n",
+           name, wg_per_cu, reps, ms, ns, ns * ghz, ghz);
+}
+
 template <int KIND> static void run(const char *name, int per_group, float *out, unsigned long long *cyc)
 {
     for (int wg_per_cu = 1; wg_per_cu <= 4; wg_per_cu *= 2) {   // 256 threads = 1 wave per SIMD
@@ -117,10 +144,20 @@ template <int KIND> static void run(const char *name, int per_group, float *out,
     }
 }
 
-int main()
+int main(int argc, char **argv)
 {
     float *out; unsigned long long *cyc;
     CK(hipMalloc(&out, 1024 * 256 * 4)); CK(hipMalloc(&cyc, 2 * 1024 * 8));
+    if (argc > 1 && !strcmp(argv[1], "long")) {
+        // solve-length bursts (0.2-0.4 s): what clock and what issue rate does the chip SUSTAIN on the
+        // instruction mixes of the fused main kernels?
+        run_long<4>("2 x v_mul_f32 + v_max3_f32", 3, out, cyc, 3, 60);
+        run_long<4>("2 x v_mul_f32 + v_max3_f32", 3, out, cyc, 4, 40);
+        run_long<21>("v_mul_f64 + v_max_f64 (3 pairs)", 1, out, cyc, 2, 100);
+        run_long<21>("v_mul_f64 + v_max_f64 (3 pairs)", 1, out, cyc, 3, 70);
+        run_long<5>("v_mul + v_cmp + 2 x v_cndmask", 4, out, cyc, 3, 40);
+        return 0;
+    }
     run<0>("v_mul_f32 (v,v)", 1, out, cyc);
     run<3>("v_mul_f32 (s,v)", 1, out, cyc);
     run<2>("v_max_f32", 1, out, cyc);
