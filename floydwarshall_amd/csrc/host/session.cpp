@@ -77,8 +77,8 @@ int Session::ensure_solved()
         // fwx_matrix_query_exact rebuilds the reference's `_path` lists -- under exact ties (the
         // 1.0 edges of Algorithms.hs:35 make them common) the list the reference stored can be a
         // longer route than the one the next-hops describe.  Requests need rates and paths, not
-        // `hops`: from kFusedFrom vertices on the device matrix carries none, so that the solve
-        // takes the fused engine (64 pivots per pass); solved_matrix() computes them on demand.
+        // `hops`: from kFusedFrom vertices on the resident matrix carries none (one n x n array, its
+        // upload and its panel traffic less per re-solve); solved_matrix() computes them on demand.
         int rc = FWX_OK;
         dev_hops_ = m.n() < kFusedFrom;
         if (!dev_) {

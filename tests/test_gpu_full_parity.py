@@ -33,7 +33,7 @@ def _threads():
 @pytest.mark.parametrize("dtype", [np.float64, np.float32])
 def test_n4096_whole_solve_rate_next_hops_every_engine(dtype):
     """N = 4096, rates + next + hops, D2 (market-like: long winning paths): the whole oracle solve
-    against PERK, FUSED (hops rebuilt from the path trace) and AUTO, all fields, and U."""
+    against PERK, FUSED (hops carried through the panels) and AUTO, all fields, and U."""
     n = 4096
     rate, nxt, hops = synth.make("d2", n, dtype, seed=synth.BASE_SEED + 41)
     er, en, eh = rate.copy(), nxt.copy(), hops.copy()

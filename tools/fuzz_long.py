@@ -50,7 +50,7 @@ with np.errstate(all="ignore"):
                     dm.solve(engine=eng)
                     dm.upload(rate, nxt, hops)       # second solve on the same handle
                     dm.solve(engine=eng)
-                    gr, gn, hp = dm.download()       # FUSED: hops rebuilt from the trace
+                    gr, gn, hp = dm.download()       # FUSED: hops carried through the panels
                     assert_bits_equal(gr, er, "rate")
                     assert np.array_equal(gn, en) and np.array_equal(hp, eh)
                     for i in range(m):
