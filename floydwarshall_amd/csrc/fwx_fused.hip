@@ -106,51 +106,22 @@ template <> __device__ __forceinline__ double readlane<double>(double v, int lan
     return __builtin_bit_cast(double, ((long long)hi << 32) | (unsigned int)lo);
 }
 
-// dst with lane LANE replaced by the wave-uniform value v (v_writelane_b32; the lane select is an
-// inline constant, so the one constant-bus slot is free for v).
-template <int LANE> __device__ __forceinline__ int writelane_b32(int dst, int v)
-{
-    asm("v_writelane_b32 %0, %1, %2" : "+v"(dst) : "s"(v), "n"(LANE));
-    return dst;
-}
-template <int LANE> __device__ __forceinline__ float writelane(float dst, float v)
-{
-    return __builtin_bit_cast(float, writelane_b32<LANE>(__builtin_bit_cast(int, dst),
-                                                         __builtin_bit_cast(int, v)));
-}
-template <int LANE> __device__ __forceinline__ double writelane(double dst, double v)
-{
-    const long long bv = __builtin_bit_cast(long long, v), bd = __builtin_bit_cast(long long, dst);
-    const int lo = writelane_b32<LANE>((int)(bd & 0xffffffffll), (int)(bv & 0xffffffffll));
-    const int hi = writelane_b32<LANE>((int)(bd >> 32), (int)(bv >> 32));
-    return __builtin_bit_cast(double, ((long long)hi << 32) | (unsigned int)lo);
-}
 template <> __device__ __forceinline__ int readlane<int>(int v, int lane)
 {
     return __builtin_amdgcn_readlane(v, lane);
 }
-template <int LANE> __device__ __forceinline__ int writelane(int dst, int v)
-{
-    return writelane_b32<LANE>(dst, v);
-}
-// cv[q] = lane `src_lane` of p[q] for q = 0..SB-1, gathered into one register (lane q <- cv[q])
-template <int Q, typename T>
-__device__ __forceinline__ void gather_column(const T (&p)[SB], int src_lane, T (&cv)[SB], T &cdv)
-{
-    if constexpr (Q < SB) {
-        cv[Q] = readlane<T>(p[Q], src_lane);
-        cdv = writelane<Q>(cdv, cv[Q]);
-        gather_column<Q + 1, T>(p, src_lane, cv, cdv);
-    }
-}
 
-// Row panel: snapshot panel W of the pivot rows.  Every workgroup first evolves the 64 x 64
-// diagonal block itself (lanes = block columns) to obtain Cd[r][t] = D_t[k0+r][k0+t] in LDS --
-// redundant across workgroups, but it removes a kernel boundary and a single-workgroup launch from
-// the critical path -- and then its own strip of 64 columns.
-// HAS_LAST: also keeps the path trace of the pivot rows (PathLog): `last` of each entry is carried
-// through the 64 pivots beside its rate, and at_row[k0+t][j] = last of (k0+t, j) at time k0+t is
-// exported with the snapshot.  last_rows / at_rows point at row k0 of the n x n matrices.
+// Row panel: snapshot panel W of the pivot rows.  Every workgroup evolves the 64 x 64 diagonal
+// block itself (lanes = block columns: redundant across workgroups, but it removes a kernel boundary
+// and a single-workgroup launch from the critical path) TOGETHER with its own strip of 64 columns,
+// in ONE loop over the 16 sub-blocks: a wave holds the diagonal-block part AND the strip part of
+// its SB rows, and the pivot-column operand of a row at time t -- D_t[k0+r][k0+t] -- is simply lane
+// t of that row's own diagonal-block register (v_readlane), used for both parts.  (Round 1 ran the
+// diagonal block and the strip as two loops, 32 barriers, with the column operands going through
+// LDS: 35 us per panel at N = 16384 f32; merged: 16 barriers and no LDS round trip for them.)
+// HAS_LAST: also keeps the path trace of the pivot rows (PathLog): `last` of each strip entry is
+// carried through the 64 pivots beside its rate, and at_row[k0+t][j] = last of (k0+t, j) at time
+// k0+t is exported with the snapshot.  last_rows / at_rows point at row k0 of the trace matrices.
 // HAS_HOPS: also carries `hops` (= length _path) of the pivot rows: hops' = hops[i][k] + hops[k][j]
 // on every successful relaxation (Algorithms.hs:55), and exports wh_out[t][j] = hops of (k0+t, j) at
 // time k0+t beside the rate snapshot.  hops_rows points at row k0 of the hops matrix.
@@ -160,22 +131,45 @@ __global__ __launch_bounds__(PANEL_THREADS) void fused_rowpanel(const T *rows, i
                                                       int32_t *at_rows, const int32_t *hops_rows,
                                                       int32_t *wh_out)
 {
-    __shared__ T s_line[B][64];                    // published pivot rows (time-t), per phase
-    __shared__ T s_cd[B][B];                       // s_cd[t][r] = D_t[k0+r][k0+t]
-    __shared__ int32_t s_hline[HAS_HOPS ? B : 1][64];   // hops of the published pivot rows
-    __shared__ int32_t s_cdh[HAS_HOPS ? B : 1][B];      // hops of D_t[k0+r][k0+t]
+    __shared__ T s_dline[B][64];                   // published pivot rows, diagonal-block part (time t)
+    __shared__ T s_sline[B][64];                   // ... strip part
+    __shared__ int32_t s_dh[HAS_HOPS ? B : 1][64];      // their hops
+    __shared__ int32_t s_sh[HAS_HOPS ? B : 1][64];
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int j = blockIdx.x * 64 + lane;
+    const bool valid = j < n;
+    const int jc = valid ? j : n - 1;
 
-    T p[SB];
-    int32_t hp[SB];                                // hops of this wave's lines (dead without HAS_HOPS)
-    // ---------------- phase 0: the diagonal block, lanes = block columns -------------------------
+    T pd[SB], ps[SB];                              // this wave's SB rows: diagonal-block / strip columns
+    int32_t hd[SB], hs[SB], lp[SB];                // hops of both parts, `last` of the strip part
 #pragma unroll
     for (int q = 0; q < SB; ++q) {
         const int r = wave * SB + q;
-        p[q] = (r < bt && lane < bt) ? rows[(size_t)r * n + k0 + lane] : qnan<T>();
-        hp[q] = (HAS_HOPS && r < bt && lane < bt) ? hops_rows[(size_t)r * n + k0 + lane] : 0;
+        pd[q] = (r < bt && lane < bt) ? rows[(size_t)r * n + k0 + lane] : qnan<T>();
+        hd[q] = (HAS_HOPS && r < bt && lane < bt) ? hops_rows[(size_t)r * n + k0 + lane] : 0;
+        ps[q] = r < bt ? rows[(size_t)r * n + jc] : qnan<T>();
+        lp[q] = (HAS_LAST && r < bt) ? last_rows[(size_t)r * n + jc] : -1;
+        hs[q] = (HAS_HOPS && r < bt) ? hops_rows[(size_t)r * n + jc] : 0;
     }
+    // a strip column inside the block carries one diagonal entry: published from memory, untouched
+    const bool in_blk = valid && j >= k0 && j < k0 + bt;
+    const T dorig = in_blk ? rows[(size_t)(j - k0) * n + j] : T(0);
+    const int32_t hdorig = (HAS_HOPS && in_blk) ? hops_rows[(size_t)(j - k0) * n + j] : 0;
+
+    // one relaxation of row q by pivot t in both parts: cv = D_t[k0+r][k0+t], (wd, ws) = pivot row
+    auto relax_row = [&](int q, T cv, int32_t ch, T wd, T ws, int32_t hwd, int32_t hws, int t) {
+        const T cd = cv * wd;
+        const bool ud = pd[q] < cd;
+        pd[q] = ud ? cd : pd[q];
+        if (HAS_HOPS) hd[q] = ud ? (int32_t)((uint32_t)ch + (uint32_t)hwd) : hd[q];
+        const T cs = cv * ws;
+        const bool us = ps[q] < cs;
+        ps[q] = us ? cs : ps[q];
+        if (HAS_LAST) lp[q] = us ? k0 + t : lp[q];
+        if (HAS_HOPS) hs[q] = us ? (int32_t)((uint32_t)ch + (uint32_t)hws) : hs[q];
+    };
+
 #pragma unroll 1                                   // code size: keep the panel inside the I-cache
     for (int b = 0; b < B / SB; ++b) {
         if (b * SB >= bt) continue;                // uniform
@@ -183,30 +177,35 @@ __global__ __launch_bounds__(PANEL_THREADS) void fused_rowpanel(const T *rows, i
 #pragma unroll
             for (int tq = 0; tq < SB; ++tq) {
                 const int t = b * SB + tq;
-                T w = p[tq];
-                if (lane == t) w = qnan<T>();      // skip j == k (also hides the stale diagonal)
-                s_line[t][lane] = w;
-                const int32_t hw = HAS_HOPS ? hp[tq] : 0;
-                if (HAS_HOPS) s_hline[t][lane] = hw;
-                // column t of this wave's rows: 16 independent cross-lane reads first, gathered
-                // into one register (lane q <- row q) and published with ONE LDS store
+                if (t >= bt) continue;
+                // the pivot row at time t: every earlier pivot has been applied, pivot t leaves it alone
+                T wd = pd[tq];
+                if (lane == t) wd = qnan<T>();     // skip j == k (also hides the stale diagonal)
+                T ws = ps[tq];
+                if (j == k0 + t) ws = dorig;
+                const int32_t hwd = HAS_HOPS ? hd[tq] : 0;
+                const int32_t hws = HAS_HOPS ? (j == k0 + t ? hdorig : hs[tq]) : 0;
+                if (valid) {
+                    w_out[(size_t)t * n + j] = ws;                // the snapshot
+                    if (HAS_LAST) at_rows[(size_t)t * n + j] = j == k0 + t ? -1 : lp[tq];
+                    if (HAS_HOPS) wh_out[(size_t)t * n + j] = hws;
+                }
+                if (j == k0 + t) ws = qnan<T>();                  // skip j == k
+                s_dline[t][lane] = wd;
+                s_sline[t][lane] = ws;
+                if (HAS_HOPS) { s_dh[t][lane] = hwd; s_sh[t][lane] = hws; }
+                // column t of this wave's rows: SB independent cross-lane reads first
                 T cv[SB];
-                T cdv = T(0);
-                gather_column<0, T>(p, t, cv, cdv);
-                if (lane < SB) s_cd[t][b * SB + lane] = cdv;
-                int32_t chv[SB];
-                if (HAS_HOPS) {
-                    int32_t cdh = 0;
-                    gather_column<0, int32_t>(hp, t, chv, cdh);
-                    if (lane < SB) s_cdh[t][b * SB + lane] = cdh;
+                int32_t ch[SB];
+#pragma unroll
+                for (int q = 0; q < SB; ++q) {
+                    cv[q] = readlane<T>(pd[q], t);
+                    ch[q] = HAS_HOPS ? readlane<int>(hd[q], t) : 0;
                 }
 #pragma unroll
                 for (int q = 0; q < SB; ++q) {
-                    if (q == tq) continue;         // skip i == k
-                    const T cand = cv[q] * w;
-                    const bool up = p[q] < cand;
-                    p[q] = up ? cand : p[q];
-                    if (HAS_HOPS) hp[q] = up ? (int32_t)((uint32_t)chv[q] + (uint32_t)hw) : hp[q];
+                    if (q == tq) continue;                        // skip i == k
+                    relax_row(q, cv[q], ch[q], wd, ws, hwd, hws, t);
                 }
             }
         }
@@ -216,91 +215,17 @@ __global__ __launch_bounds__(PANEL_THREADS) void fused_rowpanel(const T *rows, i
             for (int tq = 0; tq < SB; ++tq) {
                 const int t = b * SB + tq;
                 if (t >= bt) continue;
-                const T w = s_line[t][lane];
-                const int32_t hw = HAS_HOPS ? s_hline[t][lane] : 0;
+                const T wd = s_dline[t][lane], ws = s_sline[t][lane];
+                const int32_t hwd = HAS_HOPS ? s_dh[t][lane] : 0, hws = HAS_HOPS ? s_sh[t][lane] : 0;
                 T cv[SB];
-                T cdv = T(0);
-                gather_column<0, T>(p, t, cv, cdv);
-                if (lane < SB) s_cd[t][wave * SB + lane] = cdv;
-                int32_t chv[SB];
-                if (HAS_HOPS) {
-                    int32_t cdh = 0;
-                    gather_column<0, int32_t>(hp, t, chv, cdh);
-                    if (lane < SB) s_cdh[t][wave * SB + lane] = cdh;
-                }
+                int32_t ch[SB];
 #pragma unroll
                 for (int q = 0; q < SB; ++q) {
-                    const T cand = cv[q] * w;
-                    const bool up = p[q] < cand;
-                    p[q] = up ? cand : p[q];
-                    if (HAS_HOPS) hp[q] = up ? (int32_t)((uint32_t)chv[q] + (uint32_t)hw) : hp[q];
+                    cv[q] = readlane<T>(pd[q], t);
+                    ch[q] = HAS_HOPS ? readlane<int>(hd[q], t) : 0;
                 }
-            }
-        }
-    }
-    lds_barrier();                                 // s_cd complete; s_line free for reuse
-
-    // ---------------- phase 1: this workgroup's strip of 64 columns ------------------------------
-    const int j = blockIdx.x * 64 + lane;
-    const bool valid = j < n;
-    const int jc = valid ? j : n - 1;
-    int32_t lp[HAS_LAST ? SB : 1];
 #pragma unroll
-    for (int q = 0; q < SB; ++q) {
-        const int r = wave * SB + q;
-        p[q] = r < bt ? rows[(size_t)r * n + jc] : qnan<T>();
-        if (HAS_LAST) lp[q] = r < bt ? last_rows[(size_t)r * n + jc] : -1;
-        if (HAS_HOPS) hp[q] = r < bt ? hops_rows[(size_t)r * n + jc] : 0;
-    }
-    // a column inside the block carries one diagonal entry: published from memory, untouched
-    const bool in_blk = valid && j >= k0 && j < k0 + bt;
-    const T dorig = in_blk ? rows[(size_t)(j - k0) * n + j] : T(0);
-    const int32_t hdorig = (HAS_HOPS && in_blk) ? hops_rows[(size_t)(j - k0) * n + j] : 0;
-
-#pragma unroll 1
-    for (int b = 0; b < B / SB; ++b) {
-        if (b * SB >= bt) continue;
-        if (wave == b) {
-#pragma unroll
-            for (int tq = 0; tq < SB; ++tq) {
-                const int t = b * SB + tq;
-                if (t >= bt) continue;
-                T w = p[tq];
-                if (j == k0 + t) w = dorig;
-                if (valid) w_out[(size_t)t * n + j] = w;          // the snapshot
-                if (HAS_LAST && valid) at_rows[(size_t)t * n + j] = j == k0 + t ? -1 : lp[tq];
-                const int32_t hw = HAS_HOPS ? (j == k0 + t ? hdorig : hp[tq]) : 0;
-                if (HAS_HOPS && valid) wh_out[(size_t)t * n + j] = hw;
-                if (j == k0 + t) w = qnan<T>();                   // skip j == k
-                s_line[t][lane] = w;
-                if (HAS_HOPS) s_hline[t][lane] = hw;
-#pragma unroll
-                for (int q = 0; q < SB; ++q) {
-                    if (q == tq) continue;                        // skip i == k
-                    const T cand = s_cd[t][b * SB + q] * w;
-                    const bool up = p[q] < cand;
-                    p[q] = up ? cand : p[q];
-                    if (HAS_LAST) lp[q] = up ? k0 + t : lp[q];
-                    if (HAS_HOPS) hp[q] = up ? (int32_t)((uint32_t)s_cdh[t][b * SB + q] + (uint32_t)hw) : hp[q];
-                }
-            }
-        }
-        lds_barrier();
-        if (wave > b) {            // rows above the sub-block have all been snapshotted already
-#pragma unroll
-            for (int tq = 0; tq < SB; ++tq) {
-                const int t = b * SB + tq;
-                if (t >= bt) continue;
-                const T w = s_line[t][lane];
-                const int32_t hw = HAS_HOPS ? s_hline[t][lane] : 0;
-#pragma unroll
-                for (int q = 0; q < SB; ++q) {
-                    const T cand = s_cd[t][wave * SB + q] * w;
-                    const bool up = p[q] < cand;
-                    p[q] = up ? cand : p[q];
-                    if (HAS_LAST) lp[q] = up ? k0 + t : lp[q];
-                    if (HAS_HOPS) hp[q] = up ? (int32_t)((uint32_t)s_cdh[t][wave * SB + q] + (uint32_t)hw) : hp[q];
-                }
+                for (int q = 0; q < SB; ++q) relax_row(q, cv[q], ch[q], wd, ws, hwd, hws, t);
             }
         }
     }
@@ -1039,7 +964,6 @@ __global__ __launch_bounds__(256, MINW) void fused_main_arg(float *rate, int32_t
     __shared__ float l_val[4][LCAP];            //                      the entry's new value
 
     const int tid = threadIdx.x;
-    const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int i_base = blockIdx.y * TI;
     const int j_base = blockIdx.x * TJ;

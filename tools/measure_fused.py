@@ -51,6 +51,9 @@ def main():
             rate, nxt = synth.d1_uniform(n, dt, synth.BASE_SEED + 3)
             engine.solve(rate, nxt, engine=engine.FWX_ENGINE_PERK)
             ref = (rate, nxt)
+        if "--trace-only" in sys.argv:
+            run(n, dt, True, True, False, check=ref)
+            continue
         if "--next-only" not in sys.argv:
             run(n, dt, False, False, False, check=ref)
         if "--rates-only" in sys.argv:
