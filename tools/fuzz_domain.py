@@ -46,9 +46,24 @@ def domain_matrix(rnd, n, dtype):
     return np.ascontiguousarray(rate), np.ascontiguousarray(nxt), np.ascontiguousarray(hops)
 
 
+import faulthandler  # noqa: E402
+faulthandler.enable()
 budget = float(sys.argv[1]) if len(sys.argv) > 1 else 120.0
 max_n = int(sys.argv[2]) if len(sys.argv) > 2 else 700
-rnd = np.random.default_rng(int(time.time()))
+seed = int(sys.argv[3]) if len(sys.argv) > 3 else int(time.time())
+print("fuzz_domain: seed %d" % seed, flush=True)
+rnd = np.random.default_rng(seed)
+trail = open(os.environ.get("FUZZ_TRAIL", "/dev/null"), "w")
+
+
+def note(msg):
+    """last thing attempted, for a crash that leaves no traceback"""
+    trail.seek(0)
+    trail.truncate()
+    trail.write(msg + "\n")
+    trail.flush()
+
+
 t0 = time.time()
 cases = 0
 with np.errstate(all="ignore"):
@@ -56,6 +71,7 @@ with np.errstate(all="ignore"):
         dtype = np.float64 if rnd.random() < 0.4 else np.float32
         n = int(rnd.integers(2, max_n))
         rate, nxt, hops = domain_matrix(rnd, n, dtype)
+        note("case %d: n=%d %s oracle" % (cases, n, dtype.__name__))
         er, en, eh = rate.copy(), nxt.copy(), hops.copy()
         eu = oracle.relax_mt(er, en, hops=eh, threads=8) if n > 256 else oracle.relax(er, en, eh)
         # host API, fused engine: rates only / + next / + next + hops, counted and not
@@ -64,6 +80,7 @@ with np.errstate(all="ignore"):
             gn = nxt.copy() if fields >= 1 else None
             gh = hops.copy() if fields >= 2 else None
             count = bool(rnd.integers(0, 2))
+            note("case %d: n=%d %s host solve fields=%d count=%s" % (cases, n, dtype.__name__, fields, count))
             u = engine.solve(gr, gn, gh, engine=engine.FWX_ENGINE_FUSED, count_updates=count)
             assert_bits_equal(gr, er, "rate n=%d %s fields=%d" % (n, dtype.__name__, fields))
             if gn is not None:
@@ -77,6 +94,7 @@ with np.errstate(all="ignore"):
         dst = rnd.integers(0, n, 64).astype(np.int32)
         lists = []
         for kw in (dict(devices=[0] * parts), dict(device=0)):
+            note("case %d: n=%d %s handle %s" % (cases, n, dtype.__name__, kw))
             with engine.DeviceMatrix(n, dtype, with_next=True, with_hops=True, **kw) as dm:
                 dm.enable_path_log()
                 dm.upload(rate, nxt, hops)
