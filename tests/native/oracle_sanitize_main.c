@@ -7,6 +7,7 @@
 uint64_t fwo_relax_f64(int32_t, double *, int32_t *, int32_t *, int32_t, int32_t);
 uint64_t fwo_relax_f32(int32_t, float *, int32_t *, int32_t *, int32_t, int32_t);
 uint64_t fwo_relax_mt_f32(int32_t, float *, int32_t *, int32_t *, int32_t, int32_t, int32_t);
+uint64_t fwo_relax_mt_f64(int32_t, double *, int32_t *, int32_t *, int32_t, int32_t, int32_t);
 int fwo_copy_per_k_f64(int32_t, double *, int32_t *, int32_t *);
 int32_t fwo_follow_path(int32_t, const int32_t *, int32_t, int32_t, int32_t *, int32_t);
 
@@ -41,6 +42,21 @@ int main(void)
         for (int i = 0; i < n; ++i)
             for (int j = 0; j < n; ++j)
                 if (fwo_follow_path(n, nx, i, j, path, n) != hp[i * n + j]) return 4;
+        /* the multi-threaded form with next AND hops (5 threads: ragged row split) against the
+         * single-threaded result above */
+        s = 12345u + n;
+        for (int i = 0; i < n; ++i)
+            for (int j = 0; j < n; ++j) {
+                s = s * 1664525u + 1013904223u;
+                double v = i == j ? 0.0 : 0.05 + 0.95 * (s >> 8) / 16777216.0;
+                if ((s & 63) == 0) v = 0.0;
+                r2[i * n + j] = v;
+                nx2[i * n + j] = (v > 0) ? j : -1;
+                hp2[i * n + j] = v > 0;
+            }
+        fwo_relax_mt_f64(n, r2, nx2, hp2, 0, n, 5);
+        for (size_t q = 0; q < nn; ++q)
+            if (r[q] != r2[q] || nx[q] != nx2[q] || hp[q] != hp2[q]) return 5;
         free(r); free(r2); free(f); free(f2); free(nx); free(hp); free(nx2); free(hp2); free(path);
     }
     puts("oracle sanitize ok");
