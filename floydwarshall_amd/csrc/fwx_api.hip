@@ -635,6 +635,8 @@ int fwx_matrix_destroy(fwx_matrix *m)
     if (m->plog.at_col) (void)hipFree(m->plog.at_col);
     if (m->plog.at_row) (void)hipFree(m->plog.at_row);
     if (m->next0) (void)hipFree(m->next0);
+    if (m->rate0) (void)hipFree(m->rate0);
+    if (m->hops0) (void)hipFree(m->hops0);
     if (m->walk) (void)hipFree(m->walk);
     if (m->stream) (void)hipStreamSynchronize(m->stream);
     if (m->ws) (void)hipFree(m->ws);
@@ -661,9 +663,15 @@ int fwx_matrix_upload(fwx_matrix *m, const void *rate, const int32_t *next, cons
     FWX_HIP(hipMemcpyAsync(m->rate, rate, nn * es, hipMemcpyDefault, s));
     if (m->next) FWX_HIP(hipMemcpyAsync(m->next, next, nn * 4, hipMemcpyDefault, s));
     if (m->hops) FWX_HIP(hipMemcpyAsync(m->hops, hops, nn * 4, hipMemcpyDefault, s));
-    if (m->plog.last) {     // traced matrix: keep the uploaded next-hops (paths of entries never improved)
+    if (m->plog.last || (m->keep && m->next)) {
+        // traced matrix: keep the uploaded next-hops (paths of entries never improved); kept input
         FWX_HIP(hipMemcpyAsync(m->next0, m->next, nn * 4, hipMemcpyDeviceToDevice, s));
         m->rec_ready = 0;   // the trace of an earlier input is stale
+    }
+    if (m->keep) {
+        FWX_HIP(hipMemcpyAsync(m->rate0, m->rate, nn * es, hipMemcpyDeviceToDevice, s));
+        if (m->hops) FWX_HIP(hipMemcpyAsync(m->hops0, m->hops, nn * 4, hipMemcpyDeviceToDevice, s));
+        m->kept_valid = 1;
     }
     FWX_HIP(hipStreamSynchronize(s));
     m->fresh = 1;
@@ -681,7 +689,7 @@ int fwx_matrix_enable_path_log(fwx_matrix *m)
     const size_t nn = (size_t)m->n * (size_t)m->n;
     FWX_HIP(hipMalloc((void **)&m->plog.at_col, nn * 4));
     FWX_HIP(hipMalloc((void **)&m->plog.at_row, nn * 4));
-    FWX_HIP(hipMalloc((void **)&m->next0, nn * 4));
+    if (!m->next0) FWX_HIP(hipMalloc((void **)&m->next0, nn * 4));
     FWX_HIP(hipMalloc((void **)&m->plog.last, nn * 4));      // last: `last != nullptr` = enabled
     // next0 = the UPLOADED next-hops.  If the arrays already hold an unsolved upload, keep it;
     // otherwise (nothing uploaded yet, or already solved) `fresh` is 0 and a traced solve is
@@ -690,6 +698,62 @@ int fwx_matrix_enable_path_log(fwx_matrix *m)
         FWX_HIP(hipMemcpyAsync(m->next0, m->next, nn * 4, hipMemcpyDeviceToDevice, m->stream));
         FWX_HIP(hipStreamSynchronize(m->stream));
     }
+    m->rec_ready = 0;
+    return FWX_OK;
+}
+
+int fwx_matrix_keep_input(fwx_matrix *m)
+{
+    if (!m) return FWX_ERR_INVALID;
+    if (m->keep || m->n == 0) return FWX_OK;
+    if (m->multi) return multi_keep_input(m);
+    DeviceGuard g;
+    int rc = g.enter(m->device);
+    if (rc) return rc;
+    const size_t nn = (size_t)m->n * (size_t)m->n, es = m->dtype == FWX_F64 ? 8 : 4;
+    FWX_HIP(hipMalloc(&m->rate0, nn * es));
+    if (m->next && !m->next0) FWX_HIP(hipMalloc((void **)&m->next0, nn * 4));
+    if (m->hops) FWX_HIP(hipMalloc((void **)&m->hops0, nn * 4));
+    m->keep = 1;
+    if (m->fresh) {          // an unsolved upload is in the arrays: that is the input to keep
+        hipStream_t s = m->stream;
+        FWX_HIP(hipMemcpyAsync(m->rate0, m->rate, nn * es, hipMemcpyDeviceToDevice, s));
+        if (m->next) FWX_HIP(hipMemcpyAsync(m->next0, m->next, nn * 4, hipMemcpyDeviceToDevice, s));
+        if (m->hops) FWX_HIP(hipMemcpyAsync(m->hops0, m->hops, nn * 4, hipMemcpyDeviceToDevice, s));
+        FWX_HIP(hipStreamSynchronize(s));
+        m->kept_valid = 1;
+    }
+    return FWX_OK;
+}
+
+int fwx_matrix_patch_input(fwx_matrix *m, int32_t count, const int64_t *index, const void *rate_vals,
+                           const int32_t *next_vals, const int32_t *hops_vals)
+{
+    if (!m || count < 0 || count > FWX_MAX_PATCH || (count > 0 && (!index || !rate_vals)))
+        return FWX_ERR_INVALID;
+    if (!m->keep || !m->kept_valid) return FWX_ERR_INVALID;
+    if ((next_vals && !m->next) || (hops_vals && !m->hops)) return FWX_ERR_INVALID;
+    const int64_t nn64 = (int64_t)m->n * m->n;
+    for (int32_t q = 0; q < count; ++q)
+        if (index[q] < 0 || index[q] >= nn64) return FWX_ERR_INVALID;
+    if (m->multi) return multi_patch_input(m, count, index, rate_vals, next_vals, hops_vals);
+    DeviceGuard g;
+    int rc = g.enter(m->device);
+    if (rc) return rc;
+    const size_t nn = (size_t)nn64, es = m->dtype == FWX_F64 ? 8 : 4;
+    hipStream_t s = m->stream;
+    for (int32_t q = 0; q < count; ++q) {        // a handful of entries: plain small copies
+        const size_t off = (size_t)index[q];
+        FWX_HIP(hipMemcpyAsync((char *)m->rate0 + off * es, (const char *)rate_vals + (size_t)q * es, es,
+                               hipMemcpyHostToDevice, s));
+        if (next_vals) FWX_HIP(hipMemcpyAsync(m->next0 + off, next_vals + q, 4, hipMemcpyHostToDevice, s));
+        if (hops_vals) FWX_HIP(hipMemcpyAsync(m->hops0 + off, hops_vals + q, 4, hipMemcpyHostToDevice, s));
+    }
+    FWX_HIP(hipMemcpyAsync(m->rate, m->rate0, nn * es, hipMemcpyDeviceToDevice, s));
+    if (m->next) FWX_HIP(hipMemcpyAsync(m->next, m->next0, nn * 4, hipMemcpyDeviceToDevice, s));
+    if (m->hops) FWX_HIP(hipMemcpyAsync(m->hops, m->hops0, nn * 4, hipMemcpyDeviceToDevice, s));
+    FWX_HIP(hipStreamSynchronize(s));
+    m->fresh = 1;
     m->rec_ready = 0;
     return FWX_OK;
 }

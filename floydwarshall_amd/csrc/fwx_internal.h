@@ -220,6 +220,10 @@ struct fwx_matrix {
     unsigned long long *upd;
     fwx::PathLog plog;     // path trace for exact `_path` lists (last == nullptr: disabled)
     int32_t *next0;        // the uploaded next-hop matrix: the path of an entry never improved
+    void *rate0;           // kept input (fwx_matrix_keep_input): the uploaded rates ...
+    int32_t *hops0;        // ... and hops (next0 serves both purposes)
+    int32_t keep;          // the input is kept on the device
+    int32_t kept_valid;    // ... and holds an upload
     int32_t *walk;         // scratch of the exact-path walk (stack + output)
     int32_t walk_cap;      // capacity (path entries) `walk` was sized for
     int32_t rec_ready;     // a traced solve of the current upload has completed
@@ -250,6 +254,9 @@ int multi_query_exact(fwx_matrix *m, int32_t src, int32_t dst, double *rate_out,
 int multi_query_exact_batch(fwx_matrix *m, int32_t count, const int32_t *src, const int32_t *dst,
                             int32_t *len_out, int32_t *path_out, int32_t cap);
 void multi_destroy(fwx_matrix *m);
+int multi_keep_input(fwx_matrix *m);
+int multi_patch_input(fwx_matrix *m, int32_t count, const int64_t *index, const void *rate_vals,
+                      const int32_t *next_vals, const int32_t *hops_vals);
 }  // namespace fwxi
 
 #endif

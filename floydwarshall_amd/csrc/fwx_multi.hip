@@ -71,6 +71,8 @@ struct Part {
     int32_t *next = nullptr, *hops = nullptr;
     fwx::PathLog plog;                      // slab-local trace matrices (rows x nd), or null
     int32_t *next0 = nullptr;
+    void *rate0 = nullptr;                  // kept input (fwx_matrix_keep_input)
+    int32_t *hops0 = nullptr;
     void *w[2] = {nullptr, nullptr};        // snapshot panels, 64 x nd
     int32_t *wh[2] = {nullptr, nullptr};    // their hops (iff hops)
     void *ct = nullptr;                     // pivot-column snapshots, 64 x ct_ld
@@ -208,7 +210,8 @@ static void multi_free(MultiState *M)
     for (int p = 0; p < M->parts; ++p) {
         Part &q = M->part[p];
         if (hipSetDevice(q.device) != hipSuccess) continue;
-        void *bufs[] = {q.rate, q.next, q.hops, q.plog.last, q.plog.at_col, q.plog.at_row, q.next0, q.w[0],
+        void *bufs[] = {q.rate, q.next, q.hops, q.plog.last, q.plog.at_col, q.plog.at_row, q.next0, q.rate0,
+                        q.hops0, q.w[0],
                         q.w[1], q.wh[0], q.wh[1], q.ct, q.cnt, q.cht, q.upd, q.flag};
         for (void *b : bufs)
             if (b) (void)hipFree(b);
@@ -325,8 +328,13 @@ static int multi_copy(fwx_matrix *m, void *host_rate, int32_t *host_next, int32_
         if ((rc = copy(q.rate, (char *)host_rate, es))) return rc;
         if (q.next && (rc = copy(q.next, (char *)host_next, 4))) return rc;
         if (q.hops && (rc = copy(q.hops, (char *)host_hops, 4))) return rc;
-        if (to_device && q.plog.last)
+        if (to_device && q.next0)
             FWX_HIP(hipMemcpyAsync(q.next0, q.next, (size_t)q.rows * nd * 4, hipMemcpyDeviceToDevice, q.main));
+        if (to_device && q.rate0) {
+            FWX_HIP(hipMemcpyAsync(q.rate0, q.rate, (size_t)q.rows * nd * es, hipMemcpyDeviceToDevice, q.main));
+            if (q.hops0)
+                FWX_HIP(hipMemcpyAsync(q.hops0, q.hops, (size_t)q.rows * nd * 4, hipMemcpyDeviceToDevice, q.main));
+        }
     }
     for (int p = 0; p < M.parts; ++p) {
         int rc = set_dev(M.part[p].device);
@@ -536,6 +544,7 @@ int multi_upload(fwx_matrix *m, const void *rate, const int32_t *next, const int
                               const_cast<int32_t *>(hops), true);
     if (rc) return rc;
     if (m->plog.last) m->rec_ready = 0;
+    if (m->keep) m->kept_valid = 1;
     m->fresh = 1;
     return FWX_OK;
 }
@@ -570,7 +579,7 @@ int multi_enable_path_log(fwx_matrix *m)
         const size_t bytes = (size_t)q.rows * M.nd * 4;
         FWX_HIP(hipMalloc((void **)&q.plog.at_col, bytes ? bytes : 16));
         FWX_HIP(hipMalloc((void **)&q.plog.at_row, bytes ? bytes : 16));
-        FWX_HIP(hipMalloc((void **)&q.next0, bytes ? bytes : 16));
+        if (!q.next0) FWX_HIP(hipMalloc((void **)&q.next0, bytes ? bytes : 16));
         FWX_HIP(hipMalloc((void **)&q.plog.last, bytes ? bytes : 16));
         if (m->fresh) {
             FWX_HIP(hipMemcpyAsync(q.next0, q.next, bytes, hipMemcpyDeviceToDevice, q.main));
@@ -672,6 +681,67 @@ int multi_query_exact(fwx_matrix *m, int32_t src, int32_t dst, double *rate_out,
     int32_t len = 0;
     if ((rc = multi_query_exact_batch(m, 1, &src, &dst, &len, path_out, cap))) return rc;
     return len;
+}
+
+int multi_keep_input(fwx_matrix *m)
+{
+    MultiState &M = *m->multi;
+    DevRestore keep;
+    const size_t es = m->dtype == FWX_F64 ? 8 : 4;
+    for (int p = 0; p < M.parts; ++p) {
+        Part &q = M.part[p];
+        int rc = set_dev(q.device);
+        if (rc) return rc;
+        const size_t cells = (size_t)q.rows * M.nd;
+        FWX_HIP(hipMalloc(&q.rate0, cells * es ? cells * es : 16));
+        if (q.next && !q.next0) FWX_HIP(hipMalloc((void **)&q.next0, cells * 4 ? cells * 4 : 16));
+        if (q.hops) FWX_HIP(hipMalloc((void **)&q.hops0, cells * 4 ? cells * 4 : 16));
+        if (m->fresh) {
+            FWX_HIP(hipMemcpyAsync(q.rate0, q.rate, cells * es, hipMemcpyDeviceToDevice, q.main));
+            if (q.next) FWX_HIP(hipMemcpyAsync(q.next0, q.next, cells * 4, hipMemcpyDeviceToDevice, q.main));
+            if (q.hops) FWX_HIP(hipMemcpyAsync(q.hops0, q.hops, cells * 4, hipMemcpyDeviceToDevice, q.main));
+            FWX_HIP(hipStreamSynchronize(q.main));
+        }
+    }
+    m->keep = 1;
+    m->kept_valid = m->fresh ? 1 : 0;
+    return FWX_OK;
+}
+
+int multi_patch_input(fwx_matrix *m, int32_t count, const int64_t *index, const void *rate_vals,
+                      const int32_t *next_vals, const int32_t *hops_vals)
+{
+    MultiState &M = *m->multi;
+    DevRestore keep;
+    const size_t es = m->dtype == FWX_F64 ? 8 : 4;
+    int rc;
+    for (int32_t e = 0; e < count; ++e) {
+        const int row = (int)(index[e] / m->n), col = (int)(index[e] % m->n);
+        int p = 0;
+        while (p + 1 < M.parts && row >= M.part[p + 1].row0) ++p;
+        Part &q = M.part[p];
+        if ((rc = set_dev(q.device))) return rc;
+        const size_t off = (size_t)(row - q.row0) * M.nd + col;
+        FWX_HIP(hipMemcpyAsync((char *)q.rate0 + off * es, (const char *)rate_vals + (size_t)e * es, es,
+                               hipMemcpyHostToDevice, q.main));
+        if (next_vals) FWX_HIP(hipMemcpyAsync(q.next0 + off, next_vals + e, 4, hipMemcpyHostToDevice, q.main));
+        if (hops_vals) FWX_HIP(hipMemcpyAsync(q.hops0 + off, hops_vals + e, 4, hipMemcpyHostToDevice, q.main));
+    }
+    for (int p = 0; p < M.parts; ++p) {
+        Part &q = M.part[p];
+        if ((rc = set_dev(q.device))) return rc;
+        const size_t cells = (size_t)q.rows * M.nd;
+        FWX_HIP(hipMemcpyAsync(q.rate, q.rate0, cells * es, hipMemcpyDeviceToDevice, q.main));
+        if (q.next) FWX_HIP(hipMemcpyAsync(q.next, q.next0, cells * 4, hipMemcpyDeviceToDevice, q.main));
+        if (q.hops) FWX_HIP(hipMemcpyAsync(q.hops, q.hops0, cells * 4, hipMemcpyDeviceToDevice, q.main));
+    }
+    for (int p = 0; p < M.parts; ++p) {
+        if ((rc = set_dev(M.part[p].device))) return rc;
+        FWX_HIP(hipStreamSynchronize(M.part[p].main));
+    }
+    m->fresh = 1;
+    m->rec_ready = 0;
+    return FWX_OK;
 }
 
 void multi_destroy(fwx_matrix *m)

@@ -74,6 +74,8 @@ int fwxh_session_state(const fwxh_session *s) { return s ? s->impl.state() : FWX
 
 int64_t fwxh_session_solves(const fwxh_session *s) { return s ? s->impl.solves() : -1; }
 
+int64_t fwxh_session_patched_solves(const fwxh_session *s) { return s ? s->impl.patched_solves() : -1; }
+
 int32_t fwxh_session_rate_count(const fwxh_session *s)
 {
     return s ? (int32_t)s->impl.rates().size() : -1;

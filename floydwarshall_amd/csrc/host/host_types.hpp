@@ -86,6 +86,7 @@ public:
     int parts() const;          // partitions of the resident matrix, 0 if there is none
     int state() const { return in_sync_ ? 1 : 0; }
     int64_t solves() const { return solves_; }
+    int64_t patched_solves() const { return patched_solves_; }   // ... of which from a patched kept input
     const ExchRateTimes &rates() const { return rates_; }
 
     // updateRates (ProcessRequests.hs:89-102) on parsed fields; true if applied
@@ -117,6 +118,16 @@ private:
     bool dev_hops_ = true;           // the device matrix carries `hops` (n < kFusedFrom)
     DenseMatrix initial_;            // buildMatrix output, storage kept across re-solves
     int64_t solves_ = 0;
+    // Incremental re-marshalling (row f3, the exact part).  While the vertex set is unchanged an
+    // accepted update changes exactly the entries (src,dest) and (dest,src) of buildMatrix's output:
+    // they are patched into the kept host arrays at once and sent to the input kept on the device
+    // (fwx_matrix_patch_input) at the next query, instead of rebuilding and uploading n^2 entries.
+    struct Patch { int64_t idx; double rate; int32_t next, hops; };
+    static constexpr size_t kMaxPatches = 64;    // beyond this a full marshal is as cheap
+    std::map<Vertex, int32_t> vindex_;       // vertex -> row of initial_ (valid while !rebuild_)
+    std::vector<Patch> patches_;             // entries changed since the kept device input was current
+    bool rebuild_ = true;                    // the next solve marshals from scratch
+    int64_t patched_solves_ = 0;
 };
 
 }  // namespace fwxh

@@ -37,6 +37,8 @@ void Session::drop_device()
         fwx_matrix_destroy(dev_);
         dev_ = nullptr;
     }
+    rebuild_ = true;             // the kept input went with the handle
+    patches_.clear();
 }
 
 bool Session::update_rates(int64_t time, const Vertex &src, const Vertex &dest, double fwd, double bkd)
@@ -58,7 +60,29 @@ bool Session::update_rates(int64_t time, const Vertex &src, const Vertex &dest, 
     rates_[VertexPair(dest, src)] = std::make_pair(bkd, time);
     rates_[VertexPair(src, dest)] = std::make_pair(fwd, time);
     in_sync_ = false;
-    if (!matrix_unchanged) ++version_;
+    if (matrix_unchanged) return true;
+    ++version_;
+    if (!rebuild_) {
+        // buildMatrix's output changes in exactly two entries if both vertices are known: (i,j) =
+        // (fwd, [j]) and (j,i) = (bkd, [i]) (Algorithms.hs:36-37).  A new vertex renumbers the rows,
+        // and two vertices of one currency take the 1.0 rule (:35, tested before the map): both go
+        // through the full marshal.
+        const auto si = vindex_.find(src), di = vindex_.find(dest);
+        if (si == vindex_.end() || di == vindex_.end() || src.ccy == dest.ccy ||
+            patches_.size() + 2 > kMaxPatches) {
+            rebuild_ = true;
+            patches_.clear();
+        } else {
+            const int64_t n = (int64_t)initial_.n(), i = si->second, j = di->second;
+            const Patch two[2] = {{i * n + j, fwd, (int32_t)j, 1}, {j * n + i, bkd, (int32_t)i, 1}};
+            for (const Patch &p : two) {
+                initial_.rate[(size_t)p.idx] = p.rate;
+                initial_.next[(size_t)p.idx] = p.next;
+                initial_.hops[(size_t)p.idx] = p.hops;
+                patches_.push_back(p);
+            }
+        }
+    }
     return true;
 }
 
@@ -66,6 +90,26 @@ int Session::ensure_solved()
 {
     if (solved_version_ == version_) return FWX_OK;
     DenseMatrix &m = initial_;
+    if (!rebuild_ && dev_ && !patches_.empty()) {
+        // same vertices, a few changed entries: patch the input kept on the device and solve it
+        std::vector<int64_t> idx;
+        std::vector<double> rate;
+        std::vector<int32_t> next, hops;
+        for (const Patch &p : patches_) {
+            idx.push_back(p.idx); rate.push_back(p.rate); next.push_back(p.next); hops.push_back(p.hops);
+        }
+        int rc = fwx_matrix_patch_input(dev_, (int32_t)idx.size(), idx.data(), rate.data(), next.data(),
+                                        dev_hops_ ? hops.data() : nullptr);
+        if (!rc) rc = fwx_matrix_solve(dev_, nullptr);           // runAlgo 0: a FULL solve, on the GPU
+        if (!rc) {
+            patches_.clear();
+            solved_version_ = version_;
+            ++solves_;
+            ++patched_solves_;
+            return FWX_OK;
+        }
+        drop_device();           // whatever went wrong: marshal from scratch below
+    }
     build_matrix_into(rates_, m);
     // The device handle (matrix, pristine copies, log arrays) is kept while the vertex count stays
     // the same -- a rate update between known vertices, the common case -- and only re-uploaded.
@@ -92,7 +136,10 @@ int Session::ensure_solved()
             if (rc) return rc;
             dev_multi_ = want_multi;
             dev_n_ = m.n();
-            if ((rc = fwx_matrix_enable_path_log(dev_))) { drop_device(); return rc; }
+            if ((rc = fwx_matrix_enable_path_log(dev_)) || (rc = fwx_matrix_keep_input(dev_))) {
+                drop_device();
+                return rc;
+            }
         }
         if ((rc = fwx_matrix_upload(dev_, m.rate.data(), m.next.data(),
                                     dev_hops_ ? m.hops.data() : nullptr)) ||
@@ -103,6 +150,10 @@ int Session::ensure_solved()
     } else {
         drop_device();
     }
+    vindex_.clear();
+    for (int32_t i = 0; i < m.n(); ++i) vindex_[m.vertices[(size_t)i]] = i;
+    rebuild_ = m.n() == 0;       // from here on updates between known vertices are patched in
+    patches_.clear();
     solved_version_ = version_;
     ++solves_;
     return FWX_OK;

@@ -164,6 +164,22 @@ class DeviceMatrix:
                                           _np_ptr(out), self.n), "fwx_matrix_query")
         return float(r.value), [int(x) for x in out[:ln]]
 
+    def keep_input(self):
+        """Keep the uploaded input on the device (fwx_matrix_keep_input) so that patch_input can
+        replace a few entries of it without a new upload."""
+        check(lib().fwx_matrix_keep_input(self._h), "fwx_matrix_keep_input")
+
+    def patch_input(self, index, rate_vals, next_vals=None, hops_vals=None):
+        """Replace entries index[q] = i*n + j of the KEPT input and make it the unsolved matrix again
+        (fwx_matrix_patch_input); follow with solve()."""
+        index = np.ascontiguousarray(index, dtype=np.int64)
+        rate_vals = np.ascontiguousarray(rate_vals, dtype=self.dtype)
+        nv = None if next_vals is None else np.ascontiguousarray(next_vals, dtype=np.int32)
+        hv = None if hops_vals is None else np.ascontiguousarray(hops_vals, dtype=np.int32)
+        assert index.ndim == 1 and rate_vals.shape == index.shape
+        check(lib().fwx_matrix_patch_input(self._h, len(index), _np_ptr(index), _np_ptr(rate_vals),
+                                           _np_ptr(nv), _np_ptr(hv)), "fwx_matrix_patch_input")
+
     def enable_path_log(self):
         """Keep the path trace (three n x n int32 matrices, see fwx.h) so that query_exact can
         rebuild the reference's `_path` lists exactly; a traced solve() needs a fresh upload()."""

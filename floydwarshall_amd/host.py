@@ -20,6 +20,7 @@ HOST_SIGNATURES = {
     "fwxh_session_create": (ctypes.c_int, [ctypes.POINTER(c_vp), c_i32]),
     "fwxh_session_set_devices": (ctypes.c_int, [c_vp, c_i32, ctypes.POINTER(c_i32), c_i32]),
     "fwxh_session_parts": (c_i32, [c_vp]),
+    "fwxh_session_patched_solves": (c_i64, [c_vp]),
     "fwxh_session_destroy": (ctypes.c_int, [c_vp]),
     "fwxh_session_state": (ctypes.c_int, [c_vp]),
     "fwxh_session_solves": (c_i64, [c_vp]),
@@ -150,6 +151,10 @@ class Session:
     @property
     def parts(self):
         return hlib().fwxh_session_parts(self._h)
+
+    @property
+    def patched_solves(self):
+        return hlib().fwxh_session_patched_solves(self._h)
 
     @property
     def state(self):

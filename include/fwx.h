@@ -134,6 +134,22 @@ int fwx_matrix_query(fwx_matrix *m, int32_t src, int32_t dst, double *rate_out, 
                      int32_t cap);
 int fwx_matrix_destroy(fwx_matrix *m);
 
+/* Incremental re-marshalling (SURVEY.md section 8f, row f3 -- the exact part of it).  The reference
+ * rebuilds and re-solves the whole matrix after every accepted rate update
+ * (ProcessRequests.hs:82-85, :99-102), although such an update changes TWO entries of
+ * buildMatrix's output.  With the input KEPT on the device (one more copy of each array), the host
+ * sends only the changed entries: fwx_matrix_patch_input replaces `count` entries of the kept input
+ * (index[q] = i*n + j; rate_vals in the handle's dtype; next_vals / hops_vals may be NULL =
+ * unchanged) and makes the patched input the handle's unsolved matrix again (device-to-device
+ * restore), ready for fwx_matrix_solve -- a FULL solve, so every result stays bit-identical to the
+ * reference; what is saved is buildMatrix over n^2 entries and the PCIe upload.
+ * keep_input: call once after create (before or after an upload).  patch_input needs a kept
+ * upload (FWX_ERR_INVALID otherwise); count <= FWX_MAX_PATCH.  Works on partitioned handles.     */
+#define FWX_MAX_PATCH 4096
+int fwx_matrix_keep_input(fwx_matrix *m);
+int fwx_matrix_patch_input(fwx_matrix *m, int32_t count, const int64_t *index, const void *rate_vals,
+                           const int32_t *next_vals, const int32_t *hops_vals);
+
 /* Exact `_path` lists.  Following next-hops (fwx_matrix_query) yields A best path; the reference
  * keeps, per entry, the list it concatenated when the entry was last improved
  * (`_path = ikPath ++ kjPath`, Algorithms.hs:55), and under exact ties (its built-in 1.0 edges

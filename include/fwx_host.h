@@ -55,6 +55,10 @@ int fwxh_session_set_devices(fwxh_session *s, int32_t n_parts, const int32_t *de
 int32_t fwxh_session_parts(const fwxh_session *s);   /* partitions of the resident matrix (0: none yet) */
 int fwxh_session_state(const fwxh_session *s);        /* FWXH_STATE_* as the reference would hold */
 int64_t fwxh_session_solves(const fwxh_session *s);   /* floydWarshall runs so far (GPU solves)   */
+/* ... of which started from a PATCHED kept input instead of a full buildMatrix + upload: after an
+ * update between known vertices only the two changed entries travel (fwx_matrix_patch_input); the
+ * solve itself is always the full runAlgo, so answers are bit-identical either way.              */
+int64_t fwxh_session_patched_solves(const fwxh_session *s);
 int32_t fwxh_session_rate_count(const fwxh_session *s);
 
 /* updateRates on parsed fields (ProcessRequests.hs:89-102): stores (src->dst, fwd) and

@@ -139,6 +139,97 @@ def test_requotes_of_the_same_prices_reuse_the_solve():
     assert s.solves == 2
 
 
+@pytest.mark.parametrize("n_exch,partitioned", [(6, False), (30, False), (30, True)])
+def test_incremental_updates_patch_the_kept_input(n_exch, partitioned):
+    """f3, incremental re-marshalling: after an accepted update between KNOWN vertices the session
+    sends only the two changed entries to the input kept on the device (fwx_matrix_patch_input) and
+    runs the full solve again; a new vertex (or a new exchange) goes through the full buildMatrix +
+    upload.  Every answer -- rate and the reference's exact `_path` -- must equal that of a FRESH
+    session fed the same rates (which always marshals from scratch).  6 exchanges: < 256 vertices,
+    hops resident, single-launch / per-k engines; 30 exchanges: >= 256 vertices, fused engine with
+    the trace; partitioned: the same through four logical partitions."""
+    rnd = np.random.default_rng(1000 + n_exch)
+    ccys = ["C%02d" % i for i in range(10)]
+    price = dict(zip(ccys, 0.5 + 1.5 * rnd.random(len(ccys))))
+    log = []                                           # every accepted update, in order
+
+    def quote(exch, a, b, t):
+        fwd = price[b] / price[a] * (0.97 + 0.03 * rnd.random())
+        bkd = price[a] / price[b] * (0.97 + 0.03 * rnd.random())
+        return (t, exch, a, b, fwd, bkd)
+
+    s = host.Session(device=0)
+    if partitioned:
+        s.set_devices([0, 0, 0, 0], min_vertices=0)
+    t = 1000
+    for e in range(n_exch):
+        for i in range(len(ccys)):
+            for j in range(i + 1, len(ccys)):
+                if rnd.random() < 0.5:
+                    log.append(quote("E%02d" % e, ccys[i], ccys[j], t))
+                    assert s.update_rates(*log[-1])
+    vertices = sorted({(r[1], c) for r in log for c in (r[2], r[3])})
+    assert (len(vertices) >= 256) == (n_exch == 30)
+
+    def check(n_queries=25):
+        fresh = host.Session(device=0)
+        for r in log:
+            fresh.update_rates(*r)
+        vs = sorted({(r[1], c) for r in log for c in (r[2], r[3])})
+        for _ in range(n_queries):
+            a, b = (vs[int(x)] for x in rnd.integers(0, len(vs), 2))
+            try:
+                want = fresh.find_best_rate(a, b)
+            except host.AlgoError as e:
+                with pytest.raises(host.AlgoError) as e2:
+                    s.find_best_rate(a, b)
+                assert str(e2.value) == str(e)
+                continue
+            assert s.find_best_rate(a, b) == want
+
+    check()
+    assert s.solves == 1 and s.patched_solves == 0            # first solve: full marshal
+    for step in range(6):                                       # re-quotes with CHANGED prices
+        for _ in range(int(rnd.integers(1, 4))):
+            t += 1
+            old = log[int(rnd.integers(0, len(log)))]
+            log.append(quote(old[1], old[2], old[3], t))
+            assert s.update_rates(*log[-1])
+        check(12)
+        assert s.solves == 2 + step and s.patched_solves == 1 + step
+    # a pair of known vertices that had no rate yet: still two entries (rate, next and hops change)
+    exch = "E00"
+    have = {(r[2], r[3]) for r in log if r[1] == exch} | {(r[3], r[2]) for r in log if r[1] == exch}
+    known = sorted({c for r in log if r[1] == exch for c in (r[2], r[3])})
+    missing = [(a, b) for a in known for b in known if a < b and (a, b) not in have]
+    before = (s.solves, s.patched_solves)
+    if missing:
+        t += 1
+        log.append(quote(exch, missing[0][0], missing[0][1], t))
+        assert s.update_rates(*log[-1])
+        check(12)
+        assert (s.solves, s.patched_solves) == (before[0] + 1, before[1] + 1)
+    # a NEW vertex renumbers the matrix: full marshal, then patching resumes
+    before = (s.solves, s.patched_solves)
+    t += 1
+    log.append(quote("ZNEW", ccys[0], ccys[1], t))
+    assert s.update_rates(*log[-1])
+    check(12)
+    assert (s.solves, s.patched_solves) == (before[0] + 1, before[1])
+    t += 1
+    log.append(quote("ZNEW", ccys[0], ccys[1], t))
+    assert s.update_rates(*log[-1])
+    check(12)
+    assert (s.solves, s.patched_solves) == (before[0] + 2, before[1] + 1)
+    r1, n1, h1 = s.solved_matrix()                              # the host copy was patched too
+    fresh = host.Session(device=0)
+    for r in log:
+        fresh.update_rates(*r)
+    r2, n2, h2 = fresh.solved_matrix()
+    assert_bits_equal(r1, r2, "rate")
+    assert np.array_equal(n1, n2) and np.array_equal(h1, h2)
+
+
 def test_find_best_rate_unknown_vertices_keep_state_and_cache():
     pr = load_golden("process_requests.json")
     s = _session_with(pr["rates_ex2"])

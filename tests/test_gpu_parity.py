@@ -777,6 +777,56 @@ def test_solves_on_different_host_threads_overlap_on_the_device():
     assert rate_four > 1.5 * rate_one, (rate_one, rate_four)
 
 
+@pytest.mark.parametrize("devices", [None, [0, 0, 0]])
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+def test_kept_input_and_patch(devices, dtype):
+    """fwx_matrix_keep_input / fwx_matrix_patch_input: a few entries of the kept input are replaced
+    on the device and the (full) solve of the patched input equals the solve of the same matrix
+    uploaded whole -- single-device and partitioned handles, with next + hops and the path trace."""
+    n = 300
+    rate, nxt, hops = synth.make("d2", n, dtype, seed=8)
+    kw = dict(devices=devices) if devices else dict(device=0)
+    with engine.DeviceMatrix(n, dtype, with_next=True, with_hops=True, **kw) as dm:
+        dm.enable_path_log()
+        with pytest.raises(engine.FwxError):
+            dm.patch_input([5], [1.0])                          # nothing kept yet
+        dm.keep_input()
+        with pytest.raises(engine.FwxError):
+            dm.patch_input([5], [1.0])                          # kept, but no upload yet
+        dm.upload(rate, nxt, hops)
+        dm.solve()
+        rnd = np.random.default_rng(4)
+        for step in range(3):
+            idx = rnd.integers(0, n * n, 6).astype(np.int64)
+            idx = idx[(idx // n) != (idx % n)]
+            # (only ever lower a quote: the market stays free of arbitrage and the lists stay short)
+            vals = (rate.flat[idx] * (0.9 + 0.1 * rnd.random(len(idx)))).astype(dtype)
+            if step == 1:
+                vals[0] = 0                                     # an edge disappears: no route, no path
+            nv = np.where(vals != 0, idx % n, -1).astype(np.int32)
+            hv = (vals != 0).astype(np.int32)
+            rate.flat[idx], nxt.flat[idx], hops.flat[idx] = vals, nv, hv
+            dm.patch_input(idx, vals, nv, hv)
+            u = dm.solve(count_updates=True)
+            er, en, eh = rate.copy(), nxt.copy(), hops.copy()
+            eu = oracle.relax(er, en, eh)
+            gr, gn, gh = dm.download()
+            assert_bits_equal(gr, er, "rate after patch %d" % step)
+            assert_bits_equal(gn, en, "next after patch %d" % step)
+            assert_bits_equal(gh, eh, "hops after patch %d" % step)
+            assert u == eu
+            # the trace (and its next0) follow the patched input
+            with engine.DeviceMatrix(n, dtype, with_next=True) as ref:
+                ref.enable_path_log()
+                ref.upload(rate, nxt)
+                ref.solve()
+                src = rnd.integers(0, n, 40).astype(np.int32)
+                dst = rnd.integers(0, n, 40).astype(np.int32)
+                assert dm.query_exact_batch(src, dst) == ref.query_exact_batch(src, dst)
+        with pytest.raises(engine.FwxError):
+            dm.patch_input([n * n], [1.0])                      # index out of range
+
+
 def test_caller_supplied_stream_and_v1_opts_struct():
     """fwx_opts.stream (ABI v2): the blocking call runs on the caller's stream, so work queued on it
     beforehand is ordered before the solve -- here the upload of the input itself, asynchronously on
