@@ -1160,10 +1160,14 @@ template <> struct FusedCfg<double, true> { static constexpr int BS = 16, MINW =
 
 // Below ~512 full-size tiles the launch is bound by the latency of ONE tile (64 pivots folded into
 // 64 entries per thread); 64 x 64 tiles give 4x the workgroups and a quarter of the serial work.
-static bool small_tiles(int n, int rows)
+static bool small_tiles(int n, int rows, long long thresh = 512)
 {
-    return (long long)((n + 127) / 128) * ((rows + 127) / 128) < 512;
+    return (long long)((n + 127) / 128) * ((rows + 127) / 128) < thresh;
 }
+// The arg kernel keeps a tile's workgroup busy for longer (fold + re-scan) and runs 3 workgroups per
+// CU: its 64 x 64 form pays off up to larger matrices (measured, rates + next: N = 4096 9.54 -> 8.8
+// ms, N = 6144 23.3 -> 21.8 ms, N = 8192 unchanged; gpurun_out/r02_run15_tiles.log).
+static bool small_tiles_arg(int n, int rows) { return small_tiles(n, rows, 2400); }
 
 __global__ __launch_bounds__(256) void nonneg_check_f64(const double *rate, const int32_t *next,
                                                         size_t count, int *flag)
@@ -1198,7 +1202,7 @@ static bool launch_max_form(const FusedArgs<float> &a, dim3 grid, dim3 block, in
     const int ct_vec = ((uintptr_t)a.ct % 16 == 0 && a.ct_ld % 4 == 0) ? 1 : 0;
     if (a.next) {
         // rates + next-hops (+ trace, + hops): max-form fold, then arg re-scan of the moved entries
-        if (small_tiles(a.n, a.rows)) {
+        if (small_tiles_arg(a.n, a.rows)) {
             const dim3 g((unsigned)((a.n + 63) / 64), (unsigned)((a.rows + 63) / 64));
             hipLaunchKernelGGL((fused_main_arg<3, 4>), g, block, 0, s, a.rate, a.next, a.rows, a.n, a.row0,
                                a.k0, a.bt, a.w, a.ct, a.cnt, a.ct_ld, ct_vec, skip_lo, skip_hi, last,
