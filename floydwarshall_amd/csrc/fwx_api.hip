@@ -75,9 +75,35 @@ template <typename T> bool fused_ok(int n, const void *rate, const int32_t *)
 
 // Single-GPU solve of pivots [k_begin,k_end) with the fused engine.  Per block of <= 64 pivots:
 // snapshot panel W_b, pivot-column snapshots for all rows, main kernel over all rows.
-// Look-ahead: the panel chain of block b+1 only needs the 64 pivot ROWS of b+1 at time k1, so
-// main(b) runs on those rows first, then the snapshot panel of b+1 runs on a side stream while
-// main(b) sweeps the rest of the matrix.  ws: see fused_ws_bytes.
+//
+// Look-ahead.  The panel chain of block b+1 only needs the 64 pivot ROWS of b+1 (rowpanel) and the 64
+// pivot COLUMNS of b+1 (colpanel) as pass b leaves them.
+//   rows only (small matrices): main(b) runs on the next block's rows first, then their rowpanel
+//     runs on a side stream while main(b) sweeps the rest; colpanel(b+1) follows main(b).
+//   symmetric (n >= kSymmetricMinN, 64-aligned blocks): the side stream relaxes the next block's
+//     rows AND columns with pass b's panels, then runs rowpanel(b+1) and colpanel(b+1) -- all of it
+//     beside main(b), which leaves those rows and columns alone.  The main stream then carries
+//     nothing but main kernels back to back: 37-44 us of colpanel + look-ahead launch + gaps per
+//     pass leave the critical path (616 us per pass at N = 16384 f32 rates).  The side chain takes
+//     ~120 us per pass whatever n is, so it pays once a main launch is longer than that: measured
+//     (gpurun_out/r02_run20_*.log, f32) rates only 4096: 5.60 -> 6.28 ms, 6144: 11.8 -> 12.0,
+//     8192: 22.8 -> 21.8, 16384: 155.8 -> 153.6; with next-hops 4096: 8.68 -> 8.34, 6144:
+//     21.96 -> 20.55, 8192: 47.1 -> 45.3, 16384: 303.9 -> 295.7 (with the trace 324.0 -> 312.4).
+// ws: see fused_ws_bytes.
+constexpr int kSymmetricMinN = 8192, kSymmetricMinNWithNext = 4096;
+// FWX_SYMMETRIC_MIN_N overrides the threshold (tests force the symmetric schedule at small sizes,
+// tuning runs switch it off with a huge value); read on every solve, the environment may change.
+static int symmetric_min_n(bool with_next)
+{
+    const char *e = getenv("FWX_SYMMETRIC_MIN_N");
+    if (e && *e) {
+        char *end = nullptr;
+        const long v = strtol(e, &end, 10);
+        if (end != e && v >= 0 && v <= INT32_MAX) return (int)v;
+    }
+    return with_next ? kSymmetricMinNWithNext : kSymmetricMinN;
+}
+
 template <typename T>
 int fused_range(T *rate, int32_t *next, int32_t *hops, int n, int k_begin, int k_end, void *ws,
                 unsigned long long *d_updates, hipStream_t s, fwx::PathLog plog, bool nonneg,
@@ -85,16 +111,15 @@ int fused_range(T *rate, int32_t *next, int32_t *hops, int n, int k_begin, int k
 {
     char *p = (char *)ws;
     const int ld = (n + 3) & ~3;
-    T *wbuf[2];
-    int32_t *whbuf[2] = {nullptr, nullptr}, *cht = nullptr;
-    wbuf[0] = (T *)p;              p += (size_t)FWX_FUSED_B * n * sizeof(T);
-    wbuf[1] = (T *)p;              p += (size_t)FWX_FUSED_B * n * sizeof(T);
-    T *ct = (T *)p;                p += (size_t)FWX_FUSED_B * ld * sizeof(T);
-    int32_t *cnt = (int32_t *)p;   p += (size_t)FWX_FUSED_B * ld * sizeof(int32_t);
+    T *wbuf[2], *ctbuf[2];
+    int32_t *cntbuf[2];
+    int32_t *whbuf[2] = {nullptr, nullptr}, *chtbuf[2] = {nullptr, nullptr};
+    for (int b = 0; b < 2; ++b) { wbuf[b] = (T *)p;          p += (size_t)FWX_FUSED_B * n * sizeof(T); }
+    for (int b = 0; b < 2; ++b) { ctbuf[b] = (T *)p;         p += (size_t)FWX_FUSED_B * ld * sizeof(T); }
+    for (int b = 0; b < 2; ++b) { cntbuf[b] = (int32_t *)p;  p += (size_t)FWX_FUSED_B * ld * sizeof(int32_t); }
     if (hops) {                    // hops panels of the pivot rows + hops of the pivot columns
-        whbuf[0] = (int32_t *)p;   p += (size_t)FWX_FUSED_B * n * sizeof(int32_t);
-        whbuf[1] = (int32_t *)p;   p += (size_t)FWX_FUSED_B * n * sizeof(int32_t);
-        cht = (int32_t *)p;        p += (size_t)FWX_FUSED_B * ld * sizeof(int32_t);
+        for (int b = 0; b < 2; ++b) { whbuf[b] = (int32_t *)p;  p += (size_t)FWX_FUSED_B * n * sizeof(int32_t); }
+        for (int b = 0; b < 2; ++b) { chtbuf[b] = (int32_t *)p; p += (size_t)FWX_FUSED_B * ld * sizeof(int32_t); }
     }
     if (k_end <= k_begin) return FWX_OK;
     SideStream local_side;
@@ -107,47 +132,76 @@ int fused_range(T *rate, int32_t *next, int32_t *hops, int n, int k_begin, int k
 
     fwx::FusedArgs<T> a;
     a.rate = rate; a.next = next; a.rows = n; a.n = n; a.row0 = 0;
-    a.ct = ct; a.cnt = next ? cnt : nullptr; a.ct_ld = ld; a.updates = d_updates;
+    a.ct_ld = ld; a.updates = d_updates;
     a.nonneg = nonneg;     // the caller has run the domain check (route_solve)
     a.plog = plog;         // path trace: kept by all three kernels of a pass (needs next)
     a.hops = hops;         // hops: carried by the panels, written by the main kernel (needs next)
-    a.cht = cht;
+    auto bind = [&](int k0, int bt, int bi) {       // pass (k0, bt) reads / writes buffer set bi
+        a.k0 = k0; a.bt = bt; a.w = wbuf[bi]; a.wh = whbuf[bi];
+        a.ct = ctbuf[bi]; a.cnt = next ? cntbuf[bi] : nullptr; a.cht = chtbuf[bi];
+    };
+    auto rowpanel = [&](int k0, int bt, int bi, hipStream_t st) {
+        return fwx::launch_fused_panel<T>(rate + (size_t)k0 * n, n, k0, bt, wbuf[bi], st,
+                                          plog_rows(plog, (size_t)k0 * n),
+                                          hops ? hops + (size_t)k0 * n : nullptr, whbuf[bi]);
+    };
+    const bool symmetric_ok = n >= symmetric_min_n(next != nullptr) && k_begin % FWX_FUSED_B == 0;
 
     int bi = 0;
+    bool col_ready = false;        // colpanel of the current pass already ran (on the side stream)
     {
         const int bt = k_end - k_begin < FWX_FUSED_B ? k_end - k_begin : FWX_FUSED_B;
-        FWX_HIP(fwx::launch_fused_panel<T>(rate + (size_t)k_begin * n, n, k_begin, bt, wbuf[0], s,
-                                           plog_rows(plog, (size_t)k_begin * n),
-                                           hops ? hops + (size_t)k_begin * n : nullptr, whbuf[0]));
+        FWX_HIP(rowpanel(k_begin, bt, 0, s));
     }
     for (int k0 = k_begin; k0 < k_end; k0 += FWX_FUSED_B, bi ^= 1) {
         const int bt = k_end - k0 < FWX_FUSED_B ? k_end - k0 : FWX_FUSED_B;
         const int k1 = k0 + bt;
-        a.k0 = k0; a.bt = bt; a.w = wbuf[bi]; a.wh = whbuf[bi];
-        FWX_HIP(fwx::launch_fused_colpanel<T>(a, s));
+        bind(k0, bt, bi);
+        if (!col_ready) FWX_HIP(fwx::launch_fused_colpanel<T>(a, s));
+        col_ready = false;
         if (k1 < k_end) {
             const int bt1 = k_end - k1 < FWX_FUSED_B ? k_end - k1 : FWX_FUSED_B;
-            // the next panel's rows first ...
-            FWX_HIP(fwx::launch_fused_main<T>(a, k1, k1 + bt1, s));
-            FWX_HIP(hipEventRecord(side.rows_done, s));
-            FWX_HIP(hipStreamWaitEvent(side.s, side.rows_done, 0));
-            // ... their snapshot panel on the side stream ...
-            FWX_HIP(fwx::launch_fused_panel<T>(rate + (size_t)k1 * n, n, k1, bt1, wbuf[bi ^ 1], side.s,
-                                               plog_rows(plog, (size_t)k1 * n),
-                                               hops ? hops + (size_t)k1 * n : nullptr, whbuf[bi ^ 1]));
-            FWX_HIP(hipEventRecord(side.panel_done, side.s));
-            // ... while the rest of the matrix is relaxed on the main stream
-            if (k1 % 8 == 0 && bt1 % 8 == 0) {
-                FWX_HIP(fwx::launch_fused_main<T>(a, 0, n, s, k1, k1 + bt1));   // one launch, rows skipped
+            if (symmetric_ok && bt1 == FWX_FUSED_B) {
+                // everything up to here (the previous main, this pass's panels) precedes the side chain
+                FWX_HIP(hipEventRecord(side.main_done, s));
+                FWX_HIP(hipStreamWaitEvent(side.s, side.main_done, 0));
+                // side: pass b on the next block's rows (all columns), then on its columns (the
+                // other rows) ...
+                FWX_HIP(fwx::launch_fused_main<T>(a, k1, k1 + bt1, side.s));
+                FWX_HIP(fwx::launch_fused_main<T>(a, 0, n, side.s, k1, k1 + bt1,
+                                                  fwx::FusedCols::only(k1, k1 + bt1)));
+                // ... then the next pass's panels into the other buffer set
+                FWX_HIP(rowpanel(k1, bt1, bi ^ 1, side.s));
+                bind(k1, bt1, bi ^ 1);
+                FWX_HIP(fwx::launch_fused_colpanel<T>(a, side.s));
+                FWX_HIP(hipEventRecord(side.panel_done, side.s));
+                // main: pass b everywhere else
+                bind(k0, bt, bi);
+                FWX_HIP(fwx::launch_fused_main<T>(a, 0, n, s, k1, k1 + bt1,
+                                                  fwx::FusedCols::except(k1, k1 + bt1)));
+                FWX_HIP(hipStreamWaitEvent(s, side.panel_done, 0));
+                col_ready = true;
             } else {
-                FWX_HIP(fwx::launch_fused_main<T>(a, 0, k1, s));
-                FWX_HIP(fwx::launch_fused_main<T>(a, k1 + bt1, n, s));
+                // the next panel's rows first ...
+                FWX_HIP(fwx::launch_fused_main<T>(a, k1, k1 + bt1, s));
+                FWX_HIP(hipEventRecord(side.rows_done, s));
+                FWX_HIP(hipStreamWaitEvent(side.s, side.rows_done, 0));
+                // ... their snapshot panel on the side stream ...
+                FWX_HIP(rowpanel(k1, bt1, bi ^ 1, side.s));
+                FWX_HIP(hipEventRecord(side.panel_done, side.s));
+                // ... while the rest of the matrix is relaxed on the main stream
+                if (k1 % 8 == 0 && bt1 % 8 == 0) {
+                    FWX_HIP(fwx::launch_fused_main<T>(a, 0, n, s, k1, k1 + bt1));   // one launch, rows skipped
+                } else {
+                    FWX_HIP(fwx::launch_fused_main<T>(a, 0, k1, s));
+                    FWX_HIP(fwx::launch_fused_main<T>(a, k1 + bt1, n, s));
+                }
+                FWX_HIP(hipStreamWaitEvent(s, side.panel_done, 0));
             }
-            FWX_HIP(hipStreamWaitEvent(s, side.panel_done, 0));
         } else {
             FWX_HIP(fwx::launch_fused_main<T>(a, 0, n, s));
         }
-        const int rc = thr.tick(s, 4);
+        const int rc = thr.tick(s, 6);
         if (rc) return rc;
     }
     // the side stream's work is ordered before `s` by the last panel_done wait (or it never ran)

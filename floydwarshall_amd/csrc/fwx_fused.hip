@@ -68,6 +68,19 @@ template <> struct IVec<2> { typedef int type __attribute__((ext_vector_type(2))
 
 constexpr int B = FWX_FUSED_B;
 
+// s_waitcnt immediate (gfx9 encoding: vmcnt = bits 3:0 and 15:14, expcnt 6:4, lgkmcnt 11:8):
+// all vector-memory loads have returned, the other counters untouched.
+#define FWX_WAIT_VMCNT0 0x0F70
+
+// Column controls of a main-kernel launch (symmetric look-ahead, fused_range in fwx_api.hip):
+// the grid's column tiles start at tile jt0 (a launch over a window of columns), and columns
+// [cskip_lo, cskip_hi) (multiples of 4) are left alone -- another launch of the same pass owns them.
+struct ColWin {
+    int jt0, cskip_lo, cskip_hi;
+    __host__ __device__ bool skips(int j) const { return j >= cskip_lo && j < cskip_hi; }
+    __host__ __device__ bool clear_of(int j_lo, int j_hi) const { return j_hi <= cskip_lo || j_lo >= cskip_hi; }
+};
+
 // Workgroup barrier that orders LDS traffic only.  __syncthreads() also drains the vector-memory
 // counter (vmcnt(0)), i.e. waits for the snapshot stores each panel step issues to reach memory
 // (~1 us per step, 64 steps per panel); nothing in these kernels reads those stores back.
@@ -351,7 +364,7 @@ __global__ __launch_bounds__(256, MINW) void fused_main(T *rate, int32_t *next, 
                                                         int skip_lo, int skip_hi,
                                                         unsigned long long *updates, int32_t *last,
                                                         int32_t *hops, const int32_t *cht,
-                                                        const int32_t *wh)
+                                                        const int32_t *wh, ColWin cw)
 {
     constexpr bool HAS_LAST = TRACK;
     static_assert(!HAS_LAST || HAS_NEXT, "the path trace and hops ride on the next-hop variant");
@@ -369,7 +382,7 @@ __global__ __launch_bounds__(256, MINW) void fused_main(T *rate, int32_t *next, 
 
     const int tid = threadIdx.x;
     const int i_base = blockIdx.y * TI;
-    const int j_base = blockIdx.x * TJ;
+    const int j_base = (blockIdx.x + cw.jt0) * TJ;
     if (COUNT && tid == 0) s_cnt = 0;
 
     // ---- this thread's 8 x (2 vectors) register tile -------------------------------------------
@@ -383,7 +396,7 @@ __global__ __launch_bounds__(256, MINW) void fused_main(T *rate, int32_t *next, 
 #pragma unroll
     for (int h = 0; h < NH; ++h) {
         const int j = j_base + h * HJ + tj * VW;
-        jok[h] = j < n;
+        jok[h] = j < n && !cw.skips(j);
         jcol[h] = jok[h] ? j : n - VW;
     }
     V x[RI][NH];
@@ -545,6 +558,115 @@ __global__ __launch_bounds__(256, MINW) void fused_main(T *rate, int32_t *next, 
     }
 }
 
+typedef float F32x4 __attribute__((ext_vector_type(4)));
+
+// One pivot pair of the max-form fold on a thread's RI x (NH x 4) register tile: operands from the
+// LDS stage ([u]: pivot u of the pair), all 16 products of a row first, then its 8 folds, so a
+// v_max3 never issues right behind the multiplies it depends on.  Two plain v_mul_f32 rather than
+// one v_pk_mul_f32: same issue cycles per pair, no register-pair shuffles (measured).
+template <int RI, int NH>
+__device__ __forceinline__ void max_fold_pair(const float (&sWp)[2][64 * NH], const float (&sCp)[2][16 * RI],
+                                              int ti, int tj, F32x4 (&x)[RI][NH])
+{
+    float c[RI][2], wv[NH][4][2];
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+#pragma unroll
+        for (int q = 0; q < RI / 4; ++q) {
+            const F32x4 cv = *reinterpret_cast<const F32x4 *>(&sCp[u][ti * RI + q * 4]);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) c[q * 4 + e][u] = cv[e];
+        }
+#pragma unroll
+        for (int h = 0; h < NH; ++h) {
+            const F32x4 wq = *reinterpret_cast<const F32x4 *>(&sWp[u][h * 64 + tj * 4]);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) wv[h][e][u] = wq[e];
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < RI; ++r) {
+        float p0[NH][4], p1[NH][4];
+#pragma unroll
+        for (int h = 0; h < NH; ++h)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                asm("v_mul_f32 %0, %1, %2" : "=v"(p0[h][e]) : "v"(c[r][0]), "v"(wv[h][e][0]));
+                asm("v_mul_f32 %0, %1, %2" : "=v"(p1[h][e]) : "v"(c[r][1]), "v"(wv[h][e][1]));
+            }
+#pragma unroll
+        for (int h = 0; h < NH; ++h)
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+                x[r][h][e] = __builtin_fmaxf(__builtin_fmaxf(x[r][h][e], p0[h][e]), p1[h][e]);
+    }
+}
+
+// Interior tiles of a full pass (the tile lies inside the slab, off the diagonal, away from the
+// pivot columns and from the look-ahead rows; bt == B): nothing to bound-check, nothing to patch,
+// nothing to restore.  At N = 16384 that is 98 % of the tiles, and the general path executes about
+// 900 instructions of address arithmetic, predicates and branches per tile and wave around the
+// 6144 of the fold -- scalar and 64-bit VALU work that issues at 4+ cycles, i.e. a fifth of the
+// kernel (tools/experiments/gen_loop_replay.py: the fold loop alone runs at 1.17 ns per
+// instruction, which would be 460 us per launch; the launch took 618).
+template <int RI, int NH>
+__device__ __forceinline__ void main_max_interior(float *rate, int n, int i_base, int j_base, const float *w,
+                                                  const float *ct, int ct_ld,
+                                                  float (&sW)[2][8][2][64 * NH], float (&sC)[2][8][2][16 * RI])
+{
+    constexpr int TI = 16 * RI, TJ = 64 * NH, BS = 16, NS = B / BS;
+    const int tid = threadIdx.x;
+    const int ti = tid >> 4, tj = tid & 15;
+    const int sp = tid >> 5, sv = tid & 31;
+    const bool sw_role = sv * 4 < TJ, sc_role = sv * 4 < TI;
+    const float *wp = w + (size_t)(2 * sp) * n + j_base + sv * 4;
+    const float *cp = ct + (size_t)(2 * sp) * ct_ld + i_base + sv * 4;
+    F32x4 pw[2], pc[2];
+    auto prefetch = [&]() {
+        if (sw_role) {
+            pw[0] = *reinterpret_cast<const F32x4 *>(wp);
+            pw[1] = *reinterpret_cast<const F32x4 *>(wp + n);
+        }
+        if (sc_role) {
+            pc[0] = *reinterpret_cast<const F32x4 *>(cp);
+            pc[1] = *reinterpret_cast<const F32x4 *>(cp + ct_ld);
+        }
+        wp += (size_t)BS * n;
+        cp += (size_t)BS * ct_ld;
+    };
+    auto commit = [&](int buf) {
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            if (sw_role) *reinterpret_cast<F32x4 *>(&sW[buf][sp][u][sv * 4]) = pw[u];
+            if (sc_role) *reinterpret_cast<F32x4 *>(&sC[buf][sp][u][sv * 4]) = pc[u];
+        }
+    };
+    prefetch();
+    float *xp = rate + (size_t)(i_base + ti * RI) * n + j_base + tj * 4;
+    F32x4 x[RI][NH];
+#pragma unroll
+    for (int r = 0; r < RI; ++r)
+#pragma unroll
+        for (int h = 0; h < NH; ++h) x[r][h] = *reinterpret_cast<const F32x4 *>(xp + (size_t)r * n + h * 64);
+    commit(0);
+    __syncthreads();
+    __builtin_amdgcn_s_waitcnt(FWX_WAIT_VMCNT0);   // the tile is complete here (see fused_main_max)
+#pragma unroll
+    for (int s = 0; s < NS; ++s) {
+        if (s + 1 < NS) prefetch();                  // in flight during the fold below
+#pragma unroll 1
+        for (int tp = 0; tp < BS / 2; ++tp) max_fold_pair<RI, NH>(sW[s & 1][tp], sC[s & 1][tp], ti, tj, x);
+        if (s + 1 < NS) {
+            commit((s & 1) ^ 1);
+            __syncthreads();
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < RI; ++r)
+#pragma unroll
+        for (int h = 0; h < NH; ++h) *reinterpret_cast<F32x4 *>(xp + (size_t)r * n + h * 64) = x[r][h];
+}
+
 // ------------------------------------------------------------------------------------------------
 // fused_main_max: rates-only f32 main kernel for matrices whose entries are all >= +0 and not NaN
 // (what the reference's parser guarantees: rates > 0, Parsers.hs:40; unreachable = +0.0).
@@ -564,7 +686,7 @@ template <int MINW, int UNR, int RI, int NH>
 __global__ __launch_bounds__(256, MINW) void fused_main_max(float *rate, int rows, int n, int row0,
                                                             int k0, int bt, const float *w,
                                                             const float *ct, int ct_ld, int ct_vec,
-                                                            int skip_lo, int skip_hi)
+                                                            int skip_lo, int skip_hi, ColWin cw)
 {
     typedef float V4 __attribute__((ext_vector_type(4)));
     // 16 pivots (8 pairs) per LDS stage, two stages resident: while stage s is being folded the
@@ -578,9 +700,21 @@ __global__ __launch_bounds__(256, MINW) void fused_main_max(float *rate, int row
 
     const int tid = threadIdx.x;
     const int i_base = blockIdx.y * TI;
-    const int j_base = blockIdx.x * TJ;
+    const int j_base = (blockIdx.x + cw.jt0) * TJ;
     const int ti = tid >> 4, tj = tid & 15;
     const int i0 = i_base + ti * RI;
+    {
+        const int gi = row0 + i_base;
+        const bool interior = bt == B && ct_vec && i_base + TI <= rows && j_base + TJ <= n &&
+                              !(gi < j_base + TJ && j_base < gi + TI) &&          // off the diagonal
+                              (k0 + bt <= j_base || k0 >= j_base + TJ) &&        // no pivot column
+                              (i_base + TI <= skip_lo || i_base >= skip_hi) &&   // no look-ahead rows
+                              cw.clear_of(j_base, j_base + TJ);                  // ... or columns
+        if (interior) {                                                          // workgroup-uniform
+            main_max_interior<RI, NH>(rate, n, i_base, j_base, w, ct, ct_ld, sW, sC);
+            return;
+        }
+    }
     const bool skip = i0 >= skip_lo && i0 < skip_hi;   // rows done by the look-ahead launch
     const float nanv = qnan<float>();
 
@@ -628,7 +762,7 @@ __global__ __launch_bounds__(256, MINW) void fused_main_max(float *rate, int row
 #pragma unroll
     for (int h = 0; h < NH; ++h) {
         const int j = j_base + h * HJ + tj * 4;
-        jok[h] = j < n;
+        jok[h] = j < n && !cw.skips(j);
         jcol[h] = jok[h] ? j : n - 4;
     }
     V4 x[RI][NH];
@@ -644,57 +778,19 @@ __global__ __launch_bounds__(256, MINW) void fused_main_max(float *rate, int row
 
     commit(0);
     __syncthreads();
+    // The tile is complete HERE, once.  Without this the compiler's wait-count pass carries "x may
+    // still be loading" into the fold loop and guards every first use of a tile register with
+    // s_waitcnt vmcnt(k), k = 15..0 -- and vmcnt counts the stage-(s+1) operand loads issued just
+    // above the fold as well, so each stage stalled on its own prefetch.
+    __builtin_amdgcn_s_waitcnt(FWX_WAIT_VMCNT0);
 
     int buf = 0;
     for (int s0 = 0; s0 < bt; s0 += BS, buf ^= 1) {
         const bool more = s0 + BS < bt;
         if (more) prefetch(s0 + BS);             // in flight during the fold below
         const int np = skip ? 0 : (min(BS, bt - s0) + 1) / 2;
-        // operands of one pivot pair: LDS -> registers ([..][u]: pivot u of the pair)
-        auto load_ops = [&](int tp, float (&c)[RI][2], float (&wv)[NH][4][2]) {
-#pragma unroll
-            for (int u = 0; u < 2; ++u) {
-#pragma unroll
-                for (int q = 0; q < RI / 4; ++q) {
-                    const V4 cv = *reinterpret_cast<const V4 *>(&sC[buf][tp][u][ti * RI + q * 4]);
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) c[q * 4 + e][u] = cv[e];
-                }
-#pragma unroll
-                for (int h = 0; h < NH; ++h) {
-                    const V4 wq = *reinterpret_cast<const V4 *>(&sW[buf][tp][u][h * HJ + tj * 4]);
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) wv[h][e][u] = wq[e];
-                }
-            }
-        };
-        auto fold_pair = [&](const float (&c)[RI][2], const float (&wv)[NH][4][2]) {
-#pragma unroll
-            for (int r = 0; r < RI; ++r) {
-                // All 16 products of this row first, then the 8 folds: a v_max3 never issues right
-                // behind the multiplies it depends on.  Two plain v_mul_f32 rather than one
-                // v_pk_mul_f32: same issue cycles per pair, no register-pair shuffles (measured).
-                float p0[NH][4], p1[NH][4];
-#pragma unroll
-                for (int h = 0; h < NH; ++h)
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        asm("v_mul_f32 %0, %1, %2" : "=v"(p0[h][e]) : "v"(c[r][0]), "v"(wv[h][e][0]));
-                        asm("v_mul_f32 %0, %1, %2" : "=v"(p1[h][e]) : "v"(c[r][1]), "v"(wv[h][e][1]));
-                    }
-#pragma unroll
-                for (int h = 0; h < NH; ++h)
-#pragma unroll
-                    for (int e = 0; e < 4; ++e)
-                        x[r][h][e] = __builtin_fmaxf(__builtin_fmaxf(x[r][h][e], p0[h][e]), p1[h][e]);
-            }
-        };
 #pragma unroll UNR
-        for (int tp = 0; tp < np; ++tp) {
-            float c[RI][2], wv[NH][4][2];
-            load_ops(tp, c, wv);
-            fold_pair(c, wv);
-        }
+        for (int tp = 0; tp < np; ++tp) max_fold_pair<RI, NH>(sW[buf][tp], sC[buf][tp], ti, tj, x);
         if (more) {
             commit(buf ^ 1);                      // the other buffer: nobody reads it now
             __syncthreads();
@@ -718,6 +814,96 @@ __global__ __launch_bounds__(256, MINW) void fused_main_max(float *rate, int row
     }
 }
 
+typedef double F64x2 __attribute__((ext_vector_type(2)));
+
+// One pivot of the f64 max-form fold on a thread's 8 x (4 x 2) register tile: the 8 products of a
+// row first, then its 8 folds.
+__device__ __forceinline__ void max_fold_f64(const double (&sWt)[128], const double (&sCt)[128], int ti, int tj,
+                                             F64x2 (&x)[8][4])
+{
+    double c[8], wv[4][2];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const F64x2 cv = *reinterpret_cast<const F64x2 *>(&sCt[ti * 8 + q * 2]);
+        c[q * 2] = cv[0];
+        c[q * 2 + 1] = cv[1];
+    }
+#pragma unroll
+    for (int h = 0; h < 4; ++h) {
+        const F64x2 wq = *reinterpret_cast<const F64x2 *>(&sWt[h * 32 + tj * 2]);
+        wv[h][0] = wq[0];
+        wv[h][1] = wq[1];
+    }
+#pragma unroll
+    for (int r = 0; r < 8; ++r) {
+        double p[4][2];
+#pragma unroll
+        for (int h = 0; h < 4; ++h) {
+            p[h][0] = c[r] * wv[h][0];
+            p[h][1] = c[r] * wv[h][1];
+        }
+#pragma unroll
+        for (int h = 0; h < 4; ++h) {
+            x[r][h][0] = fmax_t(x[r][h][0], p[h][0]);
+            x[r][h][1] = fmax_t(x[r][h][1], p[h][1]);
+        }
+    }
+}
+
+// Interior tiles of a full pass, f64: see main_max_interior.
+__device__ __forceinline__ void main_max_interior_f64(double *rate, int n, int i_base, int j_base, const double *w,
+                                                      const double *ct, int ct_ld, double (&sW)[2][8][128],
+                                                      double (&sC)[2][8][128])
+{
+    constexpr int BS = 8, NS = B / BS;
+    const int tid = threadIdx.x;
+    const int ti = tid >> 4, tj = tid & 15;
+    const int sp = tid >> 5, sv = tid & 31;
+    const double *wp = w + (size_t)sp * n + j_base + sv * 4;
+    const double *cp = ct + (size_t)sp * ct_ld + i_base + sv * 4;
+    F64x2 pw[2], pc[2];
+    auto prefetch = [&]() {
+        pw[0] = *reinterpret_cast<const F64x2 *>(wp);
+        pw[1] = *reinterpret_cast<const F64x2 *>(wp + 2);
+        pc[0] = *reinterpret_cast<const F64x2 *>(cp);
+        pc[1] = *reinterpret_cast<const F64x2 *>(cp + 2);
+        wp += (size_t)BS * n;
+        cp += (size_t)BS * ct_ld;
+    };
+    auto commit = [&](int buf) {
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            *reinterpret_cast<F64x2 *>(&sW[buf][sp][sv * 4 + 2 * u]) = pw[u];
+            *reinterpret_cast<F64x2 *>(&sC[buf][sp][sv * 4 + 2 * u]) = pc[u];
+        }
+    };
+    prefetch();
+    double *xp = rate + (size_t)(i_base + ti * 8) * n + j_base + tj * 2;
+    F64x2 x[8][4];
+#pragma unroll
+    for (int r = 0; r < 8; ++r)
+#pragma unroll
+        for (int h = 0; h < 4; ++h) x[r][h] = *reinterpret_cast<const F64x2 *>(xp + (size_t)r * n + h * 32);
+    commit(0);
+    __syncthreads();
+    __builtin_amdgcn_s_waitcnt(FWX_WAIT_VMCNT0);
+#pragma unroll 2
+    for (int s = 0; s < NS; ++s) {
+        const int buf = s & 1;
+        if (s + 1 < NS) prefetch();
+#pragma unroll 1
+        for (int t = 0; t < BS; ++t) max_fold_f64(sW[buf][t], sC[buf][t], ti, tj, x);
+        if (s + 1 < NS) {
+            commit(buf ^ 1);
+            __syncthreads();
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < 8; ++r)
+#pragma unroll
+        for (int h = 0; h < 4; ++h) *reinterpret_cast<F64x2 *>(xp + (size_t)r * n + h * 32) = x[r][h];
+}
+
 // ------------------------------------------------------------------------------------------------
 // fused_main_max_f64: the rates-only main kernel at the REFERENCE'S precision (Types.hs:26,
 // `_bestRate :: Double`), on the max-form domain (see fused_main_max: there the strict fold equals
@@ -733,7 +919,7 @@ template <int MINW>
 __global__ __launch_bounds__(256, MINW) void fused_main_max_f64(double *rate, int rows, int n, int row0,
                                                                 int k0, int bt, const double *w,
                                                                 const double *ct, int ct_ld, int ct_vec,
-                                                                int skip_lo, int skip_hi)
+                                                                int skip_lo, int skip_hi, ColWin cw)
 {
     typedef double V2 __attribute__((ext_vector_type(2)));
     constexpr int RI = 8, NH = 4, TI = 128, TJ = 128, HJ = 32, BS = 8;
@@ -743,9 +929,20 @@ __global__ __launch_bounds__(256, MINW) void fused_main_max_f64(double *rate, in
 
     const int tid = threadIdx.x;
     const int i_base = blockIdx.y * TI;
-    const int j_base = blockIdx.x * TJ;
+    const int j_base = (blockIdx.x + cw.jt0) * TJ;
     const int ti = tid >> 4, tj = tid & 15;
     const int i0 = i_base + ti * RI;
+    static_assert(NST == 1, "the interior path stages 8 pivots per round");
+    {
+        const int gi = row0 + i_base;
+        const bool interior = bt == B && ct_vec && (n & 1) == 0 && i_base + TI <= rows && j_base + TJ <= n &&
+                              !(gi < j_base + TJ && j_base < gi + TI) && (k0 + bt <= j_base || k0 >= j_base + TJ) &&
+                              (i_base + TI <= skip_lo || i_base >= skip_hi) && cw.clear_of(j_base, j_base + TJ);
+        if (interior) {                              // workgroup-uniform
+            main_max_interior_f64(rate, n, i_base, j_base, w, ct, ct_ld, sW, sC);
+            return;
+        }
+    }
     const bool skip = i0 >= skip_lo && i0 < skip_hi;
     const double nanv = qnan<double>();
 
@@ -789,7 +986,7 @@ __global__ __launch_bounds__(256, MINW) void fused_main_max_f64(double *rate, in
 #pragma unroll
     for (int h = 0; h < NH; ++h) {
         const int j = j_base + h * HJ + tj * 2;
-        jok[h] = j < n;
+        jok[h] = j < n && !cw.skips(j);
         jcol[h] = jok[h] ? j : n - 2;
     }
     V2 x[RI][NH];
@@ -805,50 +1002,17 @@ __global__ __launch_bounds__(256, MINW) void fused_main_max_f64(double *rate, in
 
     commit(0);
     __syncthreads();
+    __builtin_amdgcn_s_waitcnt(FWX_WAIT_VMCNT0);   // the tile is complete here: see fused_main_max
 
     int buf = 0;
     for (int s0 = 0; s0 < bt; s0 += BS, buf ^= 1) {
         const bool more = s0 + BS < bt;
         if (more) prefetch(s0 + BS);
         const int np = skip ? 0 : min(BS, bt - s0);
-        auto load_ops = [&](int t, double (&c)[RI], double (&wv)[NH][2]) {
-#pragma unroll
-            for (int q = 0; q < RI / 2; ++q) {
-                const V2 cv = *reinterpret_cast<const V2 *>(&sC[buf][t][ti * RI + q * 2]);
-                c[q * 2] = cv[0];
-                c[q * 2 + 1] = cv[1];
-            }
-#pragma unroll
-            for (int h = 0; h < NH; ++h) {
-                const V2 wq = *reinterpret_cast<const V2 *>(&sW[buf][t][h * HJ + tj * 2]);
-                wv[h][0] = wq[0];
-                wv[h][1] = wq[1];
-            }
-        };
-        auto fold = [&](const double (&c)[RI], const double (&wv)[NH][2]) {
-#pragma unroll
-            for (int r = 0; r < RI; ++r) {
-                double p[NH][2];                 // the 8 products of the row first, then the 8 folds
-#pragma unroll
-                for (int h = 0; h < NH; ++h) {
-                    p[h][0] = c[r] * wv[h][0];
-                    p[h][1] = c[r] * wv[h][1];
-                }
-#pragma unroll
-                for (int h = 0; h < NH; ++h) {
-                    x[r][h][0] = fmax_t(x[r][h][0], p[h][0]);
-                    x[r][h][1] = fmax_t(x[r][h][1], p[h][1]);
-                }
-            }
-        };
         // (reading pivot t+1's operands while pivot t is folded was tried: 423 ms against 405 ms at
         // N = 16384, and 16-pivot stages 466-490 ms: profiles/r02_experiments_not_adopted.txt)
 #pragma unroll 1
-        for (int t = 0; t < np; ++t) {
-            double cA[RI], wA[NH][2];
-            load_ops(t, cA, wA);
-            fold(cA, wA);
-        }
+        for (int t = 0; t < np; ++t) max_fold_f64(sW[buf][t], sC[buf][t], ti, tj, x);
         if (more) {
             commit(buf ^ 1);
             __syncthreads();
@@ -953,7 +1117,7 @@ __global__ __launch_bounds__(256, MINW) void fused_main_arg(float *rate, int32_t
                                                             const float *ct, const int32_t *cnt,
                                                             int ct_ld, int ct_vec, int skip_lo,
                                                             int skip_hi, int32_t *last, int32_t *hops,
-                                                            const int32_t *cht, const int32_t *wh)
+                                                            const int32_t *cht, const int32_t *wh, ColWin cw)
 {
     typedef float V4 __attribute__((ext_vector_type(4)));
     constexpr int TI = 16 * RI, TJ = 64, LCAP = 128;
@@ -966,7 +1130,8 @@ __global__ __launch_bounds__(256, MINW) void fused_main_arg(float *rate, int32_t
     const int tid = threadIdx.x;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int i_base = blockIdx.y * TI;
-    const int j_base = blockIdx.x * TJ;
+    const int j_base = (blockIdx.x + cw.jt0) * TJ;
+    if (cw.cskip_lo <= j_base && j_base + TJ <= cw.cskip_hi) return;   // the whole tile is someone else's
     const int ti = tid >> 4, tj = tid & 15;
     const int i0 = i_base + ti * RI;
     const bool skip = i0 >= skip_lo && i0 < skip_hi;   // rows done by the look-ahead launch
@@ -1001,7 +1166,7 @@ __global__ __launch_bounds__(256, MINW) void fused_main_arg(float *rate, int32_t
     }
 
     const int jcol = j_base + tj * 4;
-    const bool jok = jcol < n;
+    const bool jok = jcol < n && !cw.skips(jcol);
     const int jc = jok ? jcol : n - 4;
     V4 xa[RI], xb[RI];
     int sid[RI][4];
@@ -1196,59 +1361,51 @@ hipError_t launch_nonneg_check(const double *rate, const int32_t *next, size_t c
 
 // f32, rates only, no update counting, domain verified by the caller: the max3 kernel.
 static bool launch_max_form(const FusedArgs<float> &a, dim3 grid, dim3 block, int skip_lo,
-                            int skip_hi, hipStream_t s, int32_t *last)
+                            int skip_hi, hipStream_t s, int32_t *last, bool small, ColWin cw)
 {
     if (!a.nonneg || a.updates) return false;
     const int ct_vec = ((uintptr_t)a.ct % 16 == 0 && a.ct_ld % 4 == 0) ? 1 : 0;
     if (a.next) {
         // rates + next-hops (+ trace, + hops): max-form fold, then arg re-scan of the moved entries
-        if (small_tiles_arg(a.n, a.rows)) {
-            const dim3 g((unsigned)((a.n + 63) / 64), (unsigned)((a.rows + 63) / 64));
+        // (grid.x is the caller's: all 64-column tiles, or the tiles of a column window)
+        if (small || small_tiles_arg(a.n, a.rows)) {
+            const dim3 g(small ? grid.x : (unsigned)((a.n + 63) / 64), (unsigned)((a.rows + 63) / 64));
             hipLaunchKernelGGL((fused_main_arg<3, 4>), g, block, 0, s, a.rate, a.next, a.rows, a.n, a.row0,
                                a.k0, a.bt, a.w, a.ct, a.cnt, a.ct_ld, ct_vec, skip_lo, skip_hi, last,
-                               a.hops, a.cht, a.wh);
+                               a.hops, a.cht, a.wh, cw);
         } else {
             const dim3 g((unsigned)((a.n + 63) / 64), (unsigned)((a.rows + 127) / 128));
             hipLaunchKernelGGL((fused_main_arg<3, 8>), g, block, 0, s, a.rate, a.next, a.rows, a.n, a.row0,
                                a.k0, a.bt, a.w, a.ct, a.cnt, a.ct_ld, ct_vec, skip_lo, skip_hi, last,
-                               a.hops, a.cht, a.wh);
+                               a.hops, a.cht, a.wh, cw);
         }
         return true;
     }
-    if (small_tiles(a.n, a.rows)) {
-        const dim3 g((unsigned)((a.n + 63) / 64), (unsigned)((a.rows + 63) / 64));
-        hipLaunchKernelGGL((fused_main_max<4, 1, 4, 1>), g, block, 0, s, a.rate, a.rows, a.n, a.row0,
-                           a.k0, a.bt, a.w, a.ct, a.ct_ld, ct_vec, skip_lo, skip_hi);
+    if (small) {
+        hipLaunchKernelGGL((fused_main_max<4, 1, 4, 1>), grid, block, 0, s, a.rate, a.rows, a.n, a.row0,
+                           a.k0, a.bt, a.w, a.ct, a.ct_ld, ct_vec, skip_lo, skip_hi, cw);
     } else {
         hipLaunchKernelGGL((fused_main_max<3, 1, 8, 2>), grid, block, 0, s, a.rate, a.rows, a.n,
-                           a.row0, a.k0, a.bt, a.w, a.ct, a.ct_ld, ct_vec, skip_lo, skip_hi);
+                           a.row0, a.k0, a.bt, a.w, a.ct, a.ct_ld, ct_vec, skip_lo, skip_hi, cw);
     }
     return true;
 }
 // f64 has no packed / three-operand forms: the max form is the generic kernel with
 // v_mul_f64 + v_max_f64 (2 instructions per relaxation instead of 4).
 static bool launch_max_form(const FusedArgs<double> &a, dim3 grid, dim3 block, int skip_lo,
-                            int skip_hi, hipStream_t s, int32_t *)
+                            int skip_hi, hipStream_t s, int32_t *, bool small, ColWin cw)
 {
     if (!a.nonneg || a.next || a.updates) return false;
-    if (!small_tiles(a.n, a.rows)) {
+    if (!small) {
         const int ct_vec = ((uintptr_t)a.ct % 16 == 0 && a.ct_ld % 2 == 0) ? 1 : 0;
         const dim3 g((unsigned)((a.n + 127) / 128), (unsigned)((a.rows + 127) / 128));
         hipLaunchKernelGGL((fused_main_max_f64<2>), g, block, 0, s, a.rate, a.rows, a.n, a.row0, a.k0,
-                           a.bt, a.w, a.ct, a.ct_ld, ct_vec, skip_lo, skip_hi);
+                           a.bt, a.w, a.ct, a.ct_ld, ct_vec, skip_lo, skip_hi, cw);
         return true;
     }
-    if (small_tiles(a.n, a.rows))
-        hipLaunchKernelGGL((fused_main<double, false, false, 16, 2, 1, 4, true>), grid, block, 0, s,
-                           a.rate, a.next, a.rows, a.n, a.row0, a.k0, a.bt, a.w, a.ct, a.cnt,
-                           a.ct_ld, skip_lo, skip_hi, a.updates, nullptr, nullptr, nullptr, nullptr);
-    else
-        hipLaunchKernelGGL((fused_main<double, false, false, FusedCfg<double, false>::BS,
-                                       FusedCfg<double, false>::MINW, FusedCfg<double, false>::NH, 8,
-                                       true>),
-                           grid, block, 0, s, a.rate, a.next, a.rows, a.n, a.row0, a.k0, a.bt, a.w,
-                           a.ct, a.cnt, a.ct_ld, skip_lo, skip_hi, a.updates, nullptr, nullptr, nullptr,
-                           nullptr);
+    hipLaunchKernelGGL((fused_main<double, false, false, 16, 2, 1, 4, true>), grid, block, 0, s,
+                       a.rate, a.next, a.rows, a.n, a.row0, a.k0, a.bt, a.w, a.ct, a.cnt,
+                       a.ct_ld, skip_lo, skip_hi, a.updates, nullptr, nullptr, nullptr, nullptr, cw);
     return true;
 }
 
@@ -1318,9 +1475,11 @@ template <typename T> hipError_t launch_fused_colpanel(const FusedArgs<T> &a, hi
 
 // Main kernel on local rows [r_lo, r_hi) of the slab (the colpanel must have run on them), except
 // rows [skip_lo, skip_hi) (slab-local, multiples of 8; empty range = nothing skipped).
+// cols.c_hi > cols.c_lo: only the columns [c_lo, c_hi) (multiples of 64; 64-column tiles);
+// cols.skip_hi > cols.skip_lo: all columns but those (multiples of 4).
 template <typename T>
 hipError_t launch_fused_main(const FusedArgs<T> &full, int r_lo, int r_hi, hipStream_t s,
-                             int skip_lo, int skip_hi)
+                             int skip_lo, int skip_hi, FusedCols cols)
 {
     constexpr int VW = Vec16<T>::W;
     constexpr int TI = 128;
@@ -1329,6 +1488,15 @@ hipError_t launch_fused_main(const FusedArgs<T> &full, int r_lo, int r_hi, hipSt
     if (e != hipSuccess) return e;
     if (skip_hi > skip_lo && ((skip_lo - r_lo) % 8 != 0 || (skip_hi - r_lo) % 8 != 0))
         return hipErrorInvalidValue;
+    const bool window = cols.c_hi > cols.c_lo;
+    if (window && (cols.c_lo % 64 != 0 || cols.c_hi % 64 != 0 || cols.c_lo < 0 || cols.c_hi > full.n))
+        return hipErrorInvalidValue;
+    if (cols.skip_hi > cols.skip_lo && (cols.skip_lo % 4 != 0 || cols.skip_hi % 4 != 0))
+        return hipErrorInvalidValue;
+    ColWin cw;
+    cw.jt0 = 0;
+    cw.cskip_lo = cols.skip_hi > cols.skip_lo ? cols.skip_lo : 0;
+    cw.cskip_hi = cols.skip_hi > cols.skip_lo ? cols.skip_hi : 0;
     skip_lo -= r_lo;                    // kernel sees rows relative to its own slab
     skip_hi -= r_lo;
     FusedArgs<T> a = full;
@@ -1344,17 +1512,22 @@ hipError_t launch_fused_main(const FusedArgs<T> &full, int r_lo, int r_hi, hipSt
     a.cht = full.cht ? full.cht + r_lo : nullptr;
     const bool track = last || a.hops;
     const dim3 block(256);
-    const bool small = small_tiles(a.n, a.rows);
+    const bool small = window || small_tiles(a.n, a.rows);      // a window is swept in 64-row tiles
     const int tj = 16 * VW * (small ? 1 : (a.next ? FusedCfg<T, true>::NH : FusedCfg<T, false>::NH));
     const int ti = small ? 64 : TI;
-    const dim3 grid((unsigned)((a.n + tj - 1) / tj), (unsigned)((a.rows + ti - 1) / ti));
-    if (launch_max_form(a, grid, block, skip_lo, skip_hi, s, last)) return hipGetLastError();
+    dim3 grid((unsigned)((a.n + tj - 1) / tj), (unsigned)((a.rows + ti - 1) / ti));
+    if (window) {                                                // tj is 64 (f32) or 32 (f64) here
+        cw.jt0 = cols.c_lo / tj;
+        grid.x = (unsigned)((cols.c_hi - cols.c_lo) / tj);
+    }
+    if (launch_max_form(a, grid, block, skip_lo, skip_hi, s, last, small, cw)) return hipGetLastError();
 #define FWX_FUSED_LAUNCH(HN, CN, HL)                                                               \
     do {                                                                                           \
         if (small)                                                                                 \
             hipLaunchKernelGGL((fused_main<T, HN, CN, 16, 2, 1, 4, false, HL>), grid, block, 0, s, \
                                a.rate, a.next, a.rows, a.n, a.row0, a.k0, a.bt, a.w, a.ct, a.cnt,  \
-                               a.ct_ld, skip_lo, skip_hi, a.updates, last, a.hops, a.cht, a.wh);   \
+                               a.ct_ld, skip_lo, skip_hi, a.updates, last, a.hops, a.cht, a.wh,    \
+                               cw);                                                                \
         else                                                                                       \
             hipLaunchKernelGGL((fused_main<T, HN, CN, FusedCfg<T, HN>::BS,                         \
                                            HL ? (CN ? 2 : (FusedCfg<T, HN>::MINW > 3 ? 3 : FusedCfg<T, HN>::MINW)) \
@@ -1362,7 +1535,7 @@ hipError_t launch_fused_main(const FusedArgs<T> &full, int r_lo, int r_hi, hipSt
                                            FusedCfg<T, HN>::NH, 8, false, HL>),                    \
                                grid, block, 0, s, a.rate, a.next, a.rows, a.n, a.row0, a.k0, a.bt, \
                                a.w, a.ct, a.cnt, a.ct_ld, skip_lo, skip_hi, a.updates, last,       \
-                               a.hops, a.cht, a.wh);                                               \
+                               a.hops, a.cht, a.wh, cw);                                           \
     } while (0)
     if (track) {
         if (a.updates) FWX_FUSED_LAUNCH(true, true, true); else FWX_FUSED_LAUNCH(true, false, true);
@@ -1380,7 +1553,7 @@ hipError_t launch_fused_relax(const FusedArgs<T> &a, hipStream_t s, int skip_lo,
 {
     hipError_t e = launch_fused_colpanel<T>(a, s);   // skipped rows get snapshots nobody reads
     if (e != hipSuccess) return e;
-    return launch_fused_main<T>(a, 0, a.rows, s, skip_lo, skip_hi);
+    return launch_fused_main<T>(a, 0, a.rows, s, skip_lo, skip_hi, FusedCols());
 }
 
 template <typename T>
@@ -1408,9 +1581,9 @@ template hipError_t launch_fused_relax<double>(const FusedArgs<double> &, hipStr
 template hipError_t launch_fused_colpanel<float>(const FusedArgs<float> &, hipStream_t);
 template hipError_t launch_fused_colpanel<double>(const FusedArgs<double> &, hipStream_t);
 template hipError_t launch_fused_main<float>(const FusedArgs<float> &, int, int, hipStream_t, int,
-                                             int);
+                                             int, FusedCols);
 template hipError_t launch_fused_main<double>(const FusedArgs<double> &, int, int, hipStream_t, int,
-                                              int);
+                                              int, FusedCols);
 template hipError_t launch_fused_panel<float>(const float *, int, int, int, float *, hipStream_t, PathLog,
                                               const int32_t *, int32_t *);
 template hipError_t launch_fused_panel<double>(const double *, int, int, int, double *, hipStream_t,

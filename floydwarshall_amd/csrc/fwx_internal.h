@@ -162,9 +162,10 @@ struct DevBuf {
 
 struct SideStream {
     hipStream_t s = nullptr;
-    hipEvent_t rows_done = nullptr, panel_done = nullptr;
+    hipEvent_t rows_done = nullptr, panel_done = nullptr, main_done = nullptr;
     ~SideStream()
     {
+        if (main_done) (void)hipEventDestroy(main_done);
         if (rows_done) (void)hipEventDestroy(rows_done);
         if (panel_done) (void)hipEventDestroy(panel_done);
         if (s) (void)hipStreamDestroy(s);
@@ -174,6 +175,7 @@ struct SideStream {
         FWX_HIP(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
         FWX_HIP(hipEventCreateWithFlags(&rows_done, hipEventDisableTiming));
         FWX_HIP(hipEventCreateWithFlags(&panel_done, hipEventDisableTiming));
+        FWX_HIP(hipEventCreateWithFlags(&main_done, hipEventDisableTiming));
         return FWX_OK;
     }
 };
@@ -182,8 +184,10 @@ struct SideStream {
 inline size_t fused_ws_bytes(int n, size_t es, bool with_hops)
 {
     const size_t ld = ((size_t)n + 3) & ~(size_t)3;
-    size_t b = (size_t)FWX_FUSED_B * n * 2 * es + (size_t)FWX_FUSED_B * ld * (es + 4) + 256;
-    if (with_hops) b += (size_t)FWX_FUSED_B * n * 2 * 4 + (size_t)FWX_FUSED_B * ld * 4;
+    // two row panels W and two sets of pivot-column snapshots (Ct, CNt): pass p+1's are produced
+    // while pass p's are read (fused_range)
+    size_t b = (size_t)FWX_FUSED_B * n * 2 * es + (size_t)FWX_FUSED_B * ld * 2 * (es + 4) + 256;
+    if (with_hops) b += (size_t)FWX_FUSED_B * n * 2 * 4 + (size_t)FWX_FUSED_B * ld * 2 * 4;
     return b;
 }
 

@@ -96,9 +96,17 @@ hipError_t launch_fused_relax(const FusedArgs<T> &a, hipStream_t s, int skip_lo 
 // The two halves separately: pivot-column snapshots for all rows of the slab, then the main
 // kernel on local rows [r_lo, r_hi) (used by the look-ahead schedule).
 template <typename T> hipError_t launch_fused_colpanel(const FusedArgs<T> &a, hipStream_t s);
+// Column controls of a main launch (symmetric look-ahead): c_hi > c_lo restricts the launch to the
+// columns [c_lo, c_hi) (multiples of 64), skip_hi > skip_lo leaves the columns [skip_lo, skip_hi)
+// (multiples of 4) to another launch of the same pass.  Default: all columns.
+struct FusedCols {
+    int c_lo = 0, c_hi = 0, skip_lo = 0, skip_hi = 0;
+    static FusedCols only(int lo, int hi) { FusedCols c; c.c_lo = lo; c.c_hi = hi; return c; }
+    static FusedCols except(int lo, int hi) { FusedCols c; c.skip_lo = lo; c.skip_hi = hi; return c; }
+};
 template <typename T>
 hipError_t launch_fused_main(const FusedArgs<T> &a, int r_lo, int r_hi, hipStream_t s,
-                             int skip_lo = 0, int skip_hi = 0);
+                             int skip_lo = 0, int skip_hi = 0, FusedCols cols = FusedCols());
 
 // diag + rowpanel: snapshot panel of the pivot rows `rows_base` (bt x n, at time k0); the matrix
 // is not modified.  plog: the path trace AT THE SAME ROWS as rows_base (plog.last / plog.at_row
