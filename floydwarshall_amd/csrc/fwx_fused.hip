@@ -1054,62 +1054,17 @@ __global__ __launch_bounds__(256, MINW) void fused_main_max_f64(double *rate, in
 //      (ballot + mbcnt compaction: all 64 lanes of the re-scan below do useful work);
 //   3. one lane per item re-multiplies the 16 operand pairs of stage sid -- all 64 pivots of the
 //      tile's C and W strips stay resident in LDS for this -- finds t* by equality, and writes
-//      next = CN[t*][i] (and last = k0 + t* for the path trace).
+//      next = CN[t*][i] (and last = k0 + t* for the path trace).  The re-scan is INLINE at its 17
+//      flush points and software-pipelined: a batch issues its gather of CN[t*][i] and the batch
+//      before it stores -- as an out-of-line function every batch paid the call ABI's
+//      s_waitcnt vmcnt(0) twice (gather latency at the store, store latency at the return), which
+//      was most of the re-scan's cost (77 of 297 ms at N = 16384).
 // About 11 % of the entries move in an average pass of the N = 16384 benchmark solve (60 % in the
 // first sixteenth, 3.5 % in the last).  Bit-identical to the compare form: same products (one
 // v_mul_f32 each), same winner, same t*.  No update counting (U is the number of strict increases
 // along the fold: compare form only).
 // ------------------------------------------------------------------------------------------------
-typedef __attribute__((address_space(3))) float lds_f32;
-typedef __attribute__((address_space(3))) unsigned int lds_u32;
-
-// Re-scan of the items [0, count) of one wave's list, in batches of 64 (one lane per item).  Full
-// batches only unless `all`; the remainder (< 64 items) is moved to the front of the list and its
-// length returned.  Out of line: it is reached from 33 places of the unrolled compaction below.
-// (where the re-scan writes travels as plain scalar arguments, in registers: a struct would be
-// passed through scratch memory; last / hops: nullptr = not kept)
-__device__ __attribute__((noinline)) int arg_rescan(lds_u32 *ids, lds_f32 *vals, int count, bool all,
-                                                    const lds_f32 *sC, const lds_f32 *sW, int ti_ld,
-                                                    int tj_ld, int32_t *o_next, int32_t *o_last,
-                                                    int32_t *o_hops, const int32_t *o_cnt,
-                                                    const int32_t *o_cht, const int32_t *o_wh, int o_n,
-                                                    int o_ct_ld, int o_i_base, int o_j_base, int o_k0)
-{
-    const int lane = (int)(threadIdx.x & 63);
-    int base = 0;
-    for (; base + 64 <= count || (all && base < count); base += 64) {
-        const int it = base + lane;
-        const bool act = it < count;
-        const unsigned int id = ids[act ? it : 0];
-        const float v = act ? vals[it] : __builtin_nanf("");        // NaN never matches
-        const int il = (int)((id >> 8) & 255u), jl = (int)(id & 255u), t0 = (int)(id >> 16) * 16;
-        const lds_f32 *pc = sC + t0 * ti_ld + il;
-        const lds_f32 *pw = sW + t0 * tj_ld + jl;
-        int found = -1;
-#pragma unroll
-        for (int u = 15; u >= 0; --u) {              // descending: the smallest matching pivot wins
-            const float p = pc[u * ti_ld] * pw[u * tj_ld];
-            found = (p == v) ? t0 + u : found;
-        }
-        if (act && found >= 0) {
-            const int i = o_i_base + il, j = o_j_base + jl;
-            const size_t off = (size_t)i * o_n + j;
-            o_next[off] = o_cnt[(size_t)found * o_ct_ld + i];
-            if (o_last) o_last[off] = o_k0 + found;
-            if (o_hops)    // lengths of the two halves at the winning pivot (Algorithms.hs:55)
-                o_hops[off] = (int32_t)((uint32_t)o_cht[(size_t)found * o_ct_ld + i] +
-                                        (uint32_t)o_wh[(size_t)found * o_n + j]);
-        }
-    }
-    const int rest = count - base;                   // < 64 (0 if all)
-    if (rest > 0 && base > 0) {
-        const unsigned int id = ids[base + (lane < rest ? lane : 0)];
-        const float v = vals[base + (lane < rest ? lane : 0)];
-        __builtin_amdgcn_wave_barrier();
-        if (lane < rest) { ids[lane] = id; vals[lane] = v; }
-    }
-    return rest > 0 ? rest : 0;
-}
+constexpr int ARG_SL = 16;         // pivots per tracking stage of fused_main_arg (even, divides B)
 
 template <int MINW, int RI>
 __global__ __launch_bounds__(256, MINW) void fused_main_arg(float *rate, int32_t *next, int rows, int n,
@@ -1120,12 +1075,16 @@ __global__ __launch_bounds__(256, MINW) void fused_main_arg(float *rate, int32_t
                                                             const int32_t *cht, const int32_t *wh, ColWin cw)
 {
     typedef float V4 __attribute__((ext_vector_type(4)));
-    constexpr int TI = 16 * RI, TJ = 64, LCAP = 128;
+    // list capacity: a flush point after every second entry slot, 63 carried + 2 * 64 new items
+    constexpr int TI = 16 * RI, TJ = 64, LCAP = 192;
     // all 64 pivots of the tile's operand strips: s?[t][.], pivot t = 2 * pair + u
     __shared__ __attribute__((aligned(16))) float sW[B][TJ];
     __shared__ __attribute__((aligned(16))) float sC[B][TI];
-    __shared__ unsigned int l_id[4][LCAP];      // per-wave item lists: sid << 16 | row << 8 | column
-    __shared__ float l_val[4][LCAP];            //                      the entry's new value
+    __shared__ unsigned short l_id[4][LCAP];    // per-wave item lists: sid << 13 | row << 6 | column
+    // where the gathers of the batch in flight land (global -> LDS loads, one slot per lane):
+    // CN[t*][i], and with hops CHt[t*][i] and WH[t*][j]
+    __shared__ int32_t g_next[4][64], g_hc[4][64], g_hw[4][64];
+    static_assert(TI <= 128 && B / ARG_SL <= 8, "item id fields");
 
     const int tid = threadIdx.x;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -1209,15 +1168,16 @@ __global__ __launch_bounds__(256, MINW) void fused_main_arg(float *rate, int32_t
         }
     };
     int stages = 0;                                  // stages executed (wave-uniform)
+    constexpr int SP = ARG_SL / 2;                   // pivot pairs per stage
 #pragma unroll
-    for (int s = 0; s < 4; ++s) {
-        if (s * 8 < npairs) {
+    for (int s = 0; s < B / ARG_SL; ++s) {
+        if (s * SP < npairs) {
             const V4 (&src)[RI] = (s & 1) ? xb : xa;
             V4 (&dst)[RI] = (s & 1) ? xa : xb;
-            const int p_hi = min(s * 8 + 8, npairs);
-            pair_step(s * 8, src, dst);
+            const int p_hi = min(s * SP + SP, npairs);
+            pair_step(s * SP, src, dst);
 #pragma unroll 1
-            for (int tp = s * 8 + 1; tp < p_hi; ++tp) pair_step(tp, dst, dst);
+            for (int tp = s * SP + 1; tp < p_hi; ++tp) pair_step(tp, dst, dst);
 #pragma unroll
             for (int r = 0; r < RI; ++r)
 #pragma unroll
@@ -1233,9 +1193,91 @@ __global__ __launch_bounds__(256, MINW) void fused_main_arg(float *rate, int32_t
     // ---- 2. + 3. moved entries -> items -> t* -> next (and last) ---------------------------------
     const int gi_lo = row0 + i_base;
     const bool diag_tile = gi_lo < j_base + TJ && j_base < gi_lo + TI;
-    lds_u32 *ids = (lds_u32 *)&l_id[wave][0];
-    lds_f32 *vals = (lds_f32 *)&l_val[wave][0];
+    typedef __attribute__((address_space(1))) const void gptr_t;
+    typedef __attribute__((address_space(3))) void lptr_t;
+    unsigned short *ids = &l_id[wave][0];
+    const int lane = tid & 63;
     int count = 0;                                   // items in this wave's list (wave-uniform)
+    // The batch whose gathers are in flight.  They are global -> LDS loads (no destination
+    // register: with one, the register allocator's copies and reuse put s_waitcnt vmcnt(0) right
+    // behind the load) and the batch is retired -- LDS -> next / hops -- after the NEXT batch has
+    // been scanned, or at the end.
+    bool p_act = false;
+    size_t p_off = 0;
+    auto retire = [&]() __attribute__((always_inline)) {
+        if (p_act) {
+            // vmcnt also counts global -> LDS loads; the compiler's own wait-count pass does not put
+            // this wait here (it loses track of them across the flush points' control flow)
+            __builtin_amdgcn_s_waitcnt(FWX_WAIT_VMCNT0);
+            next[p_off] = g_next[wave][lane];
+            // lengths of the two halves at the winning pivot (Algorithms.hs:55)
+            if (hops) hops[p_off] = (int32_t)((uint32_t)g_hc[wave][lane] + (uint32_t)g_hw[wave][lane]);
+        }
+        p_act = false;
+    };
+    // Re-scan of the items [0, count) in batches of 64, one lane per item; full batches only unless
+    // `all`; the remainder (< 64 items) moves to the front of the list.  An item carries no value:
+    // sid is the LAST stage in which the entry moved, so its final value is the maximum of that
+    // stage's products, and t* the first pivot that attains it.
+    auto rescan = [&](bool all) __attribute__((always_inline)) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        int base = 0;
+        for (; base + 64 <= count || (all && base < count); base += 64) {
+            const int it = base + lane;
+            const bool act = it < count;
+            const unsigned int id = ids[act ? it : 0];
+            const int il = (int)((id >> 6) & 127u), jl = (int)(id & 63u), t0 = (int)(id >> 13) * ARG_SL;
+            const float *pc = &sC[t0][il];
+            const float *pw = &sW[t0][jl];
+            float p[ARG_SL];
+#pragma unroll
+            for (int u = 0; u < ARG_SL; ++u) p[u] = pc[u * TI] * pw[u * TJ];
+            float m = __builtin_fmaxf(p[0], p[1]);
+#pragma unroll
+            for (int u = 2; u < ARG_SL; u += 2) m = __builtin_fmaxf(__builtin_fmaxf(m, p[u]), p[u + 1]);
+            int found = -1;
+#pragma unroll
+            for (int u = ARG_SL - 1; u >= 0; --u)    // descending: the smallest matching pivot wins
+                found = (p[u] == m) ? t0 + u : found;
+            retire();                                // the previous batch: its gathers have landed
+            if (act && found >= 0) {
+                const int i = i_base + il, j = j_base + jl;
+                p_off = (size_t)i * n + j;
+                __builtin_amdgcn_global_load_lds((gptr_t *)(cnt + (size_t)found * ct_ld + i),
+                                                 (lptr_t *)&g_next[wave][0], 4, 0, 0);
+                if (last) last[p_off] = k0 + found;
+                if (hops) {
+                    __builtin_amdgcn_global_load_lds((gptr_t *)(cht + (size_t)found * ct_ld + i),
+                                                     (lptr_t *)&g_hc[wave][0], 4, 0, 0);
+                    __builtin_amdgcn_global_load_lds((gptr_t *)(wh + (size_t)found * n + j),
+                                                     (lptr_t *)&g_hw[wave][0], 4, 0, 0);
+                }
+                p_act = true;
+            }
+        }
+        const int rest = count - base;               // < 64 (<= 0 if all)
+        if (rest > 0 && base > 0) {
+            const unsigned short id = ids[base + (lane < rest ? lane : 0)];
+            __builtin_amdgcn_wave_barrier();
+            if (lane < rest) ids[lane] = id;
+        }
+        count = rest > 0 ? rest : 0;
+    };
+    // j == i is never touched (Algorithms.hs:54): a diagonal entry keeps its value and is no item.
+    // Done here, once, with its own wait: a conditional load inside the loop below would make
+    // every entry slot wait for ALL outstanding memory operations (vmcnt counts in order), i.e. for
+    // the row stores and the pipelined gathers.
+    if (diag_tile) {                                 // workgroup-uniform
+#pragma unroll
+        for (int r = 0; r < RI; ++r)
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+                if (row0 + i0 + r == jc + e) {
+                    if (i0 + r < rows && sid[r][e] >= 0) xa[r][e] = rate[(size_t)(i0 + r) * n + jc + e];
+                    sid[r][e] = -1;
+                }
+        __builtin_amdgcn_s_waitcnt(FWX_WAIT_VMCNT0);
+    }
 #pragma unroll
     for (int r = 0; r < RI; ++r) {
         const int i = i0 + r;
@@ -1245,11 +1287,6 @@ __global__ __launch_bounds__(256, MINW) void fused_main_arg(float *rate, int32_t
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
             ch[e] = row_ok && sid[r][e] >= 0;
-            // j == i is never touched (Algorithms.hs:54): the diagonal entry keeps its value
-            if (diag_tile && row0 + i == jc + e) {
-                if (ch[e]) xa[r][e] = rate[(size_t)i * n + jc + e];
-                ch[e] = false;
-            }
             any |= ch[e];
         }
         if (any) *reinterpret_cast<V4 *>(rate + (size_t)i * n + jc) = xa[r];
@@ -1259,26 +1296,16 @@ __global__ __launch_bounds__(256, MINW) void fused_main_arg(float *rate, int32_t
             if (mask) {                               // wave-uniform
                 const int pos = count + (int)__builtin_amdgcn_mbcnt_hi((unsigned int)(mask >> 32),
                                              __builtin_amdgcn_mbcnt_lo((unsigned int)mask, 0u));
-                if (ch[e]) {
-                    ids[pos] = ((unsigned int)sid[r][e] << 16) | ((unsigned int)(ti * RI + r) << 8) |
-                               (unsigned int)(tj * 4 + e);
-                    vals[pos] = xa[r][e];
-                }
+                if (ch[e])
+                    ids[pos] = (unsigned short)(((unsigned int)sid[r][e] << 13) |
+                                                ((unsigned int)(ti * RI + r) << 6) | (unsigned int)(tj * 4 + e));
                 count += __builtin_popcountll(mask);
-                if (count >= 64) {
-                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-                    count = arg_rescan(ids, vals, count, false, (const lds_f32 *)&sC[0][0],
-                                       (const lds_f32 *)&sW[0][0], TI, TJ, next, last, hops, cnt, cht, wh,
-                                       n, ct_ld, i_base, j_base, k0);
-                }
             }
+            if ((e & 1) && count >= 64) rescan(false);    // count <= 63 + 2 * 64 here
         }
     }
-    if (count > 0) {
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        arg_rescan(ids, vals, count, true, (const lds_f32 *)&sC[0][0], (const lds_f32 *)&sW[0][0], TI, TJ,
-                   next, last, hops, cnt, cht, wh, n, ct_ld, i_base, j_base, k0);
-    }
+    if (count > 0) rescan(true);
+    retire();
 }
 
 // Domain check (fwx.h "Domain"): clears bit 0 of *flag if any rate has its sign bit set or is NaN,
