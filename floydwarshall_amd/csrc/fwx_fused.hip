@@ -1064,6 +1064,8 @@ __global__ __launch_bounds__(256, MINW) void fused_main_max_f64(double *rate, in
 // v_mul_f32 each), same winner, same t*.  No update counting (U is the number of strict increases
 // along the fold: compare form only).
 // ------------------------------------------------------------------------------------------------
+// (8-pivot stages halve the re-scan's products and double the tracking compares: no difference,
+// 257.3 vs 259.3 ms at N = 16384, gpurun_out/r02_run30.log)
 constexpr int ARG_SL = 16;         // pivots per tracking stage of fused_main_arg (even, divides B)
 
 template <int MINW, int RI>
