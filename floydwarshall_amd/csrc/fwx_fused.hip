@@ -496,7 +496,25 @@ __global__ __launch_bounds__(256, MINW) void fused_main(T *rate, int32_t *next, 
         }
     }
 
-    // ---- write back (the diagonal entry, if any, is restored from memory first) ---------------
+    // ---- write back (the diagonal entry, if any, is restored from memory first: once, with its
+    // own wait -- a conditional load inside the store loop would make every store wait for all
+    // the stores before it, vmcnt counts in order) ----------------------------------------------
+    if (diag_tile) {                                 // workgroup-uniform
+#pragma unroll
+        for (int r = 0; r < RI; ++r) {
+            const int i = i0 + r, gi = row0 + i;
+            if (i >= rows || skip) continue;
+#pragma unroll
+            for (int h = 0; h < NH; ++h)
+                if (jok[h] && gi >= jcol[h] && gi < jcol[h] + VW) {
+                    const int e = gi - jcol[h];
+                    x[r][h][e] = rate[(size_t)i * n + gi];
+                    if (HAS_NEXT) nx[r][h][e] = -2;
+                    if (HAS_LAST) lp[r][h][e] = -2;
+                }
+        }
+        __builtin_amdgcn_s_waitcnt(FWX_WAIT_VMCNT0);
+    }
 #pragma unroll
     for (int r = 0; r < RI; ++r) {
         const int i = i0 + r;
@@ -505,26 +523,18 @@ __global__ __launch_bounds__(256, MINW) void fused_main(T *rate, int32_t *next, 
         for (int h = 0; h < NH; ++h) {
             if (!jok[h]) continue;
             const size_t off = (size_t)i * n + jcol[h];
-            if (diag_tile) {
-                const int gi = row0 + i;
-                if (gi >= jcol[h] && gi < jcol[h] + VW) {
-                    const int e = gi - jcol[h];
-                    x[r][h][e] = rate[off + e];
-                    if (HAS_NEXT) nx[r][h][e] = -2;
-                    if (HAS_LAST) lp[r][h][e] = -2;
-                }
-            }
             if (HAS_NEXT) {
                 // a rate changed <=> its next-hop was set: unchanged vectors are not written at all
                 bool any = false;
 #pragma unroll
                 for (int e = 0; e < VW; ++e) any |= nx[r][h][e] != -2;
                 if (any) {
-                    const IV old = *reinterpret_cast<const IV *>(next + off);
+                    // changed components only, as plain 4-byte stores: a read-modify-write of the
+                    // vector would put a load and its wait (vmcnt counts in order: a wait for every
+                    // store issued so far as well) in front of each of the tile's vectors
 #pragma unroll
                     for (int e = 0; e < VW; ++e)
-                        if (nx[r][h][e] == -2) nx[r][h][e] = old[e];
-                    *reinterpret_cast<IV *>(next + off) = nx[r][h];
+                        if (nx[r][h][e] != -2) next[off + e] = nx[r][h][e];
                     *reinterpret_cast<V *>(rate + off) = x[r][h];
                     if (HAS_LAST && hops) {   // lengths of the two halves at the winning pivot
 #pragma unroll
@@ -536,11 +546,9 @@ __global__ __launch_bounds__(256, MINW) void fused_main(T *rate, int32_t *next, 
                             }
                     }
                     if (HAS_LAST && last) {   // same vectors, same components: changed <=> lp != -2
-                        const IV oldl = *reinterpret_cast<const IV *>(last + off);
 #pragma unroll
                         for (int e = 0; e < VW; ++e)
-                            if (lp[r][h][e] == -2) lp[r][h][e] = oldl[e];
-                        *reinterpret_cast<IV *>(last + off) = lp[r][h];
+                            if (lp[r][h][e] != -2) last[off + e] = lp[r][h][e];
                     }
                 }
             } else {
@@ -797,20 +805,24 @@ __global__ __launch_bounds__(256, MINW) void fused_main_max(float *rate, int row
         }
     }
 
+    if (diag_tile) {        // the diagonal entries keep their value: restored once, with one wait
+#pragma unroll
+        for (int r = 0; r < RI; ++r) {
+            const int i = i0 + r, gi = row0 + i;
+            if (i >= rows || skip) continue;
+#pragma unroll
+            for (int h = 0; h < NH; ++h)
+                if (jok[h] && gi >= jcol[h] && gi < jcol[h] + 4) x[r][h][gi - jcol[h]] = rate[(size_t)i * n + gi];
+        }
+        __builtin_amdgcn_s_waitcnt(FWX_WAIT_VMCNT0);
+    }
 #pragma unroll
     for (int r = 0; r < RI; ++r) {
         const int i = i0 + r;
         if (i >= rows || skip) continue;
 #pragma unroll
-        for (int h = 0; h < NH; ++h) {
-            if (!jok[h]) continue;
-            const size_t off = (size_t)i * n + jcol[h];
-            if (diag_tile) {
-                const int gi = row0 + i;
-                if (gi >= jcol[h] && gi < jcol[h] + 4) x[r][h][gi - jcol[h]] = rate[off + gi - jcol[h]];
-            }
-            *reinterpret_cast<V4 *>(rate + off) = x[r][h];
-        }
+        for (int h = 0; h < NH; ++h)
+            if (jok[h]) *reinterpret_cast<V4 *>(rate + (size_t)i * n + jcol[h]) = x[r][h];
     }
 }
 
@@ -1019,20 +1031,24 @@ __global__ __launch_bounds__(256, MINW) void fused_main_max_f64(double *rate, in
         }
     }
 
+    if (diag_tile) {        // the diagonal entries keep their value: restored once, with one wait
+#pragma unroll
+        for (int r = 0; r < RI; ++r) {
+            const int i = i0 + r, gi = row0 + i;
+            if (i >= rows || skip) continue;
+#pragma unroll
+            for (int h = 0; h < NH; ++h)
+                if (jok[h] && gi >= jcol[h] && gi < jcol[h] + 2) x[r][h][gi - jcol[h]] = rate[(size_t)i * n + gi];
+        }
+        __builtin_amdgcn_s_waitcnt(FWX_WAIT_VMCNT0);
+    }
 #pragma unroll
     for (int r = 0; r < RI; ++r) {
         const int i = i0 + r;
         if (i >= rows || skip) continue;
 #pragma unroll
-        for (int h = 0; h < NH; ++h) {
-            if (!jok[h]) continue;
-            const size_t off = (size_t)i * n + jcol[h];
-            if (diag_tile) {
-                const int gi = row0 + i;
-                if (gi >= jcol[h] && gi < jcol[h] + 2) x[r][h][gi - jcol[h]] = rate[off + gi - jcol[h]];
-            }
-            *reinterpret_cast<V2 *>(rate + off) = x[r][h];
-        }
+        for (int h = 0; h < NH; ++h)
+            if (jok[h]) *reinterpret_cast<V2 *>(rate + (size_t)i * n + jcol[h]) = x[r][h];
     }
 }
 
