@@ -74,34 +74,38 @@ template <typename T> bool fused_ok(int n, const void *rate, const int32_t *)
 }
 
 // Single-GPU solve of pivots [k_begin,k_end) with the fused engine.  Per block of <= 64 pivots:
-// snapshot panel W_b, pivot-column snapshots for all rows, main kernel over all rows.
-//
-// Look-ahead.  The panel chain of block b+1 only needs the 64 pivot ROWS of b+1 (rowpanel) and the 64
-// pivot COLUMNS of b+1 (colpanel) as pass b leaves them.
-//   rows only (small matrices): main(b) runs on the next block's rows first, then their rowpanel
-//     runs on a side stream while main(b) sweeps the rest; colpanel(b+1) follows main(b).
-//   symmetric (n >= kSymmetricMinN, 64-aligned blocks): the side stream relaxes the next block's
-//     rows AND columns with pass b's panels, then runs rowpanel(b+1) and colpanel(b+1) -- all of it
-//     beside main(b), which leaves those rows and columns alone.  The main stream then carries
-//     nothing but main kernels back to back: 37-44 us of colpanel + look-ahead launch + gaps per
-//     pass leave the critical path (616 us per pass at N = 16384 f32 rates).  The side chain takes
-//     ~120 us per pass whatever n is, so it pays once a main launch is longer than that: measured
-//     (gpurun_out/r02_run20_*.log, f32) rates only 4096: 5.60 -> 6.28 ms, 6144: 11.8 -> 12.0,
-//     8192: 22.8 -> 21.8, 16384: 155.8 -> 153.6; with next-hops 4096: 8.68 -> 8.34, 6144:
-//     21.96 -> 20.55, 8192: 47.1 -> 45.3, 16384: 303.9 -> 295.7 (with the trace 324.0 -> 312.4).
+// snapshot panel W_b (rowpanel), pivot-column snapshots for all rows (colpanel), main kernel over
+// all rows.  Three schedules:
+//   serial (small matrices): rowpanel, colpanel and ONE main launch per pass in one stream.  While
+//     a main launch is not much longer than a panel kernel (~20-40 us) any look-ahead costs more --
+//     an extra latency-bound launch and two cross-stream event hops (6 + 12 us) -- than its overlap
+//     gives: N = 1024 f32 1.08 -> 0.72 ms, N = 2048 2.21 -> 1.62, N = 4096 5.62 -> 5.28
+//     (gpurun_out/r02_run33.log, r02_run34.log).
+//   symmetric look-ahead (large matrices, 64-aligned blocks): the panel chain of block b+1 only
+//     needs the 64 pivot ROWS of b+1 (rowpanel) and the 64 pivot COLUMNS of b+1 (colpanel) as pass b
+//     leaves them.  The side stream relaxes exactly those with pass b's panels, then runs
+//     rowpanel(b+1) and colpanel(b+1) -- all of it beside main(b), which leaves those rows and
+//     columns alone.  The main stream carries nothing but main kernels back to back: the gap between
+//     two of them falls from 44 to 12.5 us (616 us per pass at N = 16384 f32 rates).
+//   rows-only look-ahead (the fallback for pivot ranges that do not start on a multiple of 64):
+//     main(b) on the next block's rows first, their rowpanel on the side stream while main(b)
+//     sweeps the rest; colpanel(b+1) follows main(b).
+// Crossovers measured on f32 / f64 (r02_run34.log): rates only, serial wins up to n = 7168 and loses
+// at 8192 (22.9 vs 21.9 ms); with next-hops it wins up to 4096 (7.24 vs 7.85 ms), ties to 6144 and
+// loses from 7168; with the path trace it loses from 4096-5120 on.
 // ws: see fused_ws_bytes.
-constexpr int kSymmetricMinN = 8192, kSymmetricMinNWithNext = 4096;
-// FWX_SYMMETRIC_MIN_N overrides the threshold (tests force the symmetric schedule at small sizes,
-// tuning runs switch it off with a huge value); read on every solve, the environment may change.
-static int symmetric_min_n(bool with_next)
+constexpr int kLookaheadMinN = 8192, kLookaheadMinNWithNext = 5120, kLookaheadMinNWithTrace = 4096;
+// FWX_LOOKAHEAD_MIN_N / FWX_SYMMETRIC_MIN_N override the thresholds (tests force each schedule at
+// small sizes, tuning runs switch one off with a huge value); read on every solve.
+static int env_threshold(const char *name, int dflt)
 {
-    const char *e = getenv("FWX_SYMMETRIC_MIN_N");
+    const char *e = getenv(name);
     if (e && *e) {
         char *end = nullptr;
         const long v = strtol(e, &end, 10);
         if (end != e && v >= 0 && v <= INT32_MAX) return (int)v;
     }
-    return with_next ? kSymmetricMinNWithNext : kSymmetricMinN;
+    return dflt;
 }
 
 template <typename T>
@@ -145,7 +149,10 @@ int fused_range(T *rate, int32_t *next, int32_t *hops, int n, int k_begin, int k
                                           plog_rows(plog, (size_t)k0 * n),
                                           hops ? hops + (size_t)k0 * n : nullptr, whbuf[bi]);
     };
-    const bool symmetric_ok = n >= symmetric_min_n(next != nullptr) && k_begin % FWX_FUSED_B == 0;
+    const bool lookahead = n >= env_threshold("FWX_LOOKAHEAD_MIN_N",
+                                               !next ? kLookaheadMinN
+                                                     : plog.last ? kLookaheadMinNWithTrace : kLookaheadMinNWithNext);
+    const bool symmetric_ok = n >= env_threshold("FWX_SYMMETRIC_MIN_N", 0) && k_begin % FWX_FUSED_B == 0;
 
     int bi = 0;
     bool col_ready = false;        // colpanel of the current pass already ran (on the side stream)
@@ -159,7 +166,11 @@ int fused_range(T *rate, int32_t *next, int32_t *hops, int n, int k_begin, int k
         bind(k0, bt, bi);
         if (!col_ready) FWX_HIP(fwx::launch_fused_colpanel<T>(a, s));
         col_ready = false;
-        if (k1 < k_end) {
+        if (k1 < k_end && !lookahead) {
+            const int bt1 = k_end - k1 < FWX_FUSED_B ? k_end - k1 : FWX_FUSED_B;
+            FWX_HIP(fwx::launch_fused_main<T>(a, 0, n, s));
+            FWX_HIP(rowpanel(k1, bt1, bi ^ 1, s));
+        } else if (k1 < k_end) {
             const int bt1 = k_end - k1 < FWX_FUSED_B ? k_end - k1 : FWX_FUSED_B;
             if (symmetric_ok && bt1 == FWX_FUSED_B) {
                 // everything up to here (the previous main, this pass's panels) precedes the side chain

@@ -1,8 +1,10 @@
-"""Symmetric look-ahead of the fused engine (fused_range in csrc/fwx_api.hip): the next block's rows
-AND columns are relaxed on a side stream, beside the main kernel that skips them.  Taken from
-n = 8192 by default; FWX_SYMMETRIC_MIN_N=0 forces it here at sizes the oracle solves in seconds, for
-every kernel family behind the schedule: max form (f32 / f64 rates), arg (f32 + next, + hops, +
-trace), compare form (update counting, f64 + next, inputs outside the domain)."""
+"""The look-ahead schedules of the fused engine (fused_range in csrc/fwx_api.hip).  Small matrices
+take the serial schedule (what every other GPU test exercises); from n = 4096..8192 the next
+block's rows AND columns are relaxed on a side stream, beside the main kernel that skips them
+(symmetric look-ahead); pivot ranges that do not start on a multiple of 64 fall back to the rows-only
+look-ahead.  FWX_LOOKAHEAD_MIN_N=0 forces the look-ahead forms here at sizes the oracle solves in
+seconds, for every kernel family behind them: max form (f32 / f64 rates), arg (f32 + next, + hops,
++ trace), compare form (update counting, f64 + next, inputs outside the domain)."""
 import numpy as np
 import pytest
 
@@ -17,6 +19,7 @@ pytestmark = pytest.mark.gpu
 
 @pytest.fixture(autouse=True)
 def _force_symmetric(monkeypatch):
+    monkeypatch.setenv("FWX_LOOKAHEAD_MIN_N", "0")
     monkeypatch.setenv("FWX_SYMMETRIC_MIN_N", "0")
 
 
@@ -91,8 +94,10 @@ def test_symmetric_schedule_reused_handle_and_default_threshold(monkeypatch):
     n = 516
     rate, nxt, hops = synth.make("d1", n, np.float32, seed=77)
     outs = []
-    for min_n in ("0", "0", "1000000"):
-        monkeypatch.setenv("FWX_SYMMETRIC_MIN_N", min_n)
+    # symmetric, symmetric again, rows-only look-ahead, serial
+    for look, sym in (("0", "0"), ("0", "0"), ("0", "1000000"), ("1000000", "0")):
+        monkeypatch.setenv("FWX_LOOKAHEAD_MIN_N", look)
+        monkeypatch.setenv("FWX_SYMMETRIC_MIN_N", sym)
         with engine.DeviceMatrix(n, np.float32, with_next=True, with_hops=True) as dm:
             for _ in range(2):
                 dm.upload(rate, nxt, hops)
@@ -101,3 +106,16 @@ def test_symmetric_schedule_reused_handle_and_default_threshold(monkeypatch):
     for o in outs[1:]:
         assert_bits_equal(o[0], outs[0][0], "rate")
         assert np.array_equal(o[1], outs[0][1]) and np.array_equal(o[2], outs[0][2])
+
+
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+@pytest.mark.parametrize("count", [False, True])
+def test_rows_only_lookahead_all_fields(count, dtype, monkeypatch):
+    """The fallback form (symmetric switched off), ragged sizes and an unaligned pivot range."""
+    monkeypatch.setenv("FWX_SYMMETRIC_MIN_N", "1000000")
+    for n in (132, 260, 516):
+        rate, nxt, hops = synth.make("d2", n, dtype, seed=4300 + n)
+        _check(rate, None, None, count)
+        _check(rate, nxt, hops, count)
+    rate, nxt, hops = synth.make("t1", 324, dtype, seed=8)
+    _check(rate, nxt, hops, count, k_begin=37, k_end=300)
