@@ -154,11 +154,21 @@ int fused_range(T *rate, int32_t *next, int32_t *hops, int n, int k_begin, int k
                                                      : plog.last ? kLookaheadMinNWithTrace : kLookaheadMinNWithNext);
     const bool symmetric_ok = n >= env_threshold("FWX_SYMMETRIC_MIN_N", 0) && k_begin % FWX_FUSED_B == 0;
 
+    auto panels = [&](int k0, int bt, int bi, hipStream_t st) {   // both panels of a pass, one launch
+        bind(k0, bt, bi);
+        return fwx::launch_fused_panels<T>(a, wbuf[bi], whbuf[bi], st);
+    };
+
     int bi = 0;
-    bool col_ready = false;        // colpanel of the current pass already ran (on the side stream)
+    bool col_ready = false;        // colpanel of the current pass already ran
     {
         const int bt = k_end - k_begin < FWX_FUSED_B ? k_end - k_begin : FWX_FUSED_B;
-        FWX_HIP(rowpanel(k_begin, bt, 0, s));
+        if (!lookahead) {
+            FWX_HIP(panels(k_begin, bt, 0, s));
+            col_ready = true;
+        } else {
+            FWX_HIP(rowpanel(k_begin, bt, 0, s));
+        }
     }
     for (int k0 = k_begin; k0 < k_end; k0 += FWX_FUSED_B, bi ^= 1) {
         const int bt = k_end - k0 < FWX_FUSED_B ? k_end - k0 : FWX_FUSED_B;
@@ -169,7 +179,8 @@ int fused_range(T *rate, int32_t *next, int32_t *hops, int n, int k_begin, int k
         if (k1 < k_end && !lookahead) {
             const int bt1 = k_end - k1 < FWX_FUSED_B ? k_end - k1 : FWX_FUSED_B;
             FWX_HIP(fwx::launch_fused_main<T>(a, 0, n, s));
-            FWX_HIP(rowpanel(k1, bt1, bi ^ 1, s));
+            FWX_HIP(panels(k1, bt1, bi ^ 1, s));
+            col_ready = true;
         } else if (k1 < k_end) {
             const int bt1 = k_end - k1 < FWX_FUSED_B ? k_end - k1 : FWX_FUSED_B;
             if (symmetric_ok && bt1 == FWX_FUSED_B) {
@@ -181,10 +192,8 @@ int fused_range(T *rate, int32_t *next, int32_t *hops, int n, int k_begin, int k
                 FWX_HIP(fwx::launch_fused_main<T>(a, k1, k1 + bt1, side.s));
                 FWX_HIP(fwx::launch_fused_main<T>(a, 0, n, side.s, k1, k1 + bt1,
                                                   fwx::FusedCols::only(k1, k1 + bt1)));
-                // ... then the next pass's panels into the other buffer set
-                FWX_HIP(rowpanel(k1, bt1, bi ^ 1, side.s));
-                bind(k1, bt1, bi ^ 1);
-                FWX_HIP(fwx::launch_fused_colpanel<T>(a, side.s));
+                // ... then the next pass's panels (one launch) into the other buffer set
+                FWX_HIP(panels(k1, bt1, bi ^ 1, side.s));
                 FWX_HIP(hipEventRecord(side.panel_done, side.s));
                 // main: pass b everywhere else
                 bind(k0, bt, bi);

@@ -138,19 +138,26 @@ template <> __device__ __forceinline__ int readlane<int>(int v, int lane)
 // HAS_HOPS: also carries `hops` (= length _path) of the pivot rows: hops' = hops[i][k] + hops[k][j]
 // on every successful relaxation (Algorithms.hs:55), and exports wh_out[t][j] = hops of (k0+t, j) at
 // time k0+t beside the rate snapshot.  hops_rows points at row k0 of the hops matrix.
-template <typename T, bool HAS_LAST, bool HAS_HOPS>
-__global__ __launch_bounds__(PANEL_THREADS) void fused_rowpanel(const T *rows, int n, int k0, int bt,
-                                                      T *w_out, const int32_t *last_rows,
-                                                      int32_t *at_rows, const int32_t *hops_rows,
-                                                      int32_t *wh_out)
+// (LDS is carved from one buffer so that the row and the column panel can share a launch:
+// fused_panels below)
+template <typename T, bool HAS_HOPS> constexpr int rowpanel_lds()
 {
-    __shared__ T s_dline[B][64];                   // published pivot rows, diagonal-block part (time t)
-    __shared__ T s_sline[B][64];                   // ... strip part
-    __shared__ int32_t s_dh[HAS_HOPS ? B : 1][64];      // their hops
-    __shared__ int32_t s_sh[HAS_HOPS ? B : 1][64];
+    return 2 * B * 64 * (int)sizeof(T) + (HAS_HOPS ? 2 * B * 64 * 4 : 0);
+}
+template <typename T, bool HAS_LAST, bool HAS_HOPS>
+__device__ __forceinline__ void rowpanel_body(char *smem, int bid, const T *rows, int n, int k0, int bt,
+                                              T *w_out, const int32_t *last_rows, int32_t *at_rows,
+                                              const int32_t *hops_rows, int32_t *wh_out)
+{
+    typedef T line_t[64];
+    typedef int32_t iline_t[64];
+    line_t *s_dline = (line_t *)smem;              // published pivot rows, diagonal-block part (time t)
+    line_t *s_sline = s_dline + B;                 // ... strip part
+    iline_t *s_dh = (iline_t *)(s_sline + B);      // their hops (HAS_HOPS)
+    iline_t *s_sh = s_dh + B;
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int j = blockIdx.x * 64 + lane;
+    const int j = bid * 64 + lane;
     const bool valid = j < n;
     const int jc = valid ? j : n - 1;
 
@@ -244,6 +251,17 @@ __global__ __launch_bounds__(PANEL_THREADS) void fused_rowpanel(const T *rows, i
     }
 }
 
+template <typename T, bool HAS_LAST, bool HAS_HOPS>
+__global__ __launch_bounds__(PANEL_THREADS) void fused_rowpanel(const T *rows, int n, int k0, int bt,
+                                                      T *w_out, const int32_t *last_rows,
+                                                      int32_t *at_rows, const int32_t *hops_rows,
+                                                      int32_t *wh_out)
+{
+    __shared__ __attribute__((aligned(16))) char smem[rowpanel_lds<T, HAS_HOPS>()];
+    rowpanel_body<T, HAS_LAST, HAS_HOPS>(smem, (int)blockIdx.x, rows, n, k0, bt, w_out, last_rows, at_rows,
+                                         hops_rows, wh_out);
+}
+
 // Column panel: time-t snapshots of the 64 pivot columns for 64 rows per workgroup (lanes = rows).
 // Needs only the block columns of W (Wd[t][c] = W[t][k0+c]), so it runs on every rank.
 // HAS_LAST: the path trace of the pivot columns (PathLog): `last` of each block entry is carried
@@ -252,34 +270,49 @@ __global__ __launch_bounds__(PANEL_THREADS) void fused_rowpanel(const T *rows, i
 // HAS_HOPS: `hops` of the block columns are carried beside their rates (hops' = hops[i][k] +
 // hops[k][j], the second operand from the hops panel wh of the pivot rows), and cht[t][i] = hops
 // of (i, k0+t) at time k0+t is exported for the main kernel.
-template <typename T, bool HAS_NEXT, bool HAS_LAST, bool HAS_HOPS>
-__global__ __launch_bounds__(PANEL_THREADS) void fused_colpanel(const T *rate, const int32_t *next, int rows,
-                                                      int n, int row0, int k0, int bt, const T *w,
-                                                      T *ct, int32_t *cnt, int ct_ld,
-                                                      const int32_t *last, int32_t *at_col,
-                                                      const int32_t *hops, const int32_t *wh,
-                                                      int32_t *cht)
+// OWN_D: the workgroup evolves the 64 x 64 diagonal block itself (from the pivot rows d_rows, their
+// hops d_hops; lanes = block columns, exactly as fused_rowpanel does) TOGETHER with its column
+// lines, instead of reading the block columns of a finished snapshot panel W: the column panel then
+// does not depend on the row panel of its pass, and the two can share one launch (fused_panels).
+template <typename T, bool HAS_NEXT, bool HAS_HOPS> constexpr int colpanel_lds()
 {
-    __shared__ T s_line[B][64];                    // published pivot columns (time-t, NaN at i==k)
-    __shared__ int32_t s_nline[HAS_NEXT ? B : 1][64];
-    __shared__ T s_wd[B][B];                       // s_wd[t][c] = D_t[k0+t][k0+c]
-    __shared__ int32_t s_hline[HAS_HOPS ? B : 1][64];   // hops of the published pivot columns
-    __shared__ int32_t s_wdh[HAS_HOPS ? B : 1][B];      // hops of D_t[k0+t][k0+c]
+    return B * 64 * (int)sizeof(T) + (HAS_NEXT ? B * 64 * 4 : 0) + B * B * (int)sizeof(T) +
+           (HAS_HOPS ? B * 64 * 4 + B * B * 4 : 0);
+}
+template <typename T, bool HAS_NEXT, bool HAS_LAST, bool HAS_HOPS, bool OWN_D>
+__device__ __forceinline__ void colpanel_body(char *smem, int bid, const T *rate, const int32_t *next, int rows,
+                                              int n, int row0, int k0, int bt, const T *w, T *ct, int32_t *cnt,
+                                              int ct_ld, const int32_t *last, int32_t *at_col,
+                                              const int32_t *hops, const int32_t *wh, int32_t *cht,
+                                              const T *d_rows, const int32_t *d_hops)
+{
+    typedef T line_t[64];
+    typedef int32_t iline_t[64];
+    line_t *s_line = (line_t *)smem;               // published pivot columns (time-t, NaN at i==k)
+    line_t *s_wd = s_line + B;                     // s_wd[t][c] = D_t[k0+t][k0+c]
+    iline_t *s_nline = (iline_t *)(s_wd + B);      // (HAS_NEXT)
+    iline_t *s_hline = s_nline + (HAS_NEXT ? B : 0);   // hops of the published pivot columns (HAS_HOPS)
+    iline_t *s_wdh = s_hline + B;                  // hops of D_t[k0+t][k0+c]
+    static_assert(B == 64, "s_wd rows are 64 wide");
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int il = blockIdx.x * 64 + lane;
+    const int il = bid * 64 + lane;
     const bool valid = il < rows;
     const int ic = valid ? il : rows - 1;
     const int gi = row0 + ic;
 
-    for (int idx = threadIdx.x; idx < B * B; idx += PANEL_THREADS) {
-        const int t = idx / B, c = idx % B;
-        s_wd[t][c] = (t < bt && c < bt) ? w[(size_t)t * n + k0 + c] : qnan<T>();
-        if (HAS_HOPS) s_wdh[t][c] = (t < bt && c < bt) ? wh[(size_t)t * n + k0 + c] : 0;
+    if (!OWN_D) {
+        for (int idx = threadIdx.x; idx < B * B; idx += PANEL_THREADS) {
+            const int t = idx / B, c = idx % B;
+            s_wd[t][c] = (t < bt && c < bt) ? w[(size_t)t * n + k0 + c] : qnan<T>();
+            if (HAS_HOPS) s_wdh[t][c] = (t < bt && c < bt) ? wh[(size_t)t * n + k0 + c] : 0;
+        }
     }
 
     T d[SB];
     int32_t nx[SB], lp[HAS_LAST ? SB : 1], hd[SB];
+    T pd[OWN_D ? SB : 1];                          // this wave's SB rows of the diagonal block
+    int32_t hdd[OWN_D ? SB : 1];                   // their hops
 #pragma unroll
     for (int q = 0; q < SB; ++q) {
         const int c = wave * SB + q;
@@ -288,6 +321,10 @@ __global__ __launch_bounds__(PANEL_THREADS) void fused_colpanel(const T *rate, c
         nx[q] = (HAS_NEXT && c < bt) ? next[off] : -1;
         if (HAS_LAST) lp[q] = c < bt ? last[off] : -1;
         hd[q] = (HAS_HOPS && c < bt) ? hops[off] : 0;
+        if (OWN_D) {
+            pd[q] = (c < bt && lane < bt) ? d_rows[(size_t)c * n + k0 + lane] : qnan<T>();
+            hdd[q] = (HAS_HOPS && c < bt && lane < bt) ? d_hops[(size_t)c * n + k0 + lane] : 0;
+        }
     }
     __syncthreads();
 
@@ -299,6 +336,33 @@ __global__ __launch_bounds__(PANEL_THREADS) void fused_colpanel(const T *rate, c
             for (int tq = 0; tq < SB; ++tq) {
                 const int t = b * SB + tq;
                 if (t >= bt) continue;
+                // ---- the diagonal block: pivot row t at time t (NaN at its own column: skip j == k,
+                // which also hides the stale diagonal entry), then this wave's other rows
+                T wd = T(0);
+                int32_t hwd = 0;
+                if (OWN_D) {
+                    wd = pd[tq];
+                    if (lane == t) wd = qnan<T>();
+                    hwd = HAS_HOPS ? hdd[tq] : 0;
+                    s_wd[t][lane] = wd;
+                    if (HAS_HOPS) s_wdh[t][lane] = hwd;
+                    T cv[SB];
+                    int32_t chv[SB];
+#pragma unroll
+                    for (int q = 0; q < SB; ++q) {
+                        cv[q] = readlane<T>(pd[q], t);
+                        chv[q] = HAS_HOPS ? readlane<int>(hdd[q], t) : 0;
+                    }
+#pragma unroll
+                    for (int q = 0; q < SB; ++q) {
+                        if (q == tq) continue;                    // skip i == k
+                        const T cd = cv[q] * wd;
+                        const bool ud = pd[q] < cd;
+                        pd[q] = ud ? cd : pd[q];
+                        if (HAS_HOPS) hdd[q] = ud ? (int32_t)((uint32_t)chv[q] + (uint32_t)hwd) : hdd[q];
+                    }
+                }
+                // ---- the column lines
                 T c = d[tq];
                 const int32_t cn = nx[tq];
                 const int32_t hc = hd[tq];
@@ -315,12 +379,15 @@ __global__ __launch_bounds__(PANEL_THREADS) void fused_colpanel(const T *rate, c
 #pragma unroll
                 for (int q = 0; q < SB; ++q) {
                     if (q == tq) continue;                        // skip j == k
-                    const T cand = c * s_wd[t][b * SB + q];
+                    // D_t[k0+t][k0 + b*SB + q]: lane b*SB+q of the pivot row just published
+                    const T wv = OWN_D ? readlane<T>(wd, b * SB + q) : s_wd[t][b * SB + q];
+                    const int32_t wvh = !HAS_HOPS ? 0 : OWN_D ? readlane<int>(hwd, b * SB + q) : s_wdh[t][b * SB + q];
+                    const T cand = c * wv;
                     const bool up = d[q] < cand;
                     d[q] = up ? cand : d[q];
                     if (HAS_NEXT) nx[q] = up ? cn : nx[q];
                     if (HAS_LAST) lp[q] = up ? k0 + t : lp[q];
-                    if (HAS_HOPS) hd[q] = up ? (int32_t)((uint32_t)hc + (uint32_t)s_wdh[t][b * SB + q]) : hd[q];
+                    if (HAS_HOPS) hd[q] = up ? (int32_t)((uint32_t)hc + (uint32_t)wvh) : hd[q];
                 }
             }
         }
@@ -330,6 +397,18 @@ __global__ __launch_bounds__(PANEL_THREADS) void fused_colpanel(const T *rate, c
             for (int tq = 0; tq < SB; ++tq) {
                 const int t = b * SB + tq;
                 if (t >= bt) continue;
+                if (OWN_D) {       // rows above the sub-block are past their own pivots too
+                    const T wd = s_wd[t][lane];
+                    const int32_t hwd = HAS_HOPS ? s_wdh[t][lane] : 0;
+#pragma unroll
+                    for (int q = 0; q < SB; ++q) {
+                        const T cd = readlane<T>(pd[q], t) * wd;
+                        const int32_t chv = HAS_HOPS ? readlane<int>(hdd[q], t) : 0;
+                        const bool ud = pd[q] < cd;
+                        pd[q] = ud ? cd : pd[q];
+                        if (HAS_HOPS) hdd[q] = ud ? (int32_t)((uint32_t)chv + (uint32_t)hwd) : hdd[q];
+                    }
+                }
                 const T c = s_line[t][lane];
                 const int32_t cn = HAS_NEXT ? s_nline[t][lane] : 0;
                 const int32_t hc = HAS_HOPS ? s_hline[t][lane] : 0;
@@ -344,6 +423,44 @@ __global__ __launch_bounds__(PANEL_THREADS) void fused_colpanel(const T *rate, c
                 }
             }
         }
+    }
+}
+
+template <typename T, bool HAS_NEXT, bool HAS_LAST, bool HAS_HOPS>
+__global__ __launch_bounds__(PANEL_THREADS) void fused_colpanel(const T *rate, const int32_t *next, int rows,
+                                                      int n, int row0, int k0, int bt, const T *w,
+                                                      T *ct, int32_t *cnt, int ct_ld,
+                                                      const int32_t *last, int32_t *at_col,
+                                                      const int32_t *hops, const int32_t *wh,
+                                                      int32_t *cht)
+{
+    __shared__ __attribute__((aligned(16))) char smem[colpanel_lds<T, HAS_NEXT, HAS_HOPS>()];
+    colpanel_body<T, HAS_NEXT, HAS_LAST, HAS_HOPS, false>(smem, (int)blockIdx.x, rate, next, rows, n, row0, k0, bt,
+                                                          w, ct, cnt, ct_ld, last, at_col, hops, wh, cht,
+                                                          nullptr, nullptr);
+}
+
+// Both panels of a pass in ONE launch (single-device solves: the slab is the whole matrix): the
+// first n/64 workgroups run the row panel, the rest the column panel with its own diagonal block.
+template <typename T, bool HAS_NEXT, bool HAS_LAST, bool HAS_HOPS>
+__global__ __launch_bounds__(PANEL_THREADS) void fused_panels(int row_wgs, const T *rate, const int32_t *next,
+                                                    int n, int k0, int bt, T *w_out, T *ct, int32_t *cnt,
+                                                    int ct_ld, const int32_t *last, int32_t *at_row,
+                                                    int32_t *at_col, const int32_t *hops, int32_t *wh_out,
+                                                    int32_t *cht)
+{
+    constexpr int RL = rowpanel_lds<T, HAS_HOPS>(), CL = colpanel_lds<T, HAS_NEXT, HAS_HOPS>();
+    __shared__ __attribute__((aligned(16))) char smem[RL > CL ? RL : CL];
+    const size_t prow = (size_t)k0 * n;            // the pivot rows
+    if ((int)blockIdx.x < row_wgs) {               // workgroup-uniform
+        rowpanel_body<T, HAS_LAST, HAS_HOPS>(smem, (int)blockIdx.x, rate + prow, n, k0, bt, w_out,
+                                             HAS_LAST ? last + prow : nullptr, HAS_LAST ? at_row + prow : nullptr,
+                                             HAS_HOPS ? hops + prow : nullptr, wh_out);
+    } else {
+        colpanel_body<T, HAS_NEXT, HAS_LAST, HAS_HOPS, true>(smem, (int)blockIdx.x - row_wgs, rate, next, n, n, 0,
+                                                             k0, bt, nullptr, ct, cnt, ct_ld, last, at_col, hops,
+                                                             nullptr, cht, rate + prow,
+                                                             HAS_HOPS ? hops + prow : nullptr);
     }
 }
 
@@ -1620,6 +1737,35 @@ hipError_t launch_fused_panel(const T *rows_base, int n, int k0, int bt, T *w, h
 #undef FWX_ROWPANEL
     return hipGetLastError();
 }
+
+// Row panel and column panel of pass (a.k0, a.bt) in one launch.  The slab must be the whole matrix
+// (a.rows == a.n, a.row0 == 0: the column panel takes its diagonal block from the pivot rows);
+// w_out / wh_out: where the snapshot panel and its hops go (a.w / a.wh are not read).
+template <typename T>
+hipError_t launch_fused_panels(const FusedArgs<T> &a, T *w_out, int32_t *wh_out, hipStream_t s)
+{
+    if (a.n <= 0 || a.bt <= 0) return hipSuccess;
+    if (a.rows != a.n || a.row0 != 0 || a.bt > B || !w_out || a.ct_ld < a.rows) return hipErrorInvalidValue;
+    if (a.plog.last && !a.next) return hipErrorInvalidValue;
+    if (a.hops && (!a.next || !wh_out || !a.cht)) return hipErrorInvalidValue;
+    const int row_wgs = (a.n + 63) / 64;
+    const dim3 grid((unsigned)(2 * row_wgs)), block(PANEL_THREADS);
+#define FWX_PANELS(HN, HL, HH)                                                                      \
+    hipLaunchKernelGGL((fused_panels<T, HN, HL, HH>), grid, block, 0, s, row_wgs, a.rate, a.next, a.n, a.k0, \
+                       a.bt, w_out, a.ct, a.cnt, a.ct_ld, a.plog.last, a.plog.at_row, a.plog.at_col,  \
+                       a.hops, wh_out, a.cht)
+    if (a.plog.last) {
+        if (a.hops) FWX_PANELS(true, true, true); else FWX_PANELS(true, true, false);
+    } else if (a.next) {
+        if (a.hops) FWX_PANELS(true, false, true); else FWX_PANELS(true, false, false);
+    } else {
+        FWX_PANELS(false, false, false);
+    }
+#undef FWX_PANELS
+    return hipGetLastError();
+}
+template hipError_t launch_fused_panels<float>(const FusedArgs<float> &, float *, int32_t *, hipStream_t);
+template hipError_t launch_fused_panels<double>(const FusedArgs<double> &, double *, int32_t *, hipStream_t);
 
 template hipError_t launch_fused_relax<float>(const FusedArgs<float> &, hipStream_t, int, int);
 template hipError_t launch_fused_relax<double>(const FusedArgs<double> &, hipStream_t, int, int);

@@ -108,6 +108,13 @@ template <typename T>
 hipError_t launch_fused_main(const FusedArgs<T> &a, int r_lo, int r_hi, hipStream_t s,
                              int skip_lo = 0, int skip_hi = 0, FusedCols cols = FusedCols());
 
+// rowpanel + colpanel of pass (a.k0, a.bt) in ONE launch, for a slab that is the whole matrix
+// (a.rows == a.n, a.row0 == 0): the column panel evolves the diagonal block itself instead of
+// reading a finished W, so neither waits for the other.  Writes w_out (and wh_out with hops), a.ct,
+// a.cnt, a.cht and the trace's at_row / at_col; a.w / a.wh are not read.
+template <typename T>
+hipError_t launch_fused_panels(const FusedArgs<T> &a, T *w_out, int32_t *wh_out, hipStream_t s);
+
 // diag + rowpanel: snapshot panel of the pivot rows `rows_base` (bt x n, at time k0); the matrix
 // is not modified.  plog: the path trace AT THE SAME ROWS as rows_base (plog.last / plog.at_row
 // point at pivot row k0; at_col is not touched).  hops_rows (same rows again) / wh: the hops of the
