@@ -76,25 +76,27 @@ template <typename T> bool fused_ok(int n, const void *rate, const int32_t *)
 // Single-GPU solve of pivots [k_begin,k_end) with the fused engine.  Per block of <= 64 pivots:
 // snapshot panel W_b (rowpanel), pivot-column snapshots for all rows (colpanel), main kernel over
 // all rows.  Three schedules:
-//   serial (small matrices): rowpanel, colpanel and ONE main launch per pass in one stream.  While
-//     a main launch is not much longer than a panel kernel (~20-40 us) any look-ahead costs more --
-//     an extra latency-bound launch and two cross-stream event hops (6 + 12 us) -- than its overlap
-//     gives: N = 1024 f32 1.08 -> 0.72 ms, N = 2048 2.21 -> 1.62, N = 4096 5.62 -> 5.28
-//     (gpurun_out/r02_run33.log, r02_run34.log).
-//   symmetric look-ahead (large matrices, 64-aligned blocks): the panel chain of block b+1 only
-//     needs the 64 pivot ROWS of b+1 (rowpanel) and the 64 pivot COLUMNS of b+1 (colpanel) as pass b
-//     leaves them.  The side stream relaxes exactly those with pass b's panels, then runs
-//     rowpanel(b+1) and colpanel(b+1) -- all of it beside main(b), which leaves those rows and
-//     columns alone.  The main stream carries nothing but main kernels back to back: the gap between
-//     two of them falls from 44 to 12.5 us (616 us per pass at N = 16384 f32 rates).
+//   serial: ONE fused_panels launch (row panel + column panel as one grid) and ONE main launch
+//     per pass, in one stream.  While a main launch is not much longer than a panel kernel
+//     (20-40 us) any look-ahead costs more -- an extra latency-bound launch and two cross-stream
+//     event hops (6 + 12 us) -- than its overlap gives: N = 1024 f32 1.08 ms (rows-only look-ahead)
+//     -> 0.73 (serial, three launches) -> 0.52 (panels merged); and because the panels then run on
+//     an idle chip (25 us instead of 75 us beside a main launch) it stays level with the look-ahead
+//     forms up to the largest sizes for rates-only solves.
+//   symmetric look-ahead (large matrices with next-hops, 64-aligned blocks): the panel chain of
+//     block b+1 only needs the 64 pivot ROWS and the 64 pivot COLUMNS of b+1 as pass b leaves them.
+//     The side stream relaxes exactly those with pass b's panels, then runs fused_panels(b+1) --
+//     all of it beside main(b), which leaves those rows and columns alone.  The main stream carries
+//     nothing but main kernels back to back (gap 44 -> 12.5 us).
 //   rows-only look-ahead (the fallback for pivot ranges that do not start on a multiple of 64):
 //     main(b) on the next block's rows first, their rowpanel on the side stream while main(b)
 //     sweeps the rest; colpanel(b+1) follows main(b).
-// Crossovers measured on f32 / f64 (r02_run34.log): rates only, serial wins up to n = 7168 and loses
-// at 8192 (22.9 vs 21.9 ms); with next-hops it wins up to 4096 (7.24 vs 7.85 ms), ties to 6144 and
-// loses from 7168; with the path trace it loses from 4096-5120 on.
+// Crossovers (serial vs symmetric, ms; gpurun_out/r02_run37.log, r02_run38.log): f32 rates 8192:
+// 21.6 / 22.3, 12288: 69.1 / 69.9, 16384: 156.3 / 157.0 -> always serial; f32 + next 8192: 39.5 / 39.6,
+// 12288: 117.0 / 117.5, 16384: 266.3 / 262.2; + trace 8192: 46.1 / 45.8, 10240: 84.6 / 83.6, 16384:
+// 316.2 / 305.0; f64 + trace 8192: 137.9 / 132.6.
 // ws: see fused_ws_bytes.
-constexpr int kLookaheadMinN = 8192, kLookaheadMinNWithNext = 5120, kLookaheadMinNWithTrace = 4096;
+constexpr int kLookaheadMinN = INT32_MAX, kLookaheadMinNWithNext = 16384, kLookaheadMinNWithTrace = 8192;
 // FWX_LOOKAHEAD_MIN_N / FWX_SYMMETRIC_MIN_N override the thresholds (tests force each schedule at
 // small sizes, tuning runs switch one off with a huge value); read on every solve.
 static int env_threshold(const char *name, int dflt)
