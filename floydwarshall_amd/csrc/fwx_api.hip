@@ -290,16 +290,18 @@ int solve_host(int32_t n, T *rate, int32_t *next, int32_t *hops, const fwx_opts 
     const bool to_fused = op.engine == FWX_ENGINE_FUSED || (op.engine == FWX_ENGINE_AUTO && n >= 256);
     const int nd = (to_fused && n % VW) ? (n + VW - 1) / VW * VW : n;
     const size_t nn = (size_t)nd * (size_t)nd;
-    DevBuf d_rate, d_next, d_hops, d_upd;
-    if ((rc = d_rate.alloc(nn * sizeof(T)))) return rc;
-    if (next && (rc = d_next.alloc(nn * sizeof(int32_t)))) return rc;
-    if (hops && (rc = d_hops.alloc(nn * sizeof(int32_t)))) return rc;
-    if ((rc = d_upd.alloc((FWX_UPDATE_SHARDS + 2) * sizeof(unsigned long long)))) return rc;
+    // stream, look-ahead stream, device buffers, workspace: a pooled per-call context (CallCtx)
+    CtxLease lease;
+    if ((rc = lease.open())) return rc;
+    CallCtx &cx = *lease.c;
+    struct { void *p = nullptr; } d_rate, d_next, d_hops, d_upd;
+    if ((rc = cx.reserve(CallCtx::RATE, nn * sizeof(T), &d_rate.p))) return rc;
+    if (next && (rc = cx.reserve(CallCtx::NEXT, nn * sizeof(int32_t), &d_next.p))) return rc;
+    if (hops && (rc = cx.reserve(CallCtx::HOPS, nn * sizeof(int32_t), &d_hops.p))) return rc;
+    if ((rc = cx.reserve(CallCtx::SMALL, (FWX_UPDATE_SHARDS + 2) * sizeof(unsigned long long), &d_upd.p))) return rc;
     int *d_flag = (int *)((unsigned long long *)d_upd.p + FWX_UPDATE_SHARDS);
 
-    CallStream cs;                     // a non-blocking stream of this call's own
-    if ((rc = cs.open(op))) return rc;
-    hipStream_t s = cs.s;
+    hipStream_t s = op.has_stream ? op.stream : cx.s;   // a non-blocking stream, never the null stream
     auto copy2d = [&](void *dst, size_t dpitch, const void *src, size_t spitch, size_t es,
                       hipMemcpyKind kind) -> int {
         if (dpitch == spitch)
@@ -336,11 +338,10 @@ int solve_host(int32_t n, T *rate, int32_t *next, int32_t *hops, const fwx_opts 
         // the reference's own regime: the whole solve in one single-workgroup launch
         FWX_HIP(fwx::launch_small_solve<T>(dr, dn, dh, n, op.k_begin, op.k_end, upd, fwx::PathLog(), s));
     } else if (route == ROUTE_FUSED) {
-        DevBuf d_ws;
-        if ((rc = d_ws.alloc(fused_ws_bytes(nd, sizeof(T), dh != nullptr)))) return rc;
-        rc = fused_range<T>(dr, dn, dh, nd, op.k_begin, op.k_end, d_ws.p, upd, s, fwx::PathLog(), nonneg);
+        void *ws = nullptr;
+        if ((rc = cx.reserve(CallCtx::WS, fused_ws_bytes(nd, sizeof(T), dh != nullptr), &ws))) return rc;
+        rc = fused_range<T>(dr, dn, dh, nd, op.k_begin, op.k_end, ws, upd, s, fwx::PathLog(), nonneg, &cx.side);
         if (rc) return rc;
-        FWX_HIP(hipStreamSynchronize(s));   // d_ws is released at scope exit
     } else {
         // per-k engine; pitch nd (a matrix padded for the fused engine but found outside its domain)
         rc = relax_range<T>(dr, dn, dh, nd, nd, 0, dr + (size_t)op.k_begin * nd,
@@ -377,7 +378,8 @@ __global__ void follow_path_kernel(const int32_t *next, int n, int src, int dst,
 }
 
 template <typename T>
-int matrix_solve_typed(fwx_matrix *m, const Opts &op, unsigned long long *upd, hipStream_t s);
+int matrix_solve_typed(fwx_matrix *m, const Opts &op, unsigned long long *upd, hipStream_t s,
+                       CallCtx *cx = nullptr);
 
 // One thread per (src, dst) pair: batch path reconstruction from the next-hop matrix.
 template <typename T>
@@ -449,18 +451,19 @@ int panel_impl(const fwx_slab *b, T *w, int32_t *w_hops, unsigned long long *d_u
 
 namespace {
 template <typename T>
-int matrix_solve_typed(fwx_matrix *m, const Opts &op, unsigned long long *upd, hipStream_t s)
+int matrix_solve_typed(fwx_matrix *m, const Opts &op, unsigned long long *upd, hipStream_t s, CallCtx *cx)
 {
     const int n = m->n;
     T *r = (T *)m->rate;
     Route route;
     bool nonneg = false;
-    DevBuf tmp_flag;
     int *d_flag = m->flag;
     int rc;
-    if (!d_flag) {                       // fwx_dev_solve: a view of caller-owned memory
-        if ((rc = tmp_flag.alloc(16))) return rc;
-        d_flag = (int *)tmp_flag.p;
+    if (!d_flag) {                       // fwx_dev_solve: a view of caller-owned memory + a pooled context
+        if (!cx) return FWX_ERR_INVALID;
+        void *small = nullptr;
+        if ((rc = cx->reserve(CallCtx::SMALL, (FWX_UPDATE_SHARDS + 2) * sizeof(unsigned long long), &small))) return rc;
+        d_flag = (int *)((unsigned long long *)small + FWX_UPDATE_SHARDS);
     }
     m->fresh = 0;                        // whatever happens next, the arrays are no longer the upload
     if ((rc = route_solve<T>(op, n, op.k_begin == 0 && op.k_end == n, r, m->next, m->hops, upd != nullptr,
@@ -472,9 +475,9 @@ int matrix_solve_typed(fwx_matrix *m, const Opts &op, unsigned long long *upd, h
         return FWX_OK;
     }
     if (route == ROUTE_FUSED) {
-        // a handle keeps its workspace and look-ahead stream across solves; a view allocates per call
+        // a handle keeps its workspace and look-ahead stream across solves; a view borrows the
+        // pooled context's
         const size_t need = fused_ws_bytes(n, sizeof(T), m->hops != nullptr);
-        DevBuf tmp_ws;
         void *ws = nullptr;
         SideStream *side = nullptr;
         if (m->flag) {
@@ -490,8 +493,8 @@ int matrix_solve_typed(fwx_matrix *m, const Opts &op, unsigned long long *upd, h
             ws = m->ws;
             side = m->side;
         } else {
-            if ((rc = tmp_ws.alloc(need))) return rc;
-            ws = tmp_ws.p;
+            if ((rc = cx->reserve(CallCtx::WS, need, &ws))) return rc;
+            side = &cx->side;
         }
         rc = fused_range<T>(r, m->next, m->hops, n, op.k_begin, op.k_end, ws, upd, s, m->plog, nonneg, side);
         if (rc) return rc;
@@ -1048,17 +1051,21 @@ int fwx_dev_solve(const fwx_slab *full, const fwx_opts *opts)
     memset(&m, 0, sizeof(m));
     m.n = full->n; m.dtype = full->dtype;
     m.rate = full->rate; m.next = full->next; m.hops = full->hops;
-    CallStream cs;
-    if ((rc = cs.open(op))) return rc;
-    hipStream_t s = cs.s;
-    DevBuf upd;
+    DeviceGuard g;                       // the context belongs to the device the call runs on
+    if ((rc = g.enter(op.device))) return rc;
+    CtxLease lease;
+    if ((rc = lease.open())) return rc;
+    hipStream_t s = op.has_stream ? op.stream : lease.c->s;
+    struct { void *p = nullptr; } upd;
     if (op.updates_out) {
-        if ((rc = upd.alloc(FWX_UPDATE_SHARDS * 8))) return rc;
+        void *small = nullptr;
+        if ((rc = lease.c->reserve(CallCtx::SMALL, (FWX_UPDATE_SHARDS + 2) * sizeof(unsigned long long), &small))) return rc;
+        upd.p = small;
         FWX_HIP(hipMemsetAsync(upd.p, 0, FWX_UPDATE_SHARDS * 8, s));
     }
     rc = full->dtype == FWX_F64
-             ? matrix_solve_typed<double>(&m, op, (unsigned long long *)upd.p, s)
-             : matrix_solve_typed<float>(&m, op, (unsigned long long *)upd.p, s);
+             ? matrix_solve_typed<double>(&m, op, (unsigned long long *)upd.p, s, lease.c)
+             : matrix_solve_typed<float>(&m, op, (unsigned long long *)upd.p, s, lease.c);
     if (rc) return rc;
     FWX_HIP(hipStreamSynchronize(s));
     if (op.updates_out) return sum_updates((unsigned long long *)upd.p, op.updates_out, s);

@@ -4,6 +4,9 @@
 #define FWX_INTERNAL_H
 
 #include <hip/hip_runtime.h>
+#include <mutex>
+#include <new>
+#include <vector>
 #include <stddef.h>
 #include <stdint.h>
 
@@ -180,6 +183,116 @@ struct SideStream {
     }
 };
 
+
+// ------------------------------------------------------------------------------------------------
+// Per-call context.  fwx_solve_f64 / _f32 / fwx_dev_solve are stateless for the caller, but what a
+// call needs on the device -- a stream, the look-ahead stream and its events, device buffers for the
+// caller's arrays, the fused engine's workspace -- is expensive to create and, above all, to
+// release (hipFree and hipStreamDestroy synchronise the device): 5-12 ms per call whatever the
+// matrix order, for a 4 x 4 solve that takes 20 us.  Contexts are therefore kept in a
+// process-wide pool, one per concurrent call and device; a call takes one, grows its buffers if it
+// must, and puts it back.  Buffers above kKeepBytes are released on the way back, so a one-off
+// N = 16384 solve does not pin gigabytes; the pool itself is never torn down (no HIP calls from
+// static destructors).
+// ------------------------------------------------------------------------------------------------
+struct CallCtx {
+    enum { RATE, NEXT, HOPS, WS, SMALL, NBUF };            // SMALL: update shards + domain flag
+    static constexpr size_t kKeepBytes = (size_t)256 << 20;
+    int device = -1;
+    hipStream_t s = nullptr;
+    SideStream side;
+    void *buf[NBUF] = {nullptr, nullptr, nullptr, nullptr, nullptr};
+    size_t cap[NBUF] = {0, 0, 0, 0, 0};
+
+    int reserve(int which, size_t bytes, void **out)
+    {
+        if (cap[which] < bytes) {
+            if (buf[which]) { (void)hipFree(buf[which]); buf[which] = nullptr; cap[which] = 0; }
+            const size_t want = bytes < 4096 ? 4096 : bytes + bytes / 8;      // a little head room
+            if (hipMalloc(&buf[which], want) != hipSuccess) {
+                (void)hipGetLastError();
+                FWX_HIP(hipMalloc(&buf[which], bytes));                       // exactly, then
+                cap[which] = bytes;
+            } else {
+                cap[which] = want;
+            }
+        }
+        *out = buf[which];
+        return FWX_OK;
+    }
+    void trim()
+    {
+        for (int i = 0; i < NBUF; ++i)
+            if (cap[i] > kKeepBytes) { (void)hipFree(buf[i]); buf[i] = nullptr; cap[i] = 0; }
+    }
+    void destroy()
+    {
+        for (int i = 0; i < NBUF; ++i)
+            if (buf[i]) (void)hipFree(buf[i]);
+        if (s) (void)hipStreamDestroy(s);
+    }
+};
+
+class CtxPool {
+public:
+    // The current device must already be the call's device (DeviceGuard).
+    static int acquire(CallCtx **out)
+    {
+        int dev = 0;
+        FWX_HIP(hipGetDevice(&dev));
+        Pool &p = pool();
+        {
+            std::lock_guard<std::mutex> lk(p.mu);
+            for (size_t i = 0; i < p.free_.size(); ++i)
+                if (p.free_[i]->device == dev) {
+                    *out = p.free_[i];
+                    p.free_.erase(p.free_.begin() + (long)i);
+                    return FWX_OK;
+                }
+        }
+        CallCtx *c = new (std::nothrow) CallCtx();
+        if (!c) return FWX_ERR_OOM;
+        c->device = dev;
+        if (hipStreamCreateWithFlags(&c->s, hipStreamNonBlocking) != hipSuccess) {
+            g_last_hip = (int)hipGetLastError();
+            delete c;
+            return FWX_ERR_HIP;
+        }
+        *out = c;
+        return FWX_OK;
+    }
+    static void release(CallCtx *c)
+    {
+        if (!c) return;
+        c->trim();
+        Pool &p = pool();
+        {
+            std::lock_guard<std::mutex> lk(p.mu);
+            if (p.free_.size() < kMaxFree) { p.free_.push_back(c); return; }
+        }
+        c->destroy();          // more concurrent callers than the pool keeps: this one goes
+        delete c;
+    }
+
+private:
+    static constexpr size_t kMaxFree = 8;
+    struct Pool { std::mutex mu; std::vector<CallCtx *> free_; };
+    static Pool &pool() { static Pool *p = new Pool(); return *p; }   // leaked on purpose
+};
+
+// A context for the duration of one call.
+struct CtxLease {
+    CallCtx *c = nullptr;
+    int open() { return CtxPool::acquire(&c); }
+    ~CtxLease()
+    {
+        if (c) {       // an error return may leave work queued: the context goes back idle
+            (void)hipStreamSynchronize(c->s);
+            if (c->side.s) (void)hipStreamSynchronize(c->side.s);
+        }
+        CtxPool::release(c);
+    }
+};
 
 inline size_t fused_ws_bytes(int n, size_t es, bool with_hops)
 {
