@@ -231,12 +231,16 @@ int fused_range(T *rate, int32_t *next, int32_t *hops, int n, int k_begin, int k
     return FWX_OK;
 }
 
-// AUTO: the fused engine wherever it applies and the matrix is big enough to fill the chip.
+// AUTO: the single-launch kernel up to its 64 x 64 form, the fused engine above wherever it applies.
+constexpr int kSmallSolveAutoMax = 64;
 template <typename T> bool pick_fused(int engine, int n, const void *rate, const int32_t *hops)
 {
     if (engine == FWX_ENGINE_PERK) return false;
     if (!fused_ok<T>(n, rate, hops)) return false;
-    return engine == FWX_ENGINE_FUSED || n >= 256;   // tools/measure_small.py: fused wins from 256
+    // tools/measure_small.py (profiles/r02_small_sizes.txt): with the serial two-launch schedule
+    // the fused engine beats the per-k engine at every order, and the single-launch kernel above
+    // its 64 x 64 register form (n = 72 f64 + next: 0.13 ms against 0.20; n = 128: 0.18 / 0.36)
+    return engine == FWX_ENGINE_FUSED || n > kSmallSolveAutoMax;
 }
 
 // Which engine runs a solve of pivots [k_begin, k_end) of an order-n matrix (pivots < n only for a
@@ -250,8 +254,11 @@ int route_solve(const Opts &op, int n, bool whole, const T *rate, const int32_t 
     nonneg = false;
     (void)whole;
     if (op.engine == FWX_ENGINE_FUSED && !fused_ok<T>(n, rate, hops)) return FWX_ERR_UNSUPPORTED;
-    if (op.engine == FWX_ENGINE_AUTO && n <= FWX_SMALL_N) { route = ROUTE_SMALL; return FWX_OK; }
-    if (!pick_fused<T>(op.engine, n, rate, hops)) { route = ROUTE_PERK; return FWX_OK; }
+    // AUTO below the fused engine's range, or where it cannot read the matrix / the input lies outside
+    // its domain: the single-launch kernel while it fits (n <= FWX_SMALL_N), else one launch per pivot
+    const Route fallback = (op.engine == FWX_ENGINE_AUTO && n <= FWX_SMALL_N) ? ROUTE_SMALL : ROUTE_PERK;
+    if (op.engine == FWX_ENGINE_AUTO && n <= kSmallSolveAutoMax) { route = ROUTE_SMALL; return FWX_OK; }
+    if (!pick_fused<T>(op.engine, n, rate, hops)) { route = fallback; return FWX_OK; }
     // The fused kernels take next[i][k] as the head of ikPath ++ kjPath (Algorithms.hs:55), which
     // is the reference's list head only while a winning product never has an empty ikPath -- true
     // on the reference's own domain, checked here.  Outside it the per-k engine, which reads the
@@ -261,7 +268,7 @@ int route_solve(const Opts &op, int n, bool whole, const T *rate, const int32_t 
         const int rc = domain_bits<T>(rate, next, (size_t)n * n, d_flag, s, bits);
         if (rc) return rc;
     }
-    if (next && bits != 3) { route = ROUTE_PERK; return FWX_OK; }
+    if (next && bits != 3) { route = fallback; return FWX_OK; }
     nonneg = !counting && (next ? bits == 3 : (bits & 1) != 0);   // max-form kernels allowed
     route = ROUTE_FUSED;
     return FWX_OK;
@@ -287,7 +294,7 @@ int solve_host(int32_t n, T *rate, int32_t *next, int32_t *hops, const fwx_opts 
     // (0 < +-0 and 0 < NaN are false), so U is unchanged too.  The caller's arrays stay n x n.
     constexpr int VW = 16 / (int)sizeof(T);
     const bool whole = op.k_begin == 0 && op.k_end == n;
-    const bool to_fused = op.engine == FWX_ENGINE_FUSED || (op.engine == FWX_ENGINE_AUTO && n >= 256);
+    const bool to_fused = op.engine == FWX_ENGINE_FUSED || (op.engine == FWX_ENGINE_AUTO && n > kSmallSolveAutoMax);
     const int nd = (to_fused && n % VW) ? (n + VW - 1) / VW * VW : n;
     const size_t nn = (size_t)nd * (size_t)nd;
     // stream, look-ahead stream, device buffers, workspace: a pooled per-call context (CallCtx)

@@ -10,7 +10,7 @@ sys.path.insert(0, __file__.rsplit("/", 2)[0])
 from floydwarshall_amd import engine, synth  # noqa: E402
 
 dev = torch.device("cuda:0")
-for n in (64, 128, 132, 160, 192, 224, 256, 384, 512, 768, 1024):
+for n in (32, 48, 64, 72, 80, 96, 112, 128, 132, 160, 192, 224, 256, 384, 512, 768, 1024):
     for dt in (np.float64, np.float32):
         rate, nxt, _ = synth.make("d1", n, dt, seed=3)
         r0, n0 = torch.from_numpy(rate).to(dev), torch.from_numpy(nxt).to(dev)
