@@ -73,11 +73,12 @@ typedef enum fwx_status {
 typedef enum fwx_dtype { FWX_F32 = 0, FWX_F64 = 1 } fwx_dtype;
 
 /* Which relaxation engine runs the pivots.  All are bit-exact with the reference loop.
- * AUTO: n <= 128 -> the whole solve in one single-workgroup launch; n >= 256 -> FUSED; otherwise
- * PERK.  The fused kernels need rows that are a multiple of 16 bytes: fwx_solve_f32/f64
- * (host buffers) pad an odd-sized matrix on the device, the entry points that work on device
- * memory they do not own (fwx_matrix_*, fwx_dev_*) fall back to PERK under AUTO and refuse an
- * explicit FUSED (FWX_ERR_UNSUPPORTED).                                                          */
+ * AUTO: n <= 64 -> the whole solve in one single-workgroup launch; above -> FUSED (two launches
+ * per 64 pivots).  Where FUSED does not apply -- an input outside the domain below, or rows that
+ * are not a multiple of 16 bytes: fwx_solve_f32/f64 (host buffers) pad an odd-sized matrix on the
+ * device, the entry points that work on device memory they do not own (fwx_matrix_*, fwx_dev_*)
+ * cannot -- AUTO takes the single-launch kernel up to n = 128 and PERK above; an explicit FUSED is
+ * refused there (FWX_ERR_UNSUPPORTED).                                                            */
 typedef enum fwx_engine {
     FWX_ENGINE_AUTO = 0,
     FWX_ENGINE_PERK = 1,  /* one N x N launch per pivot k (HBM-bound streaming kernel)            */
