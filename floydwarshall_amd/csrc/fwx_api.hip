@@ -489,7 +489,11 @@ int matrix_solve_typed(fwx_matrix *m, const Opts &op, unsigned long long *upd, h
         SideStream *side = nullptr;
         if (m->flag) {
             if (m->ws_bytes < need) {
-                if (m->ws) { (void)hipFree(m->ws); m->ws = nullptr; m->ws_bytes = 0; }
+                if (m->ws) {
+                    drain_stream(s);
+                    if (m->side) m->side->drain();
+                    (void)hipFree(m->ws); m->ws = nullptr; m->ws_bytes = 0;
+                }
                 FWX_HIP(hipMalloc(&m->ws, need));
                 m->ws_bytes = need;
             }
@@ -712,6 +716,8 @@ int fwx_matrix_destroy(fwx_matrix *m)
     }
     DeviceGuard g;
     (void)g.enter(m->device);
+    drain_stream(m->stream);           // every command that used the arrays has been retired
+    if (m->side) m->side->drain();
     if (m->rate) (void)hipFree(m->rate);
     if (m->next) (void)hipFree(m->next);
     if (m->hops) (void)hipFree(m->hops);
@@ -872,7 +878,7 @@ int fwx_matrix_query_exact(fwx_matrix *m, int32_t src, int32_t dst, double *rate
             FWX_HIP(hipMemcpyAsync(&f32_rate, (float *)m->rate + idx, 4, hipMemcpyDeviceToHost, s));
     }
     if (!m->walk || m->walk_cap < cap) {      // grow-only scratch, reused across queries
-        if (m->walk) { (void)hipFree(m->walk); m->walk = nullptr; }
+        if (m->walk) { drain_stream(s); (void)hipFree(m->walk); m->walk = nullptr; }
         FWX_HIP(hipMalloc((void **)&m->walk, ((size_t)4 * cap + 1) * 4));
         m->walk_cap = cap;
     }
@@ -902,11 +908,20 @@ int fwx_matrix_query_exact_batch(fwx_matrix *m, int32_t count, const int32_t *sr
     DeviceGuard g;
     int rc = g.enter(m->device);
     if (rc) return rc;
-    DevBuf d_src, d_dst, d_len, d_paths, d_stacks;
+    // device scratch from a pooled per-call context: no hipMalloc / hipFree per query (and no hipFree
+    // right behind the kernel that used the memory: drain_stream in fwx_internal.h)
+    CtxLease lease;
+    if ((rc = lease.open())) return rc;
     const size_t c = (size_t)count;
-    if ((rc = d_src.alloc(c * 4)) || (rc = d_dst.alloc(c * 4)) || (rc = d_len.alloc(c * 4)) ||
-        (rc = d_paths.alloc(c * cap * 4)) || (rc = d_stacks.alloc(c * cap * 12)))
+    struct { void *p = nullptr; } d_src, d_dst, d_len, d_paths, d_stacks;
+    void *ids = nullptr;
+    if ((rc = lease.c->reserve(CallCtx::NEXT, c * 12, &ids)) ||
+        (rc = lease.c->reserve(CallCtx::RATE, c * cap * 4, &d_paths.p)) ||
+        (rc = lease.c->reserve(CallCtx::WS, c * cap * 12, &d_stacks.p)))
         return rc;
+    d_src.p = ids;
+    d_dst.p = (char *)ids + c * 4;
+    d_len.p = (char *)ids + c * 8;
     hipStream_t s = m->stream;
     FWX_HIP(hipMemcpyAsync(d_src.p, src, c * 4, hipMemcpyHostToDevice, s));
     FWX_HIP(hipMemcpyAsync(d_dst.p, dst, c * 4, hipMemcpyHostToDevice, s));

@@ -152,16 +152,34 @@ inline int sum_updates(unsigned long long *d_updates, uint64_t *out, hipStream_t
 }
 
 
-struct DevBuf {
+// hipFree right behind the completion of a command that used the memory can crash the HIP runtime:
+// hipStreamSynchronize returns when the awaited command's status is set, while the runtime's signal
+// handler thread is still releasing that command's resources -- among them its references to the
+// memory objects behind the kernel's pointer arguments -- and a hipFree that gets there first deletes
+// the object under it (SIGSEGV in amd::ReferenceCountedObject::release() <-
+// amd::KernelParameters::release <- amd::roc::HsaAmdSignalHandler; rocgdb backtrace in
+// gpurun_out/r02_run43_gdb.log, once per ~300-2000 create / solve / destroy cycles of tools/
+// fuzz_domain.py).  The handler retires the commands of a queue strictly in order, so one more
+// trivial command on the stream, waited for, proves that everything before it has been retired;
+// its own retirement only touches a buffer that is never freed.
+inline void drain_stream(hipStream_t s)
+{
+    static std::mutex mu;
+    static void *pad[64] = {nullptr};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return;
     void *p = nullptr;
-    ~DevBuf() { if (p) (void)hipFree(p); }
-    int alloc(size_t bytes)
     {
-        FWX_HIP(hipMalloc(&p, bytes ? bytes : 1));
-        return FWX_OK;
+        std::lock_guard<std::mutex> lk(mu);
+        if (!pad[dev] && hipMalloc(&pad[dev], 256) != hipSuccess) { (void)hipGetLastError(); pad[dev] = nullptr; }
+        p = pad[dev];
     }
-};
-
+    if (s) (void)hipStreamSynchronize(s);
+    if (p && s) {
+        (void)hipMemsetAsync(p, 0, 4, s);
+        (void)hipStreamSynchronize(s);
+    }
+}
 
 struct SideStream {
     hipStream_t s = nullptr;
@@ -173,6 +191,7 @@ struct SideStream {
         if (panel_done) (void)hipEventDestroy(panel_done);
         if (s) (void)hipStreamDestroy(s);
     }
+    void drain() { if (s) drain_stream(s); }
     int init()
     {
         FWX_HIP(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
@@ -204,10 +223,11 @@ struct CallCtx {
     void *buf[NBUF] = {nullptr, nullptr, nullptr, nullptr, nullptr};
     size_t cap[NBUF] = {0, 0, 0, 0, 0};
 
+    void drain() { drain_stream(s); side.drain(); }
     int reserve(int which, size_t bytes, void **out)
     {
         if (cap[which] < bytes) {
-            if (buf[which]) { (void)hipFree(buf[which]); buf[which] = nullptr; cap[which] = 0; }
+            if (buf[which]) { drain(); (void)hipFree(buf[which]); buf[which] = nullptr; cap[which] = 0; }
             const size_t want = bytes < 4096 ? 4096 : bytes + bytes / 8;      // a little head room
             if (hipMalloc(&buf[which], want) != hipSuccess) {
                 (void)hipGetLastError();
@@ -222,11 +242,15 @@ struct CallCtx {
     }
     void trim()
     {
+        bool any = false;
+        for (int i = 0; i < NBUF; ++i) any = any || cap[i] > kKeepBytes;
+        if (any) drain();
         for (int i = 0; i < NBUF; ++i)
             if (cap[i] > kKeepBytes) { (void)hipFree(buf[i]); buf[i] = nullptr; cap[i] = 0; }
     }
     void destroy()
     {
+        drain();
         for (int i = 0; i < NBUF; ++i)
             if (buf[i]) (void)hipFree(buf[i]);
         if (s) (void)hipStreamDestroy(s);

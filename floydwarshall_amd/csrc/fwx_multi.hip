@@ -202,8 +202,10 @@ static void multi_free(MultiState *M)
     for (int p = 0; p < M->parts; ++p) {
         Part &q = M->part[p];
         if (hipSetDevice(q.device) != hipSuccess) continue;
-        if (q.main) (void)hipStreamSynchronize(q.main);
-        if (q.side) (void)hipStreamSynchronize(q.side);
+        // every command that used this partition's arrays has been RETIRED, not just completed
+        // (drain_stream in fwx_internal.h)
+        if (q.main) drain_stream(q.main);
+        if (q.side) drain_stream(q.side);
     }
     if (M->have_comm)
         for (int p = 0; p < M->parts; ++p) (void)rccl().CommDestroy(M->comm[p]);
@@ -615,7 +617,7 @@ static int read_rate(fwx_matrix *m, int src, int dst, double *rate_out)
 static int query_scratch(MultiState &M, int32_t ints)
 {
     if (M.qscratch && M.qcap >= ints) return FWX_OK;
-    if (M.qscratch) { (void)hipFree(M.qscratch); M.qscratch = nullptr; M.qcap = 0; }
+    if (M.qscratch) { drain_stream(M.part[0].main); (void)hipFree(M.qscratch); M.qscratch = nullptr; M.qcap = 0; }
     FWX_HIP(hipMalloc((void **)&M.qscratch, (size_t)ints * 4));
     M.qcap = ints;
     return FWX_OK;
@@ -653,11 +655,20 @@ int multi_query_exact_batch(fwx_matrix *m, int32_t count, const int32_t *src, co
     Part &z = M.part[0];
     int rc = set_dev(z.device);
     if (rc) return rc;
-    DevBuf d_src, d_dst, d_len, d_paths, d_stacks;
+    // device scratch from a pooled per-call context: no hipMalloc / hipFree per query (and no hipFree
+    // right behind the kernel that used the memory: drain_stream in fwx_internal.h)
+    CtxLease lease;
+    if ((rc = lease.open())) return rc;
     const size_t c = (size_t)count;
-    if ((rc = d_src.alloc(c * 4)) || (rc = d_dst.alloc(c * 4)) || (rc = d_len.alloc(c * 4)) ||
-        (rc = d_paths.alloc(c * cap * 4)) || (rc = d_stacks.alloc(c * cap * 12)))
+    struct { void *p = nullptr; } d_src, d_dst, d_len, d_paths, d_stacks;
+    void *ids = nullptr;
+    if ((rc = lease.c->reserve(CallCtx::NEXT, c * 12, &ids)) ||
+        (rc = lease.c->reserve(CallCtx::RATE, c * cap * 4, &d_paths.p)) ||
+        (rc = lease.c->reserve(CallCtx::WS, c * cap * 12, &d_stacks.p)))
         return rc;
+    d_src.p = ids;
+    d_dst.p = (char *)ids + c * 4;
+    d_len.p = (char *)ids + c * 8;
     FWX_HIP(hipMemcpyAsync(d_src.p, src, c * 4, hipMemcpyHostToDevice, z.main));
     FWX_HIP(hipMemcpyAsync(d_dst.p, dst, c * 4, hipMemcpyHostToDevice, z.main));
     hipLaunchKernelGGL(multi_exact_paths_kernel, dim3((unsigned)((c + 63) / 64)), dim3(64), 0, z.main,

@@ -53,11 +53,13 @@ max_n = int(sys.argv[2]) if len(sys.argv) > 2 else 700
 seed = int(sys.argv[3]) if len(sys.argv) > 3 else int(time.time())
 print("fuzz_domain: seed %d" % seed, flush=True)
 rnd = np.random.default_rng(seed)
-trail = open(os.environ.get("FUZZ_TRAIL", "/dev/null"), "w")
+trail = open(os.environ["FUZZ_TRAIL"], "w") if os.environ.get("FUZZ_TRAIL") else None
 
 
 def note(msg):
     """last thing attempted, for a crash that leaves no traceback"""
+    if trail is None:
+        return
     trail.seek(0)
     trail.truncate()
     trail.write(msg + "\n")
