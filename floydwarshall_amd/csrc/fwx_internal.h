@@ -72,19 +72,6 @@ struct Opts {
 // The stream one blocking ABI call runs on: the caller's (fwx_opts.stream) or a non-blocking stream
 // of its own -- never the legacy null stream, which would serialise the call against every other
 // blocking stream of the process (torch's included) and against solves on other host threads.
-struct CallStream {
-    hipStream_t s = nullptr;
-    bool owned = false;
-    int open(const Opts &op)
-    {
-        if (op.has_stream) { s = op.stream; return FWX_OK; }
-        FWX_HIP(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
-        owned = true;
-        return FWX_OK;
-    }
-    ~CallStream() { if (owned && s) (void)hipStreamDestroy(s); }
-};
-
 // Bounds the number of launches in flight on a stream: every EVERY launches an event is recorded
 // and the host waits for the event recorded 2*EVERY launches earlier.  The GPU never idles (at
 // least EVERY launches are queued behind the one being waited for), but a solve of N = 16384

@@ -42,7 +42,9 @@
  * Threading / streams: calls are blocking unless a stream is passed explicitly (fwx_dev_*, or
  * fwx_opts.stream), may come from any OS thread, keep no global mutable state, and restore the
  * caller's current HIP device.  No entry point uses the legacy null stream: one-shot calls run on
- * a non-blocking stream of their own, a handle on the handle's own non-blocking stream, so solves
+ * a non-blocking stream of their own (taken, with the device buffers and workspace the call needs,
+ * from a process-wide pool of per-call contexts: a call creates and frees nothing on the device
+ * once the pool is warm), a handle on the handle's own non-blocking stream, so solves
  * on different host threads overlap on the device and nothing synchronises implicitly with the
  * streams of other libraries in the process (torch's included).
  */
