@@ -40,7 +40,8 @@
  * fwx_dev_check_nonneg.
  *
  * Threading / streams: calls are blocking unless a stream is passed explicitly (fwx_dev_*, or
- * fwx_opts.stream), may come from any OS thread, keep no global mutable state, and restore the
+ * fwx_opts.stream), may come from any OS thread, keep no global mutable state besides a
+ * mutex-protected pool of per-call contexts, and restore the
  * caller's current HIP device.  No entry point uses the legacy null stream: one-shot calls run on
  * a non-blocking stream of their own (taken, with the device buffers and workspace the call needs,
  * from a process-wide pool of per-call contexts: a call creates and frees nothing on the device
