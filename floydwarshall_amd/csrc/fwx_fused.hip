@@ -1443,6 +1443,236 @@ __global__ __launch_bounds__(256, MINW) void fused_main_arg(float *rate, int32_t
     retire();
 }
 
+// ------------------------------------------------------------------------------------------------
+// fused_main_arg_f64: the arg scheme (see fused_main_arg) at the REFERENCE'S precision -- rates +
+// next-hops (+ path trace, + hops) for f64 matrices inside the domain, instead of the compare form
+// (v_mul_f64 + v_cmp + three selects per relaxation).  f64 has no three-operand max: one
+// v_mul_f64 + one v_max_f64 per relaxation, one pivot at a time.  All 64 pivots of the operand
+// strips must stay in LDS for the re-scan, which fixes the tile: 64 x 64 (2 x 32 KB of operands +
+// lists = 69 KB, two workgroups per CU), 4 x 4 entries per thread.  Its fold reads 4 B of LDS
+// operands per relaxation -- at the edge of the LDS pipe -- so it is slower than
+// fused_main_max_f64's, and still well ahead of the compare form.
+// ------------------------------------------------------------------------------------------------
+template <int MINW>
+__global__ __launch_bounds__(256, MINW) void fused_main_arg_f64(double *rate, int32_t *next, int rows, int n,
+                                                                int row0, int k0, int bt, const double *w,
+                                                                const double *ct, const int32_t *cnt,
+                                                                int ct_ld, int ct_vec, int skip_lo,
+                                                                int skip_hi, int32_t *last, int32_t *hops,
+                                                                const int32_t *cht, const int32_t *wh, ColWin cw)
+{
+    typedef double V2 __attribute__((ext_vector_type(2)));
+    constexpr int RI = 4, TI = 64, TJ = 64, LCAP = 192;
+    __shared__ __attribute__((aligned(16))) double sW[B][TJ];
+    __shared__ __attribute__((aligned(16))) double sC[B][TI];
+    __shared__ unsigned short l_id[4][LCAP];    // per-wave item lists: sid << 13 | row << 6 | column
+    __shared__ int32_t g_next[4][64], g_hc[4][64], g_hw[4][64];   // gathers of the batch in flight
+
+    const int tid = threadIdx.x;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int i_base = blockIdx.y * TI;
+    const int j_base = (blockIdx.x + cw.jt0) * TJ;
+    if (cw.cskip_lo <= j_base && j_base + TJ <= cw.cskip_hi) return;   // the whole tile is someone else's
+    const int ti = tid >> 4, tj = tid & 15;
+    const int i0 = i_base + ti * RI;
+    const bool skip = i0 >= skip_lo && i0 < skip_hi;   // rows done by the look-ahead launch
+    const double nanv = qnan<double>();
+
+    // ---- stage W (NaN at j == k and past the matrix) and C (NaN at i == k, from colpanel) -------
+    for (int idx = tid; idx < B * (TJ / 2); idx += 256) {
+        const int t = idx / (TJ / 2), v = idx % (TJ / 2);
+        const int j = j_base + v * 2;
+        V2 val = V2{nanv, nanv};
+        if (t < bt && j < n) {
+            val = *reinterpret_cast<const V2 *>(w + (size_t)t * n + j);
+            const int kcol = k0 + t - j;
+            if (kcol >= 0 && kcol < 2) val[kcol] = nanv;
+        }
+        *reinterpret_cast<V2 *>(&sW[t][v * 2]) = val;
+    }
+    for (int idx = tid; idx < B * (TI / 2); idx += 256) {
+        const int t = idx / (TI / 2), v = idx % (TI / 2);
+        const int i = i_base + v * 2;
+        V2 val = V2{nanv, nanv};
+        if (t < bt) {
+            if (ct_vec && i + 2 <= rows) {
+                val = *reinterpret_cast<const V2 *>(ct + (size_t)t * ct_ld + i);
+            } else {
+                if (i < rows) val[0] = ct[(size_t)t * ct_ld + i];
+                if (i + 1 < rows) val[1] = ct[(size_t)t * ct_ld + i + 1];
+            }
+        }
+        *reinterpret_cast<V2 *>(&sC[t][v * 2]) = val;
+    }
+
+    const int jcol = j_base + tj * 4;                  // 4 columns = two 16-byte vectors
+    const bool jok = jcol < n && !cw.skips(jcol);      // n % 2 == 0 and jcol % 4 == 0: jcol + 2 may be == n
+    const bool jok2 = jok && jcol + 2 < n;
+    const int jc = jok ? jcol : n - 2;
+    const int jc2 = jok2 ? jcol + 2 : n - 2;
+    double xa[RI][4], xb[RI][4];
+    int sid[RI][4];
+#pragma unroll
+    for (int r = 0; r < RI; ++r) {
+        const int i = min(i0 + r, rows - 1);
+        const V2 a = *reinterpret_cast<const V2 *>(rate + (size_t)i * n + jc);
+        const V2 b = *reinterpret_cast<const V2 *>(rate + (size_t)i * n + jc2);
+        xa[r][0] = a[0]; xa[r][1] = a[1]; xa[r][2] = b[0]; xa[r][3] = b[1];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) sid[r][e] = -1;
+    }
+    __syncthreads();
+
+    // ---- 1. the fold: four stages of 16 pivots that ping-pong xa <-> xb --------------------------
+    const int npiv = skip ? 0 : bt;
+    auto step = [&](int t, const double (&in)[RI][4], double (&out)[RI][4]) {
+        double c[RI], wv[4];
+#pragma unroll
+        for (int q = 0; q < RI / 2; ++q) {
+            const V2 cv = *reinterpret_cast<const V2 *>(&sC[t][ti * RI + q * 2]);
+            c[q * 2] = cv[0];
+            c[q * 2 + 1] = cv[1];
+        }
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const V2 wq = *reinterpret_cast<const V2 *>(&sW[t][tj * 4 + q * 2]);
+            wv[q * 2] = wq[0];
+            wv[q * 2 + 1] = wq[1];
+        }
+#pragma unroll
+        for (int r = 0; r < RI; ++r) {
+            double p[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) p[e] = c[r] * wv[e];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) out[r][e] = fmax_t(in[r][e], p[e]);
+        }
+    };
+    int stages = 0;                                  // stages executed (wave-uniform)
+#pragma unroll
+    for (int s = 0; s < B / ARG_SL; ++s) {
+        if (s * ARG_SL < npiv) {
+            const double (&src)[RI][4] = (s & 1) ? xb : xa;
+            double (&dst)[RI][4] = (s & 1) ? xa : xb;
+            const int t_hi = min(s * ARG_SL + ARG_SL, npiv);
+            step(s * ARG_SL, src, dst);
+#pragma unroll 1
+            for (int t = s * ARG_SL + 1; t < t_hi; ++t) step(t, dst, dst);
+#pragma unroll
+            for (int r = 0; r < RI; ++r)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) sid[r][e] = (dst[r][e] != src[r][e]) ? s : sid[r][e];
+            stages = s + 1;
+        }
+    }
+    if (stages & 1) {                                // the result sits in xb: bring it to xa
+#pragma unroll
+        for (int r = 0; r < RI; ++r)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) xa[r][e] = xb[r][e];
+    }
+
+    // ---- 2. + 3. moved entries -> items -> t* -> next (and last, hops): as in fused_main_arg -----
+    typedef __attribute__((address_space(1))) const void gptr_t;
+    typedef __attribute__((address_space(3))) void lptr_t;
+    const int gi_lo = row0 + i_base;
+    const bool diag_tile = gi_lo < j_base + TJ && j_base < gi_lo + TI;
+    unsigned short *ids = &l_id[wave][0];
+    const int lane = tid & 63;
+    int count = 0;                                   // items in this wave's list (wave-uniform)
+    bool p_act = false;
+    size_t p_off = 0;
+    auto retire = [&]() __attribute__((always_inline)) {
+        if (p_act) {
+            __builtin_amdgcn_s_waitcnt(FWX_WAIT_VMCNT0);     // the global -> LDS gathers have landed
+            next[p_off] = g_next[wave][lane];
+            if (hops) hops[p_off] = (int32_t)((uint32_t)g_hc[wave][lane] + (uint32_t)g_hw[wave][lane]);
+        }
+        p_act = false;
+    };
+    auto rescan = [&](bool all) __attribute__((always_inline)) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        int base = 0;
+        for (; base + 64 <= count || (all && base < count); base += 64) {
+            const int it = base + lane;
+            const bool act = it < count;
+            const unsigned int id = ids[act ? it : 0];
+            const int il = (int)((id >> 6) & 127u), jl = (int)(id & 63u), t0 = (int)(id >> 13) * ARG_SL;
+            const double *pc = &sC[t0][il];
+            const double *pw = &sW[t0][jl];
+            double p[ARG_SL];
+#pragma unroll
+            for (int u = 0; u < ARG_SL; ++u) p[u] = pc[u * TI] * pw[u * TJ];
+            double m = p[0];
+#pragma unroll
+            for (int u = 1; u < ARG_SL; ++u) m = fmax_t(m, p[u]);
+            int found = -1;
+#pragma unroll
+            for (int u = ARG_SL - 1; u >= 0; --u)    // descending: the smallest matching pivot wins
+                found = (p[u] == m) ? t0 + u : found;
+            retire();                                // the previous batch
+            if (act && found >= 0) {
+                const int i = i_base + il, j = j_base + jl;
+                p_off = (size_t)i * n + j;
+                __builtin_amdgcn_global_load_lds((gptr_t *)(cnt + (size_t)found * ct_ld + i),
+                                                 (lptr_t *)&g_next[wave][0], 4, 0, 0);
+                if (last) last[p_off] = k0 + found;
+                if (hops) {
+                    __builtin_amdgcn_global_load_lds((gptr_t *)(cht + (size_t)found * ct_ld + i),
+                                                     (lptr_t *)&g_hc[wave][0], 4, 0, 0);
+                    __builtin_amdgcn_global_load_lds((gptr_t *)(wh + (size_t)found * n + j),
+                                                     (lptr_t *)&g_hw[wave][0], 4, 0, 0);
+                }
+                p_act = true;
+            }
+        }
+        const int rest = count - base;               // < 64 (<= 0 if all)
+        if (rest > 0 && base > 0) {
+            const unsigned short id = ids[base + (lane < rest ? lane : 0)];
+            __builtin_amdgcn_wave_barrier();
+            if (lane < rest) ids[lane] = id;
+        }
+        count = rest > 0 ? rest : 0;
+    };
+    // j == i is never touched (Algorithms.hs:54): restored once, with its own wait (see fused_main_arg)
+    if (diag_tile) {                                 // workgroup-uniform
+#pragma unroll
+        for (int r = 0; r < RI; ++r)
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+                if (jok && row0 + i0 + r == jcol + e) {
+                    if (i0 + r < rows && sid[r][e] >= 0) xa[r][e] = rate[(size_t)(i0 + r) * n + jcol + e];
+                    sid[r][e] = -1;
+                }
+        __builtin_amdgcn_s_waitcnt(FWX_WAIT_VMCNT0);
+    }
+#pragma unroll
+    for (int r = 0; r < RI; ++r) {
+        const int i = i0 + r;
+        const bool row_ok = i < rows && !skip && jok;
+        bool ch[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) ch[e] = row_ok && (e < 2 || jok2) && sid[r][e] >= 0;
+        if (ch[0] || ch[1]) *reinterpret_cast<V2 *>(rate + (size_t)i * n + jcol) = V2{xa[r][0], xa[r][1]};
+        if (ch[2] || ch[3]) *reinterpret_cast<V2 *>(rate + (size_t)i * n + jcol + 2) = V2{xa[r][2], xa[r][3]};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const unsigned long long mask = __ballot(ch[e]);
+            if (mask) {                               // wave-uniform
+                const int pos = count + (int)__builtin_amdgcn_mbcnt_hi((unsigned int)(mask >> 32),
+                                             __builtin_amdgcn_mbcnt_lo((unsigned int)mask, 0u));
+                if (ch[e])
+                    ids[pos] = (unsigned short)(((unsigned int)sid[r][e] << 13) |
+                                                ((unsigned int)(ti * RI + r) << 6) | (unsigned int)(tj * 4 + e));
+                count += __builtin_popcountll(mask);
+            }
+            if ((e & 1) && count >= 64) rescan(false);    // count <= 63 + 2 * 64 here
+        }
+    }
+    if (count > 0) rescan(true);
+    retire();
+}
+
 // Domain check (fwx.h "Domain"): clears bit 0 of *flag if any rate has its sign bit set or is NaN,
 // bit 1 if `next` is given and an entry with a non-zero rate has next < 0.
 __global__ __launch_bounds__(256) void nonneg_check_f32(const float *rate, const int32_t *next,
@@ -1523,7 +1753,7 @@ hipError_t launch_nonneg_check(const double *rate, const int32_t *next, size_t c
 
 // f32, rates only, no update counting, domain verified by the caller: the max3 kernel.
 static bool launch_max_form(const FusedArgs<float> &a, dim3 grid, dim3 block, int skip_lo,
-                            int skip_hi, hipStream_t s, int32_t *last, bool small, ColWin cw)
+                            int skip_hi, hipStream_t s, int32_t *last, bool small, ColWin cw, bool)
 {
     if (!a.nonneg || a.updates) return false;
     const int ct_vec = ((uintptr_t)a.ct % 16 == 0 && a.ct_ld % 4 == 0) ? 1 : 0;
@@ -1555,9 +1785,21 @@ static bool launch_max_form(const FusedArgs<float> &a, dim3 grid, dim3 block, in
 // f64 has no packed / three-operand forms: the max form is the generic kernel with
 // v_mul_f64 + v_max_f64 (2 instructions per relaxation instead of 4).
 static bool launch_max_form(const FusedArgs<double> &a, dim3 grid, dim3 block, int skip_lo,
-                            int skip_hi, hipStream_t s, int32_t *, bool small, ColWin cw)
+                            int skip_hi, hipStream_t s, int32_t *last, bool small, ColWin cw, bool window)
 {
-    if (!a.nonneg || a.next || a.updates) return false;
+    if (!a.nonneg || a.updates) return false;
+    if (a.next) {
+        // rates + next-hops (+ trace, + hops): 64 x 64 tiles whatever the matrix order.  The caller's
+        // grid counts 32-column tiles for a column window (f64 small form): two of them per tile here.
+        const int ct_vec = ((uintptr_t)a.ct % 16 == 0 && a.ct_ld % 2 == 0) ? 1 : 0;
+        ColWin c2 = cw;
+        c2.jt0 = window ? cw.jt0 / 2 : 0;
+        const dim3 g(window ? grid.x / 2 : (unsigned)((a.n + 63) / 64), (unsigned)((a.rows + 63) / 64));
+        hipLaunchKernelGGL((fused_main_arg_f64<2>), g, block, 0, s, a.rate, a.next, a.rows, a.n, a.row0, a.k0,
+                           a.bt, a.w, a.ct, a.cnt, a.ct_ld, ct_vec, skip_lo, skip_hi, last, a.hops, a.cht,
+                           a.wh, c2);
+        return true;
+    }
     if (!small) {
         const int ct_vec = ((uintptr_t)a.ct % 16 == 0 && a.ct_ld % 2 == 0) ? 1 : 0;
         const dim3 g((unsigned)((a.n + 127) / 128), (unsigned)((a.rows + 127) / 128));
@@ -1682,7 +1924,7 @@ hipError_t launch_fused_main(const FusedArgs<T> &full, int r_lo, int r_hi, hipSt
         cw.jt0 = cols.c_lo / tj;
         grid.x = (unsigned)((cols.c_hi - cols.c_lo) / tj);
     }
-    if (launch_max_form(a, grid, block, skip_lo, skip_hi, s, last, small, cw)) return hipGetLastError();
+    if (launch_max_form(a, grid, block, skip_lo, skip_hi, s, last, small, cw, window)) return hipGetLastError();
 #define FWX_FUSED_LAUNCH(HN, CN, HL)                                                               \
     do {                                                                                           \
         if (small)                                                                                 \
