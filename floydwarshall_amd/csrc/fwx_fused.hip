@@ -41,7 +41,14 @@ template <typename T> __device__ __forceinline__ T qnan();
 template <> __device__ __forceinline__ float qnan<float>() { return __builtin_nanf(""); }
 template <> __device__ __forceinline__ double qnan<double>() { return __builtin_nan(""); }
 
-__device__ __forceinline__ float fmax_t(float a, float b) { return __builtin_fmaxf(a, b); }
+// ONE v_max_f32 (the builtin adds a quieting `v_max_f32 x, x, x` in front, as for f64 below; the
+// three-operand folds of the main kernels call __builtin_fmaxf twice and get one v_max3_f32).
+__device__ __forceinline__ float fmax_t(float a, float b)
+{
+    float d;
+    asm("v_max_f32 %0, %1, %2" : "=v"(d) : "v"(a), "v"(b));
+    return d;
+}
 // ONE v_max_f64.  __builtin_fmax makes the compiler quiet a possible signalling NaN first -- a second
 // `v_max_f64 x, x, x` per relaxation, i.e. three 4.35-cycle f64 instructions where two suffice (the
 // f64 fused solve at N = 16384: 513 ms with the builtin).  The instruction itself already is IEEE
@@ -144,7 +151,10 @@ template <typename T, bool HAS_HOPS> constexpr int rowpanel_lds()
 {
     return 2 * B * 64 * (int)sizeof(T) + (HAS_HOPS ? 2 * B * 64 * 4 : 0);
 }
-template <typename T, bool HAS_LAST, bool HAS_HOPS>
+// MAXF (rates only, domain verified by the caller): x <- max(x, c * w) instead of compare + select --
+// the same bits on that domain (see fused_main_max; the NaN operands that encode the skip set are
+// ignored by max exactly as `x < NaN` is false), one instruction less on the serial chain.
+template <typename T, bool HAS_LAST, bool HAS_HOPS, bool MAXF = false>
 __device__ __forceinline__ void rowpanel_body(char *smem, int bid, const T *rows, int n, int k0, int bt,
                                               T *w_out, const int32_t *last_rows, int32_t *at_rows,
                                               const int32_t *hops_rows, int32_t *wh_out)
@@ -179,6 +189,11 @@ __device__ __forceinline__ void rowpanel_body(char *smem, int bid, const T *rows
 
     // one relaxation of row q by pivot t in both parts: cv = D_t[k0+r][k0+t], (wd, ws) = pivot row
     auto relax_row = [&](int q, T cv, int32_t ch, T wd, T ws, int32_t hwd, int32_t hws, int t) {
+        if (MAXF) {
+            pd[q] = fmax_t(pd[q], cv * wd);
+            ps[q] = fmax_t(ps[q], cv * ws);
+            return;
+        }
         const T cd = cv * wd;
         const bool ud = pd[q] < cd;
         pd[q] = ud ? cd : pd[q];
@@ -279,7 +294,7 @@ template <typename T, bool HAS_NEXT, bool HAS_HOPS> constexpr int colpanel_lds()
     return B * 64 * (int)sizeof(T) + (HAS_NEXT ? B * 64 * 4 : 0) + B * B * (int)sizeof(T) +
            (HAS_HOPS ? B * 64 * 4 + B * B * 4 : 0);
 }
-template <typename T, bool HAS_NEXT, bool HAS_LAST, bool HAS_HOPS, bool OWN_D>
+template <typename T, bool HAS_NEXT, bool HAS_LAST, bool HAS_HOPS, bool OWN_D, bool MAXF = false>
 __device__ __forceinline__ void colpanel_body(char *smem, int bid, const T *rate, const int32_t *next, int rows,
                                               int n, int row0, int k0, int bt, const T *w, T *ct, int32_t *cnt,
                                               int ct_ld, const int32_t *last, int32_t *at_col,
@@ -357,6 +372,7 @@ __device__ __forceinline__ void colpanel_body(char *smem, int bid, const T *rate
                     for (int q = 0; q < SB; ++q) {
                         if (q == tq) continue;                    // skip i == k
                         const T cd = cv[q] * wd;
+                        if (MAXF) { pd[q] = fmax_t(pd[q], cd); continue; }
                         const bool ud = pd[q] < cd;
                         pd[q] = ud ? cd : pd[q];
                         if (HAS_HOPS) hdd[q] = ud ? (int32_t)((uint32_t)chv[q] + (uint32_t)hwd) : hdd[q];
@@ -383,6 +399,7 @@ __device__ __forceinline__ void colpanel_body(char *smem, int bid, const T *rate
                     const T wv = OWN_D ? readlane<T>(wd, b * SB + q) : s_wd[t][b * SB + q];
                     const int32_t wvh = !HAS_HOPS ? 0 : OWN_D ? readlane<int>(hwd, b * SB + q) : s_wdh[t][b * SB + q];
                     const T cand = c * wv;
+                    if (MAXF) { d[q] = fmax_t(d[q], cand); continue; }
                     const bool up = d[q] < cand;
                     d[q] = up ? cand : d[q];
                     if (HAS_NEXT) nx[q] = up ? cn : nx[q];
@@ -403,6 +420,7 @@ __device__ __forceinline__ void colpanel_body(char *smem, int bid, const T *rate
 #pragma unroll
                     for (int q = 0; q < SB; ++q) {
                         const T cd = readlane<T>(pd[q], t) * wd;
+                        if (MAXF) { pd[q] = fmax_t(pd[q], cd); continue; }
                         const int32_t chv = HAS_HOPS ? readlane<int>(hdd[q], t) : 0;
                         const bool ud = pd[q] < cd;
                         pd[q] = ud ? cd : pd[q];
@@ -415,6 +433,7 @@ __device__ __forceinline__ void colpanel_body(char *smem, int bid, const T *rate
 #pragma unroll
                 for (int q = 0; q < SB; ++q) {
                     const T cand = c * s_wd[t][wave * SB + q];
+                    if (MAXF) { d[q] = fmax_t(d[q], cand); continue; }
                     const bool up = d[q] < cand;
                     d[q] = up ? cand : d[q];
                     if (HAS_NEXT) nx[q] = up ? cn : nx[q];
@@ -442,7 +461,7 @@ __global__ __launch_bounds__(PANEL_THREADS) void fused_colpanel(const T *rate, c
 
 // Both panels of a pass in ONE launch (single-device solves: the slab is the whole matrix): the
 // first n/64 workgroups run the row panel, the rest the column panel with its own diagonal block.
-template <typename T, bool HAS_NEXT, bool HAS_LAST, bool HAS_HOPS>
+template <typename T, bool HAS_NEXT, bool HAS_LAST, bool HAS_HOPS, bool MAXF = false>
 __global__ __launch_bounds__(PANEL_THREADS) void fused_panels(int row_wgs, const T *rate, const int32_t *next,
                                                     int n, int k0, int bt, T *w_out, T *ct, int32_t *cnt,
                                                     int ct_ld, const int32_t *last, int32_t *at_row,
@@ -453,11 +472,11 @@ __global__ __launch_bounds__(PANEL_THREADS) void fused_panels(int row_wgs, const
     __shared__ __attribute__((aligned(16))) char smem[RL > CL ? RL : CL];
     const size_t prow = (size_t)k0 * n;            // the pivot rows
     if ((int)blockIdx.x < row_wgs) {               // workgroup-uniform
-        rowpanel_body<T, HAS_LAST, HAS_HOPS>(smem, (int)blockIdx.x, rate + prow, n, k0, bt, w_out,
+        rowpanel_body<T, HAS_LAST, HAS_HOPS, MAXF>(smem, (int)blockIdx.x, rate + prow, n, k0, bt, w_out,
                                              HAS_LAST ? last + prow : nullptr, HAS_LAST ? at_row + prow : nullptr,
                                              HAS_HOPS ? hops + prow : nullptr, wh_out);
     } else {
-        colpanel_body<T, HAS_NEXT, HAS_LAST, HAS_HOPS, true>(smem, (int)blockIdx.x - row_wgs, rate, next, n, n, 0,
+        colpanel_body<T, HAS_NEXT, HAS_LAST, HAS_HOPS, true, MAXF>(smem, (int)blockIdx.x - row_wgs, rate, next, n, n, 0,
                                                              k0, bt, nullptr, ct, cnt, ct_ld, last, at_col, hops,
                                                              nullptr, cht, rate + prow,
                                                              HAS_HOPS ? hops + prow : nullptr);
@@ -2000,6 +2019,10 @@ hipError_t launch_fused_panels(const FusedArgs<T> &a, T *w_out, int32_t *wh_out,
         if (a.hops) FWX_PANELS(true, true, true); else FWX_PANELS(true, true, false);
     } else if (a.next) {
         if (a.hops) FWX_PANELS(true, false, true); else FWX_PANELS(true, false, false);
+    } else if (a.nonneg) {       // rates only, inside the domain: max form
+        hipLaunchKernelGGL((fused_panels<T, false, false, false, true>), grid, block, 0, s, row_wgs, a.rate,
+                           a.next, a.n, a.k0, a.bt, w_out, a.ct, a.cnt, a.ct_ld, a.plog.last, a.plog.at_row,
+                           a.plog.at_col, a.hops, wh_out, a.cht);
     } else {
         FWX_PANELS(false, false, false);
     }
