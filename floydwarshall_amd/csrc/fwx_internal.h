@@ -210,6 +210,23 @@ struct CallCtx {
     void *buf[NBUF] = {nullptr, nullptr, nullptr, nullptr, nullptr};
     size_t cap[NBUF] = {0, 0, 0, 0, 0};
 
+    void *pin = nullptr;               // pinned host staging for small host <-> device transfers
+    size_t pin_cap = 0;
+    // solves whose arrays sum to more than this go straight from / to the caller's memory (measured,
+    // fwx_solve_f64 + next + hops: staged wins up to n = 256 = 1 MiB, 0.92 against 1.04 ms, and loses
+    // at n = 512 = 4 MiB, 2.07 against 1.91 ms; gpurun_out/r02_call_latency_staged.txt)
+    static constexpr size_t kStageBytes = (size_t)3 << 19;
+    int reserve_pinned(size_t bytes, void **out)
+    {
+        if (pin_cap < bytes) {
+            if (pin) { drain(); (void)hipHostFree(pin); pin = nullptr; pin_cap = 0; }
+            const size_t want = bytes < ((size_t)1 << 20) ? ((size_t)1 << 20) : bytes;
+            FWX_HIP(hipHostMalloc(&pin, want, hipHostMallocDefault));
+            pin_cap = want;
+        }
+        *out = pin;
+        return FWX_OK;
+    }
     void drain() { drain_stream(s); side.drain(); }
     int reserve(int which, size_t bytes, void **out)
     {
@@ -238,6 +255,7 @@ struct CallCtx {
     void destroy()
     {
         drain();
+        if (pin) (void)hipHostFree(pin);
         for (int i = 0; i < NBUF; ++i)
             if (buf[i]) (void)hipFree(buf[i]);
         if (s) (void)hipStreamDestroy(s);
