@@ -113,7 +113,7 @@ private:
     uint64_t solved_version_ = ~0ull;
     std::vector<Vertex> vertices_;   // of the cached solve
     fwx_matrix *dev_ = nullptr;      // solved matrix, resident in HBM
-    static constexpr int32_t kFusedFrom = 256;   // fwx AUTO: fused engine from here; no resident hops
+    static constexpr int32_t kFusedFrom = 65;    // fwx AUTO: fused engine from here; no resident hops
     int32_t dev_n_ = 0;              // order of the matrix dev_ was created for
     bool dev_hops_ = true;           // the device matrix carries `hops` (n < kFusedFrom)
     DenseMatrix initial_;            // buildMatrix output, storage kept across re-solves
