@@ -8,6 +8,7 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <cmath>
 #include <new>
 
 #include "fwx.h"
@@ -249,7 +250,7 @@ enum Route { ROUTE_SMALL, ROUTE_PERK, ROUTE_FUSED };
 template <typename T>
 int route_solve(const Opts &op, int n, bool whole, const T *rate, const int32_t *next,
                 const int32_t *hops, bool counting, int *d_flag, hipStream_t s, Route &route,
-                bool &nonneg)
+                bool &nonneg, fwx_matrix *cache = nullptr)
 {
     nonneg = false;
     (void)whole;
@@ -265,8 +266,16 @@ int route_solve(const Opts &op, int n, bool whole, const T *rate, const int32_t 
     // pivot row's next-hops for exactly that case, runs the solve (same bits as the reference).
     int bits = 0;
     if (next || !counting) {
-        const int rc = domain_bits<T>(rate, next, (size_t)n * n, d_flag, s, bits);
-        if (rc) return rc;
+        // a handle remembers the answer for its arrays (fwx_matrix::dom_known); with next-hops the
+        // check reads both arrays, without them only bit 0 is meaningful -- a cached answer taken
+        // with next-hops serves both
+        if (cache && cache->dom_known) {
+            bits = cache->dom_bits;
+        } else {
+            const int rc = domain_bits<T>(rate, next, (size_t)n * n, d_flag, s, bits);
+            if (rc) return rc;
+            if (cache && (next || !cache->next)) { cache->dom_bits = bits; cache->dom_known = 1; }
+        }
     }
     if (next && bits != 3) { route = fallback; return FWX_OK; }
     nonneg = !counting && (next ? bits == 3 : (bits & 1) != 0);   // max-form kernels allowed
@@ -498,7 +507,7 @@ int matrix_solve_typed(fwx_matrix *m, const Opts &op, unsigned long long *upd, h
     }
     m->fresh = 0;                        // whatever happens next, the arrays are no longer the upload
     if ((rc = route_solve<T>(op, n, op.k_begin == 0 && op.k_end == n, r, m->next, m->hops, upd != nullptr,
-                             d_flag, s, route, nonneg)))
+                             d_flag, s, route, nonneg, m->flag ? m : nullptr)))
         return rc;
     if (route == ROUTE_SMALL) {
         FWX_HIP(fwx::launch_small_solve<T>(r, m->next, m->hops, n, op.k_begin, op.k_end, upd,
@@ -776,6 +785,7 @@ int fwx_matrix_upload(fwx_matrix *m, const void *rate, const int32_t *next, cons
     // hipMemcpyDefault: the sources may be host arrays (what an FFI hands over) or device arrays
     // (a caller that keeps its pristine input in HBM, e.g. the benchmark)
     hipStream_t s = m->stream;
+    m->dom_known = 0;                  // a new input: the domain check has to look at it
     FWX_HIP(hipMemcpyAsync(m->rate, rate, nn * es, hipMemcpyDefault, s));
     if (m->next) FWX_HIP(hipMemcpyAsync(m->next, next, nn * 4, hipMemcpyDefault, s));
     if (m->hops) FWX_HIP(hipMemcpyAsync(m->hops, hops, nn * 4, hipMemcpyDefault, s));
@@ -858,6 +868,19 @@ int fwx_matrix_patch_input(fwx_matrix *m, int32_t count, const int64_t *index, c
     if (rc) return rc;
     const size_t nn = (size_t)nn64, es = m->dtype == FWX_F64 ? 8 : 4;
     hipStream_t s = m->stream;
+    // the remembered domain answer survives a patch whose values are themselves inside the domain
+    // (rate >= +0 and not NaN; a non-zero rate comes with a next-hop >= 0); anything else, or a
+    // non-zero rate patched in without its next-hop, sends the next solve through the check again
+    if (m->dom_known) {
+        bool ok = true;
+        for (int32_t q = 0; q < count && ok; ++q) {
+            const double r = m->dtype == FWX_F64 ? ((const double *)rate_vals)[q] : (double)((const float *)rate_vals)[q];
+            ok = !(r != r) && !std::signbit(r);
+            if (ok && m->next && r != 0.0) ok = next_vals && next_vals[q] >= 0;
+        }
+        const int want = m->next ? 3 : 1;
+        if (!ok || (m->dom_bits & want) != want) m->dom_known = 0;
+    }
     for (int32_t q = 0; q < count; ++q) {        // a handful of entries: plain small copies
         const size_t off = (size_t)index[q];
         FWX_HIP(hipMemcpyAsync((char *)m->rate0 + off * es, (const char *)rate_vals + (size_t)q * es, es,

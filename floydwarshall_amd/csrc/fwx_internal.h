@@ -382,6 +382,12 @@ struct fwx_matrix {
     size_t ws_bytes;
     fwxi::SideStream *side;      // look-ahead stream + events of the fused engine, kept likewise
     int *flag;             // device int for the domain check
+    int32_t dom_known;     // dom_bits is the domain check's answer for what the arrays hold now.  The
+    int32_t dom_bits;      // domain (fwx.h) is closed under the algorithm -- products of non-negative
+                           // rates are >= +0 or NaN (which never wins), and a relaxation only succeeds
+                           // through a non-zero r[i][k], whose next-hop it copies -- so only an upload
+                           // or a patch can change the answer: the upload forgets it, a patch whose
+                           // values are themselves inside the domain keeps a "3".
     fwxi::MultiState *multi;   // non-null: a row-partitioned handle (fwx_matrix_create_multi); the
                            // single-device arrays above are then unused
 };

@@ -827,6 +827,51 @@ def test_kept_input_and_patch(devices, dtype):
             dm.patch_input([n * n], [1.0])                      # index out of range
 
 
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+def test_patches_that_leave_the_domain_are_rechecked(dtype):
+    """A handle remembers the domain check's answer for its arrays; a patch with a value outside the
+    domain (negative, NaN, -0, or a non-zero rate patched in without its next-hop) must send the
+    next solve through the check again -- and to the engine that handles such inputs."""
+    n = 260
+    rate, nxt, hops = synth.make("d1", n, dtype, seed=31)
+    with engine.DeviceMatrix(n, dtype, with_next=True, with_hops=True, device=0) as dm:
+        dm.keep_input()
+        dm.upload(rate, nxt, hops)
+        dm.solve()                                              # inside the domain: remembered
+        cases = [(np.array([7 * n + 9]), dtype(-0.75)), (np.array([3 * n + 200]), dtype(np.nan)),
+                 (np.array([11 * n + 2]), dtype(-0.0)), (np.array([5 * n + 6]), dtype(0.5))]
+        for step, (idx, val) in enumerate(cases):
+            idx = idx.astype(np.int64)
+            vals = np.array([val], dtype=dtype)
+            nv = np.array([idx[0] % n], dtype=np.int32)
+            hv = np.array([1], dtype=np.int32)
+            rate.flat[idx], nxt.flat[idx], hops.flat[idx] = vals, nv, hv
+            dm.patch_input(idx, vals, nv, hv)
+            dm.solve()
+            er, en, eh = rate.copy(), nxt.copy(), hops.copy()
+            with np.errstate(all="ignore"):
+                oracle.relax(er, en, eh)
+            gr, gn, gh = dm.download()
+            assert_bits_equal(gr, er, "rate, step %d" % step)
+            assert_bits_equal(gn, en, "next, step %d" % step)
+            assert_bits_equal(gh, eh, "hops, step %d" % step)
+    # a non-zero rate patched over a missing edge WITHOUT its next-hop: a positive rate without a path
+    rate, nxt, hops = synth.make("t2", n, dtype, seed=32)       # sparse: zeros with next = -1
+    zi = int(np.flatnonzero((rate == 0) & (~np.eye(n, dtype=bool)))[0])
+    with engine.DeviceMatrix(n, dtype, with_next=True, device=0) as dm:
+        dm.keep_input()
+        dm.upload(rate, nxt)
+        dm.solve()
+        rate.flat[zi] = dtype(0.5)
+        dm.patch_input(np.array([zi], dtype=np.int64), np.array([0.5], dtype=dtype))
+        dm.solve()
+        er, en = rate.copy(), nxt.copy()
+        oracle.relax(er, en)
+        gr, gn, _ = dm.download()
+        assert_bits_equal(gr, er, "rate, orphan patch")
+        assert_bits_equal(gn, en, "next, orphan patch")
+
+
 def test_caller_supplied_stream_and_v1_opts_struct():
     """fwx_opts.stream (ABI v2): the blocking call runs on the caller's stream, so work queued on it
     beforehand is ordered before the solve -- here the upload of the input itself, asynchronously on
