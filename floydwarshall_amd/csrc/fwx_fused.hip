@@ -1795,6 +1795,15 @@ static bool launch_max_form(const FusedArgs<float> &a, dim3 grid, dim3 block, in
     if (small) {
         hipLaunchKernelGGL((fused_main_max<4, 1, 4, 1>), grid, block, 0, s, a.rate, a.rows, a.n, a.row0,
                            a.k0, a.bt, a.w, a.ct, a.ct_ld, ct_vec, skip_lo, skip_hi, cw);
+    } else if (small_tiles(a.n, a.rows, 3600)) {
+        // mid sizes: 128 x 64 tiles.  The 768 workgroup slots of the chip quantise a launch of 128 x 128
+        // tiles badly (N = 4096: 1024 tiles = 1.33 rounds), half-width tiles halve the step; their
+        // extra LDS operand reads cost less than that up to N = 7168 (gpurun_out/r02_run58.log:
+        // 3072: 2.65 -> 2.44 ms, 4096: 4.40 -> 4.26, 6144: 11.04 -> 10.61, 7168: 16.0 -> 15.7; from
+        // 8192 on the full tile wins: 22.35 against 22.65 ms)
+        const dim3 g((unsigned)((a.n + 63) / 64), (unsigned)((a.rows + 127) / 128));
+        hipLaunchKernelGGL((fused_main_max<3, 1, 8, 1>), g, block, 0, s, a.rate, a.rows, a.n,
+                           a.row0, a.k0, a.bt, a.w, a.ct, a.ct_ld, ct_vec, skip_lo, skip_hi, cw);
     } else {
         hipLaunchKernelGGL((fused_main_max<3, 1, 8, 2>), grid, block, 0, s, a.rate, a.rows, a.n,
                            a.row0, a.k0, a.bt, a.w, a.ct, a.ct_ld, ct_vec, skip_lo, skip_hi, cw);
