@@ -1743,7 +1743,9 @@ static bool small_tiles(int n, int rows, long long thresh = 512)
 // The arg kernel keeps a tile's workgroup busy for longer (fold + re-scan) and runs 3 workgroups per
 // CU: its 64 x 64 form pays off up to larger matrices (measured, rates + next: N = 4096 9.54 -> 8.8
 // ms, N = 6144 23.3 -> 21.8 ms, N = 8192 unchanged; gpurun_out/r02_run15_tiles.log).
-static bool small_tiles_arg(int n, int rows) { return small_tiles(n, rows, 2400); }
+// After the re-scan rewrite (gpurun_out/r02_run60.log, 64 x 64 against 128 x 64): N = 3072 3.79 / 4.03 ms,
+// 6144 18.56 / 18.88, 8192 39.17 / 38.96, 10240 70.56 / 72.02: level or ahead up to there.
+static bool small_tiles_arg(int n, int rows) { return small_tiles(n, rows, 6500); }
 
 __global__ __launch_bounds__(256) void nonneg_check_f64(const double *rate, const int32_t *next,
                                                         size_t count, int *flag)
