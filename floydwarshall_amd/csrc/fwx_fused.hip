@@ -11,20 +11,25 @@
 // re-associated (classic 3-phase blocked Floyd-Warshall is NOT exact: SURVEY.md Appendix B).
 // The snapshots themselves are produced by the same fold restricted to the pivot rows/columns:
 //
-//   fused_diag      the B x B diagonal block through its B pivots (one workgroup, LDS):
-//                   exports Wd[t][c] = D_t[k0+t][k0+c] and Cd[r][t] = D_t[k0+r][k0+t]
-//   fused_rowpanel  every column j of the B pivot rows (needs Cd): exports W[t][j]
-//   fused_colpanel  the B pivot columns of every row i (needs W's block columns): exports
-//                   Ct[t][i] (NaN where i == k: skip i==k) and CNt[t][i] = next_t[i][k0+t]
-//   fused_main      128 x 128 (f32) tile per workgroup, 8 x 8 entries per thread in registers,
-//                   W tile and C tile staged in LDS: B relaxations per entry per HBM round trip
+//   fused_rowpanel      every column j of the B pivot rows: exports W[t][j].  Each workgroup evolves the
+//                       B x B diagonal block itself, together with its strip
+//   fused_colpanel      the B pivot columns of every row i: exports Ct[t][i] (NaN where i == k: skip
+//                       i==k) and CNt[t][i] = next_t[i][k0+t].  Reads the block columns of a finished
+//                       W (partitioned solves), or -- OWN_D -- evolves the diagonal block itself
+//   fused_panels        both of them as ONE launch (single-device solves)
+//   fused_main_max      rates only, f32, inside the domain: the fold as max (two pivots per v_max3_f32),
+//                       128 x 128 tile, 8 x 8 entries per thread; fused_main_max_f64 likewise for f64
+//   fused_main_arg      rates + next-hops (+ path trace, + hops), f32 inside the domain: max-form fold,
+//                       then an arg re-scan of the entries that moved; fused_main_arg_f64 for f64
+//   fused_main          compare form (product, compare, selects): update counting and inputs outside
+//                       the domain
 //
 // Skip set: i==k via NaN in Ct, j==k via NaN injected into the staged W tile, j==i by restoring
 // the diagonal entry at write-back.  Scratch copies of diagonal entries may go stale inside the
 // panel kernels; they are provably never consumed (every consumer is an i==k or j==k case).
 //
-// Roofline: per pass 4 B read + 4 B written per entry against 3*B = 192 VALU lane-ops per entry,
-// so this kernel is VALU-bound (about 3 lane-ops per relaxation), not HBM-bound.
+// Roofline: per pass 4 B read + 4 B written per entry against 1.5*B = 96 VALU lane-ops per entry in
+// the max form (3*B in the compare form): these kernels are VALU-bound, not HBM-bound.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdlib.h>
