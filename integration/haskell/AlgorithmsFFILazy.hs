@@ -52,7 +52,7 @@ runAlgoGPULazy m
         ok "upload" =<< c_upload h pr pn nullPtr          -- the library copies: nothing is retained
       ok "solve" =<< c_solve h nullPtr                    -- runAlgo 0, on the GPU
       -- (no hops: `length _path` is the length of the list query_exact returns, and without
-      --  them a matrix of 256+ vertices takes the fused engine)
+      --  them the solve carries one n x n array less through every pass)
       return (V.generate n (\i -> V.generate n (\j -> entry fp i j)))
   where
     n = V.length m
