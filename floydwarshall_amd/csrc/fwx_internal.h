@@ -8,6 +8,7 @@
 #include <new>
 #include <vector>
 #include <stddef.h>
+#include <stdlib.h>
 #include <stdint.h>
 
 #include "fwx.h"
