@@ -3,8 +3,15 @@
 
 Contract (one JSON line from rank 0):
   python bench.py --gpus N --steps K --warmup W
-  N > 1 is launched by the driver as
-  python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+  N > 1 runs either way the driver may start it:
+    python bench.py --gpus N ...                     ONE process, N devices: the row-partitioned handle
+        behind the C ABI (fwx_matrix_create_multi, panels on RCCL) -- what a reference host binds;
+        torch-free like N = 1
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+        one process per GPU (WORLD_SIZE set): floydwarshall_amd.dist over torch.distributed / RCCL
+  --devices 0,0,...  lists the partitions' devices explicitly; a repeated device makes LOGICAL
+        partitions on one GPU (rehearses the whole N > 1 path where only one GPU exists; the line is
+        flagged INVALID_logical_partitions and is never a performance number)
 
 A "step" is ONE FULL SOLVE (all N pivots of runAlgo, /root/reference/src/lib/Algorithms.hs:42-61)
 of the synthetic dense matrix, restarted from the pristine input (a device-to-device copy inside
@@ -19,10 +26,10 @@ N = 16384, fp32, dense D1 input (floydwarshall_amd/synth.py), matrices resident 
   cpu_baseline = the oracle's multithreaded dense loop (a C restatement of the reference loop --
               the Haskell reference cannot be built here) on a bounded k-slice of the same matrix
 
-N = 1 runs WITHOUT torch: device buffers, the stream and the events come from the HIP runtime
-directly (floydwarshall_amd/hip.py), so the process holds one HIP runtime and `rocprofv3 --pmc ...
--- python3 bench.py ...` profiles exactly the benchmarked launches.  N > 1
-needs torch.distributed (RCCL) and imports torch.
+The single-process forms run WITHOUT torch: device buffers, the stream and the events come from the
+HIP runtime directly (floydwarshall_amd/hip.py), so the process holds one HIP runtime -- the one
+libfwx is built against -- and `rocprofv3 --pmc ... -- python3 bench.py ...` profiles exactly the
+benchmarked launches.  Only the torchrun form imports torch.
 """
 import argparse
 import json
@@ -55,7 +62,12 @@ def parse_args():
     ap.add_argument("--engine", default="perk", choices=["perk", "fused"],
                     help="perk: one launch per pivot (the HBM-roofline kernel the metric is defined "
                          "on); fused: 64 pivots per pass (VALU-bound, same bits)")
-    ap.add_argument("--block", type=int, default=64, help="pivots per broadcast (N > 1)")
+    ap.add_argument("--block", type=int, default=64, help="pivots per broadcast (N > 1, torchrun form)")
+    ap.add_argument("--devices", default="",
+                    help="comma-separated HIP ordinals, one per row partition (single-process N > 1 "
+                         "form); default 0..N-1.  A repeated ordinal = logical partitions (rehearsal)")
+    ap.add_argument("--exchange", default="auto", choices=["auto", "rccl", "peer"],
+                    help="panel transport of the single-process N > 1 form")
     ap.add_argument("--no-serpentine", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true",
@@ -80,7 +92,25 @@ def parse_args():
         args.n, args.dtype, args.engine, args.with_next = 32768, "f32", "fused", True
     if args.no_extras:
         args.no_fused_extra = args.no_f64_extra = True
+    args.device_list = parse_devices(args.devices, args.gpus)
+    if args.devices:
+        args.gpus = len(args.device_list)
     return args
+
+
+def parse_devices(text, gpus):
+    """--devices "0,0,1" -> [0, 0, 1]; empty -> [0, ..., gpus-1].  Raises SystemExit on nonsense."""
+    if not text:
+        if gpus < 1:
+            raise SystemExit("--gpus must be >= 1")
+        return list(range(gpus))
+    try:
+        devs = [int(x) for x in text.split(",")]
+    except ValueError:
+        raise SystemExit("--devices wants comma-separated device ordinals, got %r" % text)
+    if not devs or min(devs) < 0 or len(devs) > 32:
+        raise SystemExit("--devices: 1..32 non-negative ordinals, got %r" % text)
+    return devs
 
 
 def host_cores():
@@ -162,16 +192,17 @@ def alg_bytes_per_launch(n, es, u_per_launch, with_next):
     return es * n * n + (es + (4 if with_next else 0)) * u_per_launch + 2 * es * n
 
 
-def workload_config(args, n, k_end, serp, world):
+def workload_config(args, n, k_end, serp, world, partition=None):
     return {"workload": "N=%d dense %s rate matrix (%s), full solve = %d pivot steps per step, %s%s"
                         % (n, args.dtype, args.dist.upper(), k_end,
                            "per-k engine" if args.engine == "perk"
                            else "fused engine (64 pivots per pass)",
                            ", with next-hop matrix" if args.with_next else ""),
             "n": n, "engine": args.engine, "serpentine": serp,
-            "partition": "single GPU" if world == 1 else
-            "row-block x%d, %d-pivot snapshot panels broadcast on %s"
-            % (world, args.block, "RCCL" if args.backend == "nccl" else "gloo (rehearsal)")}
+            "partition": partition or ("single GPU" if world == 1 else
+                                       "row-block x%d, %d-pivot snapshot panels broadcast on %s, one process "
+                                       "per GPU (torch.distributed)"
+                                       % (world, args.block, "RCCL" if args.backend == "nccl" else "gloo (rehearsal)"))}
 
 
 def make_input(args, n):
@@ -204,7 +235,6 @@ def perk_solve(engine, hip, rate, nxt, n, k_end, serp, stream, upd=None, timed=F
 
 
 def run_single(args):
-    os.environ["FWX_NO_TORCH"] = "1"          # before the package maps libfwx
     from floydwarshall_amd import engine, hip
     assert "torch" not in sys.modules, "the N=1 benchmark must stay torch-free"
     n = args.n
@@ -482,6 +512,129 @@ def f64_leg(engine, hip, rate64, n, stream):
 
 
 # ------------------------------------------------------------------------------------------------
+# N > 1, ONE process: the row-partitioned handle behind the C ABI (torch-free)
+# ------------------------------------------------------------------------------------------------
+def run_multi(args):
+    """`python bench.py --gpus N` without a launcher: the call a reference host binds
+    (ProcessRequests.hs:82-84 -> floydWarshall, Algorithms.hs:19-20) with a device list --
+    fwx_matrix_create_multi over devices 0..N-1, FWX_XCHG_AUTO (= RCCL between distinct devices), one
+    host thread.  Same workload, steps and restore-from-pristine contract as N = 1: the handle keeps
+    the uploaded input on the devices and every step restores it (device-to-device, inside the timed
+    region) before the solve."""
+    from floydwarshall_amd import engine, hip
+    assert "torch" not in sys.modules, "the single-process benchmark must stay torch-free"
+    devs = args.device_list
+    world = len(devs)
+    have = hip.device_count()
+    if have < 1:
+        raise SystemExit("bench.py: no HIP device (libfwx has no CPU fallback)")
+    if max(devs) >= have:
+        raise SystemExit("bench.py: --gpus %d / --devices %s needs device ordinals < %d (this machine has "
+                         "%d HIP device%s)" % (world, ",".join(map(str, devs)), have, have,
+                                               "" if have == 1 else "s"))
+    logical = len(set(devs)) != world
+    n = args.n
+    np_dtype = np.float32 if args.dtype == "f32" else np.float64
+    es = np.dtype(np_dtype).itemsize
+    rate64, next_host = make_input(args, n)
+    rate_host = rate64 if np_dtype == np.float64 else rate64.astype(np.float32)
+    del rate64
+    if args.kslice:
+        raise SystemExit("--kslice is a single-GPU debug option")
+    xchg = {"auto": engine.FWX_XCHG_AUTO, "rccl": engine.FWX_XCHG_RCCL, "peer": engine.FWX_XCHG_PEER}[args.exchange]
+    h = engine.DeviceMatrix(n, np_dtype, with_next=args.with_next, devices=devs, exchange=xchg)
+    h.keep_input()
+    h.upload(rate_host, next_host if args.with_next else None)
+    del next_host
+    parts, transport = h.parts()
+    ranks = h.comm_ranks()
+    eng = engine.FWX_ENGINE_PERK if args.engine == "perk" else engine.FWX_ENGINE_FUSED
+    serp = not args.no_serpentine
+    relax_per_step = float(n) ** 3
+
+    def step(count=False):
+        h.patch_input([], np.empty(0, dtype=np_dtype))      # restore the kept input on every partition
+        return h.solve(engine=eng, serpentine=serp, count_updates=count)
+
+    updates = None
+    for w in range(args.warmup):
+        u = step(count=(w == 0))
+        updates = u if w == 0 else updates
+    hip.synchronize(devs)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    hip.synchronize(devs)
+    dt = time.perf_counter() - t0
+
+    bounds = [n * p // world for p in range(world + 1)]
+    slab_bytes = es * n * max(bounds[p + 1] - bounds[p] for p in range(world))
+    partition = ("row-block x%d over HIP devices %s, ONE process (fwx_matrix_create_multi), 64-pivot "
+                 "snapshot panels on %s" % (world, devs, "RCCL" if transport == engine.FWX_XCHG_RCCL
+                                            else "peer / device-to-device copies"))
+    out = {
+        "metric": "edge-relaxations/sec (N^3/t), N=%d %s" % (n, "fp32" if es == 4 else "fp64"),
+        "value": args.steps * relax_per_step / dt, "unit": "edge-relaxations/s", "n_gpus": world,
+        "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps,
+        "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": args.dtype,
+        "data": "synthetic", "config": workload_config(args, n, n, serp, world, partition),
+        "host_runtime": "HIP runtime via ctypes (no torch in the process)",
+        "exchange": {"transport": "rccl" if transport == engine.FWX_XCHG_RCCL else "peer",
+                     "rccl_ranks_in_communicator": ranks, "partitions": parts,
+                     "distinct_devices": len(set(devs))},
+    }
+    if logical:
+        out["INVALID_logical_partitions"] = ("%d partitions time-share %d device(s): a rehearsal of the "
+                                             "N > 1 code path, not a scaling number" % (world, len(set(devs))))
+    # Aggregate HBM figure: every partition streams its slab once per pivot (per-k engine) --
+    # algorithmic bytes of the whole solve over the wall time of the step (restore, panels, exchange
+    # and look-ahead included) against world x 8 TB/s (x distinct devices for a rehearsal).  A slab that
+    # fits the Infinity Cache is served from it: "effective".
+    peak = HBM_PEAK_GBPS * len(set(devs))
+    if args.engine == "perk":
+        u_solve = float(updates or 0)
+        alg_total = es * relax_per_step + (es + (4 if args.with_next else 0)) * u_solve + 2.0 * es * n * n
+        achieved = alg_total * args.steps / dt / 1e9
+        out["roofline"] = {"bound": "hbm", "achieved": achieved, "peak": peak, "unit": "GB/s",
+                           "frac": achieved / peak, "traffic": None,
+                           "kernel": "fwx::relax_k on %d row-block slabs" % world,
+                           "alg_bytes_per_solve": alg_total, "updates_per_solve": updates,
+                           "label": ("effective (the %d MiB slab of each partition fits the 256 MiB Infinity "
+                                     "Cache: not an HBM-traffic claim)" % (slab_bytes >> 20))
+                           if slab_bytes <= INFINITY_CACHE_BYTES else "aggregate over partitions",
+                           "note": "algorithmic bytes of the solve (s*N^3 + s*U + 2*s*N^2) / wall time per "
+                                   "step, all partitions; includes the device-to-device restore of the "
+                                   "input, the panel kernels and the exchange"}
+    else:
+        pass_bytes = 2.0 * es * n * n + 2 * 64 * es * n * world
+        achieved = pass_bytes * ((n + 63) // 64) * args.steps / dt / 1e9
+        out["roofline"] = {"bound": "hbm", "achieved": achieved, "peak": peak, "unit": "GB/s",
+                           "frac": achieved / peak, "traffic": None,
+                           "kernel": "fwx::fused_main* on %d row-block slabs" % world,
+                           "updates_per_solve": updates,
+                           "note": "VALU-issue-bound kernel: low HBM fraction by design"}
+    if not args.no_extras:
+        # tie the timed result to the committed whole-oracle digests where they exist (N = 16384 f32 D1)
+        got = h.download()
+        out["check"] = {"rate_digest": digest(got[0])}
+        if args.with_next:
+            out["check"]["next_digest"] = digest(got[1])
+        gold = os.path.join(ROOT, "tests", "golden", "config4_n16384_digests.json")
+        if n == 16384 and es == 4 and args.dist == "d1" and args.config in (0, 4) and os.path.exists(gold):
+            with open(gold) as f:
+                g = json.load(f)
+            out["check"]["equals_whole_oracle_solve"] = bool(
+                out["check"]["rate_digest"] == g["rate_digest"] and
+                (not args.with_next or out["check"]["next_digest"] == g["next_digest"]) and
+                (updates is None or updates == g["U"]))
+        del got
+    h.close()
+    if not args.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline(rate_host, min(args.cpu_seconds, 8.0))
+    print(json.dumps(out), flush=True)
+
+
+# ------------------------------------------------------------------------------------------------
 # N > 1: one process per GPU, torch.distributed over RCCL
 # ------------------------------------------------------------------------------------------------
 def run_dist(args, world, rank, local_rank):
@@ -574,8 +727,14 @@ def run_dist(args, world, rank, local_rank):
                            "unit": "GB/s", "frac": achieved / (HBM_PEAK_GBPS * world), "traffic": None,
                            "kernel": "fwx::fused_main* on %d row-block slabs" % world,
                            "note": "VALU-issue-bound kernel: low HBM fraction by design"}
+    out["exchange"] = {"transport": "rccl (torch.distributed)" if args.backend == "nccl" else args.backend,
+                       "ranks_in_process_group": dist.get_world_size()}
     if rank == 0:
+        if not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(make_input(args, n)[0].astype(np_dtype),
+                                               min(args.cpu_seconds, 8.0))
         print(json.dumps(out), flush=True)
+    dist.barrier()
     dist.destroy_process_group()
 
 
@@ -584,14 +743,13 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("--gpus %d needs torch.distributed.run with %d ranks" % (args.gpus, args.gpus))
+    if world > 1:                           # launched by torch.distributed.run: one process per GPU
         args.gpus = world
-    if world == 1:
-        run_single(args)
-    else:
         run_dist(args, world, rank, local_rank)
+    elif len(args.device_list) > 1 or args.devices:
+        run_multi(args)                     # no launcher: ONE process through the partitioned C-ABI handle
+    else:
+        run_single(args)
 
 
 if __name__ == "__main__":

@@ -15,8 +15,9 @@ FWX_ERR_CYCLE = -5
 FWX_ERR_CAPACITY = -6
 FWX_ERR_UNSUPPORTED = -7
 FWX_ERR_RCCL = -8
+FWX_ERR_INTERNAL = -9
 
-FWX_ABI_VERSION = 2
+FWX_ABI_VERSION = 3
 FWX_F32, FWX_F64 = 0, 1
 FWX_ENGINE_AUTO, FWX_ENGINE_PERK, FWX_ENGINE_FUSED = 0, 1, 2
 FWX_UPDATE_SHARDS = 256
@@ -70,6 +71,8 @@ SIGNATURES = {
     "fwx_device_count": (ctypes.c_int, []),
     "fwx_strerror": (ctypes.c_char_p, [ctypes.c_int]),
     "fwx_last_hip_error": (ctypes.c_int, []),
+    "fwx_hip_versions": (ctypes.c_int, [ctypes.POINTER(c_i32), ctypes.POINTER(c_i32)]),
+    "fwx_test_fail_after": (ctypes.c_int, [c_i32]),
     "fwx_solve_f64": (ctypes.c_int, [c_i32, c_vp, c_vp, c_vp, ctypes.POINTER(FwxOpts)]),
     "fwx_solve_f32": (ctypes.c_int, [c_i32, c_vp, c_vp, c_vp, ctypes.POINTER(FwxOpts)]),
     "fwx_follow_path": (ctypes.c_int, [c_i32, c_vp, c_i32, c_i32, c_vp, c_i32]),
@@ -90,6 +93,7 @@ SIGNATURES = {
     "fwx_matrix_create_multi": (ctypes.c_int, [ctypes.POINTER(c_vp), c_i32, c_i32, c_i32, c_i32, c_i32,
                                                ctypes.POINTER(c_i32), c_i32]),
     "fwx_matrix_parts": (ctypes.c_int, [c_vp, ctypes.POINTER(c_i32)]),
+    "fwx_matrix_comm_ranks": (ctypes.c_int, [c_vp]),
     "fwx_solve_multi_f64": (ctypes.c_int, [c_i32, c_vp, c_vp, c_vp, c_i32, ctypes.POINTER(c_i32), c_i32,
                                            ctypes.POINTER(FwxOpts)]),
     "fwx_solve_multi_f32": (ctypes.c_int, [c_i32, c_vp, c_vp, c_vp, c_i32, ctypes.POINTER(c_i32), c_i32,
@@ -125,17 +129,14 @@ def lib():
             raise RuntimeError(
                 "libfwx.so is missing at %s -- build it with `python -m floydwarshall_amd.build` "
                 "(hipcc, gfx950).  floydwarshall_amd has no CPU fallback." % LIB_PATH)
-        # One HIP runtime per process: torch wheels bundle their own libamdhip64.so.7 (same
-        # SONAME as /opt/rocm's).  If torch is going to be used in this process it must be loaded
-        # FIRST, so that libfwx's DT_NEEDED resolves to the copy torch initialises; the other
-        # order leaves torch with "No HIP GPUs are available".  libfwx itself does not need torch.
-        # FWX_NO_TORCH=1: a torch-free process (the N=1 benchmark, the C consumer's Python twin):
-        # libfwx then binds to the HIP runtime it was linked against and nothing else is mapped.
-        if os.environ.get("FWX_NO_TORCH") != "1":
-            try:
-                import torch  # noqa: F401
-            except ImportError:
-                pass
+        # One HIP runtime per process, and by default the one libfwx was BUILT AGAINST (/opt/rocm,
+        # found through the library's RUNPATH): nothing else is imported here.  torch wheels bundle
+        # their own libamdhip64.so.7 (same SONAME, an older ROCm); a program that needs torch in the
+        # same process (floydwarshall_amd.dist: torch.distributed) must import torch BEFORE this
+        # loader runs, so that libfwx's DT_NEEDED resolves to the copy torch initialises -- the other
+        # order leaves torch with "No HIP GPUs are available".  That pairing works but is not the one
+        # the library is built and fuzzed on; runtime_versions() reports it and a mismatch is logged
+        # once (FWX_STRICT_RUNTIME=1 turns it into an error).
         L = ctypes.CDLL(LIB_PATH)
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(L, name)  # AttributeError here = header/library mismatch
@@ -144,7 +145,30 @@ def lib():
         if L.fwx_abi_version() != FWX_ABI_VERSION:
             raise RuntimeError("libfwx ABI version mismatch")
         _LIB = L
+        _check_runtime(L)
     return _LIB
+
+
+def runtime_versions():
+    """(HIP_VERSION libfwx was compiled against, version of the HIP runtime it is bound to in this
+    process, major.minor agree).  The runtime version is 0 where hipRuntimeGetVersion fails."""
+    built, run = c_i32(0), c_i32(0)
+    same = lib().fwx_hip_versions(ctypes.byref(built), ctypes.byref(run))
+    return int(built.value), int(run.value), bool(same)
+
+
+def _check_runtime(L):
+    built, run = c_i32(0), c_i32(0)
+    if L.fwx_hip_versions(ctypes.byref(built), ctypes.byref(run)) or run.value == 0:
+        return
+    msg = ("libfwx was built against HIP %d but is bound to HIP runtime %d in this process (another "
+           "library -- a torch wheel bundles its own libamdhip64 -- was loaded first).  Load "
+           "floydwarshall_amd before it, or do not import it at all, to run on the runtime the library "
+           "was built and fuzzed on." % (built.value, run.value))
+    if os.environ.get("FWX_STRICT_RUNTIME") == "1":
+        raise RuntimeError(msg)
+    import warnings
+    warnings.warn(msg, RuntimeWarning, stacklevel=3)
 
 
 def check(status, what):

@@ -55,16 +55,46 @@ def needs_build():
     return any(os.path.getmtime(d) > t for d in _deps())
 
 
+def _headers():
+    hs = [os.path.join(ROOT, "include", f) for f in os.listdir(os.path.join(ROOT, "include"))]
+    for d in (CSRC, HOST_DIR):
+        if os.path.isdir(d):
+            hs += [os.path.join(d, f) for f in os.listdir(d) if f.endswith((".h", ".hpp"))]
+    return hs
+
+
 def build_lib(force=False, verbose=False):
+    """One object per translation unit (compiled in parallel, rebuilt only when the source or a
+    header is newer), then one link.  Objects live under build/obj (git-ignored, not shipped)."""
     if not force and not needs_build():
         return LIB
     hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
     if not os.path.exists(hipcc):
         raise RuntimeError("hipcc not found: libfwx can only be built with the ROCm toolchain")
-    cmd = [hipcc] + HIPCC_FLAGS + ["-x", "hip"] + _sources() + ["-o", LIB + ".tmp", "-ldl"]
-    if verbose:
-        print(" ".join(cmd))
-    subprocess.run(cmd, check=True)
+    objdir = os.path.join(ROOT, "build", "obj")
+    os.makedirs(objdir, exist_ok=True)
+    hdr_time = max(os.path.getmtime(h) for h in _headers())
+    compile_flags = [f for f in HIPCC_FLAGS if f != "-shared"]
+    jobs, objs = [], []
+    for src in _sources():
+        obj = os.path.join(objdir, os.path.basename(src) + ".o")
+        objs.append(obj)
+        stale = force or not os.path.exists(obj) or \
+            os.path.getmtime(obj) < max(os.path.getmtime(src), hdr_time)
+        if stale:
+            jobs.append([hipcc] + compile_flags + ["-x", "hip", "-c", src, "-o", obj])
+
+    def run(cmd):
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        subprocess.run(cmd, check=True)
+
+    if jobs:
+        from concurrent.futures import ThreadPoolExecutor
+        with ThreadPoolExecutor(max_workers=min(len(jobs), os.cpu_count() or 4)) as ex:
+            list(ex.map(run, jobs))
+    run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-fno-gpu-rdc"] + objs +
+        ["-o", LIB + ".tmp", "-ldl"])
     os.replace(LIB + ".tmp", LIB)
     build_cli(hipcc, verbose)
     return LIB

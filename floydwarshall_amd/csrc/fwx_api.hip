@@ -12,39 +12,13 @@
 #include <new>
 
 #include "fwx.h"
+#include "fwx_guard.h"
 #include "fwx_internal.h"
 #include "fwx_kernels.h"
 
 using namespace fwxi;
 
 namespace {
-
-// One launch per pivot over a slab; pivot rows from `prow0 + (k-k_begin)*stride`.
-template <typename T>
-int relax_range(T *rate, int32_t *next, int32_t *hops, int rows, int n, int row0, const T *prow0,
-                const int32_t *phops0, int64_t stride, int k_begin, int k_end, int serpentine,
-                unsigned long long *d_updates, hipStream_t s, fwx::PathLog plog = fwx::PathLog(),
-                int skip_lo = 0, int skip_hi = 0, const int32_t *pnext0 = nullptr)
-{
-    fwx::RelaxArgs<T> a;
-    Throttle thr;
-    a.rate = rate; a.next = next; a.hops = hops;
-    a.rows = rows; a.n = n; a.row0 = row0; a.updates = d_updates; a.plog = plog;
-    a.skip_lo = skip_lo; a.skip_hi = skip_hi;
-    for (int k = k_begin; k < k_end; ++k) {
-        a.prow = prow0 + (int64_t)(k - k_begin) * stride;
-        a.phops = phops0 ? phops0 + (int64_t)(k - k_begin) * stride : nullptr;
-        a.pnext = pnext0 ? pnext0 + (int64_t)(k - k_begin) * stride : nullptr;
-        a.k = k;
-        a.flip = serpentine ? (k & 1) : 0;
-        const hipError_t e = fwx::launch_relax<T>(a, s);
-        if (e == hipErrorInvalidValue) return FWX_ERR_INVALID;   // misaligned skip range
-        FWX_HIP(e);
-        const int rc = thr.tick(s);
-        if (rc) return rc;
-    }
-    return FWX_OK;
-}
 
 template <typename T>
 int fused_block(const fwx_slab *sl, int k0, int bt, const T *w, const int32_t *wh,
@@ -310,6 +284,7 @@ int solve_host(int32_t n, T *rate, int32_t *next, int32_t *hops, const fwx_opts 
     CtxLease lease;
     if ((rc = lease.open())) return rc;
     CallCtx &cx = *lease.c;
+    if (op.has_stream) cx.uses_stream(op.stream);   // drained before the context's buffers are reused
     struct { void *p = nullptr; } d_rate, d_next, d_hops, d_upd;
     if ((rc = cx.reserve(CallCtx::RATE, nn * sizeof(T), &d_rate.p))) return rc;
     if (next && (rc = cx.reserve(CallCtx::NEXT, nn * sizeof(int32_t), &d_next.p))) return rc;
@@ -661,6 +636,25 @@ int fwx_device_count(void) { return device_count(); }
 
 int fwx_last_hip_error(void) { return g_last_hip; }
 
+int fwx_hip_versions(int32_t *built_against, int32_t *runtime)
+{
+    if (built_against) *built_against = HIP_VERSION;
+    int v = 0;
+    if (hipRuntimeGetVersion(&v) != hipSuccess) {
+        (void)hipGetLastError();
+        v = 0;
+    }
+    if (runtime) *runtime = v;
+    // same major.minor: HIP_VERSION = major * 10^7 + minor * 10^5 + patch
+    return (v / 100000 == HIP_VERSION / 100000) ? 1 : 0;
+}
+
+int fwx_test_fail_after(int32_t countdown)
+{
+    g_fail_countdown = countdown > 0 ? countdown : 0;
+    return FWX_OK;
+}
+
 const char *fwx_strerror(int status)
 {
     switch (status) {
@@ -672,473 +666,516 @@ const char *fwx_strerror(int status)
     case FWX_ERR_CYCLE: return "next-hop walk does not reach the destination (cycle)";
     case FWX_ERR_CAPACITY: return "output buffer too small";
     case FWX_ERR_UNSUPPORTED: return "unsupported option combination";
+    case FWX_ERR_RCCL: return "RCCL could not be loaded or an RCCL call failed";
+    case FWX_ERR_INTERNAL: return "internal error (an exception was stopped at the C ABI)";
     default: return "unknown status";
     }
 }
 
 int fwx_solve_f64(int32_t n, double *rate, int32_t *next, int32_t *hops, const fwx_opts *opts)
 {
-    try { return solve_host<double>(n, rate, next, hops, opts); } catch (...) { return FWX_ERR_OOM; }
+    return fwxi::guarded([&]() -> int { return solve_host<double>(n, rate, next, hops, opts); });
 }
 
 int fwx_solve_f32(int32_t n, float *rate, int32_t *next, int32_t *hops, const fwx_opts *opts)
 {
-    try { return solve_host<float>(n, rate, next, hops, opts); } catch (...) { return FWX_ERR_OOM; }
+    return fwxi::guarded([&]() -> int { return solve_host<float>(n, rate, next, hops, opts); });
 }
 
 int fwx_follow_path(int32_t n, const int32_t *next, int32_t src, int32_t dst, int32_t *out,
                     int32_t cap)
 {
-    if (n < 0 || !next || src < 0 || dst < 0 || src >= n || dst >= n || cap < 0 ||
-        (cap > 0 && !out))
-        return FWX_ERR_INVALID;
-    const size_t N = (size_t)n;
-    if (next[(size_t)src * N + dst] < 0) return 0;
-    int32_t len = 0, cur = src;
-    while (cur != dst || len == 0) {
-        const int32_t nx = next[(size_t)cur * N + dst];
-        if (nx < 0 || nx >= n || len >= n) return FWX_ERR_CYCLE;
-        if (len >= cap) return FWX_ERR_CAPACITY;
-        out[len++] = nx;
-        cur = nx;
-    }
-    return len;
+    return fwxi::guarded([&]() -> int {
+        if (n < 0 || !next || src < 0 || dst < 0 || src >= n || dst >= n || cap < 0 ||
+            (cap > 0 && !out))
+            return FWX_ERR_INVALID;
+        const size_t N = (size_t)n;
+        if (next[(size_t)src * N + dst] < 0) return 0;
+        int32_t len = 0, cur = src;
+        while (cur != dst || len == 0) {
+            const int32_t nx = next[(size_t)cur * N + dst];
+            if (nx < 0 || nx >= n || len >= n) return FWX_ERR_CYCLE;
+            if (len >= cap) return FWX_ERR_CAPACITY;
+            out[len++] = nx;
+            cur = nx;
+        }
+        return len;
+    });
 }
 
 int fwx_matrix_create(fwx_matrix **out, int32_t n, int32_t dtype, int32_t with_next,
                       int32_t with_hops, int32_t device)
 {
-    if (!out || n < 0 || (dtype != FWX_F32 && dtype != FWX_F64) || (with_hops && !with_next))
-        return FWX_ERR_INVALID;
-    *out = nullptr;
-    DeviceGuard g;
-    int rc = g.enter(device);
-    if (rc) return rc;
-    int dev = 0;
-    FWX_HIP(hipGetDevice(&dev));
-    fwx_matrix *m = new (std::nothrow) fwx_matrix();
-    if (!m) return FWX_ERR_OOM;
-    memset(m, 0, sizeof(*m));
-    m->n = n; m->dtype = dtype; m->device = dev;
-    const size_t nn = (size_t)n * (size_t)n;
-    const size_t es = dtype == FWX_F64 ? 8 : 4;
-    hipError_t e = hipMalloc(&m->rate, nn * es ? nn * es : 1);
-    if (e == hipSuccess && with_next) e = hipMalloc((void **)&m->next, nn * 4 ? nn * 4 : 1);
-    if (e == hipSuccess && with_hops) e = hipMalloc((void **)&m->hops, nn * 4 ? nn * 4 : 1);
-    if (e == hipSuccess) e = hipMalloc((void **)&m->scratch, ((size_t)n + 2) * 4);
-    if (e == hipSuccess) e = hipMalloc((void **)&m->upd, FWX_UPDATE_SHARDS * 8);
-    if (e == hipSuccess) e = hipMalloc((void **)&m->flag, 16);
-    if (e == hipSuccess) e = hipStreamCreateWithFlags(&m->stream, hipStreamNonBlocking);
-    if (e != hipSuccess) {
-        g_last_hip = (int)e;
-        (void)hipGetLastError();
-        fwx_matrix_destroy(m);
-        return e == hipErrorOutOfMemory ? FWX_ERR_OOM : FWX_ERR_HIP;
-    }
-    *out = m;
-    return FWX_OK;
+    return fwxi::guarded([&]() -> int {
+        if (!out || n < 0 || (dtype != FWX_F32 && dtype != FWX_F64) || (with_hops && !with_next))
+            return FWX_ERR_INVALID;
+        *out = nullptr;
+        DeviceGuard g;
+        int rc = g.enter(device);
+        if (rc) return rc;
+        int dev = 0;
+        FWX_HIP(hipGetDevice(&dev));
+        fwx_matrix *m = new (std::nothrow) fwx_matrix();
+        if (!m) return FWX_ERR_OOM;
+        memset(m, 0, sizeof(*m));
+        m->n = n; m->dtype = dtype; m->device = dev;
+        const size_t nn = (size_t)n * (size_t)n;
+        const size_t es = dtype == FWX_F64 ? 8 : 4;
+        hipError_t e = hipMalloc(&m->rate, nn * es ? nn * es : 1);
+        if (e == hipSuccess && with_next) e = hipMalloc((void **)&m->next, nn * 4 ? nn * 4 : 1);
+        if (e == hipSuccess && with_hops) e = hipMalloc((void **)&m->hops, nn * 4 ? nn * 4 : 1);
+        if (e == hipSuccess) e = hipMalloc((void **)&m->scratch, ((size_t)n + 2) * 4);
+        if (e == hipSuccess) e = hipMalloc((void **)&m->upd, FWX_UPDATE_SHARDS * 8);
+        if (e == hipSuccess) e = hipMalloc((void **)&m->flag, 16);
+        if (e == hipSuccess) e = hipStreamCreateWithFlags(&m->stream, hipStreamNonBlocking);
+        if (e != hipSuccess) {
+            g_last_hip = (int)e;
+            (void)hipGetLastError();
+            fwx_matrix_destroy(m);
+            return e == hipErrorOutOfMemory ? FWX_ERR_OOM : FWX_ERR_HIP;
+        }
+        *out = m;
+        return FWX_OK;
+    });
 }
 
 int fwx_matrix_destroy(fwx_matrix *m)
 {
-    if (!m) return FWX_OK;
-    if (m->multi) {
-        multi_destroy(m);
+    return fwxi::guarded([&]() -> int {
+        if (!m) return FWX_OK;
+        if (m->multi) {
+            multi_destroy(m);
+            delete m;
+            return FWX_OK;
+        }
+        DeviceGuard g;
+        (void)g.enter(m->device);
+        // order: retire every command that used the arrays, then the streams and their events, then
+        // the memory
+        drain_stream(m->stream);
+        if (m->side) m->side->drain();
+        delete m->side;
+        m->side = nullptr;
+        if (m->stream) (void)hipStreamDestroy(m->stream);
+        m->stream = nullptr;
+        if (m->rate) (void)hipFree(m->rate);
+        if (m->next) (void)hipFree(m->next);
+        if (m->hops) (void)hipFree(m->hops);
+        if (m->scratch) (void)hipFree(m->scratch);
+        if (m->upd) (void)hipFree(m->upd);
+        if (m->plog.last) (void)hipFree(m->plog.last);
+        if (m->plog.at_col) (void)hipFree(m->plog.at_col);
+        if (m->plog.at_row) (void)hipFree(m->plog.at_row);
+        if (m->next0) (void)hipFree(m->next0);
+        if (m->rate0) (void)hipFree(m->rate0);
+        if (m->hops0) (void)hipFree(m->hops0);
+        if (m->walk) (void)hipFree(m->walk);
+        if (m->ws) (void)hipFree(m->ws);
+        if (m->flag) (void)hipFree(m->flag);
         delete m;
         return FWX_OK;
-    }
-    DeviceGuard g;
-    (void)g.enter(m->device);
-    drain_stream(m->stream);           // every command that used the arrays has been retired
-    if (m->side) m->side->drain();
-    if (m->rate) (void)hipFree(m->rate);
-    if (m->next) (void)hipFree(m->next);
-    if (m->hops) (void)hipFree(m->hops);
-    if (m->scratch) (void)hipFree(m->scratch);
-    if (m->upd) (void)hipFree(m->upd);
-    if (m->plog.last) (void)hipFree(m->plog.last);
-    if (m->plog.at_col) (void)hipFree(m->plog.at_col);
-    if (m->plog.at_row) (void)hipFree(m->plog.at_row);
-    if (m->next0) (void)hipFree(m->next0);
-    if (m->rate0) (void)hipFree(m->rate0);
-    if (m->hops0) (void)hipFree(m->hops0);
-    if (m->walk) (void)hipFree(m->walk);
-    if (m->stream) (void)hipStreamSynchronize(m->stream);
-    if (m->ws) (void)hipFree(m->ws);
-    if (m->flag) (void)hipFree(m->flag);
-    delete m->side;
-    if (m->stream) (void)hipStreamDestroy(m->stream);
-    delete m;
-    return FWX_OK;
+    });
 }
 
 int fwx_matrix_upload(fwx_matrix *m, const void *rate, const int32_t *next, const int32_t *hops)
 {
-    if (!m) return FWX_ERR_INVALID;
-    if (m->n == 0) return FWX_OK;
-    if (!rate || (m->next && !next) || (m->hops && !hops)) return FWX_ERR_INVALID;
-    if (m->multi) return multi_upload(m, rate, next, hops);
-    DeviceGuard g;
-    int rc = g.enter(m->device);
-    if (rc) return rc;
-    const size_t nn = (size_t)m->n * (size_t)m->n, es = m->dtype == FWX_F64 ? 8 : 4;
-    // hipMemcpyDefault: the sources may be host arrays (what an FFI hands over) or device arrays
-    // (a caller that keeps its pristine input in HBM, e.g. the benchmark)
-    hipStream_t s = m->stream;
-    m->dom_known = 0;                  // a new input: the domain check has to look at it
-    FWX_HIP(hipMemcpyAsync(m->rate, rate, nn * es, hipMemcpyDefault, s));
-    if (m->next) FWX_HIP(hipMemcpyAsync(m->next, next, nn * 4, hipMemcpyDefault, s));
-    if (m->hops) FWX_HIP(hipMemcpyAsync(m->hops, hops, nn * 4, hipMemcpyDefault, s));
-    if (m->plog.last || (m->keep && m->next)) {
-        // traced matrix: keep the uploaded next-hops (paths of entries never improved); kept input
-        FWX_HIP(hipMemcpyAsync(m->next0, m->next, nn * 4, hipMemcpyDeviceToDevice, s));
-        m->rec_ready = 0;   // the trace of an earlier input is stale
-    }
-    if (m->keep) {
-        FWX_HIP(hipMemcpyAsync(m->rate0, m->rate, nn * es, hipMemcpyDeviceToDevice, s));
-        if (m->hops) FWX_HIP(hipMemcpyAsync(m->hops0, m->hops, nn * 4, hipMemcpyDeviceToDevice, s));
-        m->kept_valid = 1;
-    }
-    FWX_HIP(hipStreamSynchronize(s));
-    m->fresh = 1;
-    return FWX_OK;
+    return fwxi::guarded([&]() -> int {
+        if (!m) return FWX_ERR_INVALID;
+        if (m->n == 0) return FWX_OK;
+        if (!rate || (m->next && !next) || (m->hops && !hops)) return FWX_ERR_INVALID;
+        if (m->multi) return multi_upload(m, rate, next, hops);
+        DeviceGuard g;
+        int rc = g.enter(m->device);
+        if (rc) return rc;
+        const size_t nn = (size_t)m->n * (size_t)m->n, es = m->dtype == FWX_F64 ? 8 : 4;
+        // hipMemcpyDefault: the sources may be host arrays (what an FFI hands over) or device arrays
+        // (a caller that keeps its pristine input in HBM, e.g. the benchmark)
+        hipStream_t s = m->stream;
+        m->dom_known = 0;                  // a new input: the domain check has to look at it
+        FWX_HIP(hipMemcpyAsync(m->rate, rate, nn * es, hipMemcpyDefault, s));
+        if (m->next) FWX_HIP(hipMemcpyAsync(m->next, next, nn * 4, hipMemcpyDefault, s));
+        if (m->hops) FWX_HIP(hipMemcpyAsync(m->hops, hops, nn * 4, hipMemcpyDefault, s));
+        if (m->plog.last || (m->keep && m->next)) {
+            // traced matrix: keep the uploaded next-hops (paths of entries never improved); kept input
+            FWX_HIP(hipMemcpyAsync(m->next0, m->next, nn * 4, hipMemcpyDeviceToDevice, s));
+            m->rec_ready = 0;   // the trace of an earlier input is stale
+        }
+        if (m->keep) {
+            FWX_HIP(hipMemcpyAsync(m->rate0, m->rate, nn * es, hipMemcpyDeviceToDevice, s));
+            if (m->hops) FWX_HIP(hipMemcpyAsync(m->hops0, m->hops, nn * 4, hipMemcpyDeviceToDevice, s));
+            m->kept_valid = 1;
+        }
+        FWX_HIP(hipStreamSynchronize(s));
+        m->fresh = 1;
+        return FWX_OK;
+    });
 }
 
 int fwx_matrix_enable_path_log(fwx_matrix *m)
 {
-    if (!m || !m->next || m->plog.last) return FWX_ERR_INVALID;
-    if (m->n == 0) return FWX_OK;
-    if (m->multi) return multi_enable_path_log(m);
-    DeviceGuard g;
-    int rc = g.enter(m->device);
-    if (rc) return rc;
-    const size_t nn = (size_t)m->n * (size_t)m->n;
-    FWX_HIP(hipMalloc((void **)&m->plog.at_col, nn * 4));
-    FWX_HIP(hipMalloc((void **)&m->plog.at_row, nn * 4));
-    if (!m->next0) FWX_HIP(hipMalloc((void **)&m->next0, nn * 4));
-    FWX_HIP(hipMalloc((void **)&m->plog.last, nn * 4));      // last: `last != nullptr` = enabled
-    // next0 = the UPLOADED next-hops.  If the arrays already hold an unsolved upload, keep it;
-    // otherwise (nothing uploaded yet, or already solved) `fresh` is 0 and a traced solve is
-    // refused until the next upload, which fills next0.
-    if (m->fresh) {
-        FWX_HIP(hipMemcpyAsync(m->next0, m->next, nn * 4, hipMemcpyDeviceToDevice, m->stream));
-        FWX_HIP(hipStreamSynchronize(m->stream));
-    }
-    m->rec_ready = 0;
-    return FWX_OK;
+    return fwxi::guarded([&]() -> int {
+        if (!m || !m->next || m->plog.last) return FWX_ERR_INVALID;
+        if (m->n == 0) return FWX_OK;
+        if (m->multi) return multi_enable_path_log(m);
+        DeviceGuard g;
+        int rc = g.enter(m->device);
+        if (rc) return rc;
+        const size_t nn = (size_t)m->n * (size_t)m->n;
+        FWX_HIP(hipMalloc((void **)&m->plog.at_col, nn * 4));
+        FWX_HIP(hipMalloc((void **)&m->plog.at_row, nn * 4));
+        if (!m->next0) FWX_HIP(hipMalloc((void **)&m->next0, nn * 4));
+        FWX_HIP(hipMalloc((void **)&m->plog.last, nn * 4));      // last: `last != nullptr` = enabled
+        // next0 = the UPLOADED next-hops.  If the arrays already hold an unsolved upload, keep it;
+        // otherwise (nothing uploaded yet, or already solved) `fresh` is 0 and a traced solve is
+        // refused until the next upload, which fills next0.
+        if (m->fresh) {
+            FWX_HIP(hipMemcpyAsync(m->next0, m->next, nn * 4, hipMemcpyDeviceToDevice, m->stream));
+            FWX_HIP(hipStreamSynchronize(m->stream));
+        }
+        m->rec_ready = 0;
+        return FWX_OK;
+    });
 }
 
 int fwx_matrix_keep_input(fwx_matrix *m)
 {
-    if (!m) return FWX_ERR_INVALID;
-    if (m->keep || m->n == 0) return FWX_OK;
-    if (m->multi) return multi_keep_input(m);
-    DeviceGuard g;
-    int rc = g.enter(m->device);
-    if (rc) return rc;
-    const size_t nn = (size_t)m->n * (size_t)m->n, es = m->dtype == FWX_F64 ? 8 : 4;
-    FWX_HIP(hipMalloc(&m->rate0, nn * es));
-    if (m->next && !m->next0) FWX_HIP(hipMalloc((void **)&m->next0, nn * 4));
-    if (m->hops) FWX_HIP(hipMalloc((void **)&m->hops0, nn * 4));
-    m->keep = 1;
-    if (m->fresh) {          // an unsolved upload is in the arrays: that is the input to keep
-        hipStream_t s = m->stream;
-        FWX_HIP(hipMemcpyAsync(m->rate0, m->rate, nn * es, hipMemcpyDeviceToDevice, s));
-        if (m->next) FWX_HIP(hipMemcpyAsync(m->next0, m->next, nn * 4, hipMemcpyDeviceToDevice, s));
-        if (m->hops) FWX_HIP(hipMemcpyAsync(m->hops0, m->hops, nn * 4, hipMemcpyDeviceToDevice, s));
-        FWX_HIP(hipStreamSynchronize(s));
-        m->kept_valid = 1;
-    }
-    return FWX_OK;
+    return fwxi::guarded([&]() -> int {
+        if (!m) return FWX_ERR_INVALID;
+        if (m->keep || m->n == 0) return FWX_OK;
+        if (m->multi) return multi_keep_input(m);
+        DeviceGuard g;
+        int rc = g.enter(m->device);
+        if (rc) return rc;
+        const size_t nn = (size_t)m->n * (size_t)m->n, es = m->dtype == FWX_F64 ? 8 : 4;
+        FWX_HIP(hipMalloc(&m->rate0, nn * es));
+        if (m->next && !m->next0) FWX_HIP(hipMalloc((void **)&m->next0, nn * 4));
+        if (m->hops) FWX_HIP(hipMalloc((void **)&m->hops0, nn * 4));
+        m->keep = 1;
+        if (m->fresh) {          // an unsolved upload is in the arrays: that is the input to keep
+            hipStream_t s = m->stream;
+            FWX_HIP(hipMemcpyAsync(m->rate0, m->rate, nn * es, hipMemcpyDeviceToDevice, s));
+            if (m->next) FWX_HIP(hipMemcpyAsync(m->next0, m->next, nn * 4, hipMemcpyDeviceToDevice, s));
+            if (m->hops) FWX_HIP(hipMemcpyAsync(m->hops0, m->hops, nn * 4, hipMemcpyDeviceToDevice, s));
+            FWX_HIP(hipStreamSynchronize(s));
+            m->kept_valid = 1;
+        }
+        return FWX_OK;
+    });
 }
 
 int fwx_matrix_patch_input(fwx_matrix *m, int32_t count, const int64_t *index, const void *rate_vals,
                            const int32_t *next_vals, const int32_t *hops_vals)
 {
-    if (!m || count < 0 || count > FWX_MAX_PATCH || (count > 0 && (!index || !rate_vals)))
-        return FWX_ERR_INVALID;
-    if (!m->keep || !m->kept_valid) return FWX_ERR_INVALID;
-    if ((next_vals && !m->next) || (hops_vals && !m->hops)) return FWX_ERR_INVALID;
-    const int64_t nn64 = (int64_t)m->n * m->n;
-    for (int32_t q = 0; q < count; ++q)
-        if (index[q] < 0 || index[q] >= nn64) return FWX_ERR_INVALID;
-    if (m->multi) return multi_patch_input(m, count, index, rate_vals, next_vals, hops_vals);
-    DeviceGuard g;
-    int rc = g.enter(m->device);
-    if (rc) return rc;
-    const size_t nn = (size_t)nn64, es = m->dtype == FWX_F64 ? 8 : 4;
-    hipStream_t s = m->stream;
-    // the remembered domain answer survives a patch whose values are themselves inside the domain
-    // (rate >= +0 and not NaN; a non-zero rate comes with a next-hop >= 0); anything else, or a
-    // non-zero rate patched in without its next-hop, sends the next solve through the check again
-    if (m->dom_known) {
-        bool ok = true;
-        for (int32_t q = 0; q < count && ok; ++q) {
-            const double r = m->dtype == FWX_F64 ? ((const double *)rate_vals)[q] : (double)((const float *)rate_vals)[q];
-            ok = !(r != r) && !std::signbit(r);
-            if (ok && m->next && r != 0.0) ok = next_vals && next_vals[q] >= 0;
+    return fwxi::guarded([&]() -> int {
+        if (!m || count < 0 || count > FWX_MAX_PATCH || (count > 0 && (!index || !rate_vals)))
+            return FWX_ERR_INVALID;
+        if (!m->keep || !m->kept_valid) return FWX_ERR_INVALID;
+        if ((next_vals && !m->next) || (hops_vals && !m->hops)) return FWX_ERR_INVALID;
+        const int64_t nn64 = (int64_t)m->n * m->n;
+        for (int32_t q = 0; q < count; ++q)
+            if (index[q] < 0 || index[q] >= nn64) return FWX_ERR_INVALID;
+        if (m->multi) return multi_patch_input(m, count, index, rate_vals, next_vals, hops_vals);
+        DeviceGuard g;
+        int rc = g.enter(m->device);
+        if (rc) return rc;
+        const size_t nn = (size_t)nn64, es = m->dtype == FWX_F64 ? 8 : 4;
+        hipStream_t s = m->stream;
+        // the remembered domain answer survives a patch whose values are themselves inside the domain
+        // (rate >= +0 and not NaN; a non-zero rate comes with a next-hop >= 0); anything else, or a
+        // non-zero rate patched in without its next-hop, sends the next solve through the check again
+        if (m->dom_known) {
+            bool ok = true;
+            for (int32_t q = 0; q < count && ok; ++q) {
+                const double r = m->dtype == FWX_F64 ? ((const double *)rate_vals)[q] : (double)((const float *)rate_vals)[q];
+                ok = !(r != r) && !std::signbit(r);
+                if (ok && m->next && r != 0.0) ok = next_vals && next_vals[q] >= 0;
+            }
+            const int want = m->next ? 3 : 1;
+            if (!ok || (m->dom_bits & want) != want) m->dom_known = 0;
         }
-        const int want = m->next ? 3 : 1;
-        if (!ok || (m->dom_bits & want) != want) m->dom_known = 0;
-    }
-    for (int32_t q = 0; q < count; ++q) {        // a handful of entries: plain small copies
-        const size_t off = (size_t)index[q];
-        FWX_HIP(hipMemcpyAsync((char *)m->rate0 + off * es, (const char *)rate_vals + (size_t)q * es, es,
-                               hipMemcpyHostToDevice, s));
-        if (next_vals) FWX_HIP(hipMemcpyAsync(m->next0 + off, next_vals + q, 4, hipMemcpyHostToDevice, s));
-        if (hops_vals) FWX_HIP(hipMemcpyAsync(m->hops0 + off, hops_vals + q, 4, hipMemcpyHostToDevice, s));
-    }
-    FWX_HIP(hipMemcpyAsync(m->rate, m->rate0, nn * es, hipMemcpyDeviceToDevice, s));
-    if (m->next) FWX_HIP(hipMemcpyAsync(m->next, m->next0, nn * 4, hipMemcpyDeviceToDevice, s));
-    if (m->hops) FWX_HIP(hipMemcpyAsync(m->hops, m->hops0, nn * 4, hipMemcpyDeviceToDevice, s));
-    FWX_HIP(hipStreamSynchronize(s));
-    m->fresh = 1;
-    m->rec_ready = 0;
-    return FWX_OK;
+        for (int32_t q = 0; q < count; ++q) {        // a handful of entries: plain small copies
+            const size_t off = (size_t)index[q];
+            FWX_HIP(hipMemcpyAsync((char *)m->rate0 + off * es, (const char *)rate_vals + (size_t)q * es, es,
+                                   hipMemcpyHostToDevice, s));
+            if (next_vals) FWX_HIP(hipMemcpyAsync(m->next0 + off, next_vals + q, 4, hipMemcpyHostToDevice, s));
+            if (hops_vals) FWX_HIP(hipMemcpyAsync(m->hops0 + off, hops_vals + q, 4, hipMemcpyHostToDevice, s));
+        }
+        FWX_HIP(hipMemcpyAsync(m->rate, m->rate0, nn * es, hipMemcpyDeviceToDevice, s));
+        if (m->next) FWX_HIP(hipMemcpyAsync(m->next, m->next0, nn * 4, hipMemcpyDeviceToDevice, s));
+        if (m->hops) FWX_HIP(hipMemcpyAsync(m->hops, m->hops0, nn * 4, hipMemcpyDeviceToDevice, s));
+        FWX_HIP(hipStreamSynchronize(s));
+        m->fresh = 1;
+        m->rec_ready = 0;
+        return FWX_OK;
+    });
 }
 
 int fwx_matrix_path_log_count(fwx_matrix *m, uint64_t *count_out)
 {
-    if (!m || !count_out) return FWX_ERR_INVALID;
-    *count_out = (m->plog.last && m->rec_ready) ? m->last_u : 0;
-    return FWX_OK;
+    return fwxi::guarded([&]() -> int {
+        if (!m || !count_out) return FWX_ERR_INVALID;
+        *count_out = (m->plog.last && m->rec_ready) ? m->last_u : 0;
+        return FWX_OK;
+    });
 }
 
 int fwx_matrix_query_exact(fwx_matrix *m, int32_t src, int32_t dst, double *rate_out,
                            int32_t *path_out, int32_t cap)
 {
-    if (!m || src < 0 || dst < 0 || src >= m->n || dst >= m->n || cap <= 0 || !path_out)
-        return FWX_ERR_INVALID;
-    if (!m->plog.last) return FWX_ERR_INVALID;
-    if (!m->rec_ready) return FWX_ERR_INVALID;             // no traced solve of this upload yet
-    if (m->multi) return multi_query_exact(m, src, dst, rate_out, path_out, cap);
-    DeviceGuard g;
-    int rc = g.enter(m->device);
-    if (rc) return rc;
-    const size_t idx = (size_t)src * m->n + dst;
-    hipStream_t s = m->stream;
-    float f32_rate = 0;
-    if (rate_out) {
-        if (m->dtype == FWX_F64)
-            FWX_HIP(hipMemcpyAsync(rate_out, (double *)m->rate + idx, 8, hipMemcpyDeviceToHost, s));
-        else
-            FWX_HIP(hipMemcpyAsync(&f32_rate, (float *)m->rate + idx, 4, hipMemcpyDeviceToHost, s));
-    }
-    if (!m->walk || m->walk_cap < cap) {      // grow-only scratch, reused across queries
-        if (m->walk) { drain_stream(s); (void)hipFree(m->walk); m->walk = nullptr; }
-        FWX_HIP(hipMalloc((void **)&m->walk, ((size_t)4 * cap + 1) * 4));
-        m->walk_cap = cap;
-    }
-    int32_t *len_dev = m->walk + (size_t)4 * cap;
-    hipLaunchKernelGGL(exact_path_kernel, dim3(1), dim3(1), 0, s, m->plog, m->next0, m->n, src,
-                       dst, m->walk, cap, len_dev);
-    FWX_HIP(hipGetLastError());
-    int32_t len = 0;
-    FWX_HIP(hipMemcpyAsync(&len, len_dev, 4, hipMemcpyDeviceToHost, s));
-    FWX_HIP(hipStreamSynchronize(s));
-    if (rate_out && m->dtype != FWX_F64) *rate_out = (double)f32_rate;
-    if (len > 0) {
-        FWX_HIP(hipMemcpyAsync(path_out, m->walk, (size_t)len * 4, hipMemcpyDeviceToHost, s));
+    return fwxi::guarded([&]() -> int {
+        if (!m || src < 0 || dst < 0 || src >= m->n || dst >= m->n || cap <= 0 || !path_out)
+            return FWX_ERR_INVALID;
+        if (!m->plog.last) return FWX_ERR_INVALID;
+        if (!m->rec_ready) return FWX_ERR_INVALID;             // no traced solve of this upload yet
+        if (m->multi) return multi_query_exact(m, src, dst, rate_out, path_out, cap);
+        DeviceGuard g;
+        int rc = g.enter(m->device);
+        if (rc) return rc;
+        const size_t idx = (size_t)src * m->n + dst;
+        hipStream_t s = m->stream;
+        float f32_rate = 0;
+        if (rate_out) {
+            if (m->dtype == FWX_F64)
+                FWX_HIP(hipMemcpyAsync(rate_out, (double *)m->rate + idx, 8, hipMemcpyDeviceToHost, s));
+            else
+                FWX_HIP(hipMemcpyAsync(&f32_rate, (float *)m->rate + idx, 4, hipMemcpyDeviceToHost, s));
+        }
+        if (!m->walk || m->walk_cap < cap) {      // grow-only scratch, reused across queries
+            if (m->walk) { drain_stream(s); (void)hipFree(m->walk); m->walk = nullptr; }
+            FWX_HIP(hipMalloc((void **)&m->walk, ((size_t)4 * cap + 1) * 4));
+            m->walk_cap = cap;
+        }
+        int32_t *len_dev = m->walk + (size_t)4 * cap;
+        hipLaunchKernelGGL(exact_path_kernel, dim3(1), dim3(1), 0, s, m->plog, m->next0, m->n, src,
+                           dst, m->walk, cap, len_dev);
+        FWX_HIP(hipGetLastError());
+        int32_t len = 0;
+        FWX_HIP(hipMemcpyAsync(&len, len_dev, 4, hipMemcpyDeviceToHost, s));
         FWX_HIP(hipStreamSynchronize(s));
-    }
-    return len;
+        if (rate_out && m->dtype != FWX_F64) *rate_out = (double)f32_rate;
+        if (len > 0) {
+            FWX_HIP(hipMemcpyAsync(path_out, m->walk, (size_t)len * 4, hipMemcpyDeviceToHost, s));
+            FWX_HIP(hipStreamSynchronize(s));
+        }
+        return len;
+    });
 }
 
 int fwx_matrix_query_exact_batch(fwx_matrix *m, int32_t count, const int32_t *src, const int32_t *dst,
                                  int32_t *len_out, int32_t *path_out, int32_t cap)
 {
-    if (!m || count < 0 || cap <= 0) return FWX_ERR_INVALID;
-    if (count == 0) return FWX_OK;
-    if (!src || !dst || !len_out || !path_out || !m->plog.last) return FWX_ERR_INVALID;
-    if (!m->rec_ready) return FWX_ERR_INVALID;
-    if (m->multi) return multi_query_exact_batch(m, count, src, dst, len_out, path_out, cap);
-    DeviceGuard g;
-    int rc = g.enter(m->device);
-    if (rc) return rc;
-    // device scratch from a pooled per-call context: no hipMalloc / hipFree per query (and no hipFree
-    // right behind the kernel that used the memory: drain_stream in fwx_internal.h)
-    CtxLease lease;
-    if ((rc = lease.open())) return rc;
-    const size_t c = (size_t)count;
-    struct { void *p = nullptr; } d_src, d_dst, d_len, d_paths, d_stacks;
-    void *ids = nullptr;
-    if ((rc = lease.c->reserve(CallCtx::NEXT, c * 12, &ids)) ||
-        (rc = lease.c->reserve(CallCtx::RATE, c * cap * 4, &d_paths.p)) ||
-        (rc = lease.c->reserve(CallCtx::WS, c * cap * 12, &d_stacks.p)))
-        return rc;
-    d_src.p = ids;
-    d_dst.p = (char *)ids + c * 4;
-    d_len.p = (char *)ids + c * 8;
-    hipStream_t s = m->stream;
-    FWX_HIP(hipMemcpyAsync(d_src.p, src, c * 4, hipMemcpyHostToDevice, s));
-    FWX_HIP(hipMemcpyAsync(d_dst.p, dst, c * 4, hipMemcpyHostToDevice, s));
-    hipLaunchKernelGGL(exact_paths_kernel, dim3((unsigned)((c + 63) / 64)), dim3(64), 0, s, m->plog,
-                       m->next0, m->n, count, (const int32_t *)d_src.p, (const int32_t *)d_dst.p,
-                       (int32_t *)d_paths.p, (int32_t *)d_stacks.p, cap, (int32_t *)d_len.p);
-    FWX_HIP(hipGetLastError());
-    FWX_HIP(hipMemcpyAsync(len_out, d_len.p, c * 4, hipMemcpyDeviceToHost, s));
-    FWX_HIP(hipMemcpyAsync(path_out, d_paths.p, c * cap * 4, hipMemcpyDeviceToHost, s));
-    FWX_HIP(hipStreamSynchronize(s));
-    return FWX_OK;
+    return fwxi::guarded([&]() -> int {
+        if (!m || count < 0 || cap <= 0) return FWX_ERR_INVALID;
+        if (count == 0) return FWX_OK;
+        if (!src || !dst || !len_out || !path_out || !m->plog.last) return FWX_ERR_INVALID;
+        if (!m->rec_ready) return FWX_ERR_INVALID;
+        if (m->multi) return multi_query_exact_batch(m, count, src, dst, len_out, path_out, cap);
+        DeviceGuard g;
+        int rc = g.enter(m->device);
+        if (rc) return rc;
+        // device scratch from a pooled per-call context: no hipMalloc / hipFree per query (and no hipFree
+        // right behind the kernel that used the memory: drain_stream in fwx_internal.h)
+        CtxLease lease;
+        if ((rc = lease.open())) return rc;
+        lease.c->uses_stream(m->stream);     // the kernel below runs on the handle's stream
+        const size_t c = (size_t)count;
+        struct { void *p = nullptr; } d_src, d_dst, d_len, d_paths, d_stacks;
+        void *ids = nullptr;
+        if ((rc = lease.c->reserve(CallCtx::NEXT, c * 12, &ids)) ||
+            (rc = lease.c->reserve(CallCtx::RATE, c * cap * 4, &d_paths.p)) ||
+            (rc = lease.c->reserve(CallCtx::WS, c * cap * 12, &d_stacks.p)))
+            return rc;
+        d_src.p = ids;
+        d_dst.p = (char *)ids + c * 4;
+        d_len.p = (char *)ids + c * 8;
+        hipStream_t s = m->stream;
+        FWX_HIP(hipMemcpyAsync(d_src.p, src, c * 4, hipMemcpyHostToDevice, s));
+        FWX_HIP(hipMemcpyAsync(d_dst.p, dst, c * 4, hipMemcpyHostToDevice, s));
+        hipLaunchKernelGGL(exact_paths_kernel, dim3((unsigned)((c + 63) / 64)), dim3(64), 0, s, m->plog,
+                           m->next0, m->n, count, (const int32_t *)d_src.p, (const int32_t *)d_dst.p,
+                           (int32_t *)d_paths.p, (int32_t *)d_stacks.p, cap, (int32_t *)d_len.p);
+        FWX_HIP(hipGetLastError());
+        FWX_HIP(hipMemcpyAsync(len_out, d_len.p, c * 4, hipMemcpyDeviceToHost, s));
+        FWX_HIP(hipMemcpyAsync(path_out, d_paths.p, c * cap * 4, hipMemcpyDeviceToHost, s));
+        FWX_HIP(hipStreamSynchronize(s));
+        return FWX_OK;
+    });
 }
 
 int fwx_matrix_download(fwx_matrix *m, void *rate, int32_t *next, int32_t *hops)
 {
-    if (!m) return FWX_ERR_INVALID;
-    if (m->n == 0) return FWX_OK;
-    if ((next && !m->next) || (hops && !m->hops)) return FWX_ERR_INVALID;
-    if (m->multi) return multi_download(m, rate, next, hops);
-    DeviceGuard g;
-    int rc = g.enter(m->device);
-    if (rc) return rc;
-    const size_t nn = (size_t)m->n * (size_t)m->n, es = m->dtype == FWX_F64 ? 8 : 4;
-    hipStream_t s = m->stream;
-    if (rate) FWX_HIP(hipMemcpyAsync(rate, m->rate, nn * es, hipMemcpyDefault, s));
-    if (next) FWX_HIP(hipMemcpyAsync(next, m->next, nn * 4, hipMemcpyDefault, s));
-    if (hops) FWX_HIP(hipMemcpyAsync(hops, m->hops, nn * 4, hipMemcpyDefault, s));
-    FWX_HIP(hipStreamSynchronize(s));
-    return FWX_OK;
+    return fwxi::guarded([&]() -> int {
+        if (!m) return FWX_ERR_INVALID;
+        if (m->n == 0) return FWX_OK;
+        if ((next && !m->next) || (hops && !m->hops)) return FWX_ERR_INVALID;
+        if (m->multi) return multi_download(m, rate, next, hops);
+        DeviceGuard g;
+        int rc = g.enter(m->device);
+        if (rc) return rc;
+        const size_t nn = (size_t)m->n * (size_t)m->n, es = m->dtype == FWX_F64 ? 8 : 4;
+        hipStream_t s = m->stream;
+        if (rate) FWX_HIP(hipMemcpyAsync(rate, m->rate, nn * es, hipMemcpyDefault, s));
+        if (next) FWX_HIP(hipMemcpyAsync(next, m->next, nn * 4, hipMemcpyDefault, s));
+        if (hops) FWX_HIP(hipMemcpyAsync(hops, m->hops, nn * 4, hipMemcpyDefault, s));
+        FWX_HIP(hipStreamSynchronize(s));
+        return FWX_OK;
+    });
 }
 
 int fwx_matrix_solve(fwx_matrix *m, const fwx_opts *opts)
 {
-    if (!m) return FWX_ERR_INVALID;
-    if (m->n == 0) return FWX_OK;
-    Opts op;
-    int rc = read_opts(opts, m->n, op);
-    if (rc) return rc;
-    if (m->multi) return multi_solve(m, op);
-    DeviceGuard g;
-    if ((rc = g.enter(m->device))) return rc;
-    hipStream_t s = op.has_stream ? op.stream : m->stream;
-    if (m->plog.last) return logged_solve(m, op, s);
-    unsigned long long *upd = op.updates_out ? m->upd : nullptr;
-    if (upd) FWX_HIP(hipMemsetAsync(upd, 0, FWX_UPDATE_SHARDS * 8, s));
-    if (m->dtype == FWX_F64)
-        rc = matrix_solve_typed<double>(m, op, upd, s);
-    else
-        rc = matrix_solve_typed<float>(m, op, upd, s);
-    if (rc) return rc;
-    FWX_HIP(hipStreamSynchronize(s));
-    if (upd) return sum_updates(upd, op.updates_out, s);
-    return FWX_OK;
+    return fwxi::guarded([&]() -> int {
+        if (!m) return FWX_ERR_INVALID;
+        if (m->n == 0) return FWX_OK;
+        Opts op;
+        int rc = read_opts(opts, m->n, op);
+        if (rc) return rc;
+        if (m->multi) return multi_solve(m, op);
+        DeviceGuard g;
+        if ((rc = g.enter(m->device))) return rc;
+        hipStream_t s = op.has_stream ? op.stream : m->stream;
+        if (m->plog.last) return logged_solve(m, op, s);
+        unsigned long long *upd = op.updates_out ? m->upd : nullptr;
+        if (upd) FWX_HIP(hipMemsetAsync(upd, 0, FWX_UPDATE_SHARDS * 8, s));
+        if (m->dtype == FWX_F64)
+            rc = matrix_solve_typed<double>(m, op, upd, s);
+        else
+            rc = matrix_solve_typed<float>(m, op, upd, s);
+        if (rc) return rc;
+        FWX_HIP(hipStreamSynchronize(s));
+        if (op.has_stream) drain_stream(s);   // the caller may destroy the handle next: nothing of this
+                                              // solve is left un-retired on a stream the handle does not own
+        if (upd) return sum_updates(upd, op.updates_out, s);
+        return FWX_OK;
+    });
 }
 
 int fwx_matrix_query(fwx_matrix *m, int32_t src, int32_t dst, double *rate_out, int32_t *path_out,
                      int32_t cap)
 {
-    if (!m || src < 0 || dst < 0 || src >= m->n || dst >= m->n || cap < 0 || (cap > 0 && !path_out))
-        return FWX_ERR_INVALID;
-    if (m->multi) return multi_query(m, src, dst, rate_out, path_out, cap);
-    DeviceGuard g;
-    int rc = g.enter(m->device);
-    if (rc) return rc;
-    const size_t idx = (size_t)src * m->n + dst;
-    hipStream_t s = m->stream;
-    float f32_rate = 0;
-    if (rate_out) {
-        if (m->dtype == FWX_F64)
-            FWX_HIP(hipMemcpyAsync(rate_out, (double *)m->rate + idx, 8, hipMemcpyDeviceToHost, s));
-        else
-            FWX_HIP(hipMemcpyAsync(&f32_rate, (float *)m->rate + idx, 4, hipMemcpyDeviceToHost, s));
-    }
-    if (!m->next) {
+    return fwxi::guarded([&]() -> int {
+        if (!m || src < 0 || dst < 0 || src >= m->n || dst >= m->n || cap < 0 || (cap > 0 && !path_out))
+            return FWX_ERR_INVALID;
+        if (m->multi) return multi_query(m, src, dst, rate_out, path_out, cap);
+        DeviceGuard g;
+        int rc = g.enter(m->device);
+        if (rc) return rc;
+        const size_t idx = (size_t)src * m->n + dst;
+        hipStream_t s = m->stream;
+        float f32_rate = 0;
+        if (rate_out) {
+            if (m->dtype == FWX_F64)
+                FWX_HIP(hipMemcpyAsync(rate_out, (double *)m->rate + idx, 8, hipMemcpyDeviceToHost, s));
+            else
+                FWX_HIP(hipMemcpyAsync(&f32_rate, (float *)m->rate + idx, 4, hipMemcpyDeviceToHost, s));
+        }
+        if (!m->next) {
+            FWX_HIP(hipStreamSynchronize(s));
+            if (rate_out && m->dtype != FWX_F64) *rate_out = (double)f32_rate;
+            return FWX_ERR_INVALID;
+        }
+        const int dcap = cap < m->n ? cap : m->n;
+        hipLaunchKernelGGL(follow_path_kernel, dim3(1), dim3(1), 0, s, m->next, m->n, src, dst,
+                           m->scratch + 1, dcap, m->scratch);
+        FWX_HIP(hipGetLastError());
+        int32_t len = 0;
+        FWX_HIP(hipMemcpyAsync(&len, m->scratch, 4, hipMemcpyDeviceToHost, s));
         FWX_HIP(hipStreamSynchronize(s));
         if (rate_out && m->dtype != FWX_F64) *rate_out = (double)f32_rate;
-        return FWX_ERR_INVALID;
-    }
-    const int dcap = cap < m->n ? cap : m->n;
-    hipLaunchKernelGGL(follow_path_kernel, dim3(1), dim3(1), 0, s, m->next, m->n, src, dst,
-                       m->scratch + 1, dcap, m->scratch);
-    FWX_HIP(hipGetLastError());
-    int32_t len = 0;
-    FWX_HIP(hipMemcpyAsync(&len, m->scratch, 4, hipMemcpyDeviceToHost, s));
-    FWX_HIP(hipStreamSynchronize(s));
-    if (rate_out && m->dtype != FWX_F64) *rate_out = (double)f32_rate;
-    if (len > 0) {
-        FWX_HIP(hipMemcpyAsync(path_out, m->scratch + 1, (size_t)len * 4, hipMemcpyDeviceToHost, s));
-        FWX_HIP(hipStreamSynchronize(s));
-    }
-    return len;
+        if (len > 0) {
+            FWX_HIP(hipMemcpyAsync(path_out, m->scratch + 1, (size_t)len * 4, hipMemcpyDeviceToHost, s));
+            FWX_HIP(hipStreamSynchronize(s));
+        }
+        return len;
+    });
 }
 
 int fwx_dev_relax(const fwx_slab *slab, const fwx_pivots *piv, int32_t serpentine,
                   unsigned long long *d_updates, void *stream)
 {
-    return fwx_dev_relax_skip(slab, piv, serpentine, d_updates, 0, 0, stream);
+    return fwxi::guarded([&]() -> int {
+        return fwx_dev_relax_skip(slab, piv, serpentine, d_updates, 0, 0, stream);
+    });
 }
 
 int fwx_dev_relax_skip(const fwx_slab *slab, const fwx_pivots *piv, int32_t serpentine,
                        unsigned long long *d_updates, int32_t skip_lo, int32_t skip_hi, void *stream)
 {
-    int rc = check_slab(slab);
-    if (rc) return rc;
-    if (!piv || piv->k_begin < 0 || piv->k_end < piv->k_begin || piv->k_end > slab->n)
-        return FWX_ERR_INVALID;
-    if (slab->rows == 0 || slab->n == 0 || piv->k_end == piv->k_begin) return FWX_OK;
-    if (!piv->rate || (slab->hops && !piv->hops)) return FWX_ERR_INVALID;
-    if (device_count() <= 0) return FWX_ERR_NO_DEVICE;
-    hipStream_t s = (hipStream_t)stream;
-    if (skip_lo < 0 || skip_hi < skip_lo || skip_hi > slab->rows ||
-        (skip_hi > skip_lo && (skip_lo % 4 || skip_hi % 4)))
-        return FWX_ERR_INVALID;
-    if (slab->dtype == FWX_F64)
-        return relax_range<double>((double *)slab->rate, slab->next, slab->hops, slab->rows,
-                                   slab->n, slab->row0, (const double *)piv->rate, piv->hops,
-                                   piv->stride, piv->k_begin, piv->k_end, serpentine, d_updates, s,
-                                   fwx::PathLog(), skip_lo, skip_hi, slab->next ? piv->next : nullptr);
-    return relax_range<float>((float *)slab->rate, slab->next, slab->hops, slab->rows, slab->n,
-                              slab->row0, (const float *)piv->rate, piv->hops, piv->stride,
-                              piv->k_begin, piv->k_end, serpentine, d_updates, s, fwx::PathLog(),
-                              skip_lo, skip_hi, slab->next ? piv->next : nullptr);
+    return fwxi::guarded([&]() -> int {
+        int rc = check_slab(slab);
+        if (rc) return rc;
+        if (!piv || piv->k_begin < 0 || piv->k_end < piv->k_begin || piv->k_end > slab->n)
+            return FWX_ERR_INVALID;
+        if (slab->rows == 0 || slab->n == 0 || piv->k_end == piv->k_begin) return FWX_OK;
+        if (!piv->rate || (slab->hops && !piv->hops)) return FWX_ERR_INVALID;
+        if (device_count() <= 0) return FWX_ERR_NO_DEVICE;
+        hipStream_t s = (hipStream_t)stream;
+        if (skip_lo < 0 || skip_hi < skip_lo || skip_hi > slab->rows ||
+            (skip_hi > skip_lo && (skip_lo % 4 || skip_hi % 4)))
+            return FWX_ERR_INVALID;
+        if (slab->dtype == FWX_F64)
+            return relax_range<double>((double *)slab->rate, slab->next, slab->hops, slab->rows,
+                                       slab->n, slab->row0, (const double *)piv->rate, piv->hops,
+                                       piv->stride, piv->k_begin, piv->k_end, serpentine, d_updates, s,
+                                       fwx::PathLog(), skip_lo, skip_hi, slab->next ? piv->next : nullptr);
+        return relax_range<float>((float *)slab->rate, slab->next, slab->hops, slab->rows, slab->n,
+                                  slab->row0, (const float *)piv->rate, piv->hops, piv->stride,
+                                  piv->k_begin, piv->k_end, serpentine, d_updates, s, fwx::PathLog(),
+                                  skip_lo, skip_hi, slab->next ? piv->next : nullptr);
+    });
 }
 
 int fwx_dev_panel(const fwx_slab *block, void *w_rate, int32_t *w_hops,
                   unsigned long long *d_updates, void *stream)
 {
-    int rc = check_slab(block);
-    if (rc) return rc;
-    if (block->rows == 0 || block->n == 0) return FWX_OK;
-    if (!w_rate || (block->hops && !w_hops)) return FWX_ERR_INVALID;
-    if (device_count() <= 0) return FWX_ERR_NO_DEVICE;
-    hipStream_t s = (hipStream_t)stream;
-    if (block->dtype == FWX_F64)
-        return panel_impl<double>(block, (double *)w_rate, w_hops, d_updates, s);
-    return panel_impl<float>(block, (float *)w_rate, w_hops, d_updates, s);
+    return fwxi::guarded([&]() -> int {
+        int rc = check_slab(block);
+        if (rc) return rc;
+        if (block->rows == 0 || block->n == 0) return FWX_OK;
+        if (!w_rate || (block->hops && !w_hops)) return FWX_ERR_INVALID;
+        if (device_count() <= 0) return FWX_ERR_NO_DEVICE;
+        hipStream_t s = (hipStream_t)stream;
+        if (block->dtype == FWX_F64)
+            return panel_impl<double>(block, (double *)w_rate, w_hops, d_updates, s);
+        return panel_impl<float>(block, (float *)w_rate, w_hops, d_updates, s);
+    });
 }
 
 int fwx_dev_solve(const fwx_slab *full, const fwx_opts *opts)
 {
-    int rc = check_slab(full);
-    if (rc) return rc;
-    if (full->row0 != 0 || full->rows != full->n) return FWX_ERR_INVALID;
-    if (full->n == 0) return FWX_OK;
-    Opts op;
-    if ((rc = read_opts(opts, full->n, op))) return rc;
-    if (device_count() <= 0) return FWX_ERR_NO_DEVICE;
-    fwx_matrix m;
-    memset(&m, 0, sizeof(m));
-    m.n = full->n; m.dtype = full->dtype;
-    m.rate = full->rate; m.next = full->next; m.hops = full->hops;
-    DeviceGuard g;                       // the context belongs to the device the call runs on
-    if ((rc = g.enter(op.device))) return rc;
-    CtxLease lease;
-    if ((rc = lease.open())) return rc;
-    hipStream_t s = op.has_stream ? op.stream : lease.c->s;
-    struct { void *p = nullptr; } upd;
-    if (op.updates_out) {
-        void *small = nullptr;
-        if ((rc = lease.c->reserve(CallCtx::SMALL, (FWX_UPDATE_SHARDS + 2) * sizeof(unsigned long long), &small))) return rc;
-        upd.p = small;
-        FWX_HIP(hipMemsetAsync(upd.p, 0, FWX_UPDATE_SHARDS * 8, s));
-    }
-    rc = full->dtype == FWX_F64
-             ? matrix_solve_typed<double>(&m, op, (unsigned long long *)upd.p, s, lease.c)
-             : matrix_solve_typed<float>(&m, op, (unsigned long long *)upd.p, s, lease.c);
-    if (rc) return rc;
-    FWX_HIP(hipStreamSynchronize(s));
-    if (op.updates_out) return sum_updates((unsigned long long *)upd.p, op.updates_out, s);
-    return FWX_OK;
+    return fwxi::guarded([&]() -> int {
+        int rc = check_slab(full);
+        if (rc) return rc;
+        if (full->row0 != 0 || full->rows != full->n) return FWX_ERR_INVALID;
+        if (full->n == 0) return FWX_OK;
+        Opts op;
+        if ((rc = read_opts(opts, full->n, op))) return rc;
+        if (device_count() <= 0) return FWX_ERR_NO_DEVICE;
+        fwx_matrix m;
+        memset(&m, 0, sizeof(m));
+        m.n = full->n; m.dtype = full->dtype;
+        m.rate = full->rate; m.next = full->next; m.hops = full->hops;
+        DeviceGuard g;                       // the context belongs to the device the call runs on
+        if ((rc = g.enter(op.device))) return rc;
+        CtxLease lease;
+        if ((rc = lease.open())) return rc;
+        hipStream_t s = op.has_stream ? op.stream : lease.c->s;
+        if (op.has_stream) lease.c->uses_stream(op.stream);
+        struct { void *p = nullptr; } upd;
+        if (op.updates_out) {
+            void *small = nullptr;
+            if ((rc = lease.c->reserve(CallCtx::SMALL, (FWX_UPDATE_SHARDS + 2) * sizeof(unsigned long long), &small))) return rc;
+            upd.p = small;
+            FWX_HIP(hipMemsetAsync(upd.p, 0, FWX_UPDATE_SHARDS * 8, s));
+        }
+        rc = full->dtype == FWX_F64
+                 ? matrix_solve_typed<double>(&m, op, (unsigned long long *)upd.p, s, lease.c)
+                 : matrix_solve_typed<float>(&m, op, (unsigned long long *)upd.p, s, lease.c);
+        if (rc) return rc;
+        FWX_HIP(hipStreamSynchronize(s));
+        if (op.updates_out) return sum_updates((unsigned long long *)upd.p, op.updates_out, s);
+        return FWX_OK;
+    });
 }
 
 int fwx_dev_follow_paths(int32_t n, const int32_t *next, int32_t count, const int32_t *src,
@@ -1146,66 +1183,74 @@ int fwx_dev_follow_paths(int32_t n, const int32_t *next, int32_t count, const in
                          int32_t dtype, double *prod_out, int32_t *path_out, int32_t cap,
                          void *stream)
 {
-    if (n < 0 || count < 0 || cap < 0 || (dtype != FWX_F32 && dtype != FWX_F64))
-        return FWX_ERR_INVALID;
-    if (count == 0) return FWX_OK;
-    if (!next || !src || !dst || !len_out || (prod_out && !edge_rate) || (path_out && cap == 0))
-        return FWX_ERR_INVALID;
-    if (device_count() <= 0) return FWX_ERR_NO_DEVICE;
-    hipStream_t s = (hipStream_t)stream;
-    const dim3 grid((unsigned)((count + 255) / 256)), block(256);
-    if (dtype == FWX_F64)
-        hipLaunchKernelGGL(follow_paths_kernel<double>, grid, block, 0, s, next, n, count, src,
-                           dst, len_out, (const double *)edge_rate, prod_out, path_out, cap);
-    else
-        hipLaunchKernelGGL(follow_paths_kernel<float>, grid, block, 0, s, next, n, count, src, dst,
-                           len_out, (const float *)edge_rate, prod_out, path_out, cap);
-    FWX_HIP(hipGetLastError());
-    return FWX_OK;
+    return fwxi::guarded([&]() -> int {
+        if (n < 0 || count < 0 || cap < 0 || (dtype != FWX_F32 && dtype != FWX_F64))
+            return FWX_ERR_INVALID;
+        if (count == 0) return FWX_OK;
+        if (!next || !src || !dst || !len_out || (prod_out && !edge_rate) || (path_out && cap == 0))
+            return FWX_ERR_INVALID;
+        if (device_count() <= 0) return FWX_ERR_NO_DEVICE;
+        hipStream_t s = (hipStream_t)stream;
+        const dim3 grid((unsigned)((count + 255) / 256)), block(256);
+        if (dtype == FWX_F64)
+            hipLaunchKernelGGL(follow_paths_kernel<double>, grid, block, 0, s, next, n, count, src,
+                               dst, len_out, (const double *)edge_rate, prod_out, path_out, cap);
+        else
+            hipLaunchKernelGGL(follow_paths_kernel<float>, grid, block, 0, s, next, n, count, src, dst,
+                               len_out, (const float *)edge_rate, prod_out, path_out, cap);
+        FWX_HIP(hipGetLastError());
+        return FWX_OK;
+    });
 }
 
 int fwx_dev_panel_snap(const fwx_slab *block, void *w_rate, int32_t *w_hops, const fwx_trace *trace,
                        void *stream)
 {
-    int rc = check_slab(block);
-    if (rc) return rc;
-    if (block->rows == 0 || block->n == 0) return FWX_OK;
-    if (!w_rate || block->rows > FWX_FUSED_B || (block->hops && !w_hops)) return FWX_ERR_INVALID;
-    if (trace && (!trace->last || !trace->at_row || !block->next)) return FWX_ERR_INVALID;
-    if (device_count() <= 0) return FWX_ERR_NO_DEVICE;
-    hipStream_t s = (hipStream_t)stream;
-    fwx::PathLog pl = fwx::PathLog();
-    if (trace) { pl.last = trace->last; pl.at_col = trace->at_col; pl.at_row = trace->at_row; }
-    if (block->dtype == FWX_F64)
-        FWX_HIP(fwx::launch_fused_panel<double>((const double *)block->rate, block->n, block->row0,
-                                                block->rows, (double *)w_rate, s, pl, block->hops, w_hops));
-    else
-        FWX_HIP(fwx::launch_fused_panel<float>((const float *)block->rate, block->n, block->row0,
-                                               block->rows, (float *)w_rate, s, pl, block->hops, w_hops));
-    return FWX_OK;
+    return fwxi::guarded([&]() -> int {
+        int rc = check_slab(block);
+        if (rc) return rc;
+        if (block->rows == 0 || block->n == 0) return FWX_OK;
+        if (!w_rate || block->rows > FWX_FUSED_B || (block->hops && !w_hops)) return FWX_ERR_INVALID;
+        if (trace && (!trace->last || !trace->at_row || !block->next)) return FWX_ERR_INVALID;
+        if (device_count() <= 0) return FWX_ERR_NO_DEVICE;
+        hipStream_t s = (hipStream_t)stream;
+        fwx::PathLog pl = fwx::PathLog();
+        if (trace) { pl.last = trace->last; pl.at_col = trace->at_col; pl.at_row = trace->at_row; }
+        if (block->dtype == FWX_F64)
+            FWX_HIP(fwx::launch_fused_panel<double>((const double *)block->rate, block->n, block->row0,
+                                                    block->rows, (double *)w_rate, s, pl, block->hops, w_hops));
+        else
+            FWX_HIP(fwx::launch_fused_panel<float>((const float *)block->rate, block->n, block->row0,
+                                                   block->rows, (float *)w_rate, s, pl, block->hops, w_hops));
+        return FWX_OK;
+    });
 }
 
 int fwx_dev_check_nonneg(const fwx_slab *slab, int32_t *d_flag, void *stream)
 {
-    int rc = check_slab(slab);
-    if (rc) return rc;
-    if (!d_flag) return FWX_ERR_INVALID;
-    if (device_count() <= 0) return FWX_ERR_NO_DEVICE;
-    hipStream_t s = (hipStream_t)stream;
-    if (slab->dtype == FWX_F64)
-        FWX_HIP(fwx::launch_nonneg_check((const double *)slab->rate, slab->next,
-                                         (size_t)slab->rows * slab->n, (int *)d_flag, s));
-    else
-        FWX_HIP(fwx::launch_nonneg_check((const float *)slab->rate, slab->next,
-                                         (size_t)slab->rows * slab->n, (int *)d_flag, s));
-    return FWX_OK;
+    return fwxi::guarded([&]() -> int {
+        int rc = check_slab(slab);
+        if (rc) return rc;
+        if (!d_flag) return FWX_ERR_INVALID;
+        if (device_count() <= 0) return FWX_ERR_NO_DEVICE;
+        hipStream_t s = (hipStream_t)stream;
+        if (slab->dtype == FWX_F64)
+            FWX_HIP(fwx::launch_nonneg_check((const double *)slab->rate, slab->next,
+                                             (size_t)slab->rows * slab->n, (int *)d_flag, s));
+        else
+            FWX_HIP(fwx::launch_nonneg_check((const float *)slab->rate, slab->next,
+                                             (size_t)slab->rows * slab->n, (int *)d_flag, s));
+        return FWX_OK;
+    });
 }
 
 int fwx_dev_relax_fused(const fwx_slab *slab, const fwx_pivots *piv, const fwx_fused_scratch *scratch,
                         const fwx_trace *trace, unsigned long long *d_updates, int32_t flags,
                         void *stream)
 {
-    return fwx_dev_relax_fused_skip(slab, piv, scratch, trace, d_updates, flags, 0, 0, stream);
+    return fwxi::guarded([&]() -> int {
+        return fwx_dev_relax_fused_skip(slab, piv, scratch, trace, d_updates, flags, 0, 0, stream);
+    });
 }
 
 int fwx_dev_relax_fused_skip(const fwx_slab *slab, const fwx_pivots *piv,
@@ -1213,27 +1258,29 @@ int fwx_dev_relax_fused_skip(const fwx_slab *slab, const fwx_pivots *piv,
                              unsigned long long *d_updates, int32_t flags, int32_t skip_lo,
                              int32_t skip_hi, void *stream)
 {
-    int rc = check_slab(slab);
-    if (rc) return rc;
-    if (!piv || piv->k_begin < 0 || piv->k_end < piv->k_begin || piv->k_end > slab->n ||
-        piv->k_end - piv->k_begin > FWX_FUSED_B)
-        return FWX_ERR_INVALID;
-    if (slab->rows == 0 || slab->n == 0 || piv->k_end == piv->k_begin) return FWX_OK;
-    if (!piv->rate || piv->stride != slab->n || !scratch || !scratch->col_rate ||
-        (slab->next && !scratch->col_next) || (slab->hops && (!scratch->col_hops || !piv->hops)))
-        return FWX_ERR_INVALID;
-    if (trace && (!slab->next || !trace->last || !trace->at_col)) return FWX_ERR_INVALID;
-    if (skip_lo < 0 || skip_hi < skip_lo || skip_hi > slab->rows ||
-        (skip_hi > skip_lo && (skip_lo % 8 || skip_hi % 8)))
-        return FWX_ERR_INVALID;
-    if (device_count() <= 0) return FWX_ERR_NO_DEVICE;
-    hipStream_t s = (hipStream_t)stream;
-    const bool nonneg = (flags & FWX_FLAG_NONNEG) != 0;
-    if (slab->dtype == FWX_F64)
-        return fused_block<double>(slab, piv->k_begin, piv->k_end - piv->k_begin, (const double *)piv->rate,
-                                   piv->hops, scratch, trace, d_updates, nonneg, s, skip_lo, skip_hi);
-    return fused_block<float>(slab, piv->k_begin, piv->k_end - piv->k_begin, (const float *)piv->rate,
-                              piv->hops, scratch, trace, d_updates, nonneg, s, skip_lo, skip_hi);
+    return fwxi::guarded([&]() -> int {
+        int rc = check_slab(slab);
+        if (rc) return rc;
+        if (!piv || piv->k_begin < 0 || piv->k_end < piv->k_begin || piv->k_end > slab->n ||
+            piv->k_end - piv->k_begin > FWX_FUSED_B)
+            return FWX_ERR_INVALID;
+        if (slab->rows == 0 || slab->n == 0 || piv->k_end == piv->k_begin) return FWX_OK;
+        if (!piv->rate || piv->stride != slab->n || !scratch || !scratch->col_rate ||
+            (slab->next && !scratch->col_next) || (slab->hops && (!scratch->col_hops || !piv->hops)))
+            return FWX_ERR_INVALID;
+        if (trace && (!slab->next || !trace->last || !trace->at_col)) return FWX_ERR_INVALID;
+        if (skip_lo < 0 || skip_hi < skip_lo || skip_hi > slab->rows ||
+            (skip_hi > skip_lo && (skip_lo % 8 || skip_hi % 8)))
+            return FWX_ERR_INVALID;
+        if (device_count() <= 0) return FWX_ERR_NO_DEVICE;
+        hipStream_t s = (hipStream_t)stream;
+        const bool nonneg = (flags & FWX_FLAG_NONNEG) != 0;
+        if (slab->dtype == FWX_F64)
+            return fused_block<double>(slab, piv->k_begin, piv->k_end - piv->k_begin, (const double *)piv->rate,
+                                       piv->hops, scratch, trace, d_updates, nonneg, s, skip_lo, skip_hi);
+        return fused_block<float>(slab, piv->k_begin, piv->k_end - piv->k_begin, (const float *)piv->rate,
+                                  piv->hops, scratch, trace, d_updates, nonneg, s, skip_lo, skip_hi);
+    });
 }
 
 }  // extern "C"

@@ -85,8 +85,13 @@ struct Throttle {
     int count = 0, slot = 0;
     ~Throttle()
     {
+        // an event is only destroyed once it has completed (the solve that recorded it synchronises its
+        // stream before it returns; on an error return this wait is what orders the two)
         for (int i = 0; i < 2; ++i)
-            if (ev[i]) (void)hipEventDestroy(ev[i]);
+            if (ev[i]) {
+                if (armed[i]) (void)hipEventSynchronize(ev[i]);
+                (void)hipEventDestroy(ev[i]);
+            }
     }
     int tick(hipStream_t s, int launches = 1)
     {
@@ -140,16 +145,19 @@ inline int sum_updates(unsigned long long *d_updates, uint64_t *out, hipStream_t
 }
 
 
-// hipFree right behind the completion of a command that used the memory can crash the HIP runtime:
-// hipStreamSynchronize returns when the awaited command's status is set, while the runtime's signal
-// handler thread is still releasing that command's resources -- among them its references to the
-// memory objects behind the kernel's pointer arguments -- and a hipFree that gets there first deletes
-// the object under it (SIGSEGV in amd::ReferenceCountedObject::release() <-
-// amd::KernelParameters::release <- amd::roc::HsaAmdSignalHandler; rocgdb backtrace in
-// gpurun_out/r02_run43_gdb.log, once per ~300-2000 create / solve / destroy cycles of tools/
-// fuzz_domain.py).  The handler retires the commands of a queue strictly in order, so one more
-// trivial command on the stream, waited for, proves that everything before it has been retired;
-// its own retirement only touches a buffer that is never freed.
+// Retire barrier.  hipStreamSynchronize returns when the awaited command's status is set; the HIP
+// runtime's signal-handler thread may still be RETIRING that command (releasing its references to the
+// memory objects behind the kernel's pointer arguments).  The handler retires the commands of a queue
+// strictly in order, so one more trivial command on the stream, waited for, proves that everything
+// before it has been retired; its own retirement only touches a buffer that is never freed.  libfwx
+// runs this before it releases anything a stream's commands used (buffers, events, the stream).
+//
+// Why it exists: tools/fuzz_domain.py died with a SIGSEGV in that handler thread (round 2, only under
+// the HIP runtime bundled with the torch wheel, ROCm 7.0, not the /opt/rocm 7.2 one libfwx is built
+// against): amd::KernelParameters::release -> amd::ReferenceCountedObject::release on the memory
+// object of a kernel's pointer argument (DESIGN.md section 7 has the disassembly-level record).  This
+// barrier made the crash rarer but did NOT remove it under that runtime, so the cause is not proven
+// to be a hipFree racing the handler; it is kept as lifetime hygiene, not as the fix.
 inline void drain_stream(hipStream_t s)
 {
     static std::mutex mu;
@@ -228,7 +236,25 @@ struct CallCtx {
         *out = pin;
         return FWX_OK;
     }
-    void drain() { drain_stream(s); side.drain(); }
+    // Streams that are not the context's own but ran commands on its buffers during the current
+    // lease: the caller's stream (fwx_opts.stream) or a handle's stream (the batch queries borrow
+    // scratch from a context).  They are drained with the context's streams before any buffer is
+    // released, regrown or handed to the next lease.
+    hipStream_t foreign[2] = {nullptr, nullptr};
+    void uses_stream(hipStream_t st)
+    {
+        if (!st || st == s || st == side.s || st == foreign[0] || st == foreign[1]) return;
+        if (!foreign[0]) foreign[0] = st;
+        else if (!foreign[1]) foreign[1] = st;
+        else { drain_stream(foreign[0]); foreign[0] = st; }
+    }
+    void drain()
+    {
+        drain_stream(s);
+        side.drain();
+        for (hipStream_t &f : foreign)
+            if (f) drain_stream(f);
+    }
     int reserve(int which, size_t bytes, void **out)
     {
         if (cap[which] < bytes) {
@@ -319,6 +345,8 @@ struct CtxLease {
         if (c) {       // an error return may leave work queued: the context goes back idle
             (void)hipStreamSynchronize(c->s);
             if (c->side.s) (void)hipStreamSynchronize(c->side.s);
+            for (hipStream_t &f : c->foreign)
+                if (f) { drain_stream(f); f = nullptr; }   // the stream belongs to someone else: forget it
         }
         CtxPool::release(c);
     }
@@ -348,6 +376,33 @@ int domain_bits(const T *rate, const int32_t *next, size_t count, int *d_flag, h
     return FWX_OK;
 }
 
+
+// One launch per pivot over a slab; pivot rows from `prow0 + (k-k_begin)*stride`.
+template <typename T>
+inline int relax_range(T *rate, int32_t *next, int32_t *hops, int rows, int n, int row0, const T *prow0,
+                const int32_t *phops0, int64_t stride, int k_begin, int k_end, int serpentine,
+                unsigned long long *d_updates, hipStream_t s, fwx::PathLog plog = fwx::PathLog(),
+                int skip_lo = 0, int skip_hi = 0, const int32_t *pnext0 = nullptr)
+{
+    fwx::RelaxArgs<T> a;
+    Throttle thr;
+    a.rate = rate; a.next = next; a.hops = hops;
+    a.rows = rows; a.n = n; a.row0 = row0; a.updates = d_updates; a.plog = plog;
+    a.skip_lo = skip_lo; a.skip_hi = skip_hi;
+    for (int k = k_begin; k < k_end; ++k) {
+        a.prow = prow0 + (int64_t)(k - k_begin) * stride;
+        a.phops = phops0 ? phops0 + (int64_t)(k - k_begin) * stride : nullptr;
+        a.pnext = pnext0 ? pnext0 + (int64_t)(k - k_begin) * stride : nullptr;
+        a.k = k;
+        a.flip = serpentine ? (k & 1) : 0;
+        const hipError_t e = fwx::launch_relax<T>(a, s);
+        if (e == hipErrorInvalidValue) return FWX_ERR_INVALID;   // misaligned skip range
+        FWX_HIP(e);
+        const int rc = thr.tick(s);
+        if (rc) return rc;
+    }
+    return FWX_OK;
+}
 
 // The path trace `off` elements further on (e.g. at pivot row k0: off = k0 * n); null stays null.
 inline fwx::PathLog plog_rows(fwx::PathLog p, size_t off)

@@ -25,6 +25,7 @@
 #include <vector>
 
 #include "fwx.h"
+#include "fwx_guard.h"
 #include "fwx_internal.h"
 #include "fwx_kernels.h"
 
@@ -38,6 +39,7 @@ struct RcclApi {
     decltype(&ncclBroadcast) Broadcast = nullptr;
     decltype(&ncclGroupStart) GroupStart = nullptr;
     decltype(&ncclGroupEnd) GroupEnd = nullptr;
+    decltype(&ncclCommCount) CommCount = nullptr;
     bool ok = false;
 };
 
@@ -54,7 +56,9 @@ static RcclApi &rccl()
         api.Broadcast = (decltype(api.Broadcast))dlsym(api.lib, "ncclBroadcast");
         api.GroupStart = (decltype(api.GroupStart))dlsym(api.lib, "ncclGroupStart");
         api.GroupEnd = (decltype(api.GroupEnd))dlsym(api.lib, "ncclGroupEnd");
-        api.ok = api.CommInitAll && api.CommDestroy && api.Broadcast && api.GroupStart && api.GroupEnd;
+        api.CommCount = (decltype(api.CommCount))dlsym(api.lib, "ncclCommCount");
+        api.ok = api.CommInitAll && api.CommDestroy && api.Broadcast && api.GroupStart && api.GroupEnd &&
+                 api.CommCount;
     });
     return api;
 }
@@ -63,6 +67,62 @@ static RcclApi &rccl()
     do {                                                                                           \
         if ((call) != ncclSuccess) return FWX_ERR_RCCL;                                            \
     } while (0)
+
+// ---- communicators, cached -------------------------------------------------------------------------
+// ncclCommInitAll costs hundreds of milliseconds and a communicator is tied to nothing but its device
+// list, so communicators outlive the handles that use them: a handle takes a set from the cache (or
+// creates one) and puts it back when it is destroyed.  Like the per-call contexts the cache is never
+// torn down (no RCCL / HIP calls from static destructors).
+struct CommSet {
+    int parts = 0;
+    int devs[FWX_MAX_PARTS];
+    ncclComm_t comm[FWX_MAX_PARTS];
+};
+
+class CommCache {
+public:
+    static int acquire(int parts, const int *devs, CommSet **out)
+    {
+        Cache &c = cache();
+        {
+            std::lock_guard<std::mutex> lk(c.mu);
+            for (size_t i = 0; i < c.idle.size(); ++i)
+                if (c.idle[i]->parts == parts && memcmp(c.idle[i]->devs, devs, sizeof(int) * parts) == 0) {
+                    *out = c.idle[i];
+                    c.idle.erase(c.idle.begin() + (long)i);
+                    return FWX_OK;
+                }
+        }
+        RcclApi &api = rccl();
+        if (!api.ok) return FWX_ERR_RCCL;
+        CommSet *cs = new (std::nothrow) CommSet();
+        if (!cs) return FWX_ERR_OOM;
+        cs->parts = parts;
+        memcpy(cs->devs, devs, sizeof(int) * parts);
+        if (api.CommInitAll(cs->comm, parts, cs->devs) != ncclSuccess) {
+            delete cs;
+            return FWX_ERR_RCCL;
+        }
+        *out = cs;
+        return FWX_OK;
+    }
+    static void release(CommSet *cs)
+    {
+        if (!cs) return;
+        Cache &c = cache();
+        {
+            std::lock_guard<std::mutex> lk(c.mu);
+            if (c.idle.size() < kMaxIdle) { c.idle.push_back(cs); return; }
+        }
+        for (int p = 0; p < cs->parts; ++p) (void)rccl().CommDestroy(cs->comm[p]);
+        delete cs;
+    }
+
+private:
+    static constexpr size_t kMaxIdle = 4;
+    struct Cache { std::mutex mu; std::vector<CommSet *> idle; };
+    static Cache &cache() { static Cache *c = new Cache(); return *c; }   // leaked on purpose
+};
 
 // ---- partitions -----------------------------------------------------------------------------------
 struct Part {
@@ -89,8 +149,10 @@ struct MultiState {
     int nd = 0;                 // device order: n rounded up to a multiple of 16 bytes of elements
     int exchange = FWX_XCHG_PEER;
     Part part[FWX_MAX_PARTS];
-    ncclComm_t comm[FWX_MAX_PARTS];
-    bool have_comm = false;
+    CommSet *comms = nullptr;      // RCCL exchange: one communicator per partition (CommCache)
+    bool peer_all = true;          // every pair of distinct devices has peer access (queries walk the
+                                   // slabs from partition 0's device; the exchange does not need it)
+    size_t slab_bytes = 0;         // rate slabs, all partitions: decides whether a one-shot call keeps the handle
     int32_t *qscratch = nullptr;   // query scratch on partition 0's device
     int32_t qcap = 0;
 };
@@ -199,29 +261,29 @@ static void multi_free(MultiState *M)
 {
     if (!M) return;
     DevRestore keep;
+    // order: retire every command that used the partitions' arrays (drain_stream in fwx_internal.h),
+    // give the communicators back, destroy the streams and events, and only then free the memory
     for (int p = 0; p < M->parts; ++p) {
         Part &q = M->part[p];
         if (hipSetDevice(q.device) != hipSuccess) continue;
-        // every command that used this partition's arrays has been RETIRED, not just completed
-        // (drain_stream in fwx_internal.h)
         if (q.main) drain_stream(q.main);
         if (q.side) drain_stream(q.side);
     }
-    if (M->have_comm)
-        for (int p = 0; p < M->parts; ++p) (void)rccl().CommDestroy(M->comm[p]);
+    CommCache::release(M->comms);
+    M->comms = nullptr;
     for (int p = 0; p < M->parts; ++p) {
         Part &q = M->part[p];
         if (hipSetDevice(q.device) != hipSuccess) continue;
+        if (q.main) (void)hipStreamDestroy(q.main);
+        if (q.side) (void)hipStreamDestroy(q.side);
+        hipEvent_t evs[] = {q.rows_done, q.w_ready[0], q.w_ready[1], q.main_free[0], q.main_free[1]};
+        for (hipEvent_t e : evs)
+            if (e) (void)hipEventDestroy(e);
         void *bufs[] = {q.rate, q.next, q.hops, q.plog.last, q.plog.at_col, q.plog.at_row, q.next0, q.rate0,
                         q.hops0, q.w[0],
                         q.w[1], q.wh[0], q.wh[1], q.ct, q.cnt, q.cht, q.upd, q.flag};
         for (void *b : bufs)
             if (b) (void)hipFree(b);
-        hipEvent_t evs[] = {q.rows_done, q.w_ready[0], q.w_ready[1], q.main_free[0], q.main_free[1]};
-        for (hipEvent_t e : evs)
-            if (e) (void)hipEventDestroy(e);
-        if (q.main) (void)hipStreamDestroy(q.main);
-        if (q.side) (void)hipStreamDestroy(q.side);
         if (p == 0 && M->qscratch) (void)hipFree(M->qscratch);
     }
     delete M;
@@ -253,6 +315,7 @@ static int multi_alloc(fwx_matrix *m, int n_parts, const int32_t *devices, int e
         int rc = set_dev(q.device);
         if (rc) return rc;
         const size_t cells = (size_t)q.rows * nd;
+        M->slab_bytes += cells * es;
         FWX_HIP(hipMalloc(&q.rate, cells * es ? cells * es : 16));
         if (m->next) FWX_HIP(hipMalloc((void **)&q.next, cells * 4 ? cells * 4 : 16));
         FWX_HIP(hipMalloc(&q.w[0], (size_t)FWX_FUSED_BLOCK * nd * es));
@@ -272,27 +335,23 @@ static int multi_alloc(fwx_matrix *m, int n_parts, const int32_t *devices, int e
         hipEvent_t *evs[] = {&q.rows_done, &q.w_ready[0], &q.w_ready[1], &q.main_free[0], &q.main_free[1]};
         for (hipEvent_t *e : evs) FWX_HIP(hipEventCreateWithFlags(e, hipEventDisableTiming));
     }
-    // queries walk every slab from partition 0's device: distinct devices need peer access
+    // Peer access is wanted, not required: the QUERIES walk every slab from partition 0's device and
+    // need it (they say so when it is missing); the exchange does not -- RCCL has its own transports
+    // and hipMemcpyPeerAsync stages through the host when two devices are not peers.
     for (int p = 0; p < n_parts; ++p)
         for (int q = 0; q < n_parts; ++q) {
             if (devices[p] == devices[q]) continue;
             int rc = set_dev(devices[p]);
             if (rc) return rc;
             const hipError_t e = hipDeviceEnablePeerAccess(devices[q], 0);
-            if (e != hipSuccess && e != hipErrorPeerAccessAlreadyEnabled) {
-                g_last_hip = (int)e;
-                (void)hipGetLastError();
-                return FWX_ERR_HIP;
-            }
+            if (e != hipSuccess && e != hipErrorPeerAccessAlreadyEnabled) M->peer_all = false;
             (void)hipGetLastError();
         }
     if (exchange == FWX_XCHG_RCCL) {
-        RcclApi &api = rccl();
-        if (!api.ok) return FWX_ERR_RCCL;
         int devs[FWX_MAX_PARTS];
         for (int p = 0; p < n_parts; ++p) devs[p] = devices[p];
-        FWX_NCCL(api.CommInitAll(M->comm, n_parts, devs));
-        M->have_comm = true;
+        const int rc = CommCache::acquire(n_parts, devs, &M->comms);
+        if (rc) return rc;
     }
     // placeholders: the single-device code paths test m->next for "carries next-hops"
     return FWX_OK;
@@ -409,10 +468,10 @@ template <typename T> static int issue_panel(MultiState &M, const Block &blk, in
             Part &q = M.part[r];
             if ((rc = set_dev(q.device))) return rc;
             FWX_NCCL(api.Broadcast(q.w[slot], q.w[slot], (size_t)blk.bt * M.nd,
-                                   sizeof(T) == 8 ? ncclFloat64 : ncclFloat32, blk.owner, M.comm[r], q.side));
+                                   sizeof(T) == 8 ? ncclFloat64 : ncclFloat32, blk.owner, M.comms->comm[r], q.side));
             if (q.hops)     // the hops of the pivot rows travel with their rates
                 FWX_NCCL(api.Broadcast(q.wh[slot], q.wh[slot], (size_t)blk.bt * M.nd, ncclInt32, blk.owner,
-                                       M.comm[r], q.side));
+                                       M.comms->comm[r], q.side));
         }
         FWX_NCCL(api.GroupEnd());
         for (int r = 0; r < M.parts; ++r) {
@@ -430,6 +489,7 @@ template <typename T> static int multi_solve_typed(fwx_matrix *m, const Opts &op
     const int nd = M.nd, P = M.parts;
     const bool counting = op.updates_out != nullptr;
     const bool with_next = m->next != nullptr;
+    const bool perk = op.engine == FWX_ENGINE_PERK;
     int rc;
     // domain (fwx.h "Domain"), every slab
     int bits = 3;
@@ -455,6 +515,7 @@ template <typename T> static int multi_solve_typed(fwx_matrix *m, const Opts &op
         if (counting) FWX_HIP(hipMemsetAsync(q.upd, 0, FWX_UPDATE_SHARDS * 8, q.main));
     }
     // pivot blocks of at most 64 that never straddle two owners; real pivots only (padding is inert)
+    fail_point();
     std::vector<Block> blocks;
     for (int p = 0; p < P; ++p) {
         const Part &q = M.part[p];
@@ -478,12 +539,14 @@ template <typename T> static int multi_solve_typed(fwx_matrix *m, const Opts &op
         const Block &blk = blocks[b];
         const int slot = (int)(b & 1);
         const bool more = b + 1 < blocks.size();
-        // pivot-column snapshots on every partition
+        // fused engine: pivot-column snapshots on every partition; per-k engine: the pivot column is
+        // read from the slab itself by every launch, the main stream just waits for the panel
         for (int p = 0; p < P; ++p) {
             Part &q = M.part[p];
             if (q.rows == 0) continue;
             if ((rc = set_dev(q.device))) return rc;
             FWX_HIP(hipStreamWaitEvent(q.main, q.w_ready[slot], 0));
+            if (perk) continue;
             fwx::FusedArgs<T> a = part_args<T>(M, q, nonneg, counting);
             a.k0 = blk.k0; a.bt = blk.bt; a.w = (const T *)q.w[slot]; a.wh = q.wh[slot];
             FWX_HIP(fwx::launch_fused_colpanel<T>(a, q.main));
@@ -497,14 +560,25 @@ template <typename T> static int multi_solve_typed(fwx_matrix *m, const Opts &op
             if ((rc = set_dev(o.device))) return rc;
             fwx::FusedArgs<T> a = part_args<T>(M, o, nonneg, counting);
             a.k0 = blk.k0; a.bt = blk.bt; a.w = (const T *)o.w[slot]; a.wh = o.wh[slot];
-            FWX_HIP(fwx::launch_fused_main<T>(a, la_lo, la_hi, o.main));
+            if (!perk) {
+                FWX_HIP(fwx::launch_fused_main<T>(a, la_lo, la_hi, o.main));
+            } else {
+                // these few rows sit on the owner's critical path: one fused launch (column snapshots of
+                // just these rows + the 64 pivots), bit-identical to 64 per-k launches
+                const size_t off = (size_t)la_lo * nd;
+                a.rate += off;
+                if (a.next) a.next += off;
+                if (a.hops) a.hops += off;
+                a.rows = nb.bt; a.row0 = nb.k0;
+                FWX_HIP(fwx::launch_fused_relax<T>(a, o.main));
+            }
             FWX_HIP(hipEventRecord(o.rows_done, o.main));
             if ((rc = issue_panel<T>(M, nb, slot ^ 1))) return rc;
         }
         for (int p = 0; p < P; ++p) {
             Part &q = M.part[p];
             if ((rc = set_dev(q.device))) return rc;
-            if (q.rows > 0) {
+            if (q.rows > 0 && !perk) {
                 fwx::FusedArgs<T> a = part_args<T>(M, q, nonneg, counting);
                 a.k0 = blk.k0; a.bt = blk.bt; a.w = (const T *)q.w[slot]; a.wh = q.wh[slot];
                 if (p != la_owner) {
@@ -515,11 +589,27 @@ template <typename T> static int multi_solve_typed(fwx_matrix *m, const Opts &op
                     FWX_HIP(fwx::launch_fused_main<T>(a, 0, la_lo, q.main));
                     FWX_HIP(fwx::launch_fused_main<T>(a, la_hi, q.rows, q.main));
                 }
+            } else if (q.rows > 0) {
+                // one launch per pivot over the slab, pivot rows from the snapshot panel (BASELINE
+                // config 4: "row-partitioned, pivot-row broadcast per k" -- 64 rows per message)
+                auto sweep = [&](int lo, int hi, int skip_lo, int skip_hi) -> int {
+                    if (hi <= lo) return FWX_OK;
+                    const size_t off = (size_t)lo * nd;
+                    return relax_range<T>((T *)q.rate + off, q.next ? q.next + off : nullptr,
+                                          q.hops ? q.hops + off : nullptr, hi - lo, nd, q.row0 + lo,
+                                          (const T *)q.w[slot], q.wh[slot], nd, blk.k0, blk.k0 + blk.bt,
+                                          op.serpentine, counting ? q.upd : nullptr, q.main, fwx::PathLog(),
+                                          skip_lo, skip_hi);
+                };
+                if (p != la_owner) rc = sweep(0, q.rows, 0, 0);
+                else if (la_lo % 4 == 0 && la_hi % 4 == 0) rc = sweep(0, q.rows, la_lo, la_hi);
+                else if (!(rc = sweep(0, la_lo, 0, 0))) rc = sweep(la_hi, q.rows, 0, 0);
+                if (rc) return rc;
             }
             FWX_HIP(hipEventRecord(q.main_free[slot], q.main));
         }
         if ((rc = set_dev(M.part[0].device))) return rc;
-        if ((rc = thr.tick(M.part[0].main, 4))) return rc;
+        if ((rc = thr.tick(M.part[0].main, perk ? blk.bt + 4 : 4))) return rc;
     }
     uint64_t total = 0;
     for (int p = 0; p < P; ++p) {
@@ -559,8 +649,10 @@ int multi_download(fwx_matrix *m, void *rate, int32_t *next, int32_t *hops)
 
 int multi_solve(fwx_matrix *m, const Opts &op)
 {
-    if (op.k_begin != 0 || op.k_end != m->n) return FWX_ERR_UNSUPPORTED;
-    if (op.engine == FWX_ENGINE_PERK) return FWX_ERR_UNSUPPORTED;
+    if (m->plog.last && (op.k_begin != 0 || op.k_end != m->n))
+        return FWX_ERR_UNSUPPORTED;      // the trace covers whole solves (as on one device)
+    if (op.engine == FWX_ENGINE_PERK && m->plog.last)
+        return FWX_ERR_UNSUPPORTED;      // the per-k kernel keeps no path trace on slabs: AUTO / FUSED do
     if (m->plog.last && !m->fresh) return FWX_ERR_INVALID;   // a traced solve starts from an upload
     DevRestore keep;
     m->fresh = 0;
@@ -623,6 +715,36 @@ static int query_scratch(MultiState &M, int32_t ints)
     return FWX_OK;
 }
 
+// fwx_matrix_query where some pair of devices refused peer access: the same walk driven from the
+// host, one 4-byte read per hop from the partition that owns the row (slow, correct, rarely needed).
+static int host_walk(fwx_matrix *m, int32_t src, int32_t dst, int32_t *path_out, int32_t cap)
+{
+    MultiState &M = *m->multi;
+    auto next_of = [&](int a, int32_t *out) -> int {
+        int p = 0;
+        while (p + 1 < M.parts && a >= M.part[p + 1].row0) ++p;
+        Part &q = M.part[p];
+        int rc = set_dev(q.device);
+        if (rc) return rc;
+        FWX_HIP(hipMemcpyAsync(out, q.next + (size_t)(a - q.row0) * M.nd + dst, 4, hipMemcpyDeviceToHost, q.main));
+        FWX_HIP(hipStreamSynchronize(q.main));
+        return FWX_OK;
+    };
+    int32_t nx = -1;
+    int rc = next_of(src, &nx);
+    if (rc) return rc;
+    if (nx < 0) return 0;
+    int32_t len = 0, cur = src;
+    while (cur != dst || len == 0) {
+        if ((rc = next_of(cur, &nx))) return rc;
+        if (nx < 0 || nx >= m->n || len >= m->n) return FWX_ERR_CYCLE;
+        if (len >= cap) return FWX_ERR_CAPACITY;
+        path_out[len++] = nx;
+        cur = nx;
+    }
+    return len;
+}
+
 int multi_query(fwx_matrix *m, int32_t src, int32_t dst, double *rate_out, int32_t *path_out, int32_t cap)
 {
     MultiState &M = *m->multi;
@@ -630,6 +752,7 @@ int multi_query(fwx_matrix *m, int32_t src, int32_t dst, double *rate_out, int32
     int rc;
     if (rate_out && (rc = read_rate(m, src, dst, rate_out))) return rc;
     if (!m->next) return FWX_ERR_INVALID;
+    if (!M.peer_all) return host_walk(m, src, dst, path_out, cap);
     Part &z = M.part[0];
     if ((rc = set_dev(z.device))) return rc;
     const int dcap = cap < m->n ? cap : m->n;
@@ -651,6 +774,7 @@ int multi_query_exact_batch(fwx_matrix *m, int32_t count, const int32_t *src, co
                             int32_t *len_out, int32_t *path_out, int32_t cap)
 {
     MultiState &M = *m->multi;
+    if (!M.peer_all) return FWX_ERR_UNSUPPORTED;   // the walk reads every slab from one device
     DevRestore keep;
     Part &z = M.part[0];
     int rc = set_dev(z.device);
@@ -659,6 +783,7 @@ int multi_query_exact_batch(fwx_matrix *m, int32_t count, const int32_t *src, co
     // right behind the kernel that used the memory: drain_stream in fwx_internal.h)
     CtxLease lease;
     if ((rc = lease.open())) return rc;
+    lease.c->uses_stream(z.main);            // the kernel below runs on partition 0's stream
     const size_t c = (size_t)count;
     struct { void *p = nullptr; } d_src, d_dst, d_len, d_paths, d_stacks;
     void *ids = nullptr;
@@ -770,39 +895,114 @@ extern "C" {
 int fwx_matrix_create_multi(fwx_matrix **out, int32_t n, int32_t dtype, int32_t with_next,
                             int32_t with_hops, int32_t n_parts, const int32_t *devices, int32_t exchange)
 {
-    if (!out || n < 0 || (dtype != FWX_F32 && dtype != FWX_F64) || n_parts < 1 ||
-        n_parts > FWX_MAX_PARTS || !devices ||
-        (exchange != FWX_XCHG_AUTO && exchange != FWX_XCHG_PEER && exchange != FWX_XCHG_RCCL))
-        return FWX_ERR_INVALID;
-    *out = nullptr;
-    if (with_hops && !with_next) return FWX_ERR_INVALID;
-    const int cnt = device_count();
-    if (cnt <= 0) return FWX_ERR_NO_DEVICE;
-    for (int p = 0; p < n_parts; ++p)
-        if (devices[p] < 0 || devices[p] >= cnt) return FWX_ERR_INVALID;
-    fwx_matrix *m = new (std::nothrow) fwx_matrix();
-    if (!m) return FWX_ERR_OOM;
-    memset(m, 0, sizeof(*m));
-    m->n = n; m->dtype = dtype; m->device = devices[0];
-    m->next = with_next ? (int32_t *)(uintptr_t)16 : nullptr;   // markers only: the slabs own the arrays
-    m->hops = with_hops ? (int32_t *)(uintptr_t)16 : nullptr;
-    DevRestore keep;
-    const int rc = multi_alloc(m, n_parts, devices, exchange);
-    if (rc) {
-        multi_destroy(m);
-        delete m;
-        return rc;
-    }
-    *out = m;
-    return FWX_OK;
+    return fwxi::guarded([&]() -> int {
+        if (!out || n < 0 || (dtype != FWX_F32 && dtype != FWX_F64) || n_parts < 1 ||
+            n_parts > FWX_MAX_PARTS || !devices ||
+            (exchange != FWX_XCHG_AUTO && exchange != FWX_XCHG_PEER && exchange != FWX_XCHG_RCCL))
+            return FWX_ERR_INVALID;
+        *out = nullptr;
+        if (with_hops && !with_next) return FWX_ERR_INVALID;
+        const int cnt = device_count();
+        if (cnt <= 0) return FWX_ERR_NO_DEVICE;
+        for (int p = 0; p < n_parts; ++p)
+            if (devices[p] < 0 || devices[p] >= cnt) return FWX_ERR_INVALID;
+        fwx_matrix *m = new (std::nothrow) fwx_matrix();
+        if (!m) return FWX_ERR_OOM;
+        memset(m, 0, sizeof(*m));
+        m->n = n; m->dtype = dtype; m->device = devices[0];
+        m->next = with_next ? (int32_t *)(uintptr_t)16 : nullptr;   // markers only: the slabs own the arrays
+        m->hops = with_hops ? (int32_t *)(uintptr_t)16 : nullptr;
+        DevRestore keep;
+        const int rc = multi_alloc(m, n_parts, devices, exchange);
+        if (rc) {
+            multi_destroy(m);
+            delete m;
+            return rc;
+        }
+        *out = m;
+        return FWX_OK;
+    });
+}
+
+int fwx_matrix_comm_ranks(const fwx_matrix *m)
+{
+    if (!m) return FWX_ERR_INVALID;
+    if (!m->multi || !m->multi->comms) return 0;
+    int ranks = 0;
+    if (rccl().CommCount(m->multi->comms->comm[0], &ranks) != ncclSuccess) return FWX_ERR_RCCL;
+    return ranks;
 }
 
 int fwx_matrix_parts(const fwx_matrix *m, int32_t *exchange_out)
 {
-    if (!m) return FWX_ERR_INVALID;
-    if (exchange_out) *exchange_out = m->multi ? m->multi->exchange : FWX_XCHG_PEER;
-    return m->multi ? m->multi->parts : 1;
+    return fwxi::guarded([&]() -> int {
+        if (!m) return FWX_ERR_INVALID;
+        if (exchange_out) *exchange_out = m->multi ? m->multi->exchange : FWX_XCHG_PEER;
+        return m->multi ? m->multi->parts : 1;
+    });
 }
+
+// ---- the one-shot entry points keep their handle ---------------------------------------------------
+// fwx_solve_multi_* is stateless for the caller, like fwx_solve_*; what it needs -- the slabs, the
+// panels, two streams and five events per partition, the RCCL communicator -- used to be created and
+// destroyed per call (hipFree / hipStreamDestroy synchronise the device, ncclCommInitAll takes
+// hundreds of milliseconds).  A finished call now parks its handle here, keyed by everything that
+// shapes it; the next call with the same key takes it back and only uploads.  Handles whose rate
+// slabs add up to more than kKeepBytes are destroyed as before (a one-off N = 16384 solve must not pin
+// gigabytes),
+// at most kMaxIdle are parked, and the pool is never torn down from a static destructor.
+class MultiPool {
+public:
+    struct Key {
+        int32_t n, dtype, with_next, with_hops, parts, exchange;
+        int32_t devs[FWX_MAX_PARTS];
+        bool operator==(const Key &o) const { return memcmp(this, &o, sizeof(Key)) == 0; }
+    };
+    static Key key(int32_t n, int dtype, bool with_next, bool with_hops, int32_t parts,
+                   const int32_t *devices, int32_t exchange)
+    {
+        Key k;
+        memset(&k, 0, sizeof(k));
+        k.n = n; k.dtype = dtype; k.with_next = with_next; k.with_hops = with_hops; k.parts = parts;
+        k.exchange = exchange;
+        for (int p = 0; p < parts; ++p) k.devs[p] = devices[p];
+        return k;
+    }
+    static fwx_matrix *take(const Key &k)
+    {
+        Pool &pl = pool();
+        std::lock_guard<std::mutex> lk(pl.mu);
+        for (size_t i = 0; i < pl.idle.size(); ++i)
+            if (pl.idle[i].k == k) {
+                fwx_matrix *m = pl.idle[i].m;
+                pl.idle.erase(pl.idle.begin() + (long)i);
+                return m;
+            }
+        return nullptr;
+    }
+    static void park(const Key &k, fwx_matrix *m)
+    {
+        fwx_matrix *evict = nullptr;
+        if (m->multi->slab_bytes > kKeepBytes) {
+            evict = m;
+        } else {
+            Pool &pl = pool();
+            std::lock_guard<std::mutex> lk(pl.mu);
+            if (pl.idle.size() >= kMaxIdle) {       // the oldest goes
+                evict = pl.idle.front().m;
+                pl.idle.erase(pl.idle.begin());
+            }
+            pl.idle.push_back({k, m});
+        }
+        if (evict) fwx_matrix_destroy(evict);
+    }
+
+private:
+    static constexpr size_t kKeepBytes = (size_t)256 << 20, kMaxIdle = 2;
+    struct Entry { Key k; fwx_matrix *m; };
+    struct Pool { std::mutex mu; std::vector<Entry> idle; };
+    static Pool &pool() { static Pool *p = new Pool(); return *p; }   // leaked on purpose
+};
 
 static int solve_multi_host(int32_t n, int dtype, void *rate, int32_t *next, int32_t *hops, int32_t n_parts,
                             const int32_t *devices, int32_t exchange, const fwx_opts *opts)
@@ -810,32 +1010,47 @@ static int solve_multi_host(int32_t n, int dtype, void *rate, int32_t *next, int
     if (n < 0) return FWX_ERR_INVALID;
     if (n == 0) return FWX_OK;
     if (!rate || (hops && !next)) return FWX_ERR_INVALID;
+    if (n_parts < 1 || n_parts > FWX_MAX_PARTS || !devices) return FWX_ERR_INVALID;
     Opts op;
     int rc = read_opts(opts, n, op);
     if (rc) return rc;
-    fwx_matrix *m = nullptr;
-    if ((rc = fwx_matrix_create_multi(&m, n, dtype, next != nullptr, hops != nullptr, n_parts, devices,
-                                      exchange)))
+    const MultiPool::Key key = MultiPool::key(n, dtype, next != nullptr, hops != nullptr, n_parts, devices,
+                                              exchange);
+    // the handle is destroyed on every path that does not park it (an error or an exception leaves
+    // it in an unknown state)
+    struct Holder {
+        fwx_matrix *m = nullptr;
+        ~Holder() { if (m) fwx_matrix_destroy(m); }
+    } h;
+    h.m = MultiPool::take(key);
+    if (!h.m && (rc = fwx_matrix_create_multi(&h.m, n, dtype, next != nullptr, hops != nullptr, n_parts,
+                                              devices, exchange)))
         return rc;
-    rc = multi_upload(m, rate, next, hops);
-    if (!rc) rc = multi_solve(m, op);
-    if (!rc) rc = multi_download(m, rate, next, hops);
-    fwx_matrix_destroy(m);
-    return rc;
+    rc = multi_upload(h.m, rate, next, hops);
+    if (!rc) rc = multi_solve(h.m, op);
+    if (!rc) rc = multi_download(h.m, rate, next, hops);
+    if (rc) return rc;
+    fail_point();
+    fwx_matrix *m = h.m;
+    h.m = nullptr;
+    MultiPool::park(key, m);
+    return FWX_OK;
 }
 
 int fwx_solve_multi_f64(int32_t n, double *rate, int32_t *next, int32_t *hops, int32_t n_parts,
                         const int32_t *devices, int32_t exchange, const fwx_opts *opts)
 {
-    try { return solve_multi_host(n, FWX_F64, rate, next, hops, n_parts, devices, exchange, opts); }
-    catch (...) { return FWX_ERR_OOM; }
+    return fwxi::guarded([&]() -> int {
+        return solve_multi_host(n, FWX_F64, rate, next, hops, n_parts, devices, exchange, opts);
+    });
 }
 
 int fwx_solve_multi_f32(int32_t n, float *rate, int32_t *next, int32_t *hops, int32_t n_parts,
                         const int32_t *devices, int32_t exchange, const fwx_opts *opts)
 {
-    try { return solve_multi_host(n, FWX_F32, rate, next, hops, n_parts, devices, exchange, opts); }
-    catch (...) { return FWX_ERR_OOM; }
+    return fwxi::guarded([&]() -> int {
+        return solve_multi_host(n, FWX_F32, rate, next, hops, n_parts, devices, exchange, opts);
+    });
 }
 
 }  // extern "C"

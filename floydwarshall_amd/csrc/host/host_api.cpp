@@ -3,6 +3,7 @@
 #include <new>
 
 #include "fwx.h"
+#include "fwx_guard.h"
 #include "fwx_host.h"
 #include "host_types.hpp"
 
@@ -50,22 +51,30 @@ extern "C" {
 int fwxh_session_create(fwxh_session **out, int32_t device)
 {
     if (!out) return FWX_ERR_INVALID;
-    *out = new (std::nothrow) fwxh_session(device);
-    return *out ? FWX_OK : FWX_ERR_OOM;
+    *out = nullptr;
+    return fwxi::guarded([&]() -> int {
+        *out = new (std::nothrow) fwxh_session(device);
+        return *out ? FWX_OK : FWX_ERR_OOM;
+    });
 }
 
 int fwxh_session_destroy(fwxh_session *s)
 {
-    delete s;
-    return FWX_OK;
+    return fwxi::guarded([&]() -> int {
+        delete s;
+        return FWX_OK;
+    });
 }
 
 int fwxh_session_set_devices(fwxh_session *s, int32_t n_parts, const int32_t *devices, int32_t min_vertices)
 {
     if (!s || n_parts < 0 || n_parts > FWX_MAX_PARTS || (n_parts > 0 && !devices) || min_vertices < 0)
         return FWX_ERR_INVALID;
-    s->impl.set_devices(std::vector<int32_t>(devices, devices + n_parts), min_vertices);
-    return FWX_OK;
+    return fwxi::guarded([&]() -> int {
+        fwxi::fail_point();
+        s->impl.set_devices(std::vector<int32_t>(devices, devices + n_parts), min_vertices);
+        return FWX_OK;
+    });
 }
 
 int32_t fwxh_session_parts(const fwxh_session *s) { return s ? s->impl.parts() : -1; }

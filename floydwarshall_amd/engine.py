@@ -1,7 +1,10 @@
 """Python binding over the libfwx C ABI (include/fwx.h).
 
 This is plumbing for the tests, the benchmark and the multi-GPU driver: numpy arrays for the
-host-buffer entry points, raw device pointers (from torch tensors) for the device step API.
+host-buffer entry points, raw device pointers for the device step API.  Device memory is owned by
+floydwarshall_amd.hip.DeviceArray (the HIP runtime through ctypes: no torch in the process, so libfwx
+runs on the runtime it was built against) or, for floydwarshall_amd.dist, by torch tensors; every
+function here takes either and allocates its outputs like its inputs.
 The functions mirror the reference's seam, floydWarshall = runAlgo 0 . buildMatrix
 (/root/reference/src/lib/Algorithms.hs:19-20): `solve` IS runAlgo on the dense form.
 """
@@ -73,12 +76,12 @@ def solve(rate, nxt=None, hops=None, *, device=-1, engine=FWX_ENGINE_AUTO, k_beg
 
 
 def solve_multi(rate, nxt=None, hops=None, *, devices=(0,), exchange=FWX_XCHG_AUTO,
-                count_updates=False):
+                engine=FWX_ENGINE_AUTO, k_begin=0, k_end=0, count_updates=False):
     """runAlgo in place on host numpy arrays, row-partitioned over `devices` (one partition per
     entry; a device may repeat = logical partitions on one GPU) from ONE process:
     fwx_solve_multi_f64 / _f32."""
     _check_arrays(rate, nxt, hops)
-    o, u = _opts(want_updates=count_updates)
+    o, u = _opts(engine=engine, k_begin=k_begin, k_end=k_end, want_updates=count_updates)
     devs = (ctypes.c_int32 * len(devices))(*devices)
     fn = lib().fwx_solve_multi_f64 if rate.dtype == np.float64 else lib().fwx_solve_multi_f32
     check(fn(rate.shape[0], _np_ptr(rate), _np_ptr(nxt), _np_ptr(hops), len(devices), devs, exchange,
@@ -122,6 +125,10 @@ class DeviceMatrix:
         x = ctypes.c_int32(0)
         p = check(lib().fwx_matrix_parts(self._h, ctypes.byref(x)), "fwx_matrix_parts")
         return p, int(x.value)
+
+    def comm_ranks(self):
+        """Ranks of the RCCL communicator the partitions exchange panels on (0: not RCCL)."""
+        return check(lib().fwx_matrix_comm_ranks(self._h), "fwx_matrix_comm_ranks")
 
     def upload(self, rate, nxt=None, hops=None):
         _check_arrays(rate, nxt, hops)
@@ -264,13 +271,33 @@ def _slab(rate_t, next_t, hops_t, n, row0):
     return s
 
 
-def _stream_ptr(stream=None):
-    """hipStream_t for a launch: an explicit hip.Stream (or raw handle), else torch's current stream."""
+def _is_torch(t):
+    return type(t).__module__.split(".")[0] == "torch"
+
+
+def _stream_ptr(stream=None, like=None):
+    """hipStream_t for a launch: an explicit hip.Stream / torch stream (or raw handle); else the
+    current torch stream if `like` is a torch tensor, else this module's default hip.Stream."""
     if stream is not None:
-        h = getattr(stream, "ptr", stream)
+        h = getattr(stream, "ptr", None)
+        if h is None:
+            h = getattr(stream, "cuda_stream", stream)
         return h if isinstance(h, ctypes.c_void_p) else ctypes.c_void_p(h)
-    import torch
-    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    if like is not None and _is_torch(like):
+        import torch
+        return ctypes.c_void_p(torch.cuda.current_stream(like.device).cuda_stream)
+    from . import hip
+    return hip.default_stream().ptr
+
+
+def _empty_like_device(like, shape, dtype_name):
+    """Uninitialised device array on the device of `like` (torch tensor -> torch tensor, hip.DeviceArray
+    -> hip.DeviceArray)."""
+    if _is_torch(like):
+        import torch
+        return torch.empty(tuple(shape), dtype=getattr(torch, dtype_name), device=like.device)
+    from . import hip
+    return hip.DeviceArray(shape, np.dtype(dtype_name))
 
 
 def dev_relax(rate_t, n, row0, k_begin, k_end, *, pivots_t=None, pivot_hops_t=None, next_t=None,
@@ -302,7 +329,7 @@ def dev_relax(rate_t, n, row0, k_begin, k_end, *, pivots_t=None, pivot_hops_t=No
     upd = ctypes.c_void_p(updates_t.data_ptr()) if updates_t is not None else None
     lo, hi = skip if skip else (0, 0)
     check(lib().fwx_dev_relax_skip(ctypes.byref(s), ctypes.byref(p), int(bool(serpentine)), upd,
-                                   int(lo), int(hi), _stream_ptr(stream)), "fwx_dev_relax_skip")
+                                   int(lo), int(hi), _stream_ptr(stream, rate_t)), "fwx_dev_relax_skip")
 
 
 def dev_panel(block_rate_t, n, k0, w_rate_t, *, next_t=None, hops_t=None, w_hops_t=None,
@@ -313,36 +340,60 @@ def dev_panel(block_rate_t, n, k0, w_rate_t, *, next_t=None, hops_t=None, w_hops
     upd = ctypes.c_void_p(updates_t.data_ptr()) if updates_t is not None else None
     wh = ctypes.c_void_p(w_hops_t.data_ptr()) if w_hops_t is not None else None
     check(lib().fwx_dev_panel(ctypes.byref(s), ctypes.c_void_p(w_rate_t.data_ptr()), wh, upd,
-                              _stream_ptr()), "fwx_dev_panel")
+                              _stream_ptr(None, block_rate_t)), "fwx_dev_panel")
+
+
+def _alloc(shape, dtype, device, fill=None):
+    """Device array of a torch dtype (on torch `device`) or of a numpy dtype (hip.DeviceArray on the
+    current HIP device; `device` is then ignored)."""
+    if type(dtype).__module__.split(".")[0] == "torch":
+        import torch
+        if fill is None:
+            return torch.empty(tuple(shape), dtype=dtype, device=device)
+        return torch.full(tuple(shape), fill, dtype=dtype, device=device)
+    from . import hip
+    a = hip.DeviceArray(shape, dtype)
+    return a if fill is None else a.fill_(fill)
+
+
+def _int32_of(dtype):
+    if type(dtype).__module__.split(".")[0] == "torch":
+        import torch
+        return torch.int32
+    return np.int32
 
 
 class FusedWorkspace:
     """Device scratch of the fused engine for slabs of up to `rows` rows: snapshot panels W (two,
-    for look-ahead; with hops also their hops panels WH), pivot-column snapshots Ct / CNt / CHt."""
+    for look-ahead; with hops also their hops panels WH), pivot-column snapshots Ct / CNt / CHt.
+    dtype: a torch dtype (arrays are torch tensors on `device`) or a numpy dtype (hip.DeviceArray)."""
 
-    def __init__(self, n, rows, dtype, device, with_next=False, with_hops=False):
-        import torch
+    def __init__(self, n, rows, dtype, device=None, with_next=False, with_hops=False):
         B = FWX_FUSED_BLOCK
-        self.w = [torch.empty((B, n), dtype=dtype, device=device) for _ in range(2)]
-        self.wh = [torch.empty((B, n), dtype=torch.int32, device=device) for _ in range(2)] \
-            if with_hops else [None, None]
+        i32 = _int32_of(dtype)
+        self.w = [_alloc((B, n), dtype, device) for _ in range(2)]
+        self.wh = [_alloc((B, n), i32, device) for _ in range(2)] if with_hops else [None, None]
         ld = (max(rows, 1) + 3) & ~3
         self.ld = ld
-        self.ct = torch.empty((B, ld), dtype=dtype, device=device)
-        self.cnt = torch.empty((B, ld), dtype=torch.int32, device=device) if with_next else None
-        self.cht = torch.empty((B, ld), dtype=torch.int32, device=device) if with_hops else None
+        self.ct = _alloc((B, ld), dtype, device)
+        self.cnt = _alloc((B, ld), i32, device) if with_next else None
+        self.cht = _alloc((B, ld), i32, device) if with_hops else None
 
 
 class Trace:
     """Path trace of a slab (fwx.h fwx_trace): three rows x n int32 device arrays, LOCAL rows, all
-    -1 before a solve.  rows(lo, hi) gives the views a panel of pivot rows needs."""
+    -1 before a solve.  rows(lo, hi) gives the views a panel of pivot rows needs.  device: a
+    torch.device (torch tensors) or None (hip.DeviceArray on the current HIP device)."""
 
     def __init__(self, rows, n, device=None, _views=None):
-        import torch
         if _views is not None:
             self.last, self.at_col, self.at_row = _views
-        else:
+        elif device is not None:
+            import torch
             self.last, self.at_col, self.at_row = (torch.full((rows, n), -1, dtype=torch.int32, device=device)
+                                                   for _ in range(3))
+        else:
+            self.last, self.at_col, self.at_row = (_alloc((rows, n), np.int32, None, fill=-1)
                                                    for _ in range(3))
 
     def rows(self, lo, hi):
@@ -371,18 +422,25 @@ def dev_panel_snap(block_rate_t, n, k0, w_rate_t, *, block_next_t=None, block_ho
         assert w_hops_t is not None and tuple(w_hops_t.shape) == tuple(block_rate_t.shape)
         wh = ctypes.c_void_p(w_hops_t.data_ptr())
     check(lib().fwx_dev_panel_snap(ctypes.byref(s), ctypes.c_void_p(w_rate_t.data_ptr()), wh,
-                                   _trace_ref(trace), _stream_ptr()), "fwx_dev_panel_snap")
+                                   _trace_ref(trace), _stream_ptr(None, block_rate_t)), "fwx_dev_panel_snap")
 
 
 def dev_domain_bits(rate_t, n, row0=0, next_t=None):
     """Domain check of one slab (fwx.h "Domain"; synchronises): bit 0 = every rate is >= +0.0 and
     not NaN, bit 1 = no entry has a non-zero rate and next < 0 (always set without next_t)."""
-    import torch
     s = _slab(rate_t, next_t, None, n, row0)
-    flag = torch.full((1,), 3, dtype=torch.int32, device=rate_t.device)
-    check(lib().fwx_dev_check_nonneg(ctypes.byref(s), ctypes.c_void_p(flag.data_ptr()),
-                                     _stream_ptr()), "fwx_dev_check_nonneg")
-    return int(flag.item())
+    if _is_torch(rate_t):
+        import torch
+        flag = torch.full((1,), 3, dtype=torch.int32, device=rate_t.device)
+        check(lib().fwx_dev_check_nonneg(ctypes.byref(s), ctypes.c_void_p(flag.data_ptr()),
+                                         _stream_ptr(None, rate_t)), "fwx_dev_check_nonneg")
+        return int(flag.item())
+    from . import hip
+    st = hip.default_stream()
+    flag = hip.DeviceArray.from_numpy(np.full((1,), 3, dtype=np.int32), st)
+    check(lib().fwx_dev_check_nonneg(ctypes.byref(s), ctypes.c_void_p(flag.data_ptr()), st.ptr),
+          "fwx_dev_check_nonneg")
+    return int(flag.numpy(st)[0])
 
 
 def dev_check_nonneg(rate_t, n, row0=0):
@@ -418,7 +476,7 @@ def dev_relax_fused(rate_t, n, row0, k0, k1, w_t, ws, *, next_t=None, hops_t=Non
     check(lib().fwx_dev_relax_fused_skip(ctypes.byref(s), ctypes.byref(p), ctypes.byref(sc),
                                          _trace_ref(trace), upd,
                                          _lib.FWX_FLAG_NONNEG if nonneg else 0, int(lo), int(hi),
-                                         _stream_ptr()),
+                                         _stream_ptr(None, rate_t)),
           "fwx_dev_relax_fused_skip")
 
 
@@ -432,8 +490,8 @@ def dev_solve_fused(rate_t, n, k_begin=0, k_end=None, *, next_t=None, hops_t=Non
     if nonneg is None:
         bits = dev_domain_bits(rate_t, n, 0, next_t)
         nonneg = updates_t is None and (bits == 3 if next_t is not None else bool(bits & 1))
-    ws = ws or FusedWorkspace(n, n, rate_t.dtype, rate_t.device, with_next=next_t is not None,
-                              with_hops=hops_t is not None)
+    ws = ws or FusedWorkspace(n, n, rate_t.dtype, getattr(rate_t, "device", None),
+                              with_next=next_t is not None, with_hops=hops_t is not None)
     B = FWX_FUSED_BLOCK
     for k0 in range(k_begin, k_end, B):
         k1 = min(k_end, k0 + B)
@@ -451,40 +509,44 @@ def dev_solve_fused(rate_t, n, k_begin=0, k_end=None, *, next_t=None, hops_t=Non
 def dev_follow_paths(next_t, src_t, dst_t, *, edge_rate_t=None, path_cap=0):
     """Batch path reconstruction on the device (fwx_dev_follow_paths).  next_t: full n x n int32
     next-hop matrix; src_t/dst_t: int32 vectors.  Returns (len, prod or None, paths or None) as
-    device tensors; asynchronous on the current stream."""
-    import torch
+    device arrays of the same kind as next_t; asynchronous on the current / default stream."""
     n = next_t.shape[0]
-    assert next_t.is_cuda and next_t.is_contiguous() and next_t.dtype == torch.int32
-    assert src_t.dtype == torch.int32 and dst_t.dtype == torch.int32 and src_t.shape == dst_t.shape
+    assert next_t.is_cuda and next_t.is_contiguous() and _dtype_name(next_t) == "int32"
+    assert _dtype_name(src_t) == "int32" and _dtype_name(dst_t) == "int32"
+    assert tuple(src_t.shape) == tuple(dst_t.shape)
     count = src_t.numel()
-    dev = next_t.device
-    len_t = torch.empty(count, dtype=torch.int32, device=dev)
-    prod_t = torch.empty(count, dtype=torch.float64, device=dev) if edge_rate_t is not None else None
-    path_t = torch.empty((count, path_cap), dtype=torch.int32, device=dev) if path_cap else None
+    len_t = _empty_like_device(next_t, (count,), "int32")
+    prod_t = _empty_like_device(next_t, (count,), "float64") if edge_rate_t is not None else None
+    path_t = _empty_like_device(next_t, (count, path_cap), "int32") if path_cap else None
     code = FWX_F32
     if edge_rate_t is not None:
-        assert edge_rate_t.is_cuda and edge_rate_t.is_contiguous() and edge_rate_t.shape == next_t.shape
+        assert edge_rate_t.is_cuda and edge_rate_t.is_contiguous()
+        assert tuple(edge_rate_t.shape) == tuple(next_t.shape)
         code = _tensor_dtype_code(edge_rate_t)
     vp = ctypes.c_void_p
     check(lib().fwx_dev_follow_paths(
         n, vp(next_t.data_ptr()), count, vp(src_t.data_ptr()), vp(dst_t.data_ptr()),
         vp(len_t.data_ptr()), vp(edge_rate_t.data_ptr()) if edge_rate_t is not None else None, code,
         vp(prod_t.data_ptr()) if prod_t is not None else None,
-        vp(path_t.data_ptr()) if path_t is not None else None, path_cap, _stream_ptr()),
+        vp(path_t.data_ptr()) if path_t is not None else None, path_cap, _stream_ptr(None, next_t)),
         "fwx_dev_follow_paths")
     return len_t, prod_t, path_t
 
 
 def dev_solve(rate_t, *, next_t=None, hops_t=None, engine=FWX_ENGINE_AUTO, k_begin=0, k_end=0,
               serpentine=True, count_updates=False, stream=None):
-    """fwx_dev_solve: whole solve (or a pivot range) on a torch tensor holding the entire n x n
+    """fwx_dev_solve: whole solve (or a pivot range) on a device array holding the entire n x n
     matrix, in place, BLOCKING.  The fused engine runs with look-ahead on an internal side stream.
-    Work queued on torch's current stream must be finished first: this synchronises it."""
+    Work queued on the current / default stream must be finished first: this synchronises it."""
     n = rate_t.shape[0]
     assert tuple(rate_t.shape) == (n, n)
     if stream is None:
-        import torch
-        torch.cuda.current_stream().synchronize()
+        if _is_torch(rate_t):
+            import torch
+            torch.cuda.current_stream(rate_t.device).synchronize()
+        else:
+            from . import hip
+            hip.default_stream().synchronize()
     s = _slab(rate_t, next_t, hops_t, n, 0)
     o, u = _opts(-1, engine, k_begin, k_end, 0, serpentine, count_updates, stream=stream)
     check(lib().fwx_dev_solve(ctypes.byref(s), ctypes.byref(o)), "fwx_dev_solve")

@@ -37,7 +37,7 @@ def rt():
             "hipGetDevice": [ctypes.POINTER(ci)], "hipDeviceSynchronize": [],
             "hipMalloc": [ctypes.POINTER(vp), sz], "hipFree": [vp],
             "hipMemcpy": [vp, vp, sz, ci], "hipMemcpyAsync": [vp, vp, sz, ci, vp],
-            "hipMemsetAsync": [vp, ci, sz, vp],
+            "hipMemsetAsync": [vp, ci, sz, vp], "hipMemsetD32Async": [vp, ci, sz, vp],
             "hipStreamCreateWithFlags": [ctypes.POINTER(vp), ctypes.c_uint], "hipStreamDestroy": [vp],
             "hipStreamSynchronize": [vp],
             "hipEventCreate": [ctypes.POINTER(vp)], "hipEventDestroy": [vp],
@@ -69,8 +69,37 @@ def set_device(i):
     _ck(rt().hipSetDevice(int(i)), "hipSetDevice")
 
 
-def synchronize():
-    _ck(rt().hipDeviceSynchronize(), "hipDeviceSynchronize")
+def synchronize(devices=None):
+    """hipDeviceSynchronize on the current device, or on each device of `devices` (the current device
+    is restored)."""
+    if devices is None:
+        _ck(rt().hipDeviceSynchronize(), "hipDeviceSynchronize")
+        return
+    cur = ctypes.c_int(0)
+    _ck(rt().hipGetDevice(ctypes.byref(cur)), "hipGetDevice")
+    for d in sorted(set(devices)):
+        set_device(d)
+        _ck(rt().hipDeviceSynchronize(), "hipDeviceSynchronize")
+    set_device(cur.value)
+
+
+def mem_get_info():
+    """(free, total) bytes of the current device."""
+    free, total = ctypes.c_size_t(0), ctypes.c_size_t(0)
+    _ck(rt().hipMemGetInfo(ctypes.byref(free), ctypes.byref(total)), "hipMemGetInfo")
+    return int(free.value), int(total.value)
+
+
+_DEFAULT_STREAM = None
+
+
+def default_stream():
+    """The stream engine.py's device-pointer API launches on when the caller names none: one
+    process-wide non-blocking stream (never the legacy null stream)."""
+    global _DEFAULT_STREAM
+    if _DEFAULT_STREAM is None:
+        _DEFAULT_STREAM = Stream()
+    return _DEFAULT_STREAM
 
 
 class Stream:
@@ -196,6 +225,11 @@ class DeviceArray:
                                     stream.ptr), "hipMemcpyAsync D2D")
         return self
 
+    def clone(self, stream=None):
+        """A new array with the same contents (device-to-device copy on `stream` / the default stream)."""
+        return DeviceArray(self.shape, self.dtype).copy_(self, stream if stream is not None
+                                                         else default_stream())
+
     def zero_(self, stream=None):
         _ck(rt().hipMemsetAsync(self._ptr, 0, self.nbytes, stream.ptr if stream is not None else None),
             "hipMemsetAsync")
@@ -203,9 +237,19 @@ class DeviceArray:
             synchronize()
         return self
 
+    def fill_(self, value, stream=None):
+        """Every element = value (32-bit element types only: int32 / float32)."""
+        assert self.dtype.itemsize == 4
+        word = int(np.array([value], dtype=self.dtype).view(np.int32)[0])
+        st = stream if stream is not None else default_stream()
+        _ck(rt().hipMemsetD32Async(self._ptr, word, self.nbytes // 4, st.ptr), "hipMemsetD32Async")
+        st.synchronize()
+        return self
+
     def numpy(self, stream=None):
-        if stream is not None:
-            stream.synchronize()
+        # what the default stream (or `stream`) has queued on this array is finished first; hipMemcpy
+        # itself does not wait for non-blocking streams
+        (stream if stream is not None else default_stream()).synchronize()
         out = np.empty(self.shape, dtype=self.dtype)
         _ck(rt().hipMemcpy(out.ctypes.data, self._ptr, self.nbytes, hipMemcpyDeviceToHost), "hipMemcpy D2H")
         return out

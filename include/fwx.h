@@ -59,7 +59,7 @@
 extern "C" {
 #endif
 
-#define FWX_ABI_VERSION 2
+#define FWX_ABI_VERSION 3
 
 typedef enum fwx_status {
     FWX_OK = 0,
@@ -70,7 +70,8 @@ typedef enum fwx_status {
     FWX_ERR_CYCLE = -5,       /* fwx_follow_path: next-hops do not reach dst within n hops        */
     FWX_ERR_CAPACITY = -6,    /* fwx_follow_path: output buffer too small                         */
     FWX_ERR_UNSUPPORTED = -7, /* option combination not implemented                               */
-    FWX_ERR_RCCL = -8         /* librccl.so.1 could not be loaded, or an RCCL call failed         */
+    FWX_ERR_RCCL = -8,        /* librccl.so.1 could not be loaded, or an RCCL call failed         */
+    FWX_ERR_INTERNAL = -9     /* an unexpected C++ exception was stopped at the boundary          */
 } fwx_status;
 
 typedef enum fwx_dtype { FWX_F32 = 0, FWX_F64 = 1 } fwx_dtype;
@@ -108,6 +109,17 @@ int fwx_abi_version(void);
 int fwx_device_count(void);              /* number of HIP devices, 0 if none (never an error)      */
 const char *fwx_strerror(int status);
 int fwx_last_hip_error(void);            /* hipError_t of the last FWX_ERR_HIP on this thread      */
+/* HIP_VERSION libfwx was compiled against and the version of the HIP runtime it is bound to in this
+ * process (hipRuntimeGetVersion; 0 if that fails).  Returns 1 if major.minor agree, else 0.  They
+ * differ when another library mapped its own libamdhip64 first -- a torch wheel bundles one -- and
+ * libfwx's DT_NEEDED resolved to that copy: it works, but it is not the pairing the library was
+ * built and fuzzed on, so hosts should load libfwx before such a library or
+ * at least log the mismatch (floydwarshall_amd/_lib.py does both).                                  */
+int fwx_hip_versions(int32_t *built_against, int32_t *runtime);
+/* TEST HOOK for the exception barrier: arms a countdown on the calling thread; the countdown-th
+ * internal allocation point reached by later calls on this thread throws std::bad_alloc, which the
+ * boundary must turn into FWX_ERR_OOM with nothing leaked.  0 disarms.  Not for production use.     */
+int fwx_test_fail_after(int32_t countdown);
 
 /* ---- one-shot host-buffer entry points: what the reference-side FFI binds --------------------
  * Replace runAlgo (Algorithms.hs:42-61) for a matrix produced by buildMatrix (:26-40).
@@ -200,11 +212,16 @@ int fwx_matrix_query_exact_batch(fwx_matrix *m, int32_t count, const int32_t *sr
  *   FWX_XCHG_PEER  hipMemcpyPeerAsync from the owner's panel into every other partition's panel
  *                  buffer (plain device-to-device copies when the device is the same).
  *   FWX_XCHG_AUTO  RCCL when there are >= 2 partitions on pairwise distinct devices, else PEER.
- * Distinct devices get peer access enabled pairwise (queries walk the slabs from one device).
+ * Distinct devices get peer access enabled pairwise where the hardware allows; it is needed by the
+ * QUERIES only (they walk the slabs from one device: without it fwx_matrix_query walks from the host
+ * and query_exact[_batch] returns FWX_ERR_UNSUPPORTED), never by the exchange.
  *
  * A multi handle is an fwx_matrix: upload / solve / download / query / enable_path_log /
- * query_exact[_batch] / path_log_count / destroy work on it unchanged (whole pivot range only;
- * fwx_opts.engine AUTO or FUSED; fwx_opts.device / stream are ignored).  Any n: rows are padded on
+ * query_exact[_batch] / path_log_count / destroy work on it unchanged (pivot ranges as on one device:
+ * any [k_begin, k_end) without the path trace, the whole range with it;
+ * fwx_opts.engine AUTO / FUSED, or PERK = one launch per pivot and partition with the pivot rows
+ * read from the exchanged panel -- rate / next / hops, no path trace; fwx_opts.device / stream are
+ * ignored).  Any n: rows are padded on
  * the device to a multiple of 16 bytes.  rate, next, hops and the path trace are all carried
  * through the slabs (the hops of the pivot rows travel with their rates).  Not carried: matrices
  * outside the reference's domain WITH next-hops (see "Domain": the slab kernels take next[i][k];
@@ -220,8 +237,14 @@ int fwx_matrix_create_multi(fwx_matrix **out, int32_t n, int32_t dtype, int32_t 
 /* Partitions of a handle (1 for a single-device handle); exchange_out (optional) receives the
  * transport in use (FWX_XCHG_PEER / FWX_XCHG_RCCL).                                              */
 int fwx_matrix_parts(const fwx_matrix *m, int32_t *exchange_out);
+/* Ranks of the RCCL communicator the handle exchanges panels on (ncclCommCount), 0 when the
+ * exchange is not RCCL (single device, FWX_XCHG_PEER).                                            */
+int fwx_matrix_comm_ranks(const fwx_matrix *m);
 /* One-shot host-buffer form, same contract as fwx_solve_f64 / _f32 (in place, caller owns the
- * arrays): create_multi + upload + solve + download + destroy.  opts: updates_out is honoured.    */
+ * arrays): create_multi + upload + solve + download.  Like the per-call contexts of fwx_solve_*,
+ * the handle (slabs, streams, events, RCCL communicator) is parked in a process-wide pool keyed by
+ * (n, dtype, fields, device list, exchange) and reused by the next call with the same key; handles
+ * whose rate slabs exceed 256 MiB in total are destroyed on return.  opts: engine and updates_out are honoured.     */
 int fwx_solve_multi_f64(int32_t n, double *rate, int32_t *next, int32_t *hops, int32_t n_parts,
                         const int32_t *devices, int32_t exchange, const fwx_opts *opts);
 int fwx_solve_multi_f32(int32_t n, float *rate, int32_t *next, int32_t *hops, int32_t n_parts,

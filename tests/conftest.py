@@ -18,6 +18,11 @@ def pytest_configure(config):
     import oracle
     oracle.build()
     oracle.lib()
+    # Map libfwx NOW, before any test module is imported: the pytest process never imports torch
+    # (ranks that need it are spawned, helpers.spawn_ranks), so libfwx is bound to the HIP runtime it
+    # was built against (/opt/rocm) -- tests/test_abi_symbols.py checks exactly that.
+    from floydwarshall_amd import _lib
+    _lib.lib()
 
 
 @pytest.fixture(scope="session")

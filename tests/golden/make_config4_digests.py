@@ -1,9 +1,15 @@
 #!/usr/bin/env python3
-"""One whole N=16384 fp32 solve on the CPU oracle (all host cores, ~4 min on the GPU box) against
-both GPU engines, bit for bit: the headline configuration's parity record.
+"""Generator of tests/golden/config4_n16384_digests.json: ONE WHOLE N=16384 fp32 solve of the
+benchmark matrix on the CPU oracle (all host cores, ~4 min on the GPU box), with and without the
+next-hop matrix, and the same solve on every GPU engine, bit for bit.  The fixture keeps the
+oracle's side only -- xxh64 of the solved rates, of the solved next-hops, and U -- so that `-m gpu`
+tests can tie any engine, any partitioning, to the whole oracle solve in seconds.
 
-    python3 tools/full_parity_n16384.py profiles/r02_full_parity_n16384.json
+    python3 tests/golden/make_config4_digests.py profiles/full_parity.json [n] [--next]
+    python3 tests/golden/make_config4_digests.py --write-fixture rates.json next.json
 
+(round 2 ran it twice on an MI355X box: profiles/r02_full_parity_n16384.json and
+profiles/r02_full_parity_n16384_next.json; --write-fixture merges two such records.)
 Prints a progress line per 1024 pivots (the GPU box kills a silent command after 7 minutes).
 """
 import json
@@ -13,9 +19,8 @@ import time
 
 import numpy as np
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
-os.environ["FWX_NO_TORCH"] = "1"
 
 import oracle  # noqa: E402  (tools/ may use the checker; the product never does)
 from floydwarshall_amd import engine, synth  # noqa: E402
@@ -23,7 +28,25 @@ sys.path.insert(0, ROOT)
 from bench import digest, host_cores  # noqa: E402
 
 
+def write_fixture(rates_json, next_json):
+    a, b = json.load(open(rates_json)), json.load(open(next_json))
+    assert a["ok"] and b["ok"] and a["n"] == b["n"] and a["U"] == b["U"]
+    assert a["rate_digest_oracle"] == b["rate_digest_oracle"]
+    fix = {"n": a["n"], "dtype": a["dtype"],
+           "input": "synth.d1_uniform(n, float32, BASE_SEED + 3): bench.py's matrix",
+           "oracle": "oracle.relax_mt, whole solve (%.0f s rates only, %.0f s with next-hops)"
+                     % (a["oracle_seconds"], b["oracle_seconds"]),
+           "U": a["U"], "rate_digest": a["rate_digest_oracle"], "next_digest": b["next_digest_oracle"],
+           "made_by": "tests/golden/make_config4_digests.py"}
+    with open(os.path.join(ROOT, "tests", "golden", "config4_n16384_digests.json"), "w") as f:
+        json.dump(fix, f, indent=1)
+    print(json.dumps(fix))
+
+
 def main():
+    if len(sys.argv) > 3 and sys.argv[1] == "--write-fixture":
+        write_fixture(sys.argv[2], sys.argv[3])
+        return 0
     out_path = sys.argv[1] if len(sys.argv) > 1 else None
     n = int(sys.argv[2]) if len(sys.argv) > 2 else 16384
     with_next = "--next" in sys.argv

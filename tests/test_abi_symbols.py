@@ -38,7 +38,8 @@ def test_binding_table_covers_the_engine_header():
 
 def test_abi_version_and_strerror():
     L = _lib.lib()
-    assert L.fwx_abi_version() == 2
+    assert L.fwx_abi_version() == 3 == _lib.FWX_ABI_VERSION
+    assert b"RCCL" in L.fwx_strerror(_lib.FWX_ERR_RCCL) and b"exception" in L.fwx_strerror(_lib.FWX_ERR_INTERNAL)
     assert L.fwx_strerror(0) == b"ok"
     assert b"no HIP device" in L.fwx_strerror(_lib.FWX_ERR_NO_DEVICE)
     assert L.fwx_device_count() >= 0
@@ -50,6 +51,36 @@ def test_no_cuda_symbols_or_torch_in_the_abi():
     out = subprocess.run(["ldd", _lib.LIB_PATH], capture_output=True, text=True).stdout
     assert "torch" not in out and "python" not in out
     assert "amdhip64" in out
+
+
+def test_libfwx_runs_on_the_hip_runtime_it_was_built_against():
+    """The loader imports nothing besides libfwx (no torch), so the library's DT_NEEDED resolves
+    through its RUNPATH to /opt/rocm's libamdhip64 -- the runtime it was compiled against.  (A process
+    that imports torch FIRST gets torch's bundled runtime instead and a RuntimeWarning saying so.)"""
+    import sys
+    assert "torch" not in sys.modules, "the pytest process must stay torch-free (helpers.spawn_ranks)"
+    built, runtime, same = _lib.runtime_versions()
+    assert built > 0
+    assert runtime == 0 or same, (built, runtime)       # 0: no HIP runtime initialisable (CPU box)
+    maps = open("/proc/self/maps").read()
+    hip_libs = {ln.split()[-1] for ln in maps.splitlines() if "libamdhip64" in ln}
+    assert len(hip_libs) == 1 and "torch" not in next(iter(hip_libs)), hip_libs
+
+
+def test_exception_barrier_without_a_device():
+    """fwx_test_fail_after arms a bad_alloc at the next internal allocation point of this thread;
+    the boundary must turn it into FWX_ERR_OOM (host mirror entry point: needs no GPU)."""
+    from floydwarshall_amd import host
+    L = _lib.lib()
+    s = host.Session()
+    try:
+        devs = (ctypes.c_int32 * 2)(0, 0)
+        assert L.fwx_test_fail_after(1) == _lib.FWX_OK
+        assert host.hlib().fwxh_session_set_devices(s._h, 2, devs, 0) == _lib.FWX_ERR_OOM
+        assert host.hlib().fwxh_session_set_devices(s._h, 2, devs, 0) == _lib.FWX_OK   # disarmed again
+        assert L.fwx_test_fail_after(0) == _lib.FWX_OK
+    finally:
+        s.close()
 
 
 def test_follow_path_host_side():

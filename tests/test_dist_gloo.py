@@ -9,9 +9,6 @@ import sys
 
 import numpy as np
 import pytest
-import torch
-import torch.distributed as dist
-import torch.multiprocessing as mp
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -75,6 +72,8 @@ class OracleBackend:
 
 
 def _worker(rank, world, port, n, block, lookahead, kind, with_next, outdir):
+    import torch
+    import torch.distributed as dist
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -114,9 +113,8 @@ def _free_port():
 def test_partitioned_solve_equals_single_process_oracle(tmp_path, world, n, block, lookahead, kind):
     import oracle
     from floydwarshall_amd import synth
-    from helpers import assert_bits_equal
-    mp.spawn(_worker, args=(world, _free_port(), n, block, lookahead, kind, True, str(tmp_path)),
-             nprocs=world, join=True)
+    from helpers import assert_bits_equal, spawn_ranks
+    spawn_ranks(_worker, (world, _free_port(), n, block, lookahead, kind, True, str(tmp_path)), world)
     rate, nxt, hops = synth.make(kind, n, np.float32, seed=4242)
     oracle.relax(rate, nxt, hops)
     got_r = np.concatenate([np.load(tmp_path / ("rate_%d.npy" % r)) for r in range(world)])

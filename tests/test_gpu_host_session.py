@@ -351,8 +351,7 @@ def engine_follow(nxt, i, j):
 def test_no_device_memory_leak_over_many_sessions_and_logged_solves():
     """Handles own device memory (solved matrix, path trace, walk buffers): a few
     hundred create / solve / query / destroy cycles must leave the free HBM where it was."""
-    import torch
-    from floydwarshall_amd import engine, synth
+    from floydwarshall_amd import engine, hip, synth
     price = [1.0, 1.7, 0.6, 2.3, 0.9, 1.2, 3.1]                     # a potential: no arbitrage anywhere
     rows = [(1000 + i, "X%d" % (i % 5), "C%d" % (i % 7), "C%d" % ((i * 3 + 1) % 7),
              0.98 * price[(i * 3 + 1) % 7] / price[i % 7], 0.97 * price[i % 7] / price[(i * 3 + 1) % 7])
@@ -381,12 +380,12 @@ def test_no_device_memory_leak_over_many_sessions_and_logged_solves():
 
     for _ in range(5):
         cycle()                                   # warm allocator pools and lazy runtime state
-    torch.cuda.synchronize()
-    free0, _ = torch.cuda.mem_get_info()
+    hip.synchronize()
+    free0, _ = hip.mem_get_info()
     for _ in range(100):
         cycle()
-    torch.cuda.synchronize()
-    free1, _ = torch.cuda.mem_get_info()
+    hip.synchronize()
+    free1, _ = hip.mem_get_info()
     assert free0 - free1 < 32 << 20, "device memory shrank by %d bytes" % (free0 - free1)
 
 

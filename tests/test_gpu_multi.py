@@ -154,3 +154,202 @@ def test_n4096_partitioned_whole_solve():
         assert_bits_equal(gr, er, "rate P=%d" % parts)
         assert_bits_equal(gn, en, "next P=%d" % parts)
         assert u == eu
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+@pytest.mark.parametrize("parts", [1, 2, 3, 8])
+def test_per_k_engine_on_partitions(parts, dtype):
+    """FWX_ENGINE_PERK on a partitioned handle -- BASELINE config 4's shape: one launch per pivot and
+    partition, pivot rows read from the exchanged 64-row snapshot panel, the look-ahead rows by one
+    fused launch.  rate / next / hops and U against the oracle, ragged sizes included."""
+    for kind, n in (("d1", 512), ("t1", 300), ("t2", 257), ("d2", 1000)):
+        rate, nxt, hops = synth.make(kind, n, dtype, seed=parts * 100 + n)
+        er, en, eh = rate.copy(), nxt.copy(), hops.copy()
+        eu = oracle.relax(er, en, eh)
+        gr, gn, gh = rate.copy(), nxt.copy(), hops.copy()
+        u = engine.solve_multi(gr, gn, gh, devices=[0] * parts, engine=engine.FWX_ENGINE_PERK,
+                               count_updates=True)
+        assert_bits_equal(gr, er, "rate %s n=%d P=%d" % (kind, n, parts))
+        assert_bits_equal(gn, en, "next %s n=%d P=%d" % (kind, n, parts))
+        assert_bits_equal(gh, eh, "hops %s n=%d P=%d" % (kind, n, parts))
+        assert u == eu
+        gr = rate.copy()
+        engine.solve_multi(gr, devices=[0] * parts, engine=engine.FWX_ENGINE_PERK)
+        assert_bits_equal(gr, er, "rates-only %s n=%d P=%d" % (kind, n, parts))
+    with engine.DeviceMatrix(128, dtype, with_next=True, devices=[0, 0]) as dm:
+        dm.enable_path_log()                       # the per-k kernel keeps no trace on slabs
+        rate, nxt, _ = synth.make("d1", 128, dtype, seed=1)
+        dm.upload(rate, nxt)
+        with pytest.raises(engine.FwxError) as e:
+            dm.solve(engine=engine.FWX_ENGINE_PERK)
+        assert e.value.status == FWX_ERR_UNSUPPORTED
+
+
+@pytest.mark.parametrize("eng", [engine.FWX_ENGINE_FUSED, engine.FWX_ENGINE_PERK])
+def test_pivot_ranges_on_a_partitioned_handle(eng):
+    """A solve over [k_begin, k_end) is resumable on partitions as on one device (no trace):
+    three ragged ranges in a row equal the oracle's whole solve, and each stage its prefix."""
+    n = 700
+    rate, nxt, hops = synth.make("t1", n, np.float32, seed=12)
+    with engine.DeviceMatrix(n, np.float32, with_next=True, with_hops=True, devices=[0, 0, 0]) as dm:
+        dm.upload(rate, nxt, hops)
+        er, en, eh = rate.copy(), nxt.copy(), hops.copy()
+        for k0, k1 in ((0, 37), (37, 411), (411, n)):
+            oracle.relax(er, en, eh, k0, k1)
+            dm.solve(engine=eng, k_begin=k0, k_end=k1)
+            gr, gn, gh = dm.download()
+            assert_bits_equal(gr, er, "rate after [%d,%d)" % (k0, k1))
+            assert_bits_equal(gn, en, "next after [%d,%d)" % (k0, k1))
+            assert_bits_equal(gh, eh, "hops after [%d,%d)" % (k0, k1))
+
+
+def test_exception_barrier_and_no_leak_on_the_multi_path():
+    """fwx.h: no C++ exception crosses the ABI.  fwx_test_fail_after arms a bad_alloc at the next
+    internal allocation point: the partitioned solve must come back as FWX_ERR_OOM -- through
+    fwx_matrix_solve on a handle and through the one-shot entry point, whose handle must be destroyed
+    on the way out (free HBM returns to where it was) -- and the next call must work."""
+    from floydwarshall_amd import _lib, hip
+    n = 1024
+    rate, nxt, _ = synth.make("d1", n, np.float32, seed=5)
+    er, en, _ = _expect(rate, nxt)
+    L = _lib.lib()
+    with engine.DeviceMatrix(n, np.float32, with_next=True, devices=[0, 0]) as dm:
+        dm.upload(rate, nxt)
+        L.fwx_test_fail_after(1)
+        with pytest.raises(engine.FwxError) as e:
+            dm.solve()
+        assert e.value.status == _lib.FWX_ERR_OOM
+        dm.upload(rate, nxt)
+        dm.solve()
+        assert_bits_equal(dm.download()[0], er, "handle solve after the injected failure")
+    engine.solve_multi(rate.copy(), nxt.copy(), devices=[0, 0, 0])       # warm: pool, RCCL-free path
+    hip.synchronize()
+    free0, _ = hip.mem_get_info()
+    for countdown in (1, 2):               # 1: inside the solve; 2: after the download, before parking
+        L.fwx_test_fail_after(countdown)
+        with pytest.raises(engine.FwxError) as e:
+            engine.solve_multi(rate.copy(), nxt.copy(), devices=[0, 0, 0])
+        assert e.value.status == _lib.FWX_ERR_OOM
+    L.fwx_test_fail_after(0)
+    hip.synchronize()
+    free1, _ = hip.mem_get_info()
+    assert free1 >= free0, "the failed one-shot calls leaked %d bytes of HBM" % (free0 - free1)
+    gr, gn = rate.copy(), nxt.copy()
+    engine.solve_multi(gr, gn, devices=[0, 0, 0])
+    assert_bits_equal(gr, er, "one-shot after the injected failures")
+    assert_bits_equal(gn, en, "next")
+
+
+def test_one_shot_calls_reuse_their_handle():
+    """fwx_solve_multi_* parks its handle (slabs, streams, events, communicator) keyed by shape and
+    device list; the second call with the same key must not pay create + destroy again, and calls
+    with other keys in between must not confuse the pool."""
+    import time
+    n = 2048
+    rate, nxt, _ = synth.make("d2", n, np.float64, seed=8)
+    er, en, _ = _expect(rate, nxt)
+    times = []
+    for i in range(4):
+        gr, gn = rate.copy(), nxt.copy()
+        t0 = time.perf_counter()
+        engine.solve_multi(gr, gn, devices=[0, 0])
+        times.append(time.perf_counter() - t0)
+        assert_bits_equal(gr, er, "rate, call %d" % i)
+        assert_bits_equal(gn, en, "next, call %d" % i)
+        if i == 1:                         # another key in between: different shape and field set
+            small, _, _ = synth.make("d1", 256, np.float32, seed=3)
+            es = small.copy()
+            oracle.relax(es)
+            engine.solve_multi(small, devices=[0, 0, 0])
+            assert_bits_equal(small, es, "the other key")
+    # a handle solve of the same matrix, device resident upload/download included, for scale
+    with engine.DeviceMatrix(n, np.float64, with_next=True, devices=[0, 0]) as dm:
+        t0 = time.perf_counter()
+        dm.upload(rate, nxt)
+        dm.solve()
+        dm.download()
+        t_handle = time.perf_counter() - t0
+    assert min(times[1:]) < 1.5 * t_handle, (times, t_handle)
+
+
+def test_config4_n16384_p8_partitioned_equals_the_whole_oracle_solve():
+    """BASELINE config 4 at its own size: N = 16384 f32, P = 8 row partitions (logical: one GPU here),
+    rates + next-hops through fwx_solve_multi_f32, on both engines -- against the committed digests
+    of the WHOLE CPU-oracle solve of this matrix (tests/golden/config4_n16384_digests.json, made by
+    tests/golden/make_config4_digests.py: 270 s + 205 s of oracle on the GPU box's host cores)."""
+    from helpers import digest, load_golden
+    gold = load_golden("config4_n16384_digests.json")
+    n = gold["n"]
+    rate, nxt = synth.d1_uniform(n, np.float32, synth.BASE_SEED + 3)
+    for eng in (engine.FWX_ENGINE_FUSED, engine.FWX_ENGINE_PERK):
+        gr, gn = rate.copy(), nxt.copy()
+        u = engine.solve_multi(gr, gn, devices=[0] * 8, engine=eng, count_updates=True)
+        assert digest(gr) == gold["rate_digest"], "rates, engine %d" % eng
+        assert digest(gn) == gold["next_digest"], "next-hops, engine %d" % eng
+        assert u == gold["U"]
+    gr = rate.copy()
+    engine.solve_multi(gr, devices=[0] * 8)                     # rates only: max-form kernels on slabs
+    assert digest(gr) == gold["rate_digest"]
+
+
+def test_config5_n32768_p8_partitioned_with_next_hops_and_path_lengths():
+    """BASELINE config 5 as SURVEY.md 8d states it: N = 32768 f32, rates + next + hops, P = 8 row
+    partitions (logical).  Oracle parity on a mid-solve pivot slice taken from the partitioned state;
+    monotonicity; 10^6 sampled best-rate paths (every walk ends at dst, its length is hops[src][dst],
+    the product of the INPUT edge rates along it is the solved rate to fp32 rounding); then the same
+    matrix through a traced partitioned handle: same bits, and the reference's exact `_path` lists
+    for a sample, rebuilt from the slab-local trace, have the stored length and rate."""
+    from helpers import dev, host
+    n, P = 32768, 8
+    rate0, next0 = synth.d1_uniform(n, np.float32, synth.BASE_SEED + 4)
+    hops0 = (next0 >= 0).astype(np.int32)
+    with engine.DeviceMatrix(n, np.float32, with_next=True, with_hops=True, devices=[0] * P) as dm:
+        dm.upload(rate0, next0, hops0)
+        dm.solve(k_begin=0, k_end=4096)
+        er, en, eh = dm.download()
+        oracle.relax_mt(er, en, 4096, 4098, hops=eh)             # the oracle continues from the GPU state
+        dm.solve(k_begin=4096, k_end=4098)
+        gr, gn, gh = dm.download()
+        assert_bits_equal(gr, er, "rate after the oracle slice")
+        assert_bits_equal(gn, en, "next after the oracle slice")
+        assert_bits_equal(gh, eh, "hops after the oracle slice")
+        del er, en, eh, gr, gn, gh
+        dm.solve(k_begin=4098, k_end=n)
+        rate, nxt, hops = dm.download()
+    assert bool((rate >= rate0).all())
+    rnd = np.random.default_rng(7)
+    src = rnd.integers(0, n, 1000000).astype(np.int32)
+    dst = rnd.integers(0, n, 1000000).astype(np.int32)
+    d_next, d_rate0 = dev(nxt), dev(rate0)
+    ln, prod, _ = engine.dev_follow_paths(d_next, dev(src), dev(dst), edge_rate_t=d_rate0)
+    ln, prod = host(ln), host(prod)
+    del d_next, d_rate0
+    same = src == dst
+    assert bool((ln[same] == 0).all()) and bool((ln[~same] >= 1).all())
+    assert np.array_equal(ln, hops[src, dst]), "walk length == hops"
+    solved = rate[src, dst].astype(np.float64)
+    rel = (np.abs(prod - solved) / np.maximum(solved, 1e-30))[~same]
+    assert float(rel.max()) < 2e-5, float(rel.max())
+    # the traced, partitioned solve of the same input: same bits; exact lists through the slab trace
+    with engine.DeviceMatrix(n, np.float32, with_next=True, devices=[0] * P) as dm:
+        dm.enable_path_log()
+        dm.upload(rate0, next0)
+        dm.solve()
+        tr, tn, _ = dm.download()
+        assert_bits_equal(tr, rate, "traced partitioned rates vs the ranged solve")
+        assert_bits_equal(tn, nxt, "traced partitioned next-hops")
+        del tr, tn
+        q = 4000
+        lists = dm.query_exact_batch(src[:q], dst[:q], cap=256)
+    for i in range(q):
+        s, d, path = int(src[i]), int(dst[i]), lists[i]
+        assert len(path) == hops[s, d]
+        if s == d:
+            assert path == []
+            continue
+        assert path[-1] == d
+        p, cur = 1.0, s
+        for v in path:
+            p *= float(rate0[cur, v])
+            cur = v
+        assert abs(p - float(rate[s, d])) <= 2e-5 * float(rate[s, d])
