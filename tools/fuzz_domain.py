@@ -12,6 +12,11 @@ import time
 
 import numpy as np
 
+if os.environ.get("FUZZ_IMPORT_TORCH") == "1":
+    # torch FIRST: libfwx then binds to the HIP runtime bundled with the torch wheel (what every Python
+    # caller got in rounds 1-2, and what floydwarshall_amd.dist still gets).  Default: no torch in the
+    # process, libfwx on the runtime it was built against.
+    import torch  # noqa: F401
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))

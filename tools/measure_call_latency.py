@@ -9,7 +9,6 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-os.environ["FWX_NO_TORCH"] = "1"
 from floydwarshall_amd import engine, synth  # noqa: E402
 
 for dt in (np.float64, np.float32):

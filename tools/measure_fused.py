@@ -10,7 +10,6 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-os.environ["FWX_NO_TORCH"] = "1"
 from floydwarshall_amd import engine, hip, synth  # noqa: E402
 
 

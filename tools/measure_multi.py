@@ -11,7 +11,6 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-os.environ["FWX_NO_TORCH"] = "1"
 from floydwarshall_amd import engine, synth  # noqa: E402
 
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 16384
