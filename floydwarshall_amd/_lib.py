@@ -85,6 +85,9 @@ SIGNATURES = {
     "fwx_matrix_destroy": (ctypes.c_int, [c_vp]),
     "fwx_matrix_keep_input": (ctypes.c_int, [c_vp]),
     "fwx_matrix_patch_input": (ctypes.c_int, [c_vp, c_i32, c_vp, c_vp, c_vp, c_vp]),
+    "fwx_matrix_enable_resume": (ctypes.c_int, [c_vp, c_i32]),
+    "fwx_matrix_resolve": (ctypes.c_int, [c_vp, c_i32, c_vp, c_vp, c_vp, c_vp, ctypes.POINTER(FwxOpts),
+                                          ctypes.POINTER(c_i32)]),
     "fwx_matrix_enable_path_log": (ctypes.c_int, [c_vp]),
     "fwx_matrix_path_log_count": (ctypes.c_int, [c_vp, ctypes.POINTER(ctypes.c_uint64)]),
     "fwx_matrix_query_exact": (ctypes.c_int, [c_vp, c_i32, c_i32, ctypes.POINTER(ctypes.c_double),

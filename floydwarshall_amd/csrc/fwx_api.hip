@@ -88,7 +88,7 @@ static int env_threshold(const char *name, int dflt)
 template <typename T>
 int fused_range(T *rate, int32_t *next, int32_t *hops, int n, int k_begin, int k_end, void *ws,
                 unsigned long long *d_updates, hipStream_t s, fwx::PathLog plog, bool nonneg,
-                SideStream *kept_side = nullptr)
+                SideStream *kept_side = nullptr, Resume *rec = nullptr)
 {
     char *p = (char *)ws;
     const int ld = (n + 3) & ~3;
@@ -103,6 +103,33 @@ int fused_range(T *rate, int32_t *next, int32_t *hops, int n, int k_begin, int k
         for (int b = 0; b < 2; ++b) { chtbuf[b] = (int32_t *)p; p += (size_t)FWX_FUSED_B * ld * sizeof(int32_t); }
     }
     if (k_end <= k_begin) return FWX_OK;
+    // Resumable handle: every pass writes its panels to their place in the all-pivot arrays (row k of
+    // each = pivot k) instead of a ping-pong buffer, and the state is copied at the checkpoint pivots.
+    if (rec && k_begin % FWX_FUSED_B) rec = nullptr;      // passes must start on multiples of 64
+    auto panel_set = [&](int k0, int b) {
+        if (!rec) return;
+        wbuf[b] = (T *)rec->w + (size_t)k0 * n;
+        ctbuf[b] = (T *)rec->ct + (size_t)k0 * ld;
+        cntbuf[b] = rec->cnt ? rec->cnt + (size_t)k0 * ld : nullptr;
+        whbuf[b] = rec->wh ? rec->wh + (size_t)k0 * n : nullptr;
+        chtbuf[b] = rec->cht ? rec->cht + (size_t)k0 * ld : nullptr;
+    };
+    auto checkpoint = [&](int k0) -> int {        // the state at the START of step k0, if it is one
+        if (!rec) return FWX_OK;
+        for (size_t c = 0; c < rec->pivot.size(); ++c) {
+            if (rec->pivot[c] != k0) continue;
+            const size_t nn = (size_t)n * n;
+            FWX_HIP(hipMemcpyAsync(rec->rate[c], rate, nn * sizeof(T), hipMemcpyDeviceToDevice, s));
+            if (next) FWX_HIP(hipMemcpyAsync(rec->next[c], next, nn * 4, hipMemcpyDeviceToDevice, s));
+            if (hops) FWX_HIP(hipMemcpyAsync(rec->hops[c], hops, nn * 4, hipMemcpyDeviceToDevice, s));
+            if (plog.last) {
+                FWX_HIP(hipMemcpyAsync(rec->last[c], plog.last, nn * 4, hipMemcpyDeviceToDevice, s));
+                FWX_HIP(hipMemcpyAsync(rec->at_col[c], plog.at_col, nn * 4, hipMemcpyDeviceToDevice, s));
+                FWX_HIP(hipMemcpyAsync(rec->at_row[c], plog.at_row, nn * 4, hipMemcpyDeviceToDevice, s));
+            }
+        }
+        return FWX_OK;
+    };
     SideStream local_side;
     SideStream &side = kept_side ? *kept_side : local_side;
     if (!side.s) {
@@ -118,10 +145,12 @@ int fused_range(T *rate, int32_t *next, int32_t *hops, int n, int k_begin, int k
     a.plog = plog;         // path trace: kept by all three kernels of a pass (needs next)
     a.hops = hops;         // hops: carried by the panels, written by the main kernel (needs next)
     auto bind = [&](int k0, int bt, int bi) {       // pass (k0, bt) reads / writes buffer set bi
+        panel_set(k0, bi);
         a.k0 = k0; a.bt = bt; a.w = wbuf[bi]; a.wh = whbuf[bi];
         a.ct = ctbuf[bi]; a.cnt = next ? cntbuf[bi] : nullptr; a.cht = chtbuf[bi];
     };
     auto rowpanel = [&](int k0, int bt, int bi, hipStream_t st) {
+        panel_set(k0, bi);
         return fwx::launch_fused_panel<T>(rate + (size_t)k0 * n, n, k0, bt, wbuf[bi], st,
                                           plog_rows(plog, (size_t)k0 * n),
                                           hops ? hops + (size_t)k0 * n : nullptr, whbuf[bi]);
@@ -150,6 +179,9 @@ int fused_range(T *rate, int32_t *next, int32_t *hops, int n, int k_begin, int k
     for (int k0 = k_begin; k0 < k_end; k0 += FWX_FUSED_B, bi ^= 1) {
         const int bt = k_end - k0 < FWX_FUSED_B ? k_end - k0 : FWX_FUSED_B;
         const int k1 = k0 + bt;
+        // everything queued on `s` so far (the previous pass, whose side chain `s` has waited for)
+        // precedes this copy; this pass's panels only READ the matrix
+        if (k0 > k_begin) { const int rc = checkpoint(k0); if (rc) return rc; }
         bind(k0, bt, bi);
         if (!col_ready) FWX_HIP(fwx::launch_fused_colpanel<T>(a, s));
         col_ready = false;
@@ -485,6 +517,7 @@ int matrix_solve_typed(fwx_matrix *m, const Opts &op, unsigned long long *upd, h
                              d_flag, s, route, nonneg, m->flag ? m : nullptr)))
         return rc;
     if (route == ROUTE_SMALL) {
+        if (m->resume) { m->resume->valid_upto = 0; m->resume->state_at = -1; }
         FWX_HIP(fwx::launch_small_solve<T>(r, m->next, m->hops, n, op.k_begin, op.k_end, upd,
                                            m->plog, s));
         return FWX_OK;
@@ -515,11 +548,26 @@ int matrix_solve_typed(fwx_matrix *m, const Opts &op, unsigned long long *upd, h
             if ((rc = cx->reserve(CallCtx::WS, need, &ws))) return rc;
             side = &cx->side;
         }
-        rc = fused_range<T>(r, m->next, m->hops, n, op.k_begin, op.k_end, ws, upd, s, m->plog, nonneg, side);
+        // a resumable handle records the panels of every pass and the checkpoints it walks over; what
+        // it holds beyond k_begin belongs to an older solve until this one has finished
+        // a resumable handle records the panels of every pass and the checkpoints it walks over -- if
+        // this solve continues the kept input's own solve (the arrays are that input at time k_begin)
+        Resume *rec = nullptr;
+        if (m->flag && m->resume) {
+            Resume &R = *m->resume;
+            const bool chain = m->kept_valid && R.state_at == op.k_begin && op.k_begin % FWX_FUSED_B == 0 &&
+                               op.k_begin <= R.valid_upto;
+            R.valid_upto = chain ? op.k_begin : 0;      // beyond k_begin: an older solve's, until this one ends
+            R.state_at = -1;
+            if (chain) rec = &R;
+        }
+        rc = fused_range<T>(r, m->next, m->hops, n, op.k_begin, op.k_end, ws, upd, s, m->plog, nonneg, side, rec);
         if (rc) return rc;
         FWX_HIP(hipStreamSynchronize(s));
+        if (rec) rec->valid_upto = rec->state_at = op.k_end;
         return FWX_OK;
     }
+    if (m->resume) { m->resume->valid_upto = 0; m->resume->state_at = -1; }   // nothing was recorded
     return relax_range<T>(r, m->next, m->hops, n, n, 0, r + (size_t)op.k_begin * n,
                           m->hops ? m->hops + (size_t)op.k_begin * n : nullptr, n, op.k_begin,
                           op.k_end, op.serpentine, upd, s, m->plog, 0, 0,
@@ -528,17 +576,21 @@ int matrix_solve_typed(fwx_matrix *m, const Opts &op, unsigned long long *upd, h
 
 // Solve with the path trace (PathLog): one pass.  `last` starts at -1 everywhere; the kernels set
 // it on every successful relaxation and copy its column k / row k into at_col / at_row at step k.
-int logged_solve(fwx_matrix *m, const Opts &op_in, hipStream_t s)
+// resumed: the arrays AND the trace hold a restored checkpoint at time op.k_begin
+// (fwx_matrix_resolve); the solve continues from there to the end.
+int logged_solve(fwx_matrix *m, const Opts &op_in, hipStream_t s, bool resumed = false)
 {
-    if (op_in.k_begin != 0 || op_in.k_end != m->n)
+    if ((!resumed && op_in.k_begin != 0) || op_in.k_end != m->n)
         return FWX_ERR_UNSUPPORTED;              // the trace covers whole solves
-    if (!m->fresh) return FWX_ERR_INVALID;       // a traced solve starts from an uploaded input
+    if (!resumed && !m->fresh) return FWX_ERR_INVALID;   // a traced solve starts from an uploaded input
     const Opts &op = op_in;                      // engines as for any matrix: single launch, fused
                                                  //   (no hops), per-k -- all three keep the trace
     const size_t nn = (size_t)m->n * (size_t)m->n;
-    FWX_HIP(hipMemsetAsync(m->plog.last, 0xFF, nn * 4, s));
-    FWX_HIP(hipMemsetAsync(m->plog.at_col, 0xFF, nn * 4, s));
-    FWX_HIP(hipMemsetAsync(m->plog.at_row, 0xFF, nn * 4, s));
+    if (!resumed) {
+        FWX_HIP(hipMemsetAsync(m->plog.last, 0xFF, nn * 4, s));
+        FWX_HIP(hipMemsetAsync(m->plog.at_col, 0xFF, nn * 4, s));
+        FWX_HIP(hipMemsetAsync(m->plog.at_row, 0xFF, nn * 4, s));
+    }
     unsigned long long *upd = op.updates_out ? m->upd : nullptr;   // counting costs registers
     if (upd) FWX_HIP(hipMemsetAsync(upd, 0, FWX_UPDATE_SHARDS * 8, s));
     m->fresh = 0;
@@ -626,6 +678,115 @@ __global__ __launch_bounds__(64) void exact_paths_kernel(fwx::PathLog plog, cons
     }
     len_out[qi] = len;
 }
+// Replay of patched input entries through the pivots [0, c) they were not part of (Resume in
+// fwx_internal.h).  One wave per entry (i, j): lane l of chunk q forms the candidate of pivot
+// k = 64 q + l from the stored panels, c[k] = ct[k][i] * w[k][j] -- the very operands step k used --
+// and the wave folds the chunk at once: on the reference's domain the strict fold of Algorithms.hs:55
+// ends at max(x, max_k c[k]) (a NaN candidate never wins), and its LAST update is the FIRST pivot that
+// attains that maximum, which gives next = cnt[k*][i], hops = cht[k*][i] + wh[k*][j], last = k*.
+// Checkpoints are multiples of 64, so the value at every checkpoint <= c falls on a chunk boundary
+// and is written into that checkpoint; the value at time c goes to the live arrays.
+struct ReplayTargets {
+    enum { MAX = 20 };
+    int count;
+    int pivot[MAX];
+    void *rate[MAX];
+    int32_t *next[MAX], *hops[MAX], *last[MAX];
+};
+
+template <typename T>
+__global__ __launch_bounds__(64) void replay_entries_kernel(const int64_t *index, int n, int ld, int c,
+                                                            const T *rate0, const int32_t *next0,
+                                                            const int32_t *hops0, const T *w, const T *ct,
+                                                            const int32_t *cnt, const int32_t *wh,
+                                                            const int32_t *cht, ReplayTargets tg)
+{
+    const int64_t idx = index[blockIdx.x];
+    const int i = (int)(idx / n), j = (int)(idx % n), lane = threadIdx.x;
+    T x = rate0[idx];
+    int nx = next0 ? next0[idx] : -1, hp = hops0 ? hops0[idx] : 0, last = -1;
+    int t = 0;
+    for (int k0 = 0; k0 <= c; k0 += 64) {
+        while (t < tg.count && tg.pivot[t] == k0) {
+            if (lane == 0) {
+                ((T *)tg.rate[t])[idx] = x;
+                if (tg.next[t]) tg.next[t][idx] = nx;
+                if (tg.hops[t]) tg.hops[t][idx] = hp;
+                if (tg.last[t]) tg.last[t][idx] = last;
+            }
+            ++t;
+        }
+        if (k0 == c || i == j) continue;                 // a diagonal entry is never a target (:54)
+        const int k = k0 + lane;
+        T v = ct[(size_t)k * ld + i] * w[(size_t)k * n + j];
+        int arg = k;
+        if (!(v == v)) v = -INFINITY;                    // NaN (inf * 0) never wins a strict compare
+        for (int d = 1; d < 64; d <<= 1) {               // max, earliest pivot on ties
+            const T ov = __shfl_xor(v, d);
+            const int oa = __shfl_xor(arg, d);
+            if (ov > v || (ov == v && oa < arg)) { v = ov; arg = oa; }
+        }
+        if (x < v) {
+            x = v;
+            last = arg;
+            if (cnt) nx = cnt[(size_t)arg * ld + i];
+            if (cht) hp = cht[(size_t)arg * ld + i] + wh[(size_t)arg * n + j];
+        }
+    }
+}
+
+void resume_free(Resume *r)
+{
+    if (!r) return;
+    auto drop = [](void *p) { if (p) (void)hipFree(p); };
+    for (void *p : r->rate) drop(p);
+    for (auto *v : {&r->next, &r->hops, &r->last, &r->at_col, &r->at_row})
+        for (int32_t *p : *v) drop(p);
+    drop(r->w); drop(r->ct); drop(r->cnt); drop(r->wh); drop(r->cht); drop(r->idx);
+    delete r;
+}
+
+template <typename T>
+int resolve_typed(fwx_matrix *m, int32_t count, const int64_t *index, int c_idx, hipStream_t s)
+{
+    Resume &R = *m->resume;
+    const int n = m->n, c = R.pivot[(size_t)c_idx];
+    const size_t nn = (size_t)n * n;
+    // the state at the start of step c ...
+    FWX_HIP(hipMemcpyAsync(m->rate, R.rate[(size_t)c_idx], nn * sizeof(T), hipMemcpyDeviceToDevice, s));
+    if (m->next) FWX_HIP(hipMemcpyAsync(m->next, R.next[(size_t)c_idx], nn * 4, hipMemcpyDeviceToDevice, s));
+    if (m->hops) FWX_HIP(hipMemcpyAsync(m->hops, R.hops[(size_t)c_idx], nn * 4, hipMemcpyDeviceToDevice, s));
+    if (m->plog.last) {
+        FWX_HIP(hipMemcpyAsync(m->plog.last, R.last[(size_t)c_idx], nn * 4, hipMemcpyDeviceToDevice, s));
+        FWX_HIP(hipMemcpyAsync(m->plog.at_col, R.at_col[(size_t)c_idx], nn * 4, hipMemcpyDeviceToDevice, s));
+        FWX_HIP(hipMemcpyAsync(m->plog.at_row, R.at_row[(size_t)c_idx], nn * 4, hipMemcpyDeviceToDevice, s));
+    }
+    // ... except the patched entries, replayed from the patched input through the stored panels into
+    // the live arrays and into every checkpoint up to c (which thereby stay valid for the new input)
+    ReplayTargets tg;
+    memset(&tg, 0, sizeof(tg));
+    for (int q = 0; q <= c_idx; ++q) {
+        const int t = tg.count++;
+        tg.pivot[t] = R.pivot[(size_t)q];
+        tg.rate[t] = R.rate[(size_t)q];
+        tg.next[t] = m->next ? R.next[(size_t)q] : nullptr;
+        tg.hops[t] = m->hops ? R.hops[(size_t)q] : nullptr;
+        tg.last[t] = m->plog.last ? R.last[(size_t)q] : nullptr;
+    }
+    {
+        const int t = tg.count++;
+        tg.pivot[t] = c;
+        tg.rate[t] = m->rate; tg.next[t] = m->next; tg.hops[t] = m->hops; tg.last[t] = m->plog.last;
+    }
+    int64_t *d_index = R.idx;
+    FWX_HIP(hipMemcpyAsync(d_index, index, (size_t)count * 8, hipMemcpyHostToDevice, s));
+    hipLaunchKernelGGL(replay_entries_kernel<T>, dim3((unsigned)count), dim3(64), 0, s, d_index, n, R.ld, c,
+                       (const T *)m->rate0, m->next ? m->next0 : nullptr, m->hops ? m->hops0 : nullptr,
+                       (const T *)R.w, (const T *)R.ct, m->next ? R.cnt : nullptr, R.wh, R.cht, tg);
+    FWX_HIP(hipGetLastError());
+    return FWX_OK;
+}
+
 }  // namespace
 
 extern "C" {
@@ -770,6 +931,8 @@ int fwx_matrix_destroy(fwx_matrix *m)
         if (m->rate0) (void)hipFree(m->rate0);
         if (m->hops0) (void)hipFree(m->hops0);
         if (m->walk) (void)hipFree(m->walk);
+        resume_free(m->resume);
+        m->resume = nullptr;
         if (m->ws) (void)hipFree(m->ws);
         if (m->flag) (void)hipFree(m->flag);
         delete m;
@@ -792,6 +955,7 @@ int fwx_matrix_upload(fwx_matrix *m, const void *rate, const int32_t *next, cons
         // (a caller that keeps its pristine input in HBM, e.g. the benchmark)
         hipStream_t s = m->stream;
         m->dom_known = 0;                  // a new input: the domain check has to look at it
+        if (m->resume) m->resume->valid_upto = 0;   // ... and nothing of the old solve can be resumed
         FWX_HIP(hipMemcpyAsync(m->rate, rate, nn * es, hipMemcpyDefault, s));
         if (m->next) FWX_HIP(hipMemcpyAsync(m->next, next, nn * 4, hipMemcpyDefault, s));
         if (m->hops) FWX_HIP(hipMemcpyAsync(m->hops, hops, nn * 4, hipMemcpyDefault, s));
@@ -807,6 +971,7 @@ int fwx_matrix_upload(fwx_matrix *m, const void *rate, const int32_t *next, cons
         }
         FWX_HIP(hipStreamSynchronize(s));
         m->fresh = 1;
+        if (m->resume) m->resume->state_at = m->keep ? 0 : -1;
         return FWX_OK;
     });
 }
@@ -880,6 +1045,7 @@ int fwx_matrix_patch_input(fwx_matrix *m, int32_t count, const int64_t *index, c
         if (rc) return rc;
         const size_t nn = (size_t)nn64, es = m->dtype == FWX_F64 ? 8 : 4;
         hipStream_t s = m->stream;
+        if (m->resume) m->resume->valid_upto = 0;   // the kept input changes without a replay
         // the remembered domain answer survives a patch whose values are themselves inside the domain
         // (rate >= +0 and not NaN; a non-zero rate comes with a next-hop >= 0); anything else, or a
         // non-zero rate patched in without its next-hop, sends the next solve through the check again
@@ -906,6 +1072,136 @@ int fwx_matrix_patch_input(fwx_matrix *m, int32_t count, const int64_t *index, c
         FWX_HIP(hipStreamSynchronize(s));
         m->fresh = 1;
         m->rec_ready = 0;
+        if (m->resume) m->resume->state_at = 0;      // the patched kept input, unsolved
+        return FWX_OK;
+    });
+}
+
+int fwx_matrix_enable_resume(fwx_matrix *m, int32_t checkpoints)
+{
+    return fwxi::guarded([&]() -> int {
+        if (!m || checkpoints < 1 || checkpoints > FWX_MAX_CHECKPOINTS) return FWX_ERR_INVALID;
+        if (m->multi) return FWX_ERR_UNSUPPORTED;
+        if (m->resume) return FWX_ERR_INVALID;
+        if (!m->keep) return FWX_ERR_INVALID;                // replays start from the kept input
+        const int n = m->n;
+        const bool f64 = m->dtype == FWX_F64;
+        // resumable = the fused engine can run the handle's arrays (fwx.h fwx_engine)
+        if (n <= kSmallSolveAutoMax || n % (f64 ? 2 : 4) != 0) return FWX_ERR_UNSUPPORTED;
+        DeviceGuard g;
+        int rc = g.enter(m->device);
+        if (rc) return rc;
+        fail_point();
+        Resume *R = new Resume();
+        m->resume = R;            // owned by the handle from here on: destroy releases a partial set
+        const size_t es = f64 ? 8 : 4, nn = (size_t)n * n;
+        R->ld = (n + 3) & ~3;
+        // checkpoints at the multiples of 64 closest to q * n / (checkpoints + 1)
+        for (int q = 1; q <= checkpoints; ++q) {
+            int p = (int)(((int64_t)n * q / (checkpoints + 1) + 32) / 64 * 64);
+            if (p <= 0 || p >= n || (!R->pivot.empty() && p <= R->pivot.back())) continue;
+            R->pivot.push_back(p);
+        }
+        R->count = (int)R->pivot.size();
+        auto alloc = [&](void **p, size_t bytes) -> int { FWX_HIP(hipMalloc(p, bytes)); return FWX_OK; };
+        for (int q = 0; q < R->count; ++q) {
+            void *p = nullptr;
+            if ((rc = alloc(&p, nn * es))) return rc;
+            R->rate.push_back(p);
+            if (m->next) { if ((rc = alloc(&p, nn * 4))) return rc; R->next.push_back((int32_t *)p); }
+            if (m->hops) { if ((rc = alloc(&p, nn * 4))) return rc; R->hops.push_back((int32_t *)p); }
+            if (m->plog.last)
+                for (auto *v : {&R->last, &R->at_col, &R->at_row}) {
+                    if ((rc = alloc(&p, nn * 4))) return rc;
+                    v->push_back((int32_t *)p);
+                }
+        }
+        const size_t pan = (size_t)n * R->ld;
+        if ((rc = alloc(&R->w, nn * es)) || (rc = alloc(&R->ct, pan * es))) return rc;
+        if (m->next && (rc = alloc((void **)&R->cnt, pan * 4))) return rc;
+        if (m->hops && ((rc = alloc((void **)&R->wh, nn * 4)) || (rc = alloc((void **)&R->cht, pan * 4)))) return rc;
+        if ((rc = alloc((void **)&R->idx, (size_t)FWX_MAX_PATCH * 8))) return rc;
+        R->state_at = (m->fresh && m->kept_valid) ? 0 : -1;
+        return R->count;
+    });
+}
+
+int fwx_matrix_resolve(fwx_matrix *m, int32_t count, const int64_t *index, const void *rate_vals,
+                       const int32_t *next_vals, const int32_t *hops_vals, const fwx_opts *opts,
+                       int32_t *resumed_from)
+{
+    return fwxi::guarded([&]() -> int {
+        if (resumed_from) *resumed_from = 0;
+        if (!m || count < 0 || count > FWX_MAX_PATCH || (count > 0 && (!index || !rate_vals)))
+            return FWX_ERR_INVALID;
+        if (!m->keep || !m->kept_valid) return FWX_ERR_INVALID;
+        if ((next_vals && !m->next) || (hops_vals && !m->hops)) return FWX_ERR_INVALID;
+        const int64_t nn64 = (int64_t)m->n * m->n;
+        int64_t lowest = m->n;                       // min over the patched entries' indices
+        for (int32_t q = 0; q < count; ++q) {
+            if (index[q] < 0 || index[q] >= nn64) return FWX_ERR_INVALID;
+            const int64_t i = index[q] / m->n, j = index[q] % m->n;
+            lowest = i < lowest ? i : lowest;
+            lowest = j < lowest ? j : lowest;
+        }
+        Opts op;
+        int rc = read_opts(opts, m->n, op);
+        if (rc) return rc;
+        // the checkpoint to resume from: the last one at or before `lowest` that still belongs to the
+        // solve of the kept input -- on a handle that records them, on the reference's domain
+        // (the fused engine ran and will run again), for a whole-range uncounted solve
+        int c_idx = -1;
+        Resume *R = m->multi ? nullptr : m->resume;
+        if (R && count > 0 && m->dom_known && !op.updates_out && !op.has_stream && op.k_begin == 0 &&
+            op.k_end == m->n && op.engine != FWX_ENGINE_PERK)
+            for (int q = 0; q < R->count; ++q)
+                if (R->pivot[(size_t)q] <= lowest && R->pivot[(size_t)q] <= R->valid_upto) c_idx = q;
+        if (c_idx >= 0) {
+            // are the patched values inside the domain?  (fwx_matrix_patch_input keeps dom_known only then)
+            bool ok = true;
+            for (int32_t q = 0; q < count && ok; ++q) {
+                const double r = m->dtype == FWX_F64 ? ((const double *)rate_vals)[q] : (double)((const float *)rate_vals)[q];
+                ok = !(r != r) && !std::signbit(r);
+                if (ok && m->next && r != 0.0) ok = next_vals && next_vals[q] >= 0;
+            }
+            const int want = m->next ? 3 : 1;
+            if (!ok || (m->dom_bits & want) != want) c_idx = -1;
+        }
+        if (c_idx < 0) {
+            // nothing to resume from: the patched input from pivot 0 (which records anew)
+            if ((rc = fwx_matrix_patch_input(m, count, index, rate_vals, next_vals, hops_vals))) return rc;
+            return fwx_matrix_solve(m, opts);
+        }
+        DeviceGuard g;
+        if ((rc = g.enter(m->device))) return rc;
+        hipStream_t s = m->stream;
+        const size_t es = m->dtype == FWX_F64 ? 8 : 4;
+        const int keep_valid = R->valid_upto;
+        R->valid_upto = 0;                           // until the resumed solve has finished
+        for (int32_t q = 0; q < count; ++q) {        // the kept input first: the replay reads it
+            const size_t off = (size_t)index[q];
+            FWX_HIP(hipMemcpyAsync((char *)m->rate0 + off * es, (const char *)rate_vals + (size_t)q * es, es,
+                                   hipMemcpyHostToDevice, s));
+            if (next_vals) FWX_HIP(hipMemcpyAsync(m->next0 + off, next_vals + q, 4, hipMemcpyHostToDevice, s));
+            if (hops_vals) FWX_HIP(hipMemcpyAsync(m->hops0 + off, hops_vals + q, 4, hipMemcpyHostToDevice, s));
+        }
+        rc = m->dtype == FWX_F64 ? resolve_typed<double>(m, count, index, c_idx, s)
+                                 : resolve_typed<float>(m, count, index, c_idx, s);
+        if (rc) return rc;
+        m->fresh = 0;
+        m->rec_ready = 0;
+        R->valid_upto = keep_valid;                  // panels < c and checkpoints <= c hold again
+        op.k_begin = R->pivot[(size_t)c_idx];
+        R->state_at = op.k_begin;                    // the live arrays: the NEW kept input at time c
+        if (m->plog.last) {
+            rc = logged_solve(m, op, s, true);
+        } else {
+            rc = m->dtype == FWX_F64 ? matrix_solve_typed<double>(m, op, nullptr, s)
+                                     : matrix_solve_typed<float>(m, op, nullptr, s);
+            if (!rc) FWX_HIP(hipStreamSynchronize(s));
+        }
+        if (rc) { R->valid_upto = 0; return rc; }
+        if (resumed_from) *resumed_from = op.k_begin;
         return FWX_OK;
     });
 }

@@ -413,6 +413,31 @@ inline fwx::PathLog plog_rows(fwx::PathLog p, size_t off)
 
 struct MultiState;   // fwx_multi.hip: the partitions of a multi-device handle
 
+// Resumable solves (fwx_matrix_enable_resume): what a handle keeps so
+// that a solve of a PATCHED input can start at a stored state instead of at pivot 0.
+//   panels      the time-k snapshots the fused engine produces anyway, for ALL pivots instead of two
+//               ping-pong buffers: w[k][j] = row k at time k, ct[k][i] = column k at time k (NaN at
+//               i == k), cnt / wh / cht likewise for next-hops and hops
+//   checkpoint  a copy of the state (rate, next, hops, the three trace arrays) at the START of step
+//               pivot[c], a multiple of 64
+// An input entry (i,j) is an OPERAND only in steps i and j, so patched entries cannot influence any
+// other entry before step m = min over their indices: the state at a checkpoint <= m is the stored
+// one except for the patched entries themselves, and those are replayed through the pivots before
+// the checkpoint from the stored panels (their operands (i,k), (k,j), k < m, are not patched).
+struct Resume {
+    int count = 0, ld = 0;
+    std::vector<int> pivot;                        // ascending, each a multiple of 64 in (0, n)
+    std::vector<void *> rate;
+    std::vector<int32_t *> next, hops, last, at_col, at_row;
+    void *w = nullptr, *ct = nullptr;              // n x n, n x ld elements of the handle's dtype
+    int32_t *cnt = nullptr, *wh = nullptr, *cht = nullptr;
+    int64_t *idx = nullptr;                        // FWX_MAX_PATCH entry indices of a resolve, on the device
+    int valid_upto = 0;    // panels of pivots [0, valid_upto) and checkpoints with pivot <= valid_upto
+                           // belong to the solve of the CURRENT kept input (0: nothing to resume from)
+    int state_at = -1;     // the live arrays hold the kept input brought to the start of step state_at
+                           // (0 right after an upload / patch; -1: unknown, e.g. solved twice over)
+};
+
 }  // namespace fwxi
 
 struct fwx_matrix {
@@ -446,6 +471,7 @@ struct fwx_matrix {
                            // values are themselves inside the domain keeps a "3".
     fwxi::MultiState *multi;   // non-null: a row-partitioned handle (fwx_matrix_create_multi); the
                            // single-device arrays above are then unused
+    fwxi::Resume *resume;  // non-null: panels of all pivots + state checkpoints are kept (f3)
 };
 
 

@@ -85,6 +85,19 @@ int64_t fwxh_session_solves(const fwxh_session *s) { return s ? s->impl.solves()
 
 int64_t fwxh_session_patched_solves(const fwxh_session *s) { return s ? s->impl.patched_solves() : -1; }
 
+int64_t fwxh_session_resumed_solves(const fwxh_session *s) { return s ? s->impl.resumed_solves() : -1; }
+
+int64_t fwxh_session_resumed_pivots(const fwxh_session *s) { return s ? s->impl.resumed_pivots() : -1; }
+
+int fwxh_session_set_checkpoints(fwxh_session *s, int32_t checkpoints)
+{
+    if (!s || checkpoints < 0 || checkpoints > FWX_MAX_CHECKPOINTS) return FWX_ERR_INVALID;
+    return fwxi::guarded([&]() -> int {
+        s->impl.set_checkpoints(checkpoints);
+        return FWX_OK;
+    });
+}
+
 int32_t fwxh_session_rate_count(const fwxh_session *s)
 {
     return s ? (int32_t)s->impl.rates().size() : -1;

@@ -87,6 +87,10 @@ public:
     int state() const { return in_sync_ ? 1 : 0; }
     int64_t solves() const { return solves_; }
     int64_t patched_solves() const { return patched_solves_; }   // ... of which from a patched kept input
+    int64_t resumed_solves() const { return resumed_solves_; }   // ... of which resumed at a checkpoint > 0
+    int64_t resumed_pivots() const { return resumed_pivots_; }   // pivots those did NOT have to run, in total
+    // checkpoints a resident matrix keeps for resumed re-solves (0 = off); takes effect with the next handle
+    void set_checkpoints(int32_t c) { checkpoints_ = c; drop_device(); solved_version_ = ~0ull; }
     const ExchRateTimes &rates() const { return rates_; }
 
     // updateRates (ProcessRequests.hs:89-102) on parsed fields; true if applied
@@ -128,6 +132,8 @@ private:
     std::vector<Patch> patches_;             // entries changed since the kept device input was current
     bool rebuild_ = true;                    // the next solve marshals from scratch
     int64_t patched_solves_ = 0;
+    int64_t resumed_solves_ = 0, resumed_pivots_ = 0;
+    int32_t checkpoints_ = 7;                // state checkpoints of a resident matrix (fwx_matrix_enable_resume)
 };
 
 }  // namespace fwxh

@@ -98,14 +98,20 @@ int Session::ensure_solved()
         for (const Patch &p : patches_) {
             idx.push_back(p.idx); rate.push_back(p.rate); next.push_back(p.next); hops.push_back(p.hops);
         }
-        int rc = fwx_matrix_patch_input(dev_, (int32_t)idx.size(), idx.data(), rate.data(), next.data(),
-                                        dev_hops_ ? hops.data() : nullptr);
-        if (!rc) rc = fwx_matrix_solve(dev_, nullptr);           // runAlgo 0: a FULL solve, on the GPU
+        // runAlgo on the patched input: from the last stored state the changed entries cannot have
+        // influenced (fwx_matrix_resolve; bit-identical to runAlgo 0), else from pivot 0
+        int32_t started = 0;
+        const int rc = fwx_matrix_resolve(dev_, (int32_t)idx.size(), idx.data(), rate.data(), next.data(),
+                                          dev_hops_ ? hops.data() : nullptr, nullptr, &started);
         if (!rc) {
             patches_.clear();
             solved_version_ = version_;
             ++solves_;
             ++patched_solves_;
+            if (started > 0) {
+                ++resumed_solves_;
+                resumed_pivots_ += started;
+            }
             return FWX_OK;
         }
         drop_device();           // whatever went wrong: marshal from scratch below
@@ -139,6 +145,16 @@ int Session::ensure_solved()
             if ((rc = fwx_matrix_enable_path_log(dev_)) || (rc = fwx_matrix_keep_input(dev_))) {
                 drop_device();
                 return rc;
+            }
+            // state checkpoints + panels, so that a re-solve after a price change can resume (f3);
+            // where the fused engine cannot run the matrix (small, odd order, partitions) it just
+            // stays a full solve
+            if (checkpoints_ > 0) {
+                rc = fwx_matrix_enable_resume(dev_, checkpoints_);
+                if (rc < 0 && rc != FWX_ERR_UNSUPPORTED) {
+                    drop_device();
+                    return rc;
+                }
             }
         }
         if ((rc = fwx_matrix_upload(dev_, m.rate.data(), m.next.data(),

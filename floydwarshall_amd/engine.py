@@ -187,6 +187,26 @@ class DeviceMatrix:
         check(lib().fwx_matrix_patch_input(self._h, len(index), _np_ptr(index), _np_ptr(rate_vals),
                                            _np_ptr(nv), _np_ptr(hv)), "fwx_matrix_patch_input")
 
+    def enable_resume(self, checkpoints=7):
+        """Keep state checkpoints + the panels of every pivot so that resolve() can resume
+        (fwx_matrix_enable_resume); returns the number of checkpoints placed."""
+        return check(lib().fwx_matrix_enable_resume(self._h, int(checkpoints)), "fwx_matrix_enable_resume")
+
+    def resolve(self, index, rate_vals, next_vals=None, hops_vals=None, **kw):
+        """patch_input + solve in one call, resuming from the last checkpoint the changed entries
+        cannot have influenced (fwx_matrix_resolve).  Returns the pivot the solve started at."""
+        index = np.ascontiguousarray(index, dtype=np.int64)
+        rate_vals = np.ascontiguousarray(rate_vals, dtype=self.dtype)
+        nv = None if next_vals is None else np.ascontiguousarray(next_vals, dtype=np.int32)
+        hv = None if hops_vals is None else np.ascontiguousarray(hops_vals, dtype=np.int32)
+        assert index.ndim == 1 and rate_vals.shape == index.shape
+        o, _u = _opts(want_updates=kw.pop("count_updates", False), **kw)   # _u: keeps updates_out alive
+        started = ctypes.c_int32(0)
+        check(lib().fwx_matrix_resolve(self._h, len(index), _np_ptr(index), _np_ptr(rate_vals), _np_ptr(nv),
+                                       _np_ptr(hv), ctypes.byref(o), ctypes.byref(started)),
+              "fwx_matrix_resolve")
+        return int(started.value)
+
     def enable_path_log(self):
         """Keep the path trace (three n x n int32 matrices, see fwx.h) so that query_exact can
         rebuild the reference's `_path` lists exactly; a traced solve() needs a fresh upload()."""

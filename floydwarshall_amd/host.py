@@ -21,6 +21,9 @@ HOST_SIGNATURES = {
     "fwxh_session_set_devices": (ctypes.c_int, [c_vp, c_i32, ctypes.POINTER(c_i32), c_i32]),
     "fwxh_session_parts": (c_i32, [c_vp]),
     "fwxh_session_patched_solves": (c_i64, [c_vp]),
+    "fwxh_session_resumed_solves": (c_i64, [c_vp]),
+    "fwxh_session_resumed_pivots": (c_i64, [c_vp]),
+    "fwxh_session_set_checkpoints": (ctypes.c_int, [c_vp, c_i32]),
     "fwxh_session_destroy": (ctypes.c_int, [c_vp]),
     "fwxh_session_state": (ctypes.c_int, [c_vp]),
     "fwxh_session_solves": (c_i64, [c_vp]),
@@ -155,6 +158,19 @@ class Session:
     @property
     def patched_solves(self):
         return hlib().fwxh_session_patched_solves(self._h)
+
+    @property
+    def resumed_solves(self):
+        """Patched solves that started at a checkpoint > 0 (fwx_matrix_resolve) instead of pivot 0."""
+        return hlib().fwxh_session_resumed_solves(self._h)
+
+    @property
+    def resumed_pivots(self):
+        return hlib().fwxh_session_resumed_pivots(self._h)
+
+    def set_checkpoints(self, checkpoints):
+        """State checkpoints the next resident matrix keeps for resumed re-solves (0 = off)."""
+        check(hlib().fwxh_session_set_checkpoints(self._h, int(checkpoints)), "fwxh_session_set_checkpoints")
 
     @property
     def state(self):

@@ -166,6 +166,35 @@ int fwx_matrix_keep_input(fwx_matrix *m);
 int fwx_matrix_patch_input(fwx_matrix *m, int32_t count, const int64_t *index, const void *rate_vals,
                            const int32_t *next_vals, const int32_t *hops_vals);
 
+/* Resume instead of re-solve (row f3, exactly).  An input entry (i,j) is an OPERAND of runAlgo only in
+ * steps i and j (Algorithms.hs:58-60: step k reads r[i][k] and r[k][j]), so changing entries cannot
+ * influence any OTHER entry before step m = the smallest index among them: up to there the old solve
+ * and the new one differ in the changed entries alone.  A resumable handle therefore keeps, from its
+ * last solve, (a) the state (rate, next, hops, path trace) at a few CHECKPOINT pivots and (b) the
+ * time-k snapshots of every pivot row and column -- the panels the fused engine produces anyway.
+ * fwx_matrix_resolve(changed entries) restores the last checkpoint c <= m, replays just the changed
+ * entries through pivots [0, c) from the stored panels (their operands there are unchanged entries),
+ * and runs pivots [c, n) only.  Every operand, product and compare is the one a from-scratch solve
+ * performs: results are bit-identical (rates, next, hops, exact `_path` lists); the saving is c / n of
+ * the solve.  The checkpoints and panels are refreshed as the resumed solve passes them.
+ *
+ * enable_resume: after create (+ enable_path_log) and keep_input, before the upload whose solve is to
+ *   be resumable; `checkpoints` in 1..FWX_MAX_CHECKPOINTS, spread evenly over the pivots on multiples
+ *   of 64; returns the number placed (n < 128 leaves room for none: 0), or FWX_ERR_UNSUPPORTED where
+ *   the fused engine cannot run the handle's arrays (n <= 64, rows not a multiple of 16 bytes,
+ *   partitioned handles).  Memory: one copy of every array per checkpoint + ~2.5 more for the panels.
+ * resolve: fwx_matrix_patch_input + fwx_matrix_solve in one call, resuming where it can.  Falls back
+ *   to exactly that pair (a full solve from the patched kept input, which records afresh) when there
+ *   is nothing to resume from: no checkpoint at or below m, the previous solve did not record (other
+ *   engine, input outside the reference's domain, a pivot range), a patch value outside the domain,
+ *   or opts asking for U, a stream, a pivot range or the per-k engine.  *resumed_from (optional)
+ *   receives the pivot the solve started at (0 = full solve).                                       */
+#define FWX_MAX_CHECKPOINTS 16
+int fwx_matrix_enable_resume(fwx_matrix *m, int32_t checkpoints);
+int fwx_matrix_resolve(fwx_matrix *m, int32_t count, const int64_t *index, const void *rate_vals,
+                       const int32_t *next_vals, const int32_t *hops_vals, const fwx_opts *opts,
+                       int32_t *resumed_from);
+
 /* Exact `_path` lists.  Following next-hops (fwx_matrix_query) yields A best path; the reference
  * keeps, per entry, the list it concatenated when the entry was last improved
  * (`_path = ikPath ++ kjPath`, Algorithms.hs:55), and under exact ties (its built-in 1.0 edges

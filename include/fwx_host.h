@@ -59,6 +59,15 @@ int64_t fwxh_session_solves(const fwxh_session *s);   /* floydWarshall runs so f
  * update between known vertices only the two changed entries travel (fwx_matrix_patch_input); the
  * solve itself is always the full runAlgo, so answers are bit-identical either way.              */
 int64_t fwxh_session_patched_solves(const fwxh_session *s);
+/* ... of which did not start at pivot 0: the resident matrix keeps state checkpoints and the panels
+ * of every pivot (fwx_matrix_enable_resume in fwx.h), and a solve after a price change between the
+ * vertices u, v resumes at the last checkpoint <= min(u, v) -- the changed entries are operands of
+ * steps u and v only (Algorithms.hs:58-60), so nothing else can differ before.  Bit-identical to
+ * runAlgo 0; resumed_pivots = the pivots those solves skipped, in total.  set_checkpoints: how many
+ * the next resident matrix keeps (default 7, 0 = never resume; drops the resident matrix).         */
+int64_t fwxh_session_resumed_solves(const fwxh_session *s);
+int64_t fwxh_session_resumed_pivots(const fwxh_session *s);
+int fwxh_session_set_checkpoints(fwxh_session *s, int32_t checkpoints);
 int32_t fwxh_session_rate_count(const fwxh_session *s);
 
 /* updateRates on parsed fields (ProcessRequests.hs:89-102): stores (src->dst, fwd) and
