@@ -71,7 +71,18 @@ template <typename T> bool fused_ok(int n, const void *rate, const int32_t *)
 // 12288: 117.0 / 117.5, 16384: 266.3 / 262.2; + trace 8192: 46.1 / 45.8, 10240: 84.6 / 83.6, 16384:
 // 316.2 / 305.0; f64 + trace 8192: 137.9 / 132.6.
 // ws: see fused_ws_bytes.
+//   double pass (rates only inside the domain -- the max-form kernels --, 64-aligned blocks, large
+//     matrices): the main kernel applies TWO passes (128 pivots) per launch, which halves the tile
+//     traffic and the per-tile overhead that kept it at 0.75 of its issue bound.  It needs the
+//     panels of both passes up front, so the look-ahead is two deep: beside main(P) -- which leaves
+//     the 128 rows and 128 columns of the NEXT pair of blocks alone -- the side stream brings
+//     exactly that cross up to date with the pair being applied (two launches of 128 pivots), runs
+//     the panels of the first block of the next pair, applies that one pass to the rows and columns
+//     of the second block, and runs its panels.  An entry that main(P+1) then folds again with a
+//     pass it has already seen does not move (max is idempotent; the compare form would not move or
+//     count it either), so main(P+1) simply covers everything but the cross after it.
 constexpr int kLookaheadMinN = INT32_MAX, kLookaheadMinNWithNext = 16384, kLookaheadMinNWithTrace = 8192;
+constexpr int kDoublePassMinN = 12288;   // FWX_DOUBLE_PASS_MIN_N overrides (measured: see DESIGN.md 4.2)
 // FWX_LOOKAHEAD_MIN_N / FWX_SYMMETRIC_MIN_N override the thresholds (tests force each schedule at
 // small sizes, tuning runs switch one off with a huge value); read on every solve.
 static int env_threshold(const char *name, int dflt)
@@ -164,6 +175,74 @@ int fused_range(T *rate, int32_t *next, int32_t *hops, int n, int k_begin, int k
         bind(k0, bt, bi);
         return fwx::launch_fused_panels<T>(a, wbuf[bi], whbuf[bi], st);
     };
+
+    // ---- double pass: see the header comment ----------------------------------------------------
+    if (!next && nonneg && !d_updates && !rec && k_begin % FWX_FUSED_B == 0 &&
+        n >= env_threshold("FWX_DOUBLE_PASS_MIN_N", kDoublePassMinN) && k_end - k_begin >= 4 * FWX_FUSED_B) {
+        constexpr int Bq = FWX_FUSED_B;
+        const int nb = (k_end - k_begin) / Bq;          // full blocks; a ragged tail is handled below
+        const int pairs = nb / 2;
+        // four panel sets, as two adjacent pairs: block q lives in set q & 3, so a pair (2P, 2P + 1)
+        // is contiguous in W (128 rows) and in Ct (128 lines)
+        T *w4 = (T *)ws;
+        T *ct4 = w4 + (size_t)4 * Bq * n;
+        auto set_of = [&](int q) { return q & 3; };
+        auto bind4 = [&](int q, int blocks) {           // pivots of `blocks` blocks starting at block q
+            a.k0 = k_begin + q * Bq; a.bt = blocks * Bq;
+            a.w = w4 + (size_t)set_of(q) * Bq * n; a.wh = nullptr;
+            a.ct = ct4 + (size_t)set_of(q) * Bq * ld; a.cnt = nullptr; a.cht = nullptr;
+        };
+        auto panels4 = [&](int q, hipStream_t st) {
+            bind4(q, 1);
+            return fwx::launch_fused_panels<T>(a, w4 + (size_t)set_of(q) * Bq * n, nullptr, st);
+        };
+        // pivots of `blocks` blocks from block q onto the rows [lo, hi) (all columns) and the columns
+        // [lo, hi) (the other rows)
+        auto cross = [&](int q, int blocks, int lo, int hi, hipStream_t st) -> hipError_t {
+            if (hi <= lo) return hipSuccess;
+            bind4(q, blocks);
+            hipError_t e = fwx::launch_fused_main<T>(a, lo, hi, st);
+            if (e != hipSuccess) return e;
+            return fwx::launch_fused_main<T>(a, 0, n, st, lo, hi, fwx::FusedCols::only(lo, hi));
+        };
+        auto rows_of = [&](int q) { return k_begin + q * Bq; };
+        // chain(0): panels of block 0, that pass onto block 1's rows and columns, panels of block 1
+        FWX_HIP(panels4(0, s));
+        FWX_HIP(cross(0, 1, rows_of(1), rows_of(2), s));
+        FWX_HIP(panels4(1, s));
+        for (int P = 0; P < pairs; ++P) {
+            const int q = 2 * P;
+            const int q_lo = q + 2, q_hi = q + 4 < nb ? q + 4 : nb;     // blocks of the next pair (or the odd last one)
+            const int x_lo = rows_of(q_lo), x_hi = rows_of(q_hi);
+            if (q_hi > q_lo) {
+                FWX_HIP(hipEventRecord(side.main_done, s));       // main(P - 1) and chain(P) precede
+                FWX_HIP(hipStreamWaitEvent(side.s, side.main_done, 0));
+                FWX_HIP(cross(q, 2, x_lo, x_hi, side.s));         // the pair being applied onto the next cross
+                FWX_HIP(panels4(q_lo, side.s));
+                if (q_hi - q_lo == 2) {
+                    FWX_HIP(cross(q_lo, 1, rows_of(q_lo + 1), x_hi, side.s));
+                    FWX_HIP(panels4(q_lo + 1, side.s));
+                }
+                FWX_HIP(hipEventRecord(side.panel_done, side.s));
+                bind4(q, 2);
+                FWX_HIP(fwx::launch_fused_main<T>(a, 0, n, s, x_lo, x_hi, fwx::FusedCols::except(x_lo, x_hi)));
+                FWX_HIP(hipStreamWaitEvent(s, side.panel_done, 0));
+            } else {
+                bind4(q, 2);
+                FWX_HIP(fwx::launch_fused_main<T>(a, 0, n, s));
+            }
+            const int rc = thr.tick(s, 8);
+            if (rc) return rc;
+        }
+        if (nb & 1) {                                   // the odd last block: its panels are ready
+            bind4(nb - 1, 1);
+            FWX_HIP(fwx::launch_fused_main<T>(a, 0, n, s));
+        }
+        FWX_HIP(hipStreamSynchronize(s));
+        k_begin += nb * Bq;                             // a ragged tail (< 64 pivots) takes the serial form
+        if (k_end <= k_begin) return FWX_OK;
+        bind(k_begin, k_end - k_begin, 0);              // (restores the two-set bindings below)
+    }
 
     int bi = 0;
     bool col_ready = false;        // colpanel of the current pass already ran

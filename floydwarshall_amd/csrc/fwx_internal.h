@@ -358,6 +358,9 @@ inline size_t fused_ws_bytes(int n, size_t es, bool with_hops)
     // two row panels W and two sets of pivot-column snapshots (Ct, CNt): pass p+1's are produced
     // while pass p's are read (fused_range)
     size_t b = (size_t)FWX_FUSED_B * n * 2 * es + (size_t)FWX_FUSED_B * ld * 2 * (es + 4) + 256;
+    // the double-pass schedule of rates-only solves keeps FOUR panel sets (two passes being applied,
+    // two being produced): two more W and Ct panels
+    b += (size_t)FWX_FUSED_B * n * 2 * es + (size_t)FWX_FUSED_B * ld * 2 * es;
     if (with_hops) b += (size_t)FWX_FUSED_B * n * 2 * 4 + (size_t)FWX_FUSED_B * ld * 2 * 4;
     return b;
 }
