@@ -82,7 +82,10 @@ template <typename T> bool fused_ok(int n, const void *rate, const int32_t *)
 //     pass it has already seen does not move (max is idempotent; the compare form would not move or
 //     count it either), so main(P+1) simply covers everything but the cross after it.
 constexpr int kLookaheadMinN = INT32_MAX, kLookaheadMinNWithNext = 16384, kLookaheadMinNWithTrace = 8192;
-constexpr int kDoublePassMinN = 12288;   // FWX_DOUBLE_PASS_MIN_N overrides (measured: see DESIGN.md 4.2)
+// crossover (single / double pass, ms; profiles/r03_double_pass_crossover.txt): f32 4096: 4.10 / 4.74,
+// 6144: 10.47 / 10.18, 8192: 21.2 / 20.0, 12288: 68.1 / 61.0, 16384: 152.0 / 135.3; f64 6144: 23.1 / 22.1,
+// 16384: 355 / 324 -- below ~6000 the side chain (five launches per 128 pivots) is the critical path
+constexpr int kDoublePassMinN = 6144;    // FWX_DOUBLE_PASS_MIN_N overrides
 // FWX_LOOKAHEAD_MIN_N / FWX_SYMMETRIC_MIN_N override the thresholds (tests force each schedule at
 // small sizes, tuning runs switch one off with a huge value); read on every solve.
 static int env_threshold(const char *name, int dflt)

@@ -1486,280 +1486,6 @@ __global__ __launch_bounds__(256, MINW) void fused_main_arg(float *rate, int32_t
 }
 
 // ------------------------------------------------------------------------------------------------
-// fused_main_arg_wide: fused_main_arg on the 128 x 128 tile of fused_main_max (8 x 8 entries per
-// thread, 2 B of LDS operand reads per relaxation instead of 3: the 128 x 64 tile's fold was bound
-// by exactly those reads, 193 ms of a 252 ms solve at N = 16384 against 154 ms for the rates kernel).
-// Two rate tiles of 64 registers each leave no room for a `sid` register per entry, so the tracking
-// is PACKED: after every stage one v_cmp_lt (old < new: the entry moved) and one v_addc_co
-// (word = 2 * word + carry-in) shift the answer into the row's word -- 8 entries per row, 4 stages:
-// 32 bits, bit 31 - (8 s + c) = "entry c of this row moved in stage s".  Same two instructions per
-// entry and stage as compare + select, 8 registers instead of 64.  The bits of one entry are 8
-// apart, (word >> (7 - c)) & 0x01010101, and travel as they are in the upper part of a 32-bit item
-// id (bit 0 / 8 / 16 / 24 = stage 3 / 2 / 1 / 0; column in bits 1-7, row in bits 9-15); the re-scan
-// takes the newest stage from them.  All 64 pivots of both operand strips stay in LDS (64 KB), the
-// lists are flushed once per row of the thread tile (9 inline re-scans instead of 17): 76 KB, two
-// workgroups per CU.  Bit-identical to fused_main_arg and to the compare form.
-// ------------------------------------------------------------------------------------------------
-template <int MINW>
-__global__ __launch_bounds__(256, MINW) void fused_main_arg_wide(float *rate, int32_t *next, int rows, int n,
-                                                                 int row0, int k0, int bt, const float *w,
-                                                                 const float *ct, const int32_t *cnt,
-                                                                 int ct_ld, int ct_vec, int skip_lo,
-                                                                 int skip_hi, int32_t *last, int32_t *hops,
-                                                                 const int32_t *cht, const int32_t *wh, ColWin cw)
-{
-    typedef float V4 __attribute__((ext_vector_type(4)));
-    // list capacity: one flush point per row of the thread tile: 63 carried + 8 * 64 new items
-    constexpr int RI = 8, NH = 2, TI = 128, TJ = 128, LCAP = 576;
-    __shared__ __attribute__((aligned(16))) float sW[B][TJ];
-    __shared__ __attribute__((aligned(16))) float sC[B][TI];
-    __shared__ unsigned int l_id[4][LCAP];      // per-wave item lists: stage bits | row << 9 | column << 1
-    __shared__ int32_t g_next[4][64], g_hc[4][64], g_hw[4][64];   // gathers of the batch in flight
-    static_assert(B / ARG_SL == 4, "four tracking stages: one byte lane per stage in a row's word");
-
-    const int tid = threadIdx.x;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int i_base = blockIdx.y * TI;
-    const int j_base = (blockIdx.x + cw.jt0) * TJ;
-    if (cw.cskip_lo <= j_base && j_base + TJ <= cw.cskip_hi) return;   // the whole tile is someone else's
-    const int ti = tid >> 4, tj = tid & 15;
-    const int i0 = i_base + ti * RI;
-    const bool skip = i0 >= skip_lo && i0 < skip_hi;   // rows done by the look-ahead launch
-    const float nanv = qnan<float>();
-
-    // ---- stage W (NaN at j == k and past the matrix) and C (NaN at i == k, from colpanel) -------
-    for (int idx = tid; idx < B * (TJ / 4); idx += 256) {
-        const int t = idx / (TJ / 4), v = idx % (TJ / 4);
-        const int j = j_base + v * 4;
-        V4 val = V4{nanv, nanv, nanv, nanv};
-        if (t < bt && j < n) {
-            val = *reinterpret_cast<const V4 *>(w + (size_t)t * n + j);
-            const int kcol = k0 + t - j;
-            if (kcol >= 0 && kcol < 4) val[kcol] = nanv;
-        }
-        *reinterpret_cast<V4 *>(&sW[t][v * 4]) = val;
-    }
-    for (int idx = tid; idx < B * (TI / 4); idx += 256) {
-        const int t = idx / (TI / 4), v = idx % (TI / 4);
-        const int i = i_base + v * 4;
-        V4 val = V4{nanv, nanv, nanv, nanv};
-        if (t < bt) {
-            if (ct_vec && i + 4 <= rows) {
-                val = *reinterpret_cast<const V4 *>(ct + (size_t)t * ct_ld + i);
-            } else {
-#pragma unroll
-                for (int e = 0; e < 4; ++e)
-                    if (i + e < rows) val[e] = ct[(size_t)t * ct_ld + i + e];
-            }
-        }
-        *reinterpret_cast<V4 *>(&sC[t][v * 4]) = val;
-    }
-
-    int jc[NH];
-    bool jok[NH];
-#pragma unroll
-    for (int h = 0; h < NH; ++h) {
-        const int j = j_base + h * 64 + tj * 4;
-        jok[h] = j < n && !cw.skips(j);
-        jc[h] = jok[h] ? j : n - 4;
-    }
-    V4 xa[RI][NH], xb[RI][NH];
-    unsigned int moved[RI];                          // the packed tracking words, one per row
-#pragma unroll
-    for (int r = 0; r < RI; ++r) {
-        const int i = min(i0 + r, rows - 1);
-#pragma unroll
-        for (int h = 0; h < NH; ++h) xa[r][h] = *reinterpret_cast<const V4 *>(rate + (size_t)i * n + jc[h]);
-        moved[r] = 0u;
-    }
-    __syncthreads();
-
-    // ---- 1. the fold: two pivots per v_max3_f32, four stages that ping-pong xa <-> xb -----------
-    const int npairs = skip ? 0 : (bt + 1) / 2;
-    auto pair_step = [&](int tp, const V4 (&in)[RI][NH], V4 (&out)[RI][NH]) {
-        float c[RI][2], wv[NH][4][2];
-#pragma unroll
-        for (int u = 0; u < 2; ++u) {
-#pragma unroll
-            for (int q = 0; q < RI / 4; ++q) {
-                const V4 cv = *reinterpret_cast<const V4 *>(&sC[2 * tp + u][ti * RI + q * 4]);
-#pragma unroll
-                for (int e = 0; e < 4; ++e) c[q * 4 + e][u] = cv[e];
-            }
-#pragma unroll
-            for (int h = 0; h < NH; ++h) {
-                const V4 wq = *reinterpret_cast<const V4 *>(&sW[2 * tp + u][h * 64 + tj * 4]);
-#pragma unroll
-                for (int e = 0; e < 4; ++e) wv[h][e][u] = wq[e];
-            }
-        }
-#pragma unroll
-        for (int r = 0; r < RI; ++r) {
-            float p0[NH][4], p1[NH][4];
-#pragma unroll
-            for (int h = 0; h < NH; ++h)
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    asm("v_mul_f32 %0, %1, %2" : "=v"(p0[h][e]) : "v"(c[r][0]), "v"(wv[h][e][0]));
-                    asm("v_mul_f32 %0, %1, %2" : "=v"(p1[h][e]) : "v"(c[r][1]), "v"(wv[h][e][1]));
-                }
-#pragma unroll
-            for (int h = 0; h < NH; ++h)
-#pragma unroll
-                for (int e = 0; e < 4; ++e)
-                    out[r][h][e] = __builtin_fmaxf(__builtin_fmaxf(in[r][h][e], p0[h][e]), p1[h][e]);
-        }
-    };
-    int stages = 0;                                  // stages executed (wave-uniform)
-    constexpr int SP = ARG_SL / 2;                   // pivot pairs per stage
-#pragma unroll
-    for (int s = 0; s < B / ARG_SL; ++s) {
-        if (s * SP < npairs) {
-            const V4 (&src)[RI][NH] = (s & 1) ? xb : xa;
-            V4 (&dst)[RI][NH] = (s & 1) ? xa : xb;
-            const int p_hi = min(s * SP + SP, npairs);
-            pair_step(s * SP, src, dst);
-#pragma unroll 1
-            for (int tp = s * SP + 1; tp < p_hi; ++tp) pair_step(tp, dst, dst);
-            // moved in this stage <=> old < new (the fold only ever increases an entry; no NaN here)
-#pragma unroll
-            for (int r = 0; r < RI; ++r)
-#pragma unroll
-                for (int h = 0; h < NH; ++h)
-#pragma unroll
-                    for (int e = 0; e < 4; ++e)
-                        asm("v_cmp_lt_f32 vcc, %1, %2\n\tv_addc_co_u32 %0, vcc, %0, %0, vcc"
-                            : "+v"(moved[r])
-                            : "v"(src[r][h][e]), "v"(dst[r][h][e])
-                            : "vcc");
-            stages = s + 1;
-        }
-    }
-    if (stages & 1) {                                // the result sits in xb: bring it to xa
-#pragma unroll
-        for (int r = 0; r < RI; ++r)
-#pragma unroll
-            for (int h = 0; h < NH; ++h) xa[r][h] = xb[r][h];
-    }
-    if (stages < B / ARG_SL) {                       // a short pass: move the bits to their byte lanes
-#pragma unroll
-        for (int r = 0; r < RI; ++r) moved[r] = stages ? moved[r] << (8 * (B / ARG_SL - stages)) : 0u;
-    }
-
-    // ---- 2. + 3. moved entries -> items -> t* -> next (and last, hops): as in fused_main_arg -----
-    const int gi_lo = row0 + i_base;
-    const bool diag_tile = gi_lo < j_base + TJ && j_base < gi_lo + TI;
-    typedef __attribute__((address_space(1))) const void gptr_t;
-    typedef __attribute__((address_space(3))) void lptr_t;
-    unsigned int *ids = &l_id[wave][0];
-    const int lane = tid & 63;
-    int count = 0;                                   // items in this wave's list (wave-uniform)
-    bool p_act = false;
-    size_t p_off = 0;
-    auto retire = [&]() __attribute__((always_inline)) {
-        if (p_act) {
-            __builtin_amdgcn_s_waitcnt(FWX_WAIT_VMCNT0);     // the global -> LDS gathers have landed
-            next[p_off] = g_next[wave][lane];
-            if (hops) hops[p_off] = (int32_t)((uint32_t)g_hc[wave][lane] + (uint32_t)g_hw[wave][lane]);
-        }
-        p_act = false;
-    };
-    auto rescan = [&](bool all) __attribute__((always_inline)) {
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        int base = 0;
-        for (; base + 64 <= count || (all && base < count); base += 64) {
-            const int it = base + lane;
-            const bool act = it < count;
-            const unsigned int id = ids[act ? it : 0];
-            const int il = (int)((id >> 9) & 127u), jl = (int)((id >> 1) & 127u);
-            // the newest stage in which the entry moved: bit 0 / 8 / 16 / 24 = stage 3 / 2 / 1 / 0
-            const int t0 = ((id & 1u) ? 3 : (id & 0x100u) ? 2 : (id & 0x10000u) ? 1 : 0) * ARG_SL;
-            const float *pc = &sC[t0][il];
-            const float *pw = &sW[t0][jl];
-            float p[ARG_SL];
-#pragma unroll
-            for (int u = 0; u < ARG_SL; ++u) p[u] = pc[u * TI] * pw[u * TJ];
-            float m = __builtin_fmaxf(p[0], p[1]);
-#pragma unroll
-            for (int u = 2; u < ARG_SL; u += 2) m = __builtin_fmaxf(__builtin_fmaxf(m, p[u]), p[u + 1]);
-            int found = -1;
-#pragma unroll
-            for (int u = ARG_SL - 1; u >= 0; --u)    // descending: the smallest matching pivot wins
-                found = (p[u] == m) ? t0 + u : found;
-            retire();                                // the previous batch: its gathers have landed
-            if (act && found >= 0) {
-                const int i = i_base + il, j = j_base + jl;
-                p_off = (size_t)i * n + j;
-                __builtin_amdgcn_global_load_lds((gptr_t *)(cnt + (size_t)found * ct_ld + i),
-                                                 (lptr_t *)&g_next[wave][0], 4, 0, 0);
-                if (last) last[p_off] = k0 + found;
-                if (hops) {
-                    __builtin_amdgcn_global_load_lds((gptr_t *)(cht + (size_t)found * ct_ld + i),
-                                                     (lptr_t *)&g_hc[wave][0], 4, 0, 0);
-                    __builtin_amdgcn_global_load_lds((gptr_t *)(wh + (size_t)found * n + j),
-                                                     (lptr_t *)&g_hw[wave][0], 4, 0, 0);
-                }
-                p_act = true;
-            }
-        }
-        const int rest = count - base;               // < 64 (<= 0 if all)
-        if (rest > 0 && base > 0) {
-            const unsigned int id = ids[base + (lane < rest ? lane : 0)];
-            __builtin_amdgcn_wave_barrier();
-            if (lane < rest) ids[lane] = id;
-        }
-        count = rest > 0 ? rest : 0;
-    };
-    // j == i is never touched (Algorithms.hs:54): restored once, with its own wait (see fused_main_arg)
-    if (diag_tile) {                                 // workgroup-uniform
-#pragma unroll
-        for (int r = 0; r < RI; ++r)
-#pragma unroll
-            for (int h = 0; h < NH; ++h)
-#pragma unroll
-                for (int e = 0; e < 4; ++e)
-                    if (jok[h] && row0 + i0 + r == jc[h] + e) {
-                        const unsigned int bits = 0x01010101u << (7 - (h * 4 + e));
-                        if (i0 + r < rows && (moved[r] & bits)) xa[r][h][e] = rate[(size_t)(i0 + r) * n + jc[h] + e];
-                        moved[r] &= ~bits;
-                    }
-        __builtin_amdgcn_s_waitcnt(FWX_WAIT_VMCNT0);
-    }
-    const unsigned int id_thread = ((unsigned int)(ti * RI) << 9) | ((unsigned int)(tj * 4) << 1);
-#pragma unroll
-    for (int r = 0; r < RI; ++r) {
-        const int i = i0 + r;
-        const bool row_ok = i < rows && !skip;
-#pragma unroll
-        for (int h = 0; h < NH; ++h) {
-            const bool ok = row_ok && jok[h];
-            unsigned int t[4];
-            bool any = false;
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                t[e] = ok ? (moved[r] >> (7 - (h * 4 + e))) & 0x01010101u : 0u;
-                any |= t[e] != 0u;
-            }
-            if (any) *reinterpret_cast<V4 *>(rate + (size_t)i * n + jc[h]) = xa[r][h];
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const unsigned long long mask = __ballot(t[e] != 0u);
-                if (mask) {                           // wave-uniform
-                    const int pos = count + (int)__builtin_amdgcn_mbcnt_hi((unsigned int)(mask >> 32),
-                                                 __builtin_amdgcn_mbcnt_lo((unsigned int)mask, 0u));
-                    if (t[e] != 0u)
-                        ids[pos] = t[e] | (id_thread + (((unsigned int)r << 9) | ((unsigned int)(h * 64 + e) << 1)));
-                    count += __builtin_popcountll(mask);
-                }
-            }
-        }
-        if (count >= 64) rescan(false);               // count <= 63 + 8 * 64 here
-    }
-    if (count > 0) rescan(true);
-    retire();
-}
-
-// ------------------------------------------------------------------------------------------------
 // fused_main_arg_f64: the arg scheme (see fused_main_arg) at the REFERENCE'S precision -- rates +
 // next-hops (+ path trace, + hops) for f64 matrices inside the domain, instead of the compare form
 // (v_mul_f64 + v_cmp + three selects per relaxation).  f64 has no three-operand max: one
@@ -2043,14 +1769,6 @@ static bool small_tiles(int n, int rows, long long thresh = 512)
 // After the re-scan rewrite (gpurun_out/r02_run60.log, 64 x 64 against 128 x 64): N = 3072 3.79 / 4.03 ms,
 // 6144 18.56 / 18.88, 8192 39.17 / 38.96, 10240 70.56 / 72.02: level or ahead up to there.
 static bool small_tiles_arg(int n, int rows) { return small_tiles(n, rows, 6500); }
-// ... and its 128 x 128 form (two workgroups per CU: 512 slots on the chip) from this many tiles on;
-// FWX_ARG_WIDE_MIN_TILES overrides the threshold (tuning runs, and tests that force the form at small sizes)
-static bool arg_wide_tiles(int n, int rows)
-{
-    const char *e = getenv("FWX_ARG_WIDE_MIN_TILES");         // read on every launch, like the schedule thresholds
-    const long long thresh = (e && *e) ? atoll(e) : 9000ll;
-    return (long long)((n + 127) / 128) * ((rows + 127) / 128) >= thresh;
-}
 
 __global__ __launch_bounds__(256) void nonneg_check_f64(const double *rate, const int32_t *next,
                                                         size_t count, int *flag)
@@ -2079,19 +1797,14 @@ hipError_t launch_nonneg_check(const double *rate, const int32_t *next, size_t c
 
 // f32, rates only, no update counting, domain verified by the caller: the max3 kernel.
 static bool launch_max_form(const FusedArgs<float> &a, dim3 grid, dim3 block, int skip_lo,
-                            int skip_hi, hipStream_t s, int32_t *last, bool small, ColWin cw, bool window)
+                            int skip_hi, hipStream_t s, int32_t *last, bool small, ColWin cw, bool)
 {
     if (!a.nonneg || a.updates) return false;
     const int ct_vec = ((uintptr_t)a.ct % 16 == 0 && a.ct_ld % 4 == 0) ? 1 : 0;
     if (a.next) {
         // rates + next-hops (+ trace, + hops): max-form fold, then arg re-scan of the moved entries
         // (grid.x is the caller's: all 64-column tiles, or the tiles of a column window)
-        if (!window && arg_wide_tiles(a.n, a.rows)) {
-            const dim3 g((unsigned)((a.n + 127) / 128), (unsigned)((a.rows + 127) / 128));
-            hipLaunchKernelGGL((fused_main_arg_wide<2>), g, block, 0, s, a.rate, a.next, a.rows, a.n, a.row0,
-                               a.k0, a.bt, a.w, a.ct, a.cnt, a.ct_ld, ct_vec, skip_lo, skip_hi, last,
-                               a.hops, a.cht, a.wh, cw);
-        } else if (small || small_tiles_arg(a.n, a.rows)) {
+        if (small || small_tiles_arg(a.n, a.rows)) {
             const dim3 g(small ? grid.x : (unsigned)((a.n + 63) / 64), (unsigned)((a.rows + 63) / 64));
             hipLaunchKernelGGL((fused_main_arg<3, 4>), g, block, 0, s, a.rate, a.next, a.rows, a.n, a.row0,
                                a.k0, a.bt, a.w, a.ct, a.cnt, a.ct_ld, ct_vec, skip_lo, skip_hi, last,
