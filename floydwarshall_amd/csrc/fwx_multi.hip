@@ -20,8 +20,12 @@
 #include <stdint.h>
 #include <string.h>
 
+#include <condition_variable>
+#include <functional>
 #include <mutex>
+#include <memory>
 #include <new>
+#include <thread>
 #include <vector>
 
 #include "fwx.h"
@@ -405,6 +409,84 @@ static int multi_copy(fwx_matrix *m, void *host_rate, int32_t *host_next, int32_
     return FWX_OK;
 }
 
+// One host thread per partition for the per-k engine's bulk launches.  A partitioned per-k solve issues
+// n launches PER PARTITION; from a single thread (~3.5 us each) that is 8 x 16384 x 3.5 us = 460 ms
+// for N = 16384 on 8 devices against 345 ms of kernel time per device: the host would bound the solve.
+// The orchestration (events, panels, exchange) stays on the calling thread; per block it hands every
+// partition's 64 relax_k launches to that partition's worker, waits until all of them are ENQUEUED
+// (not executed), and carries on -- so the stream order each partition sees is unchanged.
+class SweepWorkers {
+public:
+    explicit SweepWorkers(int n) : jobs_((size_t)n), rc_((size_t)n, FWX_OK)
+    {
+        threads_.reserve((size_t)n);
+        for (int p = 0; p < n; ++p) threads_.emplace_back([this, p] { loop(p); });
+    }
+    ~SweepWorkers()
+    {
+        {
+            std::lock_guard<std::mutex> lk(mu_);
+            quit_ = true;
+            ++round_;
+        }
+        cv_.notify_all();
+        for (std::thread &t : threads_) t.join();
+    }
+    void set(int p, std::function<int()> job) { jobs_[(size_t)p] = std::move(job); }
+    // runs every job that was set since the last call, each on its own thread; first error wins
+    int run_all()
+    {
+        {
+            std::lock_guard<std::mutex> lk(mu_);
+            pending_ = (int)threads_.size();
+            ++round_;
+        }
+        cv_.notify_all();
+        std::unique_lock<std::mutex> lk(mu_);
+        done_.wait(lk, [this] { return pending_ == 0; });
+        int rc = FWX_OK;
+        for (size_t p = 0; p < rc_.size(); ++p) {
+            if (rc_[p] && !rc) rc = rc_[p];
+            rc_[p] = FWX_OK;
+            jobs_[p] = nullptr;
+        }
+        return rc;
+    }
+
+private:
+    void loop(int p)
+    {
+        unsigned long long seen = 0;
+        for (;;) {
+            std::function<int()> job;
+            {
+                std::unique_lock<std::mutex> lk(mu_);
+                cv_.wait(lk, [&] { return round_ != seen; });
+                seen = round_;
+                if (quit_) return;
+                job = jobs_[(size_t)p];
+            }
+            int rc = FWX_OK;
+            if (job) {
+                try { rc = job(); } catch (...) { rc = FWX_ERR_INTERNAL; }
+            }
+            {
+                std::lock_guard<std::mutex> lk(mu_);
+                rc_[(size_t)p] = rc;
+                if (--pending_ == 0) done_.notify_one();
+            }
+        }
+    }
+    std::mutex mu_;
+    std::condition_variable cv_, done_;
+    std::vector<std::thread> threads_;
+    std::vector<std::function<int()>> jobs_;
+    std::vector<int> rc_;
+    unsigned long long round_ = 0;
+    int pending_ = 0;
+    bool quit_ = false;
+};
+
 struct Block { int k0, bt, owner; };
 
 template <typename T> static fwx::FusedArgs<T> part_args(const MultiState &M, const Part &q, bool nonneg,
@@ -529,6 +611,12 @@ template <typename T> static int multi_solve_typed(fwx_matrix *m, const Opts &op
     }
     if (blocks.empty()) return FWX_OK;
     Throttle thr;
+    // per-k engine on several partitions: one enqueueing thread per partition (see SweepWorkers)
+    std::unique_ptr<SweepWorkers> workers;
+    if (perk && P > 1) {
+        fail_point();
+        workers.reset(new SweepWorkers(P));
+    }
     {   // the first panel: its rows are at time k0 already
         Part &o = M.part[blocks[0].owner];
         if ((rc = set_dev(o.device))) return rc;
@@ -578,7 +666,8 @@ template <typename T> static int multi_solve_typed(fwx_matrix *m, const Opts &op
         for (int p = 0; p < P; ++p) {
             Part &q = M.part[p];
             if ((rc = set_dev(q.device))) return rc;
-            if (q.rows > 0 && !perk) {
+            if (perk) continue;                       // the per-k sweeps: below, all partitions at once
+            if (q.rows > 0) {
                 fwx::FusedArgs<T> a = part_args<T>(M, q, nonneg, counting);
                 a.k0 = blk.k0; a.bt = blk.bt; a.w = (const T *)q.w[slot]; a.wh = q.wh[slot];
                 if (p != la_owner) {
@@ -589,24 +678,43 @@ template <typename T> static int multi_solve_typed(fwx_matrix *m, const Opts &op
                     FWX_HIP(fwx::launch_fused_main<T>(a, 0, la_lo, q.main));
                     FWX_HIP(fwx::launch_fused_main<T>(a, la_hi, q.rows, q.main));
                 }
-            } else if (q.rows > 0) {
-                // one launch per pivot over the slab, pivot rows from the snapshot panel (BASELINE
-                // config 4: "row-partitioned, pivot-row broadcast per k" -- 64 rows per message)
-                auto sweep = [&](int lo, int hi, int skip_lo, int skip_hi) -> int {
-                    if (hi <= lo) return FWX_OK;
-                    const size_t off = (size_t)lo * nd;
-                    return relax_range<T>((T *)q.rate + off, q.next ? q.next + off : nullptr,
-                                          q.hops ? q.hops + off : nullptr, hi - lo, nd, q.row0 + lo,
-                                          (const T *)q.w[slot], q.wh[slot], nd, blk.k0, blk.k0 + blk.bt,
-                                          op.serpentine, counting ? q.upd : nullptr, q.main, fwx::PathLog(),
-                                          skip_lo, skip_hi);
-                };
-                if (p != la_owner) rc = sweep(0, q.rows, 0, 0);
-                else if (la_lo % 4 == 0 && la_hi % 4 == 0) rc = sweep(0, q.rows, la_lo, la_hi);
-                else if (!(rc = sweep(0, la_lo, 0, 0))) rc = sweep(la_hi, q.rows, 0, 0);
-                if (rc) return rc;
             }
             FWX_HIP(hipEventRecord(q.main_free[slot], q.main));
+        }
+        if (perk) {
+            // one launch per pivot over each slab, pivot rows from the snapshot panel (BASELINE config 4:
+            // "row-partitioned, pivot-row broadcast per k" -- 64 rows per message)
+            for (int p = 0; p < P; ++p) {
+                Part *qp = &M.part[p];
+                if (qp->rows == 0) continue;
+                const bool owner = p == la_owner;
+                auto job = [=, &op]() -> int {
+                    Part &q = *qp;
+                    int rc2 = set_dev(q.device);      // the worker's own current device
+                    if (rc2) return rc2;
+                    auto sweep = [&](int lo, int hi, int skip_lo, int skip_hi) -> int {
+                        if (hi <= lo) return FWX_OK;
+                        const size_t off = (size_t)lo * nd;
+                        return relax_range<T>((T *)q.rate + off, q.next ? q.next + off : nullptr,
+                                              q.hops ? q.hops + off : nullptr, hi - lo, nd, q.row0 + lo,
+                                              (const T *)q.w[slot], q.wh[slot], nd, blk.k0, blk.k0 + blk.bt,
+                                              op.serpentine, counting ? q.upd : nullptr, q.main, fwx::PathLog(),
+                                              skip_lo, skip_hi);
+                    };
+                    if (!owner) return sweep(0, q.rows, 0, 0);
+                    if (la_lo % 4 == 0 && la_hi % 4 == 0) return sweep(0, q.rows, la_lo, la_hi);
+                    if ((rc2 = sweep(0, la_lo, 0, 0))) return rc2;
+                    return sweep(la_hi, q.rows, 0, 0);
+                };
+                if (workers) workers->set(p, job);
+                else if ((rc = job())) return rc;
+            }
+            if (workers && (rc = workers->run_all())) return rc;
+            for (int p = 0; p < P; ++p) {
+                Part &q = M.part[p];
+                if ((rc = set_dev(q.device))) return rc;
+                FWX_HIP(hipEventRecord(q.main_free[slot], q.main));
+            }
         }
         if ((rc = set_dev(M.part[0].device))) return rc;
         if ((rc = thr.tick(M.part[0].main, perk ? blk.bt + 4 : 4))) return rc;
