@@ -47,7 +47,7 @@ os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 SEGMENTS = 16
 HBM_PEAK_GBPS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
 INFINITY_CACHE_BYTES = 256 << 20
-PMC_PROFILE = os.path.join("profiles", "r02_pmc_traffic.json")
+PMC_PROFILE = os.path.join("profiles", "r03_pmc_traffic.json")
 
 
 def parse_args():
@@ -158,7 +158,7 @@ def cpu_baseline(rate_host, cpu_seconds):
 def pmc_traffic(n, args):
     """HBM bytes per relax_k launch from the rocprofv3 PMC passes over THIS command (`rocprofv3 --pmc
     FETCH_SIZE -- python3 bench.py --steps 1 --warmup 0 --no-extras --no-cpu-baseline`, then
-    WRITE_SIZE; tools/pmc_summary.py turns the counter CSVs into profiles/r02_pmc_traffic.json).
+    WRITE_SIZE; tools/pmc_summary.py turns the counter CSVs into profiles/r03_pmc_traffic.json).
     Counters cannot be read from inside the process, so the line quotes the committed summary, and
     only for the exact configuration it was measured on; otherwise null."""
     path = os.path.join(ROOT, PMC_PROFILE)
@@ -402,8 +402,9 @@ def run_single(args):
                               "(panels and look-ahead launches included), not the main kernel alone"}
         out["fused_engine"] = {"value": relax_per_step / ft, "unit": "edge-relaxations/s",
                                "ms_per_step": 1e3 * ft, "steps": 2, "valu_roofline": valu,
-                               "note": "same workload on the default (AUTO) engine: fused, 64 pivots "
-                                       "per pass, bit-identical results, VALU-bound; not part of "
+                               "note": "same workload on the default (AUTO) engine: fused (from N = 6144 a "
+                                       "rates-only solve applies 128 pivots per main launch behind a two-deep "
+                                       "look-ahead, else 64), bit-identical results, VALU-bound; not part of "
                                        "`value`; best of 2, blocking fwx_matrix_solve calls"}
         # cross-check of the TIMED launches: the matrix the last timed per-k step left in HBM must
         # equal the fused engine's, bit for bit (neither is the oracle; the test-suite ties both to it)

@@ -1038,7 +1038,7 @@ def test_exact_path_lists_80_vertices(solve_engine):
     assert _exact_paths_case(m0, solve_engine=solve_engine) > 0
 
 
-from test_gpu_parity_inputs import hostile_matrix as _hostile_matrix  # noqa: E402
+from hostile_inputs import hostile_matrix as _hostile_matrix  # noqa: E402
 
 
 @pytest.mark.parametrize("dtype", [np.float64, np.float32])

@@ -165,7 +165,7 @@ def test_dense_c_equals_list_faithful_on_hostile_values(dtype):
     """Outside the reference's domain (negative rates, NaN, inf, -0, a positive rate whose path is
     empty) the dense oracle must still be the reference's loop: compare it with the list-faithful
     restatement, which concatenates whole lists and knows nothing of next-hops."""
-    from test_gpu_parity_inputs import hostile_matrix
+    from hostile_inputs import hostile_matrix
     rnd = np.random.default_rng(99)
     with np.errstate(all="ignore"):
         for n in (3, 5, 8, 13, 21):
