@@ -1062,6 +1062,7 @@ int fwx_matrix_enable_path_log(fwx_matrix *m)
 {
     return fwxi::guarded([&]() -> int {
         if (!m || !m->next || m->plog.last) return FWX_ERR_INVALID;
+        if (m->resume) return FWX_ERR_INVALID;     // the checkpoints were sized without the trace: enable it first
         if (m->n == 0) return FWX_OK;
         if (m->multi) return multi_enable_path_log(m);
         DeviceGuard g;
@@ -1174,8 +1175,15 @@ int fwx_matrix_enable_resume(fwx_matrix *m, int32_t checkpoints)
         int rc = g.enter(m->device);
         if (rc) return rc;
         fail_point();
-        Resume *R = new Resume();
-        m->resume = R;            // owned by the handle from here on: destroy releases a partial set
+        // a partial set (an allocation failed, or threw) is released again: the handle stays usable
+        struct Holder {
+            Resume *r = new Resume();
+            ~Holder() { resume_free(r); }
+        } hold;
+        Resume *R = hold.r;
+        for (auto *v : {&R->next, &R->hops, &R->last, &R->at_col, &R->at_row}) v->reserve((size_t)checkpoints);
+        R->rate.reserve((size_t)checkpoints);
+        R->pivot.reserve((size_t)checkpoints);
         const size_t es = f64 ? 8 : 4, nn = (size_t)n * n;
         R->ld = (n + 3) & ~3;
         // checkpoints at the multiples of 64 closest to q * n / (checkpoints + 1)
@@ -1204,6 +1212,8 @@ int fwx_matrix_enable_resume(fwx_matrix *m, int32_t checkpoints)
         if (m->hops && ((rc = alloc((void **)&R->wh, nn * 4)) || (rc = alloc((void **)&R->cht, pan * 4)))) return rc;
         if ((rc = alloc((void **)&R->idx, (size_t)FWX_MAX_PATCH * 8))) return rc;
         R->state_at = (m->fresh && m->kept_valid) ? 0 : -1;
+        m->resume = R;            // complete: owned by the handle from here on
+        hold.r = nullptr;
         return R->count;
     });
 }

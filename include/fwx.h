@@ -178,8 +178,8 @@ int fwx_matrix_patch_input(fwx_matrix *m, int32_t count, const int64_t *index, c
  * performs: results are bit-identical (rates, next, hops, exact `_path` lists); the saving is c / n of
  * the solve.  The checkpoints and panels are refreshed as the resumed solve passes them.
  *
- * enable_resume: after create (+ enable_path_log) and keep_input, before the upload whose solve is to
- *   be resumable; `checkpoints` in 1..FWX_MAX_CHECKPOINTS, spread evenly over the pivots on multiples
+ * enable_resume: after create, enable_path_log (if the trace is wanted: afterwards it is refused) and
+ *   keep_input, before the upload whose solve is to be resumable; `checkpoints` in 1..FWX_MAX_CHECKPOINTS, spread evenly over the pivots on multiples
  *   of 64; returns the number placed (n < 128 leaves room for none: 0), or FWX_ERR_UNSUPPORTED where
  *   the fused engine cannot run the handle's arrays (n <= 64, rows not a multiple of 16 bytes,
  *   partitioned handles).  Memory: one copy of every array per checkpoint + ~2.5 more for the panels.

@@ -152,6 +152,12 @@ def test_what_invalidates_a_recording():
         assert change(dm, 0.49) == 128
         dm.upload(rate, nxt)
         assert change(dm, 0.50) == 0                           # a new upload: solved from scratch
+    with engine.DeviceMatrix(256, np.float32, with_next=True) as dm:    # the trace must be enabled FIRST
+        dm.keep_input()
+        dm.enable_resume(2)
+        with pytest.raises(engine.FwxError) as e:
+            dm.enable_path_log()
+        assert e.value.status == FWX_ERR_INVALID
     for bad_n, dtype in ((64, np.float32), (130, np.float32), (255, np.float64)):
         with engine.DeviceMatrix(bad_n, dtype, with_next=True) as dm:   # the fused engine cannot run these
             dm.keep_input()
