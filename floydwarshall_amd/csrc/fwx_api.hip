@@ -86,19 +86,6 @@ constexpr int kLookaheadMinN = INT32_MAX, kLookaheadMinNWithNext = 16384, kLooka
 // 6144: 10.47 / 10.18, 8192: 21.2 / 20.0, 12288: 68.1 / 61.0, 16384: 152.0 / 135.3; f64 6144: 23.1 / 22.1,
 // 16384: 355 / 324 -- below ~6000 the side chain (five launches per 128 pivots) is the critical path
 constexpr int kDoublePassMinN = 6144;    // FWX_DOUBLE_PASS_MIN_N overrides
-//   lazy next-hops (rates + next, no hops / trace, whole solves of matrices whose order is a multiple of
-//     128, inside the domain): the arg kernels pay for the next-hop matrix in EVERY pass -- stage
-//     tracking, compaction and a re-scan for the ~11 % of the entries that move, on a tile shape the
-//     re-scan dictates -- although an entry's next-hop is only its LAST update's.  Here the solve runs
-//     the rates-only double pass, whose main kernels additionally STAMP every entry they move with the
-//     index of the pass pair (a uint16 per entry: compare with the value still in memory before the
-//     write-back), and the panels of every pivot are kept (W, Ct and CNt as n x n arrays, as for
-//     resumable solves).  A next-hop is RESOLVED only when somebody needs it: the pivot columns of a
-//     block right before its panels are produced (the column panel exports next[i][k] at time k) and
-//     everything once at the end -- by lazy_resolve: the first pivot of the stamped pair whose product
-//     equals the entry's value is the pivot of its last update, and its next-hop is CNt of that pivot.
-//     Same products, same winner as the arg re-scan: bit-identical next-hops.
-constexpr int kLazyNextMinN = 6144;      // FWX_LAZY_NEXT_MIN_N overrides
 // FWX_LOOKAHEAD_MIN_N / FWX_SYMMETRIC_MIN_N override the thresholds (tests force each schedule at
 // small sizes, tuning runs switch one off with a huge value); read on every solve.
 static int env_threshold(const char *name, int dflt)
@@ -193,50 +180,23 @@ int fused_range(T *rate, int32_t *next, int32_t *hops, int n, int k_begin, int k
     };
 
     // ---- double pass: see the header comment ----------------------------------------------------
-    const bool dp_shape = nonneg && !d_updates && !rec && k_begin % FWX_FUSED_B == 0 &&
-                          k_end - k_begin >= 4 * FWX_FUSED_B;
-    const bool lazy = dp_shape && next && !hops && !plog.last && k_begin == 0 && k_end == n &&
-                      lazy_next_shape_ok(n) && n >= env_threshold("FWX_LAZY_NEXT_MIN_N", kLazyNextMinN);
-    if (lazy || (dp_shape && !next && n >= env_threshold("FWX_DOUBLE_PASS_MIN_N", kDoublePassMinN))) {
+    if (!next && nonneg && !d_updates && !rec && k_begin % FWX_FUSED_B == 0 &&
+        n >= env_threshold("FWX_DOUBLE_PASS_MIN_N", kDoublePassMinN) && k_end - k_begin >= 4 * FWX_FUSED_B) {
         constexpr int Bq = FWX_FUSED_B;
         const int nb = (k_end - k_begin) / Bq;          // full blocks; a ragged tail is handled below
         const int pairs = nb / 2;
-        // rates only: four panel sets, as two adjacent pairs: block q lives in set q & 3, so a pair
-        // (2P, 2P + 1) is contiguous in W (128 rows) and in Ct (128 lines).  Lazy next-hops: the panels of
-        // ALL pivots (row k of each array = pivot k), the stamps, an error flag.
+        // four panel sets, as two adjacent pairs: block q lives in set q & 3, so a pair (2P, 2P + 1)
+        // is contiguous in W (128 rows) and in Ct (128 lines)
         T *w4 = (T *)ws;
-        T *ct4 = w4 + (lazy ? (size_t)n * n : (size_t)4 * Bq * n);
-        int32_t *cn_all = lazy ? (int32_t *)(ct4 + (size_t)n * ld) : nullptr;
-        unsigned short *stamp = lazy ? (unsigned short *)(cn_all + (size_t)n * ld) : nullptr;
-        int *lazy_err = lazy ? (int *)(stamp + (size_t)n * n) : nullptr;
-        if (lazy) {
-            FWX_HIP(hipMemsetAsync(stamp, 0xFF, (size_t)n * n * 2, s));     // FWX_STAMP_NONE everywhere
-            FWX_HIP(hipMemsetAsync(lazy_err, 0, sizeof(int), s));
-        }
-        auto set_of = [&](int q) { return lazy ? q : (q & 3); };
-        // pivots of `blocks` blocks starting at block q, for a MAIN / cross launch (rates only; lazy:
-        // stamping the pair index of those pivots)
-        auto bind4 = [&](int q, int blocks) {
+        T *ct4 = w4 + (size_t)4 * Bq * n;
+        auto set_of = [&](int q) { return q & 3; };
+        auto bind4 = [&](int q, int blocks) {           // pivots of `blocks` blocks starting at block q
             a.k0 = k_begin + q * Bq; a.bt = blocks * Bq;
             a.w = w4 + (size_t)set_of(q) * Bq * n; a.wh = nullptr;
             a.ct = ct4 + (size_t)set_of(q) * Bq * ld; a.cnt = nullptr; a.cht = nullptr;
-            a.next = nullptr;
-            a.stamp = stamp; a.stamp_val = q / 2;
-        };
-        // lazy: next-hops of the columns of block q, resolved before its column panel reads them; the
-        // newest pair that can be stamped there is g_hi, of which avail_hi pivots have panels
-        auto resolve_cols = [&](int q, int g_hi, int avail_hi, hipStream_t st) -> hipError_t {
-            if (!lazy) return hipSuccess;
-            return fwx::launch_lazy_resolve<T>(rate, next, stamp, n, 0, n, k_begin + q * Bq, Bq, w4, ct4, cn_all, ld,
-                                               k_begin, 2 * Bq, g_hi, avail_hi, lazy_err, st);
         };
         auto panels4 = [&](int q, hipStream_t st) {
             bind4(q, 1);
-            a.stamp = nullptr;
-            if (lazy) {                                 // the column panel carries next[i][k] -> CNt
-                a.next = next;
-                a.cnt = cn_all + (size_t)q * Bq * ld;
-            }
             return fwx::launch_fused_panels<T>(a, w4 + (size_t)set_of(q) * Bq * n, nullptr, st);
         };
         // pivots of `blocks` blocks from block q onto the rows [lo, hi) (all columns) and the columns
@@ -250,9 +210,8 @@ int fused_range(T *rate, int32_t *next, int32_t *hops, int n, int k_begin, int k
         };
         auto rows_of = [&](int q) { return k_begin + q * Bq; };
         // chain(0): panels of block 0, that pass onto block 1's rows and columns, panels of block 1
-        FWX_HIP(panels4(0, s));                               // (nothing is stamped yet)
+        FWX_HIP(panels4(0, s));
         FWX_HIP(cross(0, 1, rows_of(1), rows_of(2), s));
-        FWX_HIP(resolve_cols(1, 0, Bq, s));                   // pair 0: only block 0 has panels so far
         FWX_HIP(panels4(1, s));
         for (int P = 0; P < pairs; ++P) {
             const int q = 2 * P;
@@ -262,11 +221,9 @@ int fused_range(T *rate, int32_t *next, int32_t *hops, int n, int k_begin, int k
                 FWX_HIP(hipEventRecord(side.main_done, s));       // main(P - 1) and chain(P) precede
                 FWX_HIP(hipStreamWaitEvent(side.s, side.main_done, 0));
                 FWX_HIP(cross(q, 2, x_lo, x_hi, side.s));         // the pair being applied onto the next cross
-                FWX_HIP(resolve_cols(q_lo, P, 2 * Bq, side.s));   // stamps up to pair P, all of its panels exist
                 FWX_HIP(panels4(q_lo, side.s));
                 if (q_hi - q_lo == 2) {
                     FWX_HIP(cross(q_lo, 1, rows_of(q_lo + 1), x_hi, side.s));
-                    FWX_HIP(resolve_cols(q_lo + 1, P + 1, Bq, side.s));   // pair P + 1: its first block only
                     FWX_HIP(panels4(q_lo + 1, side.s));
                 }
                 FWX_HIP(hipEventRecord(side.panel_done, side.s));
@@ -283,16 +240,6 @@ int fused_range(T *rate, int32_t *next, int32_t *hops, int n, int k_begin, int k
         if (nb & 1) {                                   // the odd last block: its panels are ready
             bind4(nb - 1, 1);
             FWX_HIP(fwx::launch_fused_main<T>(a, 0, n, s));
-        }
-        a.stamp = nullptr;
-        a.next = next;
-        if (lazy) {                                     // every next-hop that is still owed, once
-            FWX_HIP(fwx::launch_lazy_resolve<T>(rate, next, stamp, n, 0, n, 0, n, w4, ct4, cn_all, ld, k_begin,
-                                                2 * Bq, pairs - 1, 2 * Bq, lazy_err, s));
-            int bad = 0;
-            FWX_HIP(hipMemcpyAsync(&bad, lazy_err, sizeof(int), hipMemcpyDeviceToHost, s));
-            FWX_HIP(hipStreamSynchronize(s));
-            return bad ? FWX_ERR_INTERNAL : FWX_OK;     // (n % 128 == 0: no odd block, no tail)
         }
         FWX_HIP(hipStreamSynchronize(s));
         k_begin += nb * Bq;                             // a ragged tail (< 64 pivots) takes the serial form
@@ -516,7 +463,7 @@ int solve_host(int32_t n, T *rate, int32_t *next, int32_t *hops, const fwx_opts 
         FWX_HIP(fwx::launch_small_solve<T>(dr, dn, dh, n, op.k_begin, op.k_end, upd, fwx::PathLog(), s));
     } else if (route == ROUTE_FUSED) {
         void *ws = nullptr;
-        if ((rc = cx.reserve(CallCtx::WS, fused_ws_bytes(nd, sizeof(T), dh != nullptr, dn != nullptr), &ws))) return rc;
+        if ((rc = cx.reserve(CallCtx::WS, fused_ws_bytes(nd, sizeof(T), dh != nullptr), &ws))) return rc;
         rc = fused_range<T>(dr, dn, dh, nd, op.k_begin, op.k_end, ws, upd, s, fwx::PathLog(), nonneg, &cx.side);
         if (rc) return rc;
     } else {
@@ -660,7 +607,7 @@ int matrix_solve_typed(fwx_matrix *m, const Opts &op, unsigned long long *upd, h
     if (route == ROUTE_FUSED) {
         // a handle keeps its workspace and look-ahead stream across solves; a view borrows the
         // pooled context's
-        const size_t need = fused_ws_bytes(n, sizeof(T), m->hops != nullptr, m->next != nullptr);
+        const size_t need = fused_ws_bytes(n, sizeof(T), m->hops != nullptr);
         void *ws = nullptr;
         SideStream *side = nullptr;
         if (m->flag) {

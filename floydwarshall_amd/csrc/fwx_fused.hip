@@ -498,17 +498,15 @@ __global__ __launch_bounds__(PANEL_THREADS) void fused_panels(int row_wgs, const
 // hops = cht[t*][i] + wh[t*][j], the lengths of the two halves Algorithms.hs:55 concatenates, as
 // exported by the column / row panels).
 template <typename T, bool HAS_NEXT, bool COUNT, int BS, int MINW, int NH, int RI, bool MAXF = false,
-          bool TRACK = false, bool MARK = false>
+          bool TRACK = false>
 __global__ __launch_bounds__(256, MINW) void fused_main(T *rate, int32_t *next, int rows, int n,
                                                         int row0, int k0, int bt, const T *w,
                                                         const T *ct, const int32_t *cnt, int ct_ld,
                                                         int skip_lo, int skip_hi,
                                                         unsigned long long *updates, int32_t *last,
                                                         int32_t *hops, const int32_t *cht,
-                                                        const int32_t *wh, ColWin cw,
-                                                        unsigned short *stamp = nullptr, int stamp_val = 0)
+                                                        const int32_t *wh, ColWin cw)
 {
-    static_assert(!MARK || !HAS_NEXT, "stamps belong to rates-only launches");
     constexpr bool HAS_LAST = TRACK;
     static_assert(!HAS_LAST || HAS_NEXT, "the path trace and hops ride on the next-hop variant");
     using V = typename Vec16<T>::type;
@@ -695,12 +693,6 @@ __global__ __launch_bounds__(256, MINW) void fused_main(T *rate, int32_t *next, 
                     }
                 }
             } else {
-                if (MARK) {          // lazy next-hops: stamp what moved (a restored diagonal equals memory)
-                    const V old = *reinterpret_cast<const V *>(rate + off);
-#pragma unroll
-                    for (int e = 0; e < VW; ++e)
-                        if (x[r][h][e] != old[e]) stamp[off + e] = (unsigned short)stamp_val;
-                }
                 *reinterpret_cast<V *>(rate + off) = x[r][h];
             }
         }
@@ -770,13 +762,11 @@ __device__ __forceinline__ void max_fold_pair(const float (&sWp)[2][64 * NH], co
 // fused_range); even.  The stage loop is a RUNTIME loop over pairs of stages (buffer 0, buffer 1):
 // one copy of the code for both pass lengths -- two unrolled instantiations in one kernel cost
 // 13 VGPRs and pushed the tile into scratch.
-// MARK (lazy next-hops, fused_range): before the tile is written back, the entries that moved -- new !=
-// the value still in memory -- get stamp[i][j] = stamp_val.
-template <int RI, int NH, bool MARK>
+template <int RI, int NH>
 __device__ __forceinline__ void main_max_interior(float *rate, int n, int i_base, int j_base, const float *w,
                                                   const float *ct, int ct_ld,
                                                   float (&sW)[2][8][2][64 * NH], float (&sC)[2][8][2][16 * RI],
-                                                  int ns, unsigned short *stamp, int stamp_val)
+                                                  int ns)
 {
     constexpr int TI = 16 * RI, TJ = 64 * NH, BS = 16;
     const int tid = threadIdx.x;
@@ -831,18 +821,6 @@ __device__ __forceinline__ void main_max_interior(float *rate, int n, int i_base
             __syncthreads();
         }
     }
-    if (MARK) {
-        unsigned short *sp = stamp + (size_t)(i_base + ti * RI) * n + j_base + tj * 4;
-#pragma unroll
-        for (int r = 0; r < RI; ++r)
-#pragma unroll
-            for (int h = 0; h < NH; ++h) {
-                const F32x4 old = *reinterpret_cast<const F32x4 *>(xp + (size_t)r * n + h * 64);
-#pragma unroll
-                for (int e = 0; e < 4; ++e)
-                    if (x[r][h][e] != old[e]) sp[(size_t)r * n + h * 64 + e] = (unsigned short)stamp_val;
-            }
-    }
 #pragma unroll
     for (int r = 0; r < RI; ++r)
 #pragma unroll
@@ -864,12 +842,11 @@ __device__ __forceinline__ void main_max_interior(float *rate, int n, int i_base
 // compare form.  The caller must have verified the domain (fwx_dev_check_nonneg); with next-hops
 // the same fold runs in fused_main_arg, which recovers the winning pivot afterwards.
 // ------------------------------------------------------------------------------------------------
-template <int MINW, int UNR, int RI, int NH, bool MARK = false>
+template <int MINW, int UNR, int RI, int NH>
 __global__ __launch_bounds__(256, MINW) void fused_main_max(float *rate, int rows, int n, int row0,
                                                             int k0, int bt, const float *w,
                                                             const float *ct, int ct_ld, int ct_vec,
-                                                            int skip_lo, int skip_hi, ColWin cw,
-                                                            unsigned short *stamp, int stamp_val)
+                                                            int skip_lo, int skip_hi, ColWin cw)
 {
     typedef float V4 __attribute__((ext_vector_type(4)));
     // 16 pivots (8 pairs) per LDS stage, two stages resident: while stage s is being folded the
@@ -894,7 +871,7 @@ __global__ __launch_bounds__(256, MINW) void fused_main_max(float *rate, int row
                               (i_base + TI <= skip_lo || i_base >= skip_hi) &&   // no look-ahead rows
                               cw.clear_of(j_base, j_base + TJ);                  // ... or columns
         if (interior) {                                                          // workgroup-uniform
-            main_max_interior<RI, NH, MARK>(rate, n, i_base, j_base, w, ct, ct_ld, sW, sC, bt / 16, stamp, stamp_val);
+            main_max_interior<RI, NH>(rate, n, i_base, j_base, w, ct, ct_ld, sW, sC, bt / 16);
             return;
         }
     }
@@ -997,15 +974,7 @@ __global__ __launch_bounds__(256, MINW) void fused_main_max(float *rate, int row
         if (i >= rows || skip) continue;
 #pragma unroll
         for (int h = 0; h < NH; ++h)
-            if (jok[h]) {
-                if (MARK) {          // (a restored diagonal entry equals memory: never marked)
-                    const V4 old = *reinterpret_cast<const V4 *>(rate + (size_t)i * n + jcol[h]);
-#pragma unroll
-                    for (int e = 0; e < 4; ++e)
-                        if (x[r][h][e] != old[e]) stamp[(size_t)i * n + jcol[h] + e] = (unsigned short)stamp_val;
-                }
-                *reinterpret_cast<V4 *>(rate + (size_t)i * n + jcol[h]) = x[r][h];
-            }
+            if (jok[h]) *reinterpret_cast<V4 *>(rate + (size_t)i * n + jcol[h]) = x[r][h];
     }
 }
 
@@ -1047,11 +1016,9 @@ __device__ __forceinline__ void max_fold_f64(const double (&sWt)[128], const dou
 
 // Interior tiles of a full pass, f64: see main_max_interior.
 // ns: 8-pivot stages per tile (8 = one pass, 16 = a double pass); even, a runtime loop as in main_max_interior
-template <bool MARK>
 __device__ __forceinline__ void main_max_interior_f64(double *rate, int n, int i_base, int j_base, const double *w,
                                                       const double *ct, int ct_ld, double (&sW)[2][8][128],
-                                                      double (&sC)[2][8][128], int ns, unsigned short *stamp,
-                                                      int stamp_val)
+                                                      double (&sC)[2][8][128], int ns)
 {
     constexpr int BS = 8;
     const int tid = threadIdx.x;
@@ -1101,18 +1068,6 @@ __device__ __forceinline__ void main_max_interior_f64(double *rate, int n, int i
             __syncthreads();
         }
     }
-    if (MARK) {
-        unsigned short *sp = stamp + (size_t)(i_base + ti * 8) * n + j_base + tj * 2;
-#pragma unroll
-        for (int r = 0; r < 8; ++r)
-#pragma unroll
-            for (int h = 0; h < 4; ++h) {
-                const F64x2 old = *reinterpret_cast<const F64x2 *>(xp + (size_t)r * n + h * 32);
-#pragma unroll
-                for (int e = 0; e < 2; ++e)
-                    if (x[r][h][e] != old[e]) sp[(size_t)r * n + h * 32 + e] = (unsigned short)stamp_val;
-            }
-    }
 #pragma unroll
     for (int r = 0; r < 8; ++r)
 #pragma unroll
@@ -1130,12 +1085,11 @@ __device__ __forceinline__ void main_max_interior_f64(double *rate, int n, int i
 // the LDS pipe was the second limit after the canonicalising v_max, see fmax_t).  8 pivots per LDS
 // stage, two stages resident, the next stage prefetched into registers during the fold.
 // ------------------------------------------------------------------------------------------------
-template <int MINW, bool MARK = false>
+template <int MINW>
 __global__ __launch_bounds__(256, MINW) void fused_main_max_f64(double *rate, int rows, int n, int row0,
                                                                 int k0, int bt, const double *w,
                                                                 const double *ct, int ct_ld, int ct_vec,
-                                                                int skip_lo, int skip_hi, ColWin cw,
-                                                                unsigned short *stamp, int stamp_val)
+                                                                int skip_lo, int skip_hi, ColWin cw)
 {
     typedef double V2 __attribute__((ext_vector_type(2)));
     constexpr int RI = 8, NH = 4, TI = 128, TJ = 128, HJ = 32, BS = 8;
@@ -1156,7 +1110,7 @@ __global__ __launch_bounds__(256, MINW) void fused_main_max_f64(double *rate, in
                               (k0 + bt <= j_base || k0 >= j_base + TJ) &&
                               (i_base + TI <= skip_lo || i_base >= skip_hi) && cw.clear_of(j_base, j_base + TJ);
         if (interior) {                              // workgroup-uniform
-            main_max_interior_f64<MARK>(rate, n, i_base, j_base, w, ct, ct_ld, sW, sC, bt / 8, stamp, stamp_val);
+            main_max_interior_f64(rate, n, i_base, j_base, w, ct, ct_ld, sW, sC, bt / 8);
             return;
         }
     }
@@ -1253,15 +1207,7 @@ __global__ __launch_bounds__(256, MINW) void fused_main_max_f64(double *rate, in
         if (i >= rows || skip) continue;
 #pragma unroll
         for (int h = 0; h < NH; ++h)
-            if (jok[h]) {
-                if (MARK) {
-                    const V2 old = *reinterpret_cast<const V2 *>(rate + (size_t)i * n + jcol[h]);
-#pragma unroll
-                    for (int e = 0; e < 2; ++e)
-                        if (x[r][h][e] != old[e]) stamp[(size_t)i * n + jcol[h] + e] = (unsigned short)stamp_val;
-                }
-                *reinterpret_cast<V2 *>(rate + (size_t)i * n + jcol[h]) = x[r][h];
-            }
+            if (jok[h]) *reinterpret_cast<V2 *>(rate + (size_t)i * n + jcol[h]) = x[r][h];
     }
 }
 
@@ -1769,130 +1715,6 @@ __global__ __launch_bounds__(256, MINW) void fused_main_arg_f64(double *rate, in
     retire();
 }
 
-// ------------------------------------------------------------------------------------------------
-// lazy_resolve: next-hops of the entries a rates-only solve has stamped (fused_range "lazy next-hops").
-// An entry's stamp names the pass GROUP (the pivots of one main launch) that moved it last; its
-// next-hop is then next[i][k*] as it stood at time k*, i.e. cnt_all[k*][i], with k* the first pivot of
-// that group whose product ct_all[k][i] * w_all[k][j] EQUALS the entry's value -- the strict fold's
-// last update is the first pivot that attains the final value (see fused_main_arg), the product is
-// the same single multiply, and the entry has not moved since (or its stamp would be newer).
-// One workgroup per 64 x 64 tile of the region; it collects the set of groups present in the tile,
-// and for each (newest first) stages the group's operand strips 32 pivots at a time and lets every
-// thread search for its own entries of that group; the chunks of a group stop as soon as its entries
-// are all found.  Pivot k's own column (j == k) is skipped as in the solve; its own row has NaN in ct.
-// ------------------------------------------------------------------------------------------------
-template <typename T>
-__global__ __launch_bounds__(256) void lazy_resolve(const T *rate, int32_t *next, unsigned short *stamp, int n,
-                                                    int r0, int c0, const T *w_all, const T *ct_all,
-                                                    const int32_t *cnt_all, int ld, int k_base, int group,
-                                                    int g_hi, int avail_hi, int *err)
-{
-    constexpr int CH = 32;                               // pivots staged at a time
-    __shared__ T sW[CH][64];
-    __shared__ T sC[CH][64];
-    __shared__ int32_t sN[CH][64];
-    __shared__ unsigned int present[16];                 // groups present in the tile: up to 512
-    const int tid = threadIdx.x;
-    const int ti = tid >> 4, tj = tid & 15;              // 4 rows x 4 columns per thread
-    const int i_base = r0 + blockIdx.y * 64, j_base = c0 + blockIdx.x * 64;
-    if (tid < 16) present[tid] = 0u;
-    __syncthreads();
-    int st[4][4];
-    T v[4][4];
-    bool any = false;
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-        const size_t off = (size_t)(i_base + ti * 4 + r) * n + j_base + tj * 4;
-        const uint2 sv = *reinterpret_cast<const uint2 *>(stamp + off);      // 4 x uint16
-        st[r][0] = (int)(sv.x & 0xFFFFu); st[r][1] = (int)(sv.x >> 16);
-        st[r][2] = (int)(sv.y & 0xFFFFu); st[r][3] = (int)(sv.y >> 16);
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            v[r][e] = rate[off + e];
-            if (st[r][e] != (int)FWX_STAMP_NONE) {
-                any = true;
-                atomicOr(&present[(st[r][e] >> 5) & 15], 1u << (st[r][e] & 31));
-            }
-        }
-    }
-    __syncthreads();
-    unsigned int pres[16];
-#pragma unroll
-    for (int q = 0; q < 16; ++q) pres[q] = present[q];   // workgroup-uniform from here on
-    for (int wd = 15; wd >= 0; --wd) {
-        while (pres[wd]) {
-            const int g = wd * 32 + 31 - __builtin_clz(pres[wd]);
-            pres[wd] &= ~(1u << (g & 31));
-            const int avail = g == g_hi ? avail_hi : group;
-            const int kg = k_base + g * group;
-            bool mine = false;                            // this thread still has an unresolved entry of group g
-#pragma unroll
-            for (int r = 0; r < 4; ++r)
-#pragma unroll
-                for (int e = 0; e < 4; ++e) mine |= st[r][e] == g;
-            for (int t0 = 0; t0 < avail; t0 += CH) {
-                __syncthreads();                          // the previous chunk has been read
-                for (int idx = tid; idx < CH * 16; idx += 256) {
-                    const int t = idx >> 4, q = idx & 15;
-                    const int k = kg + t0 + t;
-                    const bool ok = t0 + t < avail;
-                    typedef T V4 __attribute__((ext_vector_type(4)));
-                    typedef int IV4 __attribute__((ext_vector_type(4)));
-                    V4 wv, cv;
-                    IV4 nv;
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        wv[e] = ok ? w_all[(size_t)k * n + j_base + q * 4 + e] : qnan<T>();
-                        cv[e] = ok ? ct_all[(size_t)k * ld + i_base + q * 4 + e] : qnan<T>();
-                        nv[e] = ok ? cnt_all[(size_t)k * ld + i_base + q * 4 + e] : -1;
-                    }
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        sW[t][q * 4 + e] = wv[e];
-                        sC[t][q * 4 + e] = cv[e];
-                        sN[t][q * 4 + e] = nv[e];
-                    }
-                }
-                __syncthreads();
-                if (mine) {
-#pragma unroll
-                    for (int r = 0; r < 4; ++r)
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) {
-                            if (st[r][e] != g) continue;
-                            const int il = ti * 4 + r, jl = tj * 4 + e;
-                            for (int t = 0; t < CH; ++t) {
-                                if (kg + t0 + t == j_base + jl) continue;            // skip j == k
-                                if (sC[t][il] * sW[t][jl] == v[r][e]) {
-                                    next[(size_t)(i_base + il) * n + j_base + jl] = sN[t][il];
-                                    st[r][e] = (int)FWX_STAMP_NONE;
-                                    break;
-                                }
-                            }
-                        }
-                    mine = false;
-#pragma unroll
-                    for (int r = 0; r < 4; ++r)
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) mine |= st[r][e] == g;
-                }
-                if (!__syncthreads_or(mine)) break;       // every entry of this group has its pivot
-            }
-            if (mine) atomicExch(err, 1);                 // no pivot of the group produces the value: a bug
-        }
-    }
-    if (any) {                                            // the tile's stamps: all resolved
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const size_t off = (size_t)(i_base + ti * 4 + r) * n + j_base + tj * 4;
-            uint2 sv;
-            sv.x = (unsigned int)st[r][0] | ((unsigned int)st[r][1] << 16);
-            sv.y = (unsigned int)st[r][2] | ((unsigned int)st[r][3] << 16);
-            *reinterpret_cast<uint2 *>(stamp + off) = sv;
-        }
-    }
-}
-
 // Domain check (fwx.h "Domain"): clears bit 0 of *flag if any rate has its sign bit set or is NaN,
 // bit 1 if `next` is given and an entry with a non-zero rate has next < 0.
 __global__ __launch_bounds__(256) void nonneg_check_f32(const float *rate, const int32_t *next,
@@ -1995,19 +1817,9 @@ static bool launch_max_form(const FusedArgs<float> &a, dim3 grid, dim3 block, in
         }
         return true;
     }
-#define FWX_MAX_LAUNCH(MINW, RI, NH, G)                                                                      \
-    do {                                                                                                    \
-        if (a.stamp)                                                                                        \
-            hipLaunchKernelGGL((fused_main_max<MINW, 1, RI, NH, true>), G, block, 0, s, a.rate, a.rows, a.n, \
-                               a.row0, a.k0, a.bt, a.w, a.ct, a.ct_ld, ct_vec, skip_lo, skip_hi, cw,        \
-                               a.stamp, a.stamp_val);                                                       \
-        else                                                                                                \
-            hipLaunchKernelGGL((fused_main_max<MINW, 1, RI, NH, false>), G, block, 0, s, a.rate, a.rows, a.n, \
-                               a.row0, a.k0, a.bt, a.w, a.ct, a.ct_ld, ct_vec, skip_lo, skip_hi, cw,        \
-                               (unsigned short *)nullptr, 0);                                               \
-    } while (0)
     if (small) {
-        FWX_MAX_LAUNCH(4, 4, 1, grid);
+        hipLaunchKernelGGL((fused_main_max<4, 1, 4, 1>), grid, block, 0, s, a.rate, a.rows, a.n, a.row0,
+                           a.k0, a.bt, a.w, a.ct, a.ct_ld, ct_vec, skip_lo, skip_hi, cw);
     } else if (small_tiles(a.n, a.rows, 3600)) {
         // mid sizes: 128 x 64 tiles.  The 768 workgroup slots of the chip quantise a launch of 128 x 128
         // tiles badly (N = 4096: 1024 tiles = 1.33 rounds), half-width tiles halve the step; their
@@ -2015,11 +1827,12 @@ static bool launch_max_form(const FusedArgs<float> &a, dim3 grid, dim3 block, in
         // 3072: 2.65 -> 2.44 ms, 4096: 4.40 -> 4.26, 6144: 11.04 -> 10.61, 7168: 16.0 -> 15.7; from
         // 8192 on the full tile wins: 22.35 against 22.65 ms)
         const dim3 g((unsigned)((a.n + 63) / 64), (unsigned)((a.rows + 127) / 128));
-        FWX_MAX_LAUNCH(3, 8, 1, g);
+        hipLaunchKernelGGL((fused_main_max<3, 1, 8, 1>), g, block, 0, s, a.rate, a.rows, a.n,
+                           a.row0, a.k0, a.bt, a.w, a.ct, a.ct_ld, ct_vec, skip_lo, skip_hi, cw);
     } else {
-        FWX_MAX_LAUNCH(3, 8, 2, grid);
+        hipLaunchKernelGGL((fused_main_max<3, 1, 8, 2>), grid, block, 0, s, a.rate, a.rows, a.n,
+                           a.row0, a.k0, a.bt, a.w, a.ct, a.ct_ld, ct_vec, skip_lo, skip_hi, cw);
     }
-#undef FWX_MAX_LAUNCH
     return true;
 }
 // f64 has no packed / three-operand forms: the max form is the generic kernel with
@@ -2043,24 +1856,13 @@ static bool launch_max_form(const FusedArgs<double> &a, dim3 grid, dim3 block, i
     if (!small) {
         const int ct_vec = ((uintptr_t)a.ct % 16 == 0 && a.ct_ld % 2 == 0) ? 1 : 0;
         const dim3 g((unsigned)((a.n + 127) / 128), (unsigned)((a.rows + 127) / 128));
-        if (a.stamp)
-            hipLaunchKernelGGL((fused_main_max_f64<2, true>), g, block, 0, s, a.rate, a.rows, a.n, a.row0, a.k0,
-                               a.bt, a.w, a.ct, a.ct_ld, ct_vec, skip_lo, skip_hi, cw, a.stamp, a.stamp_val);
-        else
-            hipLaunchKernelGGL((fused_main_max_f64<2, false>), g, block, 0, s, a.rate, a.rows, a.n, a.row0, a.k0,
-                               a.bt, a.w, a.ct, a.ct_ld, ct_vec, skip_lo, skip_hi, cw, (unsigned short *)nullptr, 0);
+        hipLaunchKernelGGL((fused_main_max_f64<2>), g, block, 0, s, a.rate, a.rows, a.n, a.row0, a.k0,
+                           a.bt, a.w, a.ct, a.ct_ld, ct_vec, skip_lo, skip_hi, cw);
         return true;
     }
-    if (a.stamp)
-        hipLaunchKernelGGL((fused_main<double, false, false, 16, 2, 1, 4, true, false, true>), grid, block, 0, s,
-                           a.rate, a.next, a.rows, a.n, a.row0, a.k0, a.bt, a.w, a.ct, a.cnt,
-                           a.ct_ld, skip_lo, skip_hi, a.updates, nullptr, nullptr, nullptr, nullptr, cw,
-                           a.stamp, a.stamp_val);
-    else
-        hipLaunchKernelGGL((fused_main<double, false, false, 16, 2, 1, 4, true>), grid, block, 0, s,
-                           a.rate, a.next, a.rows, a.n, a.row0, a.k0, a.bt, a.w, a.ct, a.cnt,
-                           a.ct_ld, skip_lo, skip_hi, a.updates, nullptr, nullptr, nullptr, nullptr, cw,
-                           (unsigned short *)nullptr, 0);
+    hipLaunchKernelGGL((fused_main<double, false, false, 16, 2, 1, 4, true>), grid, block, 0, s,
+                       a.rate, a.next, a.rows, a.n, a.row0, a.k0, a.bt, a.w, a.ct, a.cnt,
+                       a.ct_ld, skip_lo, skip_hi, a.updates, nullptr, nullptr, nullptr, nullptr, cw);
     return true;
 }
 
@@ -2168,8 +1970,6 @@ hipError_t launch_fused_main(const FusedArgs<T> &full, int r_lo, int r_hi, hipSt
     if ((last || full.hops) && !a.next) return hipErrorInvalidValue;
     a.hops = full.hops ? full.hops + (size_t)r_lo * full.n : nullptr;
     a.cht = full.cht ? full.cht + r_lo : nullptr;
-    a.stamp = full.stamp ? full.stamp + (size_t)r_lo * full.n : nullptr;
-    if (a.stamp && (a.next || a.updates || !a.nonneg)) return hipErrorInvalidValue;   // rates-only max form
     const bool track = last || a.hops;
     const dim3 block(256);
     const bool small = window || small_tiles(a.n, a.rows);      // a window is swept in 64-row tiles
@@ -2187,7 +1987,7 @@ hipError_t launch_fused_main(const FusedArgs<T> &full, int r_lo, int r_hi, hipSt
             hipLaunchKernelGGL((fused_main<T, HN, CN, 16, 2, 1, 4, false, HL>), grid, block, 0, s, \
                                a.rate, a.next, a.rows, a.n, a.row0, a.k0, a.bt, a.w, a.ct, a.cnt,  \
                                a.ct_ld, skip_lo, skip_hi, a.updates, last, a.hops, a.cht, a.wh,    \
-                               cw, (unsigned short *)nullptr, 0);                                  \
+                               cw);                                                                \
         else                                                                                       \
             hipLaunchKernelGGL((fused_main<T, HN, CN, FusedCfg<T, HN>::BS,                         \
                                            HL ? (CN ? 2 : (FusedCfg<T, HN>::MINW > 3 ? 3 : FusedCfg<T, HN>::MINW)) \
@@ -2195,7 +1995,7 @@ hipError_t launch_fused_main(const FusedArgs<T> &full, int r_lo, int r_hi, hipSt
                                            FusedCfg<T, HN>::NH, 8, false, HL>),                    \
                                grid, block, 0, s, a.rate, a.next, a.rows, a.n, a.row0, a.k0, a.bt, \
                                a.w, a.ct, a.cnt, a.ct_ld, skip_lo, skip_hi, a.updates, last,       \
-                               a.hops, a.cht, a.wh, cw, (unsigned short *)nullptr, 0);             \
+                               a.hops, a.cht, a.wh, cw);                                           \
     } while (0)
     if (track) {
         if (a.updates) FWX_FUSED_LAUNCH(true, true, true); else FWX_FUSED_LAUNCH(true, false, true);
@@ -2266,27 +2066,6 @@ hipError_t launch_fused_panels(const FusedArgs<T> &a, T *w_out, int32_t *wh_out,
 #undef FWX_PANELS
     return hipGetLastError();
 }
-template <typename T>
-hipError_t launch_lazy_resolve(const T *rate, int32_t *next, unsigned short *stamp, int n, int r0, int rows,
-                               int c0, int cols, const T *w_all, const T *ct_all, const int32_t *cnt_all,
-                               int ld, int k_base, int group, int g_hi, int avail_hi, int *err, hipStream_t s)
-{
-    if (rows <= 0 || cols <= 0 || g_hi < 0) return hipSuccess;
-    if (rows % 64 || cols % 64 || r0 % 4 || c0 % 4 || n % 4 || r0 + rows > n || c0 + cols > n || g_hi >= 512 ||
-        group <= 0 || avail_hi <= 0 || avail_hi > group)
-        return hipErrorInvalidValue;
-    const dim3 grid((unsigned)(cols / 64), (unsigned)(rows / 64)), block(256);
-    hipLaunchKernelGGL((lazy_resolve<T>), grid, block, 0, s, rate, next, stamp, n, r0, c0, w_all, ct_all, cnt_all,
-                       ld, k_base, group, g_hi, avail_hi, err);
-    return hipGetLastError();
-}
-template hipError_t launch_lazy_resolve<float>(const float *, int32_t *, unsigned short *, int, int, int, int, int,
-                                               const float *, const float *, const int32_t *, int, int, int, int,
-                                               int, int *, hipStream_t);
-template hipError_t launch_lazy_resolve<double>(const double *, int32_t *, unsigned short *, int, int, int, int, int,
-                                                const double *, const double *, const int32_t *, int, int, int,
-                                                int, int, int *, hipStream_t);
-
 template hipError_t launch_fused_panels<float>(const FusedArgs<float> &, float *, int32_t *, hipStream_t);
 template hipError_t launch_fused_panels<double>(const FusedArgs<double> &, double *, int32_t *, hipStream_t);
 

@@ -352,16 +352,7 @@ struct CtxLease {
     }
 };
 
-// Lazy next-hops (fused_range): all-pivot panels W / Ct / CNt, a uint16 stamp per entry, an error flag.
-// Applies to rates + next solves (no hops, no trace) of matrices whose order is a multiple of 128.
-inline bool lazy_next_shape_ok(int n) { return n >= 256 && n % 128 == 0 && n / 128 <= 512; }
-inline size_t lazy_next_ws_bytes(int n, size_t es)
-{
-    const size_t ld = ((size_t)n + 3) & ~(size_t)3;
-    return (size_t)n * n * es + (size_t)n * ld * (es + 4) + (size_t)n * n * 2 + 256;
-}
-
-inline size_t fused_ws_bytes(int n, size_t es, bool with_hops, bool with_next = false)
+inline size_t fused_ws_bytes(int n, size_t es, bool with_hops)
 {
     const size_t ld = ((size_t)n + 3) & ~(size_t)3;
     // two row panels W and two sets of pivot-column snapshots (Ct, CNt): pass p+1's are produced
@@ -371,10 +362,6 @@ inline size_t fused_ws_bytes(int n, size_t es, bool with_hops, bool with_next = 
     // two being produced): two more W and Ct panels
     b += (size_t)FWX_FUSED_B * n * 2 * es + (size_t)FWX_FUSED_B * ld * 2 * es;
     if (with_hops) b += (size_t)FWX_FUSED_B * n * 2 * 4 + (size_t)FWX_FUSED_B * ld * 2 * 4;
-    if (with_next && !with_hops && lazy_next_shape_ok(n)) {
-        const size_t lz = lazy_next_ws_bytes(n, es);
-        if (lz > b) b = lz;
-    }
     return b;
 }
 

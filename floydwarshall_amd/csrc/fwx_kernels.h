@@ -80,24 +80,7 @@ template <typename T> struct FusedArgs {
                            // and not NaN and, if next is carried, no positive rate lacks a path:
                            // the max-form kernels may run (f32: rates only, or rates + next + trace)
     PathLog plog = PathLog();   // path trace (needs next): rows x n like rate / next, LOCAL rows
-    // Lazy next-hops (fused_range in fwx_api.hip): a rates-only launch (next == nullptr) that also
-    // writes stamp[i][j] = stamp_val for every entry it moved (rows x n uint16, like rate)
-    unsigned short *stamp = nullptr;
-    int stamp_val = 0;
 };
-
-// Lazy next-hop resolution (see fused_range): every entry of the region rows [r0, r0 + rows) x columns
-// [c0, c0 + cols) (multiples of 64) whose stamp is not FWX_STAMP_NONE gets its next-hop from the pass
-// group that moved it last -- the first pivot k of group `stamp` with ct_all[k][i] * w_all[k][j] equal to
-// the entry's rate (the strict fold's last update is the first pivot that attains the final value),
-// next = cnt_all[k][i] -- and its stamp cleared.  Group g covers the pivots [k_base + g * group,
-// k_base + (g + 1) * group); of group g_hi only the first avail_hi pivots have panels yet.  *err is
-// set to 1 if an entry finds no such pivot (an engine bug, never an input property).
-#define FWX_STAMP_NONE 0xFFFFu
-template <typename T>
-hipError_t launch_lazy_resolve(const T *rate, int32_t *next, unsigned short *stamp, int n, int r0, int rows,
-                               int c0, int cols, const T *w_all, const T *ct_all, const int32_t *cnt_all,
-                               int ld, int k_base, int group, int g_hi, int avail_hi, int *err, hipStream_t s);
 
 // Domain check (fwx.h "Domain").  *flag is a device int preset to 3; bit 0 is cleared if any of the
 // `count` rates is negative, -0 or NaN; bit 1 is cleared if `next` is given and some entry has a
