@@ -1274,6 +1274,30 @@ __global__ __launch_bounds__(256, MINW) void fused_main_arg(float *rate, int32_t
     const float nanv = qnan<float>();
 
     // ---- stage W (NaN at j == k and past the matrix) and C (NaN at i == k, from colpanel) -------
+    // A full pass on a tile inside the slab (all but the edge tiles): straight-line copies from two
+    // pointers, no bounds, no per-vector patch -- the pivot columns, if the tile holds any, are
+    // poisoned afterwards.  (The general loops below spend ~25 instructions of 64-bit address
+    // arithmetic and predicates per vector, a tenth of the tile's fold.)
+    const bool full_tile = bt == B && ct_vec == 1 && i_base + TI <= rows && j_base + TJ <= n;   // workgroup-uniform
+    if (full_tile) {
+        static_assert(TJ == 64, "16 vectors per W row");
+        const float *wp = w + (size_t)(tid >> 4) * n + j_base + (tid & 15) * 4;
+#pragma unroll
+        for (int q = 0; q < B / 16; ++q)
+            *reinterpret_cast<V4 *>(&sW[(tid >> 4) + 16 * q][(tid & 15) * 4]) =
+                *reinterpret_cast<const V4 *>(wp + (size_t)(16 * q) * n);
+        constexpr int CV = TI / 4, CR = 256 / CV;              // vectors per C row, rows per sweep
+        const float *cp = ct + (size_t)(tid / CV) * ct_ld + i_base + (tid % CV) * 4;
+#pragma unroll
+        for (int q = 0; q < B / CR; ++q)
+            *reinterpret_cast<V4 *>(&sC[tid / CV + CR * q][(tid % CV) * 4]) =
+                *reinterpret_cast<const V4 *>(cp + (size_t)(CR * q) * ct_ld);
+        if (k0 + bt > j_base && k0 < j_base + TJ) {            // skip j == k: the pivots' own columns
+            __syncthreads();
+            const int col = k0 + tid - j_base;
+            if (tid < B && col >= 0 && col < TJ) sW[tid][col] = nanv;
+        }
+    } else {
     for (int idx = tid; idx < B * (TJ / 4); idx += 256) {
         const int t = idx / (TJ / 4), v = idx % (TJ / 4);
         const int j = j_base + v * 4;
@@ -1299,6 +1323,7 @@ __global__ __launch_bounds__(256, MINW) void fused_main_arg(float *rate, int32_t
             }
         }
         *reinterpret_cast<V4 *>(&sC[t][v * 4]) = val;
+    }
     }
 
     const int jcol = j_base + tj * 4;
@@ -1521,6 +1546,26 @@ __global__ __launch_bounds__(256, MINW) void fused_main_arg_f64(double *rate, in
     const double nanv = qnan<double>();
 
     // ---- stage W (NaN at j == k and past the matrix) and C (NaN at i == k, from colpanel) -------
+    // full pass on a tile inside the slab: straight-line copies, the pivot columns poisoned afterwards
+    // (see fused_main_arg)
+    const bool full_tile = bt == B && ct_vec == 1 && i_base + TI <= rows && j_base + TJ <= n;   // workgroup-uniform
+    if (full_tile) {
+        static_assert(TI == 64 && TJ == 64, "32 vectors per operand row");
+        const double *wp = w + (size_t)(tid >> 5) * n + j_base + (tid & 31) * 2;
+        const double *cp = ct + (size_t)(tid >> 5) * ct_ld + i_base + (tid & 31) * 2;
+#pragma unroll
+        for (int q = 0; q < B / 8; ++q) {
+            *reinterpret_cast<V2 *>(&sW[(tid >> 5) + 8 * q][(tid & 31) * 2]) =
+                *reinterpret_cast<const V2 *>(wp + (size_t)(8 * q) * n);
+            *reinterpret_cast<V2 *>(&sC[(tid >> 5) + 8 * q][(tid & 31) * 2]) =
+                *reinterpret_cast<const V2 *>(cp + (size_t)(8 * q) * ct_ld);
+        }
+        if (k0 + bt > j_base && k0 < j_base + TJ) {            // skip j == k: the pivots' own columns
+            __syncthreads();
+            const int col = k0 + tid - j_base;
+            if (tid < B && col >= 0 && col < TJ) sW[tid][col] = nanv;
+        }
+    } else {
     for (int idx = tid; idx < B * (TJ / 2); idx += 256) {
         const int t = idx / (TJ / 2), v = idx % (TJ / 2);
         const int j = j_base + v * 2;
@@ -1545,6 +1590,7 @@ __global__ __launch_bounds__(256, MINW) void fused_main_arg_f64(double *rate, in
             }
         }
         *reinterpret_cast<V2 *>(&sC[t][v * 2]) = val;
+    }
     }
 
     const int jcol = j_base + tj * 4;                  // 4 columns = two 16-byte vectors
@@ -1800,8 +1846,11 @@ static bool launch_max_form(const FusedArgs<float> &a, dim3 grid, dim3 block, in
                             int skip_hi, hipStream_t s, int32_t *last, bool small, ColWin cw, bool)
 {
     if (!a.nonneg || a.updates) return false;
-    const int ct_vec = ((uintptr_t)a.ct % 16 == 0 && a.ct_ld % 4 == 0) ? 1 : 0;
+    int ct_vec = ((uintptr_t)a.ct % 16 == 0 && a.ct_ld % 4 == 0) ? 1 : 0;
     if (a.next) {
+        // (tuning runs: FWX_ARG_GENERAL_STAGING=1 keeps the arg kernels on their general staging loops)
+        static const bool general = [] { const char *e = getenv("FWX_ARG_GENERAL_STAGING"); return e && *e == '1'; }();
+        if (ct_vec && general) ct_vec = 2;
         // rates + next-hops (+ trace, + hops): max-form fold, then arg re-scan of the moved entries
         // (grid.x is the caller's: all 64-column tiles, or the tiles of a column window)
         if (small || small_tiles_arg(a.n, a.rows)) {
@@ -1844,7 +1893,9 @@ static bool launch_max_form(const FusedArgs<double> &a, dim3 grid, dim3 block, i
     if (a.next) {
         // rates + next-hops (+ trace, + hops): 64 x 64 tiles whatever the matrix order.  The caller's
         // grid counts 32-column tiles for a column window (f64 small form): two of them per tile here.
-        const int ct_vec = ((uintptr_t)a.ct % 16 == 0 && a.ct_ld % 2 == 0) ? 1 : 0;
+        int ct_vec = ((uintptr_t)a.ct % 16 == 0 && a.ct_ld % 2 == 0) ? 1 : 0;
+        static const bool general = [] { const char *e = getenv("FWX_ARG_GENERAL_STAGING"); return e && *e == '1'; }();
+        if (ct_vec && general) ct_vec = 2;
         ColWin c2 = cw;
         c2.jt0 = window ? cw.jt0 / 2 : 0;
         const dim3 g(window ? grid.x / 2 : (unsigned)((a.n + 63) / 64), (unsigned)((a.rows + 63) / 64));

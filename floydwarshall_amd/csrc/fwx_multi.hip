@@ -1012,8 +1012,14 @@ int fwx_matrix_create_multi(fwx_matrix **out, int32_t n, int32_t dtype, int32_t 
         if (with_hops && !with_next) return FWX_ERR_INVALID;
         const int cnt = device_count();
         if (cnt <= 0) return FWX_ERR_NO_DEVICE;
-        for (int p = 0; p < n_parts; ++p)
-            if (devices[p] < 0 || devices[p] >= cnt) return FWX_ERR_INVALID;
+        int32_t resolved[FWX_MAX_PARTS];              // -1 = the caller's current device
+        int cur = 0;
+        FWX_HIP(hipGetDevice(&cur));
+        for (int p = 0; p < n_parts; ++p) {
+            resolved[p] = devices[p] == -1 ? cur : devices[p];
+            if (resolved[p] < 0 || resolved[p] >= cnt) return FWX_ERR_INVALID;
+        }
+        devices = resolved;
         fwx_matrix *m = new (std::nothrow) fwx_matrix();
         if (!m) return FWX_ERR_OOM;
         memset(m, 0, sizeof(*m));
@@ -1122,6 +1128,14 @@ static int solve_multi_host(int32_t n, int dtype, void *rate, int32_t *next, int
     Opts op;
     int rc = read_opts(opts, n, op);
     if (rc) return rc;
+    int32_t resolved[FWX_MAX_PARTS];                  // -1 = the caller's current device: the pool keys on ordinals
+    {
+        int cur = 0;
+        if (device_count() <= 0) return FWX_ERR_NO_DEVICE;
+        FWX_HIP(hipGetDevice(&cur));
+        for (int p = 0; p < n_parts; ++p) resolved[p] = devices[p] == -1 ? cur : devices[p];
+        devices = resolved;
+    }
     const MultiPool::Key key = MultiPool::key(n, dtype, next != nullptr, hops != nullptr, n_parts, devices,
                                               exchange);
     // the handle is destroyed on every path that does not park it (an error or an exception leaves

@@ -119,7 +119,14 @@ int Session::ensure_solved()
     build_matrix_into(rates_, m);
     // The device handle (matrix, pristine copies, log arrays) is kept while the vertex count stays
     // the same -- a rate update between known vertices, the common case -- and only re-uploaded.
-    const bool want_multi = !devices_.empty() && m.n() >= multi_from_;
+    const bool want_parts = !devices_.empty() && m.n() >= multi_from_;
+    // An ODD vertex count: a single-device handle cannot run the fused engine on rows that are not a
+    // multiple of 16 bytes (fwx.h fwx_engine) and would fall back to one launch per pivot; the
+    // partitioned handle pads its slabs on the device, so ONE partition on the session's device is the
+    // same solve on the fused engine (bit-identical; it cannot resume: fwx_matrix_enable_resume says
+    // FWX_ERR_UNSUPPORTED and the re-solves stay full, as they were).
+    const bool pad_odd = !want_parts && m.n() >= kFusedFrom && m.n() % 2 != 0;
+    const bool want_multi = want_parts || pad_odd;
     if (dev_ && (dev_n_ != m.n() || dev_multi_ != want_multi)) drop_device();
     vertices_ = m.vertices;
     if (m.n() > 0) {
@@ -134,7 +141,10 @@ int Session::ensure_solved()
         if (!dev_) {
             // one floydWarshall call, the whole node behind it: a partitioned handle is an
             // ordinary fwx_matrix (same upload / solve / query_exact below)
-            rc = want_multi ? fwx_matrix_create_multi(&dev_, m.n(), FWX_F64, 1, dev_hops_ ? 1 : 0,
+            const int32_t one = device_;          // -1 = the caller's current device, as in fwx_matrix_create
+            rc = pad_odd    ? fwx_matrix_create_multi(&dev_, m.n(), FWX_F64, 1, dev_hops_ ? 1 : 0, 1, &one,
+                                                      FWX_XCHG_PEER)
+               : want_multi ? fwx_matrix_create_multi(&dev_, m.n(), FWX_F64, 1, dev_hops_ ? 1 : 0,
                                                       (int32_t)devices_.size(), devices_.data(),
                                                       FWX_XCHG_AUTO)
                             : fwx_matrix_create(&dev_, m.n(), FWX_F64, 1, dev_hops_ ? 1 : 0,

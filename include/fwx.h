@@ -232,7 +232,7 @@ int fwx_matrix_query_exact_batch(fwx_matrix *m, int32_t count, const int32_t *sr
  * stream while every partition sweeps the rest of its slab).  No operand and no order changes:
  * results are bit-identical to the single-device solve and to the reference loop.
  *
- * devices[p] = HIP ordinal of partition p.  A device may be listed MORE THAN ONCE (logical
+ * devices[p] = HIP ordinal of partition p (-1 = the caller's current device).  A device may be listed MORE THAN ONCE (logical
  * partitions on one GPU: how the partitioned schedule is tested where only one GPU exists).
  * exchange:
  *   FWX_XCHG_RCCL  ncclBroadcast of each panel on RCCL (ncclCommInitAll over the devices, one

@@ -230,6 +230,52 @@ def test_incremental_updates_patch_the_kept_input(n_exch, partitioned):
     assert np.array_equal(n1, n2) and np.array_equal(h1, h2)
 
 
+def test_odd_vertex_counts_take_the_fused_engine_through_a_padded_handle():
+    """243 vertices: rows of an f64 matrix of odd order are not a multiple of 16 bytes, which a
+    single-device handle can only solve one launch per pivot; the session uses a ONE-partition handle,
+    whose slab is padded on the device.  Answers and exact paths as a fresh session / the oracle."""
+    rnd = np.random.default_rng(27)
+    ccys = ["C%d" % i for i in range(9)]
+    price = dict(zip(ccys, 0.5 + 1.5 * rnd.random(len(ccys))))
+    log = []
+    t = 500
+    for e in range(27):
+        for i in range(len(ccys)):
+            a, b = ccys[i], ccys[(i + 1) % len(ccys)]
+            log.append((t, "E%02d" % e, a, b, price[b] / price[a] * (0.97 + 0.03 * rnd.random()),
+                        price[a] / price[b] * (0.97 + 0.03 * rnd.random())))
+    s = host.Session(device=0)
+    for r in log:
+        assert s.update_rates(*r)
+    vs, rate0, next0 = s.build_matrix()
+    assert len(vs) == 243
+    er, en = rate0.copy(), next0.copy()
+    oracle.relax(er, en)
+    gr, gn, _ = s.solved_matrix()
+    assert_bits_equal(gr, er, "rate")
+    assert np.array_equal(gn, en)
+    assert s.parts == 1
+    for step in range(4):                                   # price changes: patched, full re-solves
+        t += 1
+        old = log[int(rnd.integers(0, len(log)))]
+        log.append((t, old[1], old[2], old[3], old[4] * 0.99, old[5]))
+        assert s.update_rates(*log[-1])
+        fresh = host.Session(device=0)
+        for r in log:
+            fresh.update_rates(*r)
+        for _ in range(8):
+            a, b = (vs[int(x)] for x in rnd.integers(0, len(vs), 2))
+            try:
+                want = fresh.find_best_rate(a, b)
+            except host.AlgoError as err:
+                with pytest.raises(host.AlgoError) as e2:
+                    s.find_best_rate(a, b)
+                assert str(e2.value) == str(err)
+                continue
+            assert s.find_best_rate(a, b) == want
+    assert s.patched_solves == 4 and s.resumed_solves == 0
+
+
 def test_find_best_rate_unknown_vertices_keep_state_and_cache():
     pr = load_golden("process_requests.json")
     s = _session_with(pr["rates_ex2"])
