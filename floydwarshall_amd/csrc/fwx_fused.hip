@@ -1405,15 +1405,24 @@ __global__ __launch_bounds__(256, MINW) void fused_main_arg(float *rate, int32_t
     // behind the load) and the batch is retired -- LDS -> next / hops -- after the NEXT batch has
     // been scanned, or at the end.
     bool p_act = false;
-    size_t p_off = 0;
+    // everything the re-scan addresses, relative to the tile: uniform base pointers + 32-bit offsets
+    // (a 64-bit multiply-add chain per gather and store otherwise)
+    int32_t *const next_t = next + (size_t)i_base * n + j_base;
+    int32_t *const last_t = last ? last + (size_t)i_base * n + j_base : nullptr;
+    int32_t *const hops_t = hops ? hops + (size_t)i_base * n + j_base : nullptr;
+    const int32_t *const cnt_t = cnt + i_base;
+    const int32_t *const cht_t = cht ? cht + i_base : nullptr;
+    const int32_t *const wh_t = wh ? wh + j_base : nullptr;
+    float *const rate_t = rate + (size_t)i_base * n + j_base;
+    unsigned int p_off = 0;
     auto retire = [&]() __attribute__((always_inline)) {
         if (p_act) {
             // vmcnt also counts global -> LDS loads; the compiler's own wait-count pass does not put
             // this wait here (it loses track of them across the flush points' control flow)
             __builtin_amdgcn_s_waitcnt(FWX_WAIT_VMCNT0);
-            next[p_off] = g_next[wave][lane];
+            next_t[p_off] = g_next[wave][lane];
             // lengths of the two halves at the winning pivot (Algorithms.hs:55)
-            if (hops) hops[p_off] = (int32_t)((uint32_t)g_hc[wave][lane] + (uint32_t)g_hw[wave][lane]);
+            if (hops) hops_t[p_off] = (int32_t)((uint32_t)g_hc[wave][lane] + (uint32_t)g_hw[wave][lane]);
         }
         p_act = false;
     };
@@ -1440,18 +1449,18 @@ __global__ __launch_bounds__(256, MINW) void fused_main_arg(float *rate, int32_t
             int found = -1;
 #pragma unroll
             for (int u = ARG_SL - 1; u >= 0; --u)    // descending: the smallest matching pivot wins
-                found = (p[u] == m) ? t0 + u : found;
+                found = (p[u] == m) ? u : found;      // (stage-relative: inline constants, one add below)
             retire();                                // the previous batch: its gathers have landed
             if (act && found >= 0) {
-                const int i = i_base + il, j = j_base + jl;
-                p_off = (size_t)i * n + j;
-                __builtin_amdgcn_global_load_lds((gptr_t *)(cnt + (size_t)found * ct_ld + i),
-                                                 (lptr_t *)&g_next[wave][0], 4, 0, 0);
-                if (last) last[p_off] = k0 + found;
+                found += t0;
+                p_off = (unsigned int)il * (unsigned int)n + (unsigned int)jl;
+                const unsigned int c_off = (unsigned int)found * (unsigned int)ct_ld + (unsigned int)il;
+                __builtin_amdgcn_global_load_lds((gptr_t *)(cnt_t + c_off), (lptr_t *)&g_next[wave][0], 4, 0, 0);
+                if (last) last_t[p_off] = k0 + found;
                 if (hops) {
-                    __builtin_amdgcn_global_load_lds((gptr_t *)(cht + (size_t)found * ct_ld + i),
-                                                     (lptr_t *)&g_hc[wave][0], 4, 0, 0);
-                    __builtin_amdgcn_global_load_lds((gptr_t *)(wh + (size_t)found * n + j),
+                    __builtin_amdgcn_global_load_lds((gptr_t *)(cht_t + c_off), (lptr_t *)&g_hc[wave][0], 4, 0, 0);
+                    __builtin_amdgcn_global_load_lds((gptr_t *)(wh_t + ((unsigned int)found * (unsigned int)n +
+                                                                        (unsigned int)jl)),
                                                      (lptr_t *)&g_hw[wave][0], 4, 0, 0);
                 }
                 p_act = true;
@@ -1491,10 +1500,11 @@ __global__ __launch_bounds__(256, MINW) void fused_main_arg(float *rate, int32_t
             ch[e] = row_ok && sid[r][e] >= 0;
             any |= ch[e];
         }
-        if (any) *reinterpret_cast<V4 *>(rate + (size_t)i * n + jc) = xa[r];
+        if (any)                                  // (any => the row and the columns are inside: jc == jcol)
+            *reinterpret_cast<V4 *>(rate_t + ((unsigned int)(ti * RI + r) * (unsigned int)n + (unsigned int)(tj * 4))) = xa[r];
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-            const unsigned long long mask = __ballot(ch[e]);
+            const unsigned long long mask = __builtin_amdgcn_ballot_w64(ch[e]);
             if (mask) {                               // wave-uniform
                 const int pos = count + (int)__builtin_amdgcn_mbcnt_hi((unsigned int)(mask >> 32),
                                              __builtin_amdgcn_mbcnt_lo((unsigned int)mask, 0u));
@@ -1669,12 +1679,20 @@ __global__ __launch_bounds__(256, MINW) void fused_main_arg_f64(double *rate, in
     const int lane = tid & 63;
     int count = 0;                                   // items in this wave's list (wave-uniform)
     bool p_act = false;
-    size_t p_off = 0;
+    // tile-relative addressing of the re-scan: uniform base pointers + 32-bit offsets (see fused_main_arg)
+    int32_t *const next_t = next + (size_t)i_base * n + j_base;
+    int32_t *const last_t = last ? last + (size_t)i_base * n + j_base : nullptr;
+    int32_t *const hops_t = hops ? hops + (size_t)i_base * n + j_base : nullptr;
+    const int32_t *const cnt_t = cnt + i_base;
+    const int32_t *const cht_t = cht ? cht + i_base : nullptr;
+    const int32_t *const wh_t = wh ? wh + j_base : nullptr;
+    double *const rate_t = rate + (size_t)i_base * n + j_base;
+    unsigned int p_off = 0;
     auto retire = [&]() __attribute__((always_inline)) {
         if (p_act) {
             __builtin_amdgcn_s_waitcnt(FWX_WAIT_VMCNT0);     // the global -> LDS gathers have landed
-            next[p_off] = g_next[wave][lane];
-            if (hops) hops[p_off] = (int32_t)((uint32_t)g_hc[wave][lane] + (uint32_t)g_hw[wave][lane]);
+            next_t[p_off] = g_next[wave][lane];
+            if (hops) hops_t[p_off] = (int32_t)((uint32_t)g_hc[wave][lane] + (uint32_t)g_hw[wave][lane]);
         }
         p_act = false;
     };
@@ -1697,18 +1715,18 @@ __global__ __launch_bounds__(256, MINW) void fused_main_arg_f64(double *rate, in
             int found = -1;
 #pragma unroll
             for (int u = ARG_SL - 1; u >= 0; --u)    // descending: the smallest matching pivot wins
-                found = (p[u] == m) ? t0 + u : found;
+                found = (p[u] == m) ? u : found;      // (stage-relative: inline constants, one add below)
             retire();                                // the previous batch
             if (act && found >= 0) {
-                const int i = i_base + il, j = j_base + jl;
-                p_off = (size_t)i * n + j;
-                __builtin_amdgcn_global_load_lds((gptr_t *)(cnt + (size_t)found * ct_ld + i),
-                                                 (lptr_t *)&g_next[wave][0], 4, 0, 0);
-                if (last) last[p_off] = k0 + found;
+                found += t0;
+                p_off = (unsigned int)il * (unsigned int)n + (unsigned int)jl;
+                const unsigned int c_off = (unsigned int)found * (unsigned int)ct_ld + (unsigned int)il;
+                __builtin_amdgcn_global_load_lds((gptr_t *)(cnt_t + c_off), (lptr_t *)&g_next[wave][0], 4, 0, 0);
+                if (last) last_t[p_off] = k0 + found;
                 if (hops) {
-                    __builtin_amdgcn_global_load_lds((gptr_t *)(cht + (size_t)found * ct_ld + i),
-                                                     (lptr_t *)&g_hc[wave][0], 4, 0, 0);
-                    __builtin_amdgcn_global_load_lds((gptr_t *)(wh + (size_t)found * n + j),
+                    __builtin_amdgcn_global_load_lds((gptr_t *)(cht_t + c_off), (lptr_t *)&g_hc[wave][0], 4, 0, 0);
+                    __builtin_amdgcn_global_load_lds((gptr_t *)(wh_t + ((unsigned int)found * (unsigned int)n +
+                                                                        (unsigned int)jl)),
                                                      (lptr_t *)&g_hw[wave][0], 4, 0, 0);
                 }
                 p_act = true;
@@ -1741,11 +1759,12 @@ __global__ __launch_bounds__(256, MINW) void fused_main_arg_f64(double *rate, in
         bool ch[4];
 #pragma unroll
         for (int e = 0; e < 4; ++e) ch[e] = row_ok && (e < 2 || jok2) && sid[r][e] >= 0;
-        if (ch[0] || ch[1]) *reinterpret_cast<V2 *>(rate + (size_t)i * n + jcol) = V2{xa[r][0], xa[r][1]};
-        if (ch[2] || ch[3]) *reinterpret_cast<V2 *>(rate + (size_t)i * n + jcol + 2) = V2{xa[r][2], xa[r][3]};
+        const unsigned int r_off = (unsigned int)(ti * RI + r) * (unsigned int)n + (unsigned int)(tj * 4);
+        if (ch[0] || ch[1]) *reinterpret_cast<V2 *>(rate_t + r_off) = V2{xa[r][0], xa[r][1]};
+        if (ch[2] || ch[3]) *reinterpret_cast<V2 *>(rate_t + r_off + 2) = V2{xa[r][2], xa[r][3]};
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-            const unsigned long long mask = __ballot(ch[e]);
+            const unsigned long long mask = __builtin_amdgcn_ballot_w64(ch[e]);
             if (mask) {                               // wave-uniform
                 const int pos = count + (int)__builtin_amdgcn_mbcnt_hi((unsigned int)(mask >> 32),
                                              __builtin_amdgcn_mbcnt_lo((unsigned int)mask, 0u));
