@@ -1243,6 +1243,71 @@ __global__ __launch_bounds__(256, MINW) void fused_main_max_f64(double *rate, in
 // 257.3 vs 259.3 ms at N = 16384, gpurun_out/r02_run30.log)
 constexpr int ARG_SL = 16;         // pivots per tracking stage of fused_main_arg (even, divides B)
 
+// gfx950 needs two wait states between a vector instruction that writes a scalar register (a compare)
+// and a vector instruction that reads it as a lane mask (a select), and it does not interlock.  Written
+// one entry at a time -- v_cmp vcc / v_cndmask vcc -- the compiler pays an s_nop per entry: a third of
+// the stage tracking, and of the pivot search of the re-scan.  These helpers do four entries per
+// statement: four compares into four mask pairs, then four selects (>= 3 instructions apart).
+//   track4: sid_e = (d_e == o_e) ? sid_e : stage      (the entry moved in this stage: remember it)
+__device__ __forceinline__ void track4(int &s0, int &s1, int &s2, int &s3, float d0, float d1, float d2,
+                                       float d3, float o0, float o1, float o2, float o3, int stage)
+{
+    unsigned long long m0, m1, m2, m3;
+    asm("v_cmp_eq_f32 %4, %8, %12\n\tv_cmp_eq_f32 %5, %9, %13\n\t"
+        "v_cmp_eq_f32 %6, %10, %14\n\tv_cmp_eq_f32 %7, %11, %15\n\t"
+        "v_cndmask_b32 %0, %16, %0, %4\n\tv_cndmask_b32 %1, %16, %1, %5\n\t"
+        "v_cndmask_b32 %2, %16, %2, %6\n\tv_cndmask_b32 %3, %16, %3, %7"
+        : "+v"(s0), "+v"(s1), "+v"(s2), "+v"(s3), "=&s"(m0), "=&s"(m1), "=&s"(m2), "=&s"(m3)
+        : "v"(d0), "v"(d1), "v"(d2), "v"(d3), "v"(o0), "v"(o1), "v"(o2), "v"(o3), "v"(stage));
+}
+__device__ __forceinline__ void track4(int &s0, int &s1, int &s2, int &s3, double d0, double d1, double d2,
+                                       double d3, double o0, double o1, double o2, double o3, int stage)
+{
+    unsigned long long m0, m1, m2, m3;
+    asm("v_cmp_eq_f64 %4, %8, %12\n\tv_cmp_eq_f64 %5, %9, %13\n\t"
+        "v_cmp_eq_f64 %6, %10, %14\n\tv_cmp_eq_f64 %7, %11, %15\n\t"
+        "v_cndmask_b32 %0, %16, %0, %4\n\tv_cndmask_b32 %1, %16, %1, %5\n\t"
+        "v_cndmask_b32 %2, %16, %2, %6\n\tv_cndmask_b32 %3, %16, %3, %7"
+        : "+v"(s0), "+v"(s1), "+v"(s2), "+v"(s3), "=&s"(m0), "=&s"(m1), "=&s"(m2), "=&s"(m3)
+        : "v"(d0), "v"(d1), "v"(d2), "v"(d3), "v"(o0), "v"(o1), "v"(o2), "v"(o3), "v"(stage));
+}
+//   compact_slot: one entry slot of the compaction.  Lanes with sid >= 0 append their item id
+//   (sid | id_row | E4) to the wave's list at LDS byte address lds_end (wave-uniform), in lane order;
+//   returns how many did.  The compare that says "moved" writes vcc, and vcc IS the ballot, the
+//   operand of both v_mbcnt and, as exec, the predicate of the store -- from C++ the ballot came back
+//   through v_cndmask + v_cmp, and two branches per slot (5 vector instructions instead of 9).
+template <int E4>
+__device__ __forceinline__ int compact_slot(int sid, unsigned int id_row, unsigned int lds_end)
+{
+    int c;
+    unsigned int t, id;
+    unsigned long long save;
+    asm volatile("v_cmp_lt_i32 vcc, -1, %[sid]\n\t"
+                 "v_or3_b32 %[id], %[sid], %[row], %[e4]\n\t"
+                 "s_and_saveexec_b64 %[save], vcc\n\t"          // (>= 2 instructions after the compare)
+                 "v_mbcnt_lo_u32_b32 %[t], vcc_lo, 0\n\t"
+                 "v_mbcnt_hi_u32_b32 %[t], vcc_hi, %[t]\n\t"
+                 "v_lshl_add_u32 %[t], %[t], 1, %[base]\n\t"
+                 "ds_write_b16 %[t], %[id]\n\t"
+                 "s_mov_b64 exec, %[save]\n\t"
+                 "s_bcnt1_i32_b64 %[c], vcc"
+                 : [c] "=s"(c), [t] "=&v"(t), [id] "=&v"(id), [save] "=&s"(save)
+                 : [sid] "v"(sid), [row] "v"(id_row), [e4] "n"(E4), [base] "s"(lds_end)
+                 : "vcc", "scc", "memory");
+    return c;
+}
+//   FWX_FIND4: found = (p == m) ? U : found for four products, HIGHEST pivot first (so that, over a
+//   descending sequence of calls, the smallest matching pivot wins); U0..U3 are literal pivot numbers
+#define FWX_FIND4(CMP, found, m, pa, ua, pb, ub, pc_, uc, pd, ud)                                        \
+    do {                                                                                                 \
+        unsigned long long fm0_, fm1_, fm2_, fm3_;                                                       \
+        asm(CMP " %1, %5, %9\n\t" CMP " %2, %6, %9\n\t" CMP " %3, %7, %9\n\t" CMP " %4, %8, %9\n\t"      \
+            "v_cndmask_b32 %0, %0, " #ua ", %1\n\tv_cndmask_b32 %0, %0, " #ub ", %2\n\t"                \
+            "v_cndmask_b32 %0, %0, " #uc ", %3\n\tv_cndmask_b32 %0, %0, " #ud ", %4"                     \
+            : "+v"(found), "=&s"(fm0_), "=&s"(fm1_), "=&s"(fm2_), "=&s"(fm3_)                             \
+            : "v"(pa), "v"(pb), "v"(pc_), "v"(pd), "v"(m));                                               \
+    } while (0)
+
 template <int MINW, int RI>
 __global__ __launch_bounds__(256, MINW) void fused_main_arg(float *rate, int32_t *next, int rows, int n,
                                                             int row0, int k0, int bt, const float *w,
@@ -1257,11 +1322,10 @@ __global__ __launch_bounds__(256, MINW) void fused_main_arg(float *rate, int32_t
     // all 64 pivots of the tile's operand strips: s?[t][.], pivot t = 2 * pair + u
     __shared__ __attribute__((aligned(16))) float sW[B][TJ];
     __shared__ __attribute__((aligned(16))) float sC[B][TI];
-    __shared__ unsigned short l_id[4][LCAP];    // per-wave item lists: sid << 13 | row << 6 | column
+    __shared__ unsigned short l_id[4][LCAP];    // per-wave item lists: row << 8 | column << 2 | stage
     // where the gathers of the batch in flight land (global -> LDS loads, one slot per lane):
     // CN[t*][i], and with hops CHt[t*][i] and WH[t*][j]
     __shared__ int32_t g_next[4][64], g_hc[4][64], g_hw[4][64];
-    static_assert(TI <= 128 && B / ARG_SL <= 8, "item id fields");
 
     const int tid = threadIdx.x;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -1341,7 +1405,10 @@ __global__ __launch_bounds__(256, MINW) void fused_main_arg(float *rate, int32_t
     __syncthreads();
 
     // ---- 1. the fold: two pivots per v_max3_f32, four stages that ping-pong xa <-> xb -----------
-    const int npairs = skip ? 0 : (bt + 1) / 2;
+    // wave-uniform: a wave folds unless ALL its rows belong to the look-ahead launch (its lanes
+    // that do are simply never stored, see row_ok below) -- a per-lane bound would put the loop
+    // counter in a vector register and the loop under an exec mask
+    const int npairs = __builtin_amdgcn_ballot_w64(!skip) ? (bt + 1) / 2 : 0;
     auto pair_step = [&](int tp, const V4 (&in)[RI], V4 (&out)[RI]) {
         float c[RI][2], wv[4][2];
 #pragma unroll
@@ -1382,8 +1449,8 @@ __global__ __launch_bounds__(256, MINW) void fused_main_arg(float *rate, int32_t
             for (int tp = s * SP + 1; tp < p_hi; ++tp) pair_step(tp, dst, dst);
 #pragma unroll
             for (int r = 0; r < RI; ++r)
-#pragma unroll
-                for (int e = 0; e < 4; ++e) sid[r][e] = (dst[r][e] != src[r][e]) ? s : sid[r][e];
+                track4(sid[r][0], sid[r][1], sid[r][2], sid[r][3], dst[r][0], dst[r][1], dst[r][2], dst[r][3],
+                       src[r][0], src[r][1], src[r][2], src[r][3], s);
             stages = s + 1;
         }
     }
@@ -1398,6 +1465,8 @@ __global__ __launch_bounds__(256, MINW) void fused_main_arg(float *rate, int32_t
     typedef __attribute__((address_space(1))) const void gptr_t;
     typedef __attribute__((address_space(3))) void lptr_t;
     unsigned short *ids = &l_id[wave][0];
+    const unsigned int ids_lds = (unsigned int)reinterpret_cast<size_t>(
+        (__attribute__((address_space(3))) unsigned short *)ids);          // its LDS byte address (uniform)
     const int lane = tid & 63;
     int count = 0;                                   // items in this wave's list (wave-uniform)
     // The batch whose gathers are in flight.  They are global -> LDS loads (no destination
@@ -1405,31 +1474,38 @@ __global__ __launch_bounds__(256, MINW) void fused_main_arg(float *rate, int32_t
     // behind the load) and the batch is retired -- LDS -> next / hops -- after the NEXT batch has
     // been scanned, or at the end.
     bool p_act = false;
-    // everything the re-scan addresses, relative to the tile: uniform base pointers + 32-bit offsets
-    // (a 64-bit multiply-add chain per gather and store otherwise)
-    int32_t *const next_t = next + (size_t)i_base * n + j_base;
-    int32_t *const last_t = last ? last + (size_t)i_base * n + j_base : nullptr;
-    int32_t *const hops_t = hops ? hops + (size_t)i_base * n + j_base : nullptr;
-    const int32_t *const cnt_t = cnt + i_base;
-    const int32_t *const cht_t = cht ? cht + i_base : nullptr;
-    const int32_t *const wh_t = wh ? wh + j_base : nullptr;
-    float *const rate_t = rate + (size_t)i_base * n + j_base;
-    unsigned int p_off = 0;
+    // Everything the re-scan and the row stores address, relative to the tile: a uniform base pointer
+    // (scalar registers) + a 32-bit BYTE offset per lane, formed by 24-bit multiply-adds
+    // (n * 4 and ct_ld * 4 < 2^24: check_fused_args) -- a 64-bit multiply-add, a move and a 64-bit
+    // shift-add per access otherwise.
+    char *const next_t = reinterpret_cast<char *>(next + (size_t)i_base * n + j_base);
+    char *const last_t = last ? reinterpret_cast<char *>(last + (size_t)i_base * n + j_base) : nullptr;
+    char *const hops_t = hops ? reinterpret_cast<char *>(hops + (size_t)i_base * n + j_base) : nullptr;
+    const char *const cnt_t = reinterpret_cast<const char *>(cnt + i_base);
+    const char *const cht_t = cht ? reinterpret_cast<const char *>(cht + i_base) : nullptr;
+    const char *const wh_t = wh ? reinterpret_cast<const char *>(wh + j_base) : nullptr;
+    char *const rate_t = reinterpret_cast<char *>(rate + (size_t)i_base * n + j_base);
+    const unsigned int n4 = (unsigned int)n * 4u, ld4 = (unsigned int)ct_ld * 4u;
+    unsigned int p_offb = 0;
     auto retire = [&]() __attribute__((always_inline)) {
         if (p_act) {
             // vmcnt also counts global -> LDS loads; the compiler's own wait-count pass does not put
             // this wait here (it loses track of them across the flush points' control flow)
             __builtin_amdgcn_s_waitcnt(FWX_WAIT_VMCNT0);
-            next_t[p_off] = g_next[wave][lane];
+            *reinterpret_cast<int32_t *>(next_t + p_offb) = g_next[wave][lane];
             // lengths of the two halves at the winning pivot (Algorithms.hs:55)
-            if (hops) hops_t[p_off] = (int32_t)((uint32_t)g_hc[wave][lane] + (uint32_t)g_hw[wave][lane]);
+            if (hops)
+                *reinterpret_cast<int32_t *>(hops_t + p_offb) =
+                    (int32_t)((uint32_t)g_hc[wave][lane] + (uint32_t)g_hw[wave][lane]);
         }
         p_act = false;
     };
     // Re-scan of the items [0, count) in batches of 64, one lane per item; full batches only unless
     // `all`; the remainder (< 64 items) moves to the front of the list.  An item carries no value:
-    // sid is the LAST stage in which the entry moved, so its final value is the maximum of that
+    // its stage is the LAST one in which the entry moved, so its final value is the maximum of that
     // stage's products, and t* the first pivot that attains it.
+    // item id = row << 8 | column << 2 | stage  (column << 2 is the byte offset into a W row as it stands)
+    static_assert(B / ARG_SL <= 4 && TI <= 128 && TJ <= 64 && ARG_SL == 16, "item id fields, FWX_FIND4 calls");
     auto rescan = [&](bool all) __attribute__((always_inline)) {
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         int base = 0;
@@ -1437,30 +1513,30 @@ __global__ __launch_bounds__(256, MINW) void fused_main_arg(float *rate, int32_t
             const int it = base + lane;
             const bool act = it < count;
             const unsigned int id = ids[act ? it : 0];
-            const int il = (int)((id >> 6) & 127u), jl = (int)(id & 63u), t0 = (int)(id >> 13) * ARG_SL;
+            const unsigned int il = id >> 8, jl4 = id & 0xFCu, t0 = (id & 3u) * ARG_SL;
             const float *pc = &sC[t0][il];
-            const float *pw = &sW[t0][jl];
+            const float *pw = reinterpret_cast<const float *>(reinterpret_cast<const char *>(&sW[t0][0]) + jl4);
             float p[ARG_SL];
 #pragma unroll
             for (int u = 0; u < ARG_SL; ++u) p[u] = pc[u * TI] * pw[u * TJ];
             float m = __builtin_fmaxf(p[0], p[1]);
 #pragma unroll
             for (int u = 2; u < ARG_SL; u += 2) m = __builtin_fmaxf(__builtin_fmaxf(m, p[u]), p[u + 1]);
-            int found = -1;
-#pragma unroll
-            for (int u = ARG_SL - 1; u >= 0; --u)    // descending: the smallest matching pivot wins
-                found = (p[u] == m) ? u : found;      // (stage-relative: inline constants, one add below)
+            int found = -1;                          // descending: the smallest matching pivot wins
+            FWX_FIND4("v_cmp_eq_f32", found, m, p[15], 15, p[14], 14, p[13], 13, p[12], 12);
+            FWX_FIND4("v_cmp_eq_f32", found, m, p[11], 11, p[10], 10, p[9], 9, p[8], 8);
+            FWX_FIND4("v_cmp_eq_f32", found, m, p[7], 7, p[6], 6, p[5], 5, p[4], 4);
+            FWX_FIND4("v_cmp_eq_f32", found, m, p[3], 3, p[2], 2, p[1], 1, p[0], 0);
             retire();                                // the previous batch: its gathers have landed
             if (act && found >= 0) {
-                found += t0;
-                p_off = (unsigned int)il * (unsigned int)n + (unsigned int)jl;
-                const unsigned int c_off = (unsigned int)found * (unsigned int)ct_ld + (unsigned int)il;
-                __builtin_amdgcn_global_load_lds((gptr_t *)(cnt_t + c_off), (lptr_t *)&g_next[wave][0], 4, 0, 0);
-                if (last) last_t[p_off] = k0 + found;
+                const unsigned int t_abs = (unsigned int)found + t0;
+                p_offb = (unsigned int)__umul24(il, n4) + jl4;
+                const unsigned int c_offb = (unsigned int)__umul24(t_abs, ld4) + il * 4u;
+                __builtin_amdgcn_global_load_lds((gptr_t *)(cnt_t + c_offb), (lptr_t *)&g_next[wave][0], 4, 0, 0);
+                if (last) *reinterpret_cast<int32_t *>(last_t + p_offb) = k0 + (int)t_abs;
                 if (hops) {
-                    __builtin_amdgcn_global_load_lds((gptr_t *)(cht_t + c_off), (lptr_t *)&g_hc[wave][0], 4, 0, 0);
-                    __builtin_amdgcn_global_load_lds((gptr_t *)(wh_t + ((unsigned int)found * (unsigned int)n +
-                                                                        (unsigned int)jl)),
+                    __builtin_amdgcn_global_load_lds((gptr_t *)(cht_t + c_offb), (lptr_t *)&g_hc[wave][0], 4, 0, 0);
+                    __builtin_amdgcn_global_load_lds((gptr_t *)(wh_t + ((unsigned int)__umul24(t_abs, n4) + jl4)),
                                                      (lptr_t *)&g_hw[wave][0], 4, 0, 0);
                 }
                 p_act = true;
@@ -1489,32 +1565,31 @@ __global__ __launch_bounds__(256, MINW) void fused_main_arg(float *rate, int32_t
                 }
         __builtin_amdgcn_s_waitcnt(FWX_WAIT_VMCNT0);
     }
+    // Lanes that own nothing here -- rows past the slab, rows of the look-ahead launch, columns outside
+    // the matrix or left to another launch -- drop their stage marks once (edge tiles and the
+    // look-ahead rows only: wave-uniform test), so that below "moved" is just sid >= 0 and the
+    // compare that says so IS the wave's ballot.
+    const bool lane_ok = !skip && jok;
+    if (__builtin_amdgcn_ballot_w64(!(lane_ok && i0 + RI <= rows))) {
+#pragma unroll
+        for (int r = 0; r < RI; ++r)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) sid[r][e] = (lane_ok && i0 + r < rows) ? sid[r][e] : -1;
+    }
+    const unsigned int lane_offb = (unsigned int)__umul24((unsigned int)(ti * RI), n4) + (unsigned int)(tj * 16);
+    const unsigned int id_lane = ((unsigned int)(ti * RI) << 8) | ((unsigned int)(tj * 4) << 2);
 #pragma unroll
     for (int r = 0; r < RI; ++r) {
-        const int i = i0 + r;
-        const bool row_ok = i < rows && !skip && jok;
-        bool ch[4];
-        bool any = false;
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            ch[e] = row_ok && sid[r][e] >= 0;
-            any |= ch[e];
-        }
-        if (any)                                  // (any => the row and the columns are inside: jc == jcol)
-            *reinterpret_cast<V4 *>(rate_t + ((unsigned int)(ti * RI + r) * (unsigned int)n + (unsigned int)(tj * 4))) = xa[r];
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            const unsigned long long mask = __builtin_amdgcn_ballot_w64(ch[e]);
-            if (mask) {                               // wave-uniform
-                const int pos = count + (int)__builtin_amdgcn_mbcnt_hi((unsigned int)(mask >> 32),
-                                             __builtin_amdgcn_mbcnt_lo((unsigned int)mask, 0u));
-                if (ch[e])
-                    ids[pos] = (unsigned short)(((unsigned int)sid[r][e] << 13) |
-                                                ((unsigned int)(ti * RI + r) << 6) | (unsigned int)(tj * 4 + e));
-                count += __builtin_popcountll(mask);
-            }
-            if ((e & 1) && count >= 64) rescan(false);    // count <= 63 + 2 * 64 here
-        }
+        const unsigned int id_row = id_lane | ((unsigned int)r << 8);
+        // (a moved entry => the row and the columns are inside: jc == jcol)
+        if (sid[r][0] >= 0 || sid[r][1] >= 0 || sid[r][2] >= 0 || sid[r][3] >= 0)
+            *reinterpret_cast<V4 *>(rate_t + (size_t)r * n4 + lane_offb) = xa[r];
+        count += compact_slot<0>(sid[r][0], id_row, ids_lds + 2u * (unsigned int)count);
+        count += compact_slot<4>(sid[r][1], id_row, ids_lds + 2u * (unsigned int)count);
+        if (count >= 64) rescan(false);               // count <= 63 + 2 * 64 here
+        count += compact_slot<8>(sid[r][2], id_row, ids_lds + 2u * (unsigned int)count);
+        count += compact_slot<12>(sid[r][3], id_row, ids_lds + 2u * (unsigned int)count);
+        if (count >= 64) rescan(false);
     }
     if (count > 0) rescan(true);
     retire();
@@ -1542,7 +1617,7 @@ __global__ __launch_bounds__(256, MINW) void fused_main_arg_f64(double *rate, in
     constexpr int RI = 4, TI = 64, TJ = 64, LCAP = 192;
     __shared__ __attribute__((aligned(16))) double sW[B][TJ];
     __shared__ __attribute__((aligned(16))) double sC[B][TI];
-    __shared__ unsigned short l_id[4][LCAP];    // per-wave item lists: sid << 13 | row << 6 | column
+    __shared__ unsigned short l_id[4][LCAP];    // per-wave item lists: row << 8 | column << 2 | stage
     __shared__ int32_t g_next[4][64], g_hc[4][64], g_hw[4][64];   // gathers of the batch in flight
 
     const int tid = threadIdx.x;
@@ -1622,7 +1697,7 @@ __global__ __launch_bounds__(256, MINW) void fused_main_arg_f64(double *rate, in
     __syncthreads();
 
     // ---- 1. the fold: four stages of 16 pivots that ping-pong xa <-> xb --------------------------
-    const int npiv = skip ? 0 : bt;
+    const int npiv = __builtin_amdgcn_ballot_w64(!skip) ? bt : 0;   // wave-uniform (see fused_main_arg)
     auto step = [&](int t, const double (&in)[RI][4], double (&out)[RI][4]) {
         double c[RI], wv[4];
 #pragma unroll
@@ -1658,8 +1733,8 @@ __global__ __launch_bounds__(256, MINW) void fused_main_arg_f64(double *rate, in
             for (int t = s * ARG_SL + 1; t < t_hi; ++t) step(t, dst, dst);
 #pragma unroll
             for (int r = 0; r < RI; ++r)
-#pragma unroll
-                for (int e = 0; e < 4; ++e) sid[r][e] = (dst[r][e] != src[r][e]) ? s : sid[r][e];
+                track4(sid[r][0], sid[r][1], sid[r][2], sid[r][3], dst[r][0], dst[r][1], dst[r][2], dst[r][3],
+                       src[r][0], src[r][1], src[r][2], src[r][3], s);
             stages = s + 1;
         }
     }
@@ -1676,26 +1751,33 @@ __global__ __launch_bounds__(256, MINW) void fused_main_arg_f64(double *rate, in
     const int gi_lo = row0 + i_base;
     const bool diag_tile = gi_lo < j_base + TJ && j_base < gi_lo + TI;
     unsigned short *ids = &l_id[wave][0];
+    const unsigned int ids_lds = (unsigned int)reinterpret_cast<size_t>(
+        (__attribute__((address_space(3))) unsigned short *)ids);          // its LDS byte address (uniform)
     const int lane = tid & 63;
     int count = 0;                                   // items in this wave's list (wave-uniform)
     bool p_act = false;
-    // tile-relative addressing of the re-scan: uniform base pointers + 32-bit offsets (see fused_main_arg)
-    int32_t *const next_t = next + (size_t)i_base * n + j_base;
-    int32_t *const last_t = last ? last + (size_t)i_base * n + j_base : nullptr;
-    int32_t *const hops_t = hops ? hops + (size_t)i_base * n + j_base : nullptr;
-    const int32_t *const cnt_t = cnt + i_base;
-    const int32_t *const cht_t = cht ? cht + i_base : nullptr;
-    const int32_t *const wh_t = wh ? wh + j_base : nullptr;
-    double *const rate_t = rate + (size_t)i_base * n + j_base;
-    unsigned int p_off = 0;
+    // tile-relative addressing: uniform base pointers + 32-bit byte offsets (see fused_main_arg)
+    char *const next_t = reinterpret_cast<char *>(next + (size_t)i_base * n + j_base);
+    char *const last_t = last ? reinterpret_cast<char *>(last + (size_t)i_base * n + j_base) : nullptr;
+    char *const hops_t = hops ? reinterpret_cast<char *>(hops + (size_t)i_base * n + j_base) : nullptr;
+    const char *const cnt_t = reinterpret_cast<const char *>(cnt + i_base);
+    const char *const cht_t = cht ? reinterpret_cast<const char *>(cht + i_base) : nullptr;
+    const char *const wh_t = wh ? reinterpret_cast<const char *>(wh + j_base) : nullptr;
+    char *const rate_t = reinterpret_cast<char *>(rate + (size_t)i_base * n + j_base);
+    const unsigned int n4 = (unsigned int)n * 4u, n8 = (unsigned int)n * 8u, ld4 = (unsigned int)ct_ld * 4u;
+    unsigned int p_offb = 0;
     auto retire = [&]() __attribute__((always_inline)) {
         if (p_act) {
             __builtin_amdgcn_s_waitcnt(FWX_WAIT_VMCNT0);     // the global -> LDS gathers have landed
-            next_t[p_off] = g_next[wave][lane];
-            if (hops) hops_t[p_off] = (int32_t)((uint32_t)g_hc[wave][lane] + (uint32_t)g_hw[wave][lane]);
+            *reinterpret_cast<int32_t *>(next_t + p_offb) = g_next[wave][lane];
+            if (hops)
+                *reinterpret_cast<int32_t *>(hops_t + p_offb) =
+                    (int32_t)((uint32_t)g_hc[wave][lane] + (uint32_t)g_hw[wave][lane]);
         }
         p_act = false;
     };
+    // item id = row << 8 | column << 2 | stage
+    static_assert(B / ARG_SL <= 4 && TI <= 128 && TJ <= 64 && ARG_SL == 16, "item id fields, FWX_FIND4 calls");
     auto rescan = [&](bool all) __attribute__((always_inline)) {
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         int base = 0;
@@ -1703,30 +1785,30 @@ __global__ __launch_bounds__(256, MINW) void fused_main_arg_f64(double *rate, in
             const int it = base + lane;
             const bool act = it < count;
             const unsigned int id = ids[act ? it : 0];
-            const int il = (int)((id >> 6) & 127u), jl = (int)(id & 63u), t0 = (int)(id >> 13) * ARG_SL;
+            const unsigned int il = id >> 8, jl4 = id & 0xFCu, t0 = (id & 3u) * ARG_SL;
             const double *pc = &sC[t0][il];
-            const double *pw = &sW[t0][jl];
+            const double *pw = reinterpret_cast<const double *>(reinterpret_cast<const char *>(&sW[t0][0]) + 2u * jl4);
             double p[ARG_SL];
 #pragma unroll
             for (int u = 0; u < ARG_SL; ++u) p[u] = pc[u * TI] * pw[u * TJ];
             double m = p[0];
 #pragma unroll
             for (int u = 1; u < ARG_SL; ++u) m = fmax_t(m, p[u]);
-            int found = -1;
-#pragma unroll
-            for (int u = ARG_SL - 1; u >= 0; --u)    // descending: the smallest matching pivot wins
-                found = (p[u] == m) ? u : found;      // (stage-relative: inline constants, one add below)
+            int found = -1;                          // descending: the smallest matching pivot wins
+            FWX_FIND4("v_cmp_eq_f64", found, m, p[15], 15, p[14], 14, p[13], 13, p[12], 12);
+            FWX_FIND4("v_cmp_eq_f64", found, m, p[11], 11, p[10], 10, p[9], 9, p[8], 8);
+            FWX_FIND4("v_cmp_eq_f64", found, m, p[7], 7, p[6], 6, p[5], 5, p[4], 4);
+            FWX_FIND4("v_cmp_eq_f64", found, m, p[3], 3, p[2], 2, p[1], 1, p[0], 0);
             retire();                                // the previous batch
             if (act && found >= 0) {
-                found += t0;
-                p_off = (unsigned int)il * (unsigned int)n + (unsigned int)jl;
-                const unsigned int c_off = (unsigned int)found * (unsigned int)ct_ld + (unsigned int)il;
-                __builtin_amdgcn_global_load_lds((gptr_t *)(cnt_t + c_off), (lptr_t *)&g_next[wave][0], 4, 0, 0);
-                if (last) last_t[p_off] = k0 + found;
+                const unsigned int t_abs = (unsigned int)found + t0;
+                p_offb = (unsigned int)__umul24(il, n4) + jl4;
+                const unsigned int c_offb = (unsigned int)__umul24(t_abs, ld4) + il * 4u;
+                __builtin_amdgcn_global_load_lds((gptr_t *)(cnt_t + c_offb), (lptr_t *)&g_next[wave][0], 4, 0, 0);
+                if (last) *reinterpret_cast<int32_t *>(last_t + p_offb) = k0 + (int)t_abs;
                 if (hops) {
-                    __builtin_amdgcn_global_load_lds((gptr_t *)(cht_t + c_off), (lptr_t *)&g_hc[wave][0], 4, 0, 0);
-                    __builtin_amdgcn_global_load_lds((gptr_t *)(wh_t + ((unsigned int)found * (unsigned int)n +
-                                                                        (unsigned int)jl)),
+                    __builtin_amdgcn_global_load_lds((gptr_t *)(cht_t + c_offb), (lptr_t *)&g_hc[wave][0], 4, 0, 0);
+                    __builtin_amdgcn_global_load_lds((gptr_t *)(wh_t + ((unsigned int)__umul24(t_abs, n4) + jl4)),
                                                      (lptr_t *)&g_hw[wave][0], 4, 0, 0);
                 }
                 p_act = true;
@@ -1752,29 +1834,29 @@ __global__ __launch_bounds__(256, MINW) void fused_main_arg_f64(double *rate, in
                 }
         __builtin_amdgcn_s_waitcnt(FWX_WAIT_VMCNT0);
     }
+    // lanes that own nothing here drop their stage marks once (see fused_main_arg)
+    const bool lane_ok = !skip && jok;
+    if (__builtin_amdgcn_ballot_w64(!(lane_ok && jok2 && i0 + RI <= rows))) {
+#pragma unroll
+        for (int r = 0; r < RI; ++r)
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+                sid[r][e] = (lane_ok && (e < 2 || jok2) && i0 + r < rows) ? sid[r][e] : -1;
+    }
+    const unsigned int lane_offb = (unsigned int)__umul24((unsigned int)(ti * RI), n8) + (unsigned int)(tj * 32);
+    const unsigned int id_lane = ((unsigned int)(ti * RI) << 8) | ((unsigned int)(tj * 4) << 2);
 #pragma unroll
     for (int r = 0; r < RI; ++r) {
-        const int i = i0 + r;
-        const bool row_ok = i < rows && !skip && jok;
-        bool ch[4];
-#pragma unroll
-        for (int e = 0; e < 4; ++e) ch[e] = row_ok && (e < 2 || jok2) && sid[r][e] >= 0;
-        const unsigned int r_off = (unsigned int)(ti * RI + r) * (unsigned int)n + (unsigned int)(tj * 4);
-        if (ch[0] || ch[1]) *reinterpret_cast<V2 *>(rate_t + r_off) = V2{xa[r][0], xa[r][1]};
-        if (ch[2] || ch[3]) *reinterpret_cast<V2 *>(rate_t + r_off + 2) = V2{xa[r][2], xa[r][3]};
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            const unsigned long long mask = __builtin_amdgcn_ballot_w64(ch[e]);
-            if (mask) {                               // wave-uniform
-                const int pos = count + (int)__builtin_amdgcn_mbcnt_hi((unsigned int)(mask >> 32),
-                                             __builtin_amdgcn_mbcnt_lo((unsigned int)mask, 0u));
-                if (ch[e])
-                    ids[pos] = (unsigned short)(((unsigned int)sid[r][e] << 13) |
-                                                ((unsigned int)(ti * RI + r) << 6) | (unsigned int)(tj * 4 + e));
-                count += __builtin_popcountll(mask);
-            }
-            if ((e & 1) && count >= 64) rescan(false);    // count <= 63 + 2 * 64 here
-        }
+        const unsigned int id_row = id_lane | ((unsigned int)r << 8);
+        char *const row_p = rate_t + (size_t)r * n8 + lane_offb;
+        if (sid[r][0] >= 0 || sid[r][1] >= 0) *reinterpret_cast<V2 *>(row_p) = V2{xa[r][0], xa[r][1]};
+        if (sid[r][2] >= 0 || sid[r][3] >= 0) *reinterpret_cast<V2 *>(row_p + 16) = V2{xa[r][2], xa[r][3]};
+        count += compact_slot<0>(sid[r][0], id_row, ids_lds + 2u * (unsigned int)count);
+        count += compact_slot<4>(sid[r][1], id_row, ids_lds + 2u * (unsigned int)count);
+        if (count >= 64) rescan(false);               // count <= 63 + 2 * 64 here
+        count += compact_slot<8>(sid[r][2], id_row, ids_lds + 2u * (unsigned int)count);
+        count += compact_slot<12>(sid[r][3], id_row, ids_lds + 2u * (unsigned int)count);
+        if (count >= 64) rescan(false);
     }
     if (count > 0) rescan(true);
     retire();
@@ -1975,6 +2057,9 @@ template <typename T> static hipError_t check_fused_args(const FusedArgs<T> &a)
     if (a.bt > (two ? 2 * B : B) || a.n % VW != 0 || ((uintptr_t)a.rate % 16) || ((uintptr_t)a.w % 16) ||
         (a.next && ((uintptr_t)a.next % 16)) || a.ct_ld < a.rows)
         return hipErrorInvalidValue;
+    // the arg kernels form byte offsets inside a tile with 24-bit multiplies (a row of 8-byte entries
+    // must stay below 2^24 bytes; such a matrix would not fit any memory anyway)
+    if (a.n >= (1 << 21) || a.ct_ld >= (1 << 21)) return hipErrorInvalidValue;
     return hipSuccess;
 }
 
