@@ -255,7 +255,11 @@ def run_single(args):
     if args.with_next:
         pristine_next = hip.DeviceArray.from_numpy(next_host)
         nxt = hip.DeviceArray(pristine_next.shape, np.int32)
-    del next_host
+    # (kept for the fused + next-hops leg of the default run, see below)
+    want_next_leg = (np_dtype == np.float32 and args.engine == "perk" and not args.kslice and not args.with_next
+                     and not args.no_extras and not args.no_fused_extra)
+    if not want_next_leg:
+        del next_host
     upd = hip.DeviceArray((engine.FWX_UPDATE_SHARDS,), np.int64).zero_()
     k_end = args.kslice if args.kslice > 0 else n
     serp = not args.no_serpentine
@@ -415,6 +419,41 @@ def run_single(args):
                         "what": "matrix left in HBM by the last timed per-k step vs the fused engine's"}
         del timed_result, fused_host
         h.close()
+        if want_next_leg:
+            # ... and with the next-hop matrix (Algorithms.hs:55, the head of `_path`): the arg kernel.
+            # Same bound as above -- one fold at the stream rate -- so the fraction says what the
+            # next-hops cost on top of the rates.
+            h = engine.DeviceMatrix(n, np_dtype, with_next=True, device=0)
+            pn = hip.DeviceArray.from_numpy(next_host)
+            def next_step():
+                h.upload_dev(pristine, pn)
+                t1 = time.perf_counter()
+                h.solve()
+                return time.perf_counter() - t1
+            next_step()
+            nt = min(next_step(), next_step())
+            got = h.download()
+            stream_s = relax_per_step / 2.0 * 3 * 1.104e-9 / 64.0 / 1024.0
+            leg = {"value": relax_per_step / nt, "unit": "edge-relaxations/s", "ms_per_step": 1e3 * nt, "steps": 2,
+                   "valu_roofline": {"bound": "valu-issue", "bound_ms_per_step": 1e3 * stream_s,
+                                     "frac": stream_s / nt,
+                                     "note": "against ONE fold at the sustained stream rate (the rates-only bound); "
+                                             "the kernel's own scheme -- fold + stage tracking + compaction + "
+                                             "re-scan of the moved entries -- issues ~1.45 x the fold's vector "
+                                             "cycles (DESIGN.md 4.2, profiles/r03_sq_arg_main.txt)"},
+                   "check": {"rate_digest": digest(got[0]), "next_digest": digest(got[1]),
+                             "rates_equal_rates_only_leg": digest(got[0]) == out["check"]["rate_digest"]},
+                   "note": "same workload with the next-hop matrix carried (rates + next, fused_main_arg), "
+                           "best of 2, blocking fwx_matrix_solve calls; not part of `value`"}
+            gold = os.path.join(ROOT, "tests", "golden", "config4_n16384_digests.json")
+            if n == 16384 and args.dist == "d1" and args.config in (0, 4) and os.path.exists(gold):
+                with open(gold) as f:
+                    g = json.load(f)
+                leg["check"]["equals_whole_oracle_solve"] = bool(leg["check"]["rate_digest"] == g["rate_digest"] and
+                                                                 leg["check"]["next_digest"] == g["next_digest"])
+            out["fused_engine_next"] = leg
+            del got, pn
+            h.close()
 
     if want_f64 and extras:
         out["f64"] = f64_leg(engine, hip, rate64, n, stream)
