@@ -355,3 +355,70 @@ def test_config5_n32768_p8_partitioned_with_next_hops_and_path_lengths():
             p *= float(rate0[cur, v])
             cur = v
         assert abs(p - float(rate[s, d])) <= 2e-5 * float(rate[s, d])
+
+
+def _distinct_devices():
+    return list(range(min(engine.device_count(), 8)))
+
+
+@pytest.mark.skipif("engine.device_count() < 2", reason="needs two or more MI355X in one process")
+@pytest.mark.parametrize("exchange", ["rccl", "peer"])
+def test_distinct_devices_equal_the_oracle(exchange):
+    """What the one-GPU boxes cannot run: one partition per REAL device, the snapshot panels
+    travelling over xGMI -- by grouped ncclBroadcast on an ncclCommInitAll communicator of all the
+    devices (what AUTO picks), and by peer copies.  Both engines, rate + next + hops + U against the
+    oracle, the path trace against the list-faithful restatement, a ragged order, and the one-shot
+    entry point twice (the second call from the handle pool)."""
+    devs = _distinct_devices()
+    xchg = engine.FWX_XCHG_RCCL if exchange == "rccl" else engine.FWX_XCHG_PEER
+    for kind, n, dtype in (("d1", 1024, np.float32), ("t1", 517, np.float64)):
+        rate, nxt, hops = synth.make(kind, n, dtype, seed=n)
+        er, en, eh = rate.copy(), nxt.copy(), hops.copy()
+        eu = oracle.relax(er, en, eh)
+        for eng in (engine.FWX_ENGINE_FUSED, engine.FWX_ENGINE_PERK):
+            with engine.DeviceMatrix(n, dtype, with_next=True, with_hops=True, devices=devs, exchange=xchg) as dm:
+                assert dm.parts() == (len(devs), xchg)
+                if exchange == "rccl":
+                    assert dm.comm_ranks() == len(devs)
+                dm.upload(rate, nxt, hops)
+                u = dm.solve(engine=eng, count_updates=True)
+                gr, gn, gh = dm.download()
+            assert_bits_equal(gr, er, "rate %s n=%d engine=%d" % (kind, n, eng))
+            assert_bits_equal(gn, en, "next")
+            assert_bits_equal(gh, eh, "hops")
+            assert u == eu
+        for _ in range(2):
+            gr, gn = rate.copy(), nxt.copy()
+            engine.solve_multi(gr, gn, devices=devs, exchange=xchg)
+            assert_bits_equal(gr, er, "one-shot rate")
+            assert_bits_equal(gn, en, "one-shot next")
+    n = 200
+    rate, nxt, _ = synth.make("t1", n, np.float64, seed=3)
+    m = lf.run_algo(lf.from_dense([("X", "C%03d" % i) for i in range(n)], rate, nxt), np.float64)
+    paths = lf.path_indices(m)
+    with engine.DeviceMatrix(n, np.float64, with_next=True, devices=devs, exchange=xchg) as dm:
+        dm.enable_path_log()
+        dm.upload(rate, nxt)
+        dm.solve()
+        rnd = np.random.default_rng(9)
+        src = rnd.integers(0, n, 200).astype(np.int32)
+        dst = rnd.integers(0, n, 200).astype(np.int32)
+        got = dm.query_exact_batch(src, dst)
+        for q in range(len(src)):
+            assert tuple(got[q]) == paths[src[q]][dst[q]]
+
+
+@pytest.mark.skipif("engine.device_count() < 2", reason="needs two or more MI355X in one process")
+def test_distinct_devices_config4_digests():
+    """BASELINE config 4 as it is meant (N = 16384 f32 over all the devices of the node, RCCL) against
+    the committed whole-oracle digests, per-k engine (the bench's) and fused."""
+    from helpers import digest, load_golden
+    gold = load_golden("config4_n16384_digests.json")
+    n = gold["n"]
+    rate, nxt = synth.d1_uniform(n, np.float32, synth.BASE_SEED + 3)
+    devs = _distinct_devices()
+    for eng in (engine.FWX_ENGINE_PERK, engine.FWX_ENGINE_FUSED):
+        gr, gn = rate.copy(), nxt.copy()
+        engine.solve_multi(gr, gn, devices=devs, engine=eng)
+        assert digest(gr) == gold["rate_digest"]
+        assert digest(gn) == gold["next_digest"]
