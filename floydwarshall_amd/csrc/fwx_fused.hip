@@ -1605,7 +1605,7 @@ __global__ __launch_bounds__(256, MINW) void fused_main_arg(float *rate, int32_t
 // operands per relaxation -- at the edge of the LDS pipe -- so it is slower than
 // fused_main_max_f64's, and still well ahead of the compare form.
 // ------------------------------------------------------------------------------------------------
-template <int MINW>
+template <int MINW, int RI>
 __global__ __launch_bounds__(256, MINW) void fused_main_arg_f64(double *rate, int32_t *next, int rows, int n,
                                                                 int row0, int k0, int bt, const double *w,
                                                                 const double *ct, const int32_t *cnt,
@@ -1614,7 +1614,10 @@ __global__ __launch_bounds__(256, MINW) void fused_main_arg_f64(double *rate, in
                                                                 const int32_t *cht, const int32_t *wh, ColWin cw)
 {
     typedef double V2 __attribute__((ext_vector_type(2)));
-    constexpr int RI = 4, TI = 64, TJ = 64, LCAP = 192;
+    // RI rows per thread: 64 x 64 tiles (RI = 4; 69 KB of LDS, two workgroups per CU: the shipped form)
+    // or 32 x 64 (RI = 2; 52.5 KB, three: kept as an A/B switch, slower -- see launch_max_form)
+    constexpr int TI = 16 * RI, TJ = 64, LCAP = 192;
+    static_assert(RI == 2 || RI == 4, "tile height");
     __shared__ __attribute__((aligned(16))) double sW[B][TJ];
     __shared__ __attribute__((aligned(16))) double sC[B][TI];
     __shared__ unsigned short l_id[4][LCAP];    // per-wave item lists: row << 8 | column << 2 | stage
@@ -1635,16 +1638,18 @@ __global__ __launch_bounds__(256, MINW) void fused_main_arg_f64(double *rate, in
     // (see fused_main_arg)
     const bool full_tile = bt == B && ct_vec == 1 && i_base + TI <= rows && j_base + TJ <= n;   // workgroup-uniform
     if (full_tile) {
-        static_assert(TI == 64 && TJ == 64, "32 vectors per operand row");
+        static_assert(TJ == 64, "32 vectors per W row");
         const double *wp = w + (size_t)(tid >> 5) * n + j_base + (tid & 31) * 2;
-        const double *cp = ct + (size_t)(tid >> 5) * ct_ld + i_base + (tid & 31) * 2;
 #pragma unroll
-        for (int q = 0; q < B / 8; ++q) {
+        for (int q = 0; q < B / 8; ++q)
             *reinterpret_cast<V2 *>(&sW[(tid >> 5) + 8 * q][(tid & 31) * 2]) =
                 *reinterpret_cast<const V2 *>(wp + (size_t)(8 * q) * n);
-            *reinterpret_cast<V2 *>(&sC[(tid >> 5) + 8 * q][(tid & 31) * 2]) =
-                *reinterpret_cast<const V2 *>(cp + (size_t)(8 * q) * ct_ld);
-        }
+        constexpr int CV = TI / 2, CR = 256 / CV;              // vectors per C row, rows per sweep
+        const double *cp = ct + (size_t)(tid / CV) * ct_ld + i_base + (tid % CV) * 2;
+#pragma unroll
+        for (int q = 0; q < B / CR; ++q)
+            *reinterpret_cast<V2 *>(&sC[tid / CV + CR * q][(tid % CV) * 2]) =
+                *reinterpret_cast<const V2 *>(cp + (size_t)(CR * q) * ct_ld);
         if (k0 + bt > j_base && k0 < j_base + TJ) {            // skip j == k: the pivots' own columns
             __syncthreads();
             const int col = k0 + tid - j_base;
@@ -1678,11 +1683,17 @@ __global__ __launch_bounds__(256, MINW) void fused_main_arg_f64(double *rate, in
     }
     }
 
-    const int jcol = j_base + tj * 4;                  // 4 columns = two 16-byte vectors
-    const bool jok = jcol < n && !cw.skips(jcol);      // n % 2 == 0 and jcol % 4 == 0: jcol + 2 may be == n
-    const bool jok2 = jok && jcol + 2 < n;
+    // A thread's four columns are two 16-byte vectors HALF A TILE APART: entries e = 0, 1 at columns
+    // 2 tj + e, entries e = 2, 3 at 32 + 2 tj + (e - 2).  Its two W reads per pivot then fall on 16
+    // consecutive 16-byte slots across the 16 lanes of a ds_read_b128 group = all 64 banks once; with
+    // four ADJACENT columns per thread the slots are 32 bytes apart and lanes tj, tj + 8 share banks
+    // (2-way conflicts on every W read: 39 % of the kernel's LDS cycles, gpurun_out/r03_sq_f64).
+    const int jcol = j_base + tj * 2, jcol2 = jcol + TJ / 2;
+    const bool jok = jcol < n && !cw.skips(jcol);       // n % 2 == 0, window bounds % 4 == 0: whole vectors
+    const bool jok2 = jcol2 < n && !cw.skips(jcol2);
     const int jc = jok ? jcol : n - 2;
-    const int jc2 = jok2 ? jcol + 2 : n - 2;
+    const int jc2 = jok2 ? jcol2 : n - 2;
+    auto col_of = [&](int e) { return e < 2 ? jcol + e : jcol2 + (e - 2); };
     double xa[RI][4], xb[RI][4];
     int sid[RI][4];
 #pragma unroll
@@ -1708,7 +1719,7 @@ __global__ __launch_bounds__(256, MINW) void fused_main_arg_f64(double *rate, in
         }
 #pragma unroll
         for (int q = 0; q < 2; ++q) {
-            const V2 wq = *reinterpret_cast<const V2 *>(&sW[t][tj * 4 + q * 2]);
+            const V2 wq = *reinterpret_cast<const V2 *>(&sW[t][tj * 2 + q * (TJ / 2)]);
             wv[q * 2] = wq[0];
             wv[q * 2 + 1] = wq[1];
         }
@@ -1828,34 +1839,35 @@ __global__ __launch_bounds__(256, MINW) void fused_main_arg_f64(double *rate, in
         for (int r = 0; r < RI; ++r)
 #pragma unroll
             for (int e = 0; e < 4; ++e)
-                if (jok && row0 + i0 + r == jcol + e) {
-                    if (i0 + r < rows && sid[r][e] >= 0) xa[r][e] = rate[(size_t)(i0 + r) * n + jcol + e];
+                if ((e < 2 ? jok : jok2) && row0 + i0 + r == col_of(e)) {
+                    if (i0 + r < rows && sid[r][e] >= 0) xa[r][e] = rate[(size_t)(i0 + r) * n + col_of(e)];
                     sid[r][e] = -1;
                 }
         __builtin_amdgcn_s_waitcnt(FWX_WAIT_VMCNT0);
     }
     // lanes that own nothing here drop their stage marks once (see fused_main_arg)
-    const bool lane_ok = !skip && jok;
-    if (__builtin_amdgcn_ballot_w64(!(lane_ok && jok2 && i0 + RI <= rows))) {
+    if (__builtin_amdgcn_ballot_w64(skip || !jok || !jok2 || i0 + RI > rows)) {
 #pragma unroll
         for (int r = 0; r < RI; ++r)
 #pragma unroll
             for (int e = 0; e < 4; ++e)
-                sid[r][e] = (lane_ok && (e < 2 || jok2) && i0 + r < rows) ? sid[r][e] : -1;
+                sid[r][e] = (!skip && (e < 2 ? jok : jok2) && i0 + r < rows) ? sid[r][e] : -1;
     }
-    const unsigned int lane_offb = (unsigned int)__umul24((unsigned int)(ti * RI), n8) + (unsigned int)(tj * 32);
-    const unsigned int id_lane = ((unsigned int)(ti * RI) << 8) | ((unsigned int)(tj * 4) << 2);
+    const unsigned int lane_offb = (unsigned int)__umul24((unsigned int)(ti * RI), n8) + (unsigned int)(tj * 16);
+    const unsigned int id_lane = ((unsigned int)(ti * RI) << 8) | ((unsigned int)(tj * 2) << 2);
 #pragma unroll
     for (int r = 0; r < RI; ++r) {
         const unsigned int id_row = id_lane | ((unsigned int)r << 8);
+        const unsigned int id_row2 = id_row | ((unsigned int)(TJ / 2) << 2);     // the second vector's columns
         char *const row_p = rate_t + (size_t)r * n8 + lane_offb;
         if (sid[r][0] >= 0 || sid[r][1] >= 0) *reinterpret_cast<V2 *>(row_p) = V2{xa[r][0], xa[r][1]};
-        if (sid[r][2] >= 0 || sid[r][3] >= 0) *reinterpret_cast<V2 *>(row_p + 16) = V2{xa[r][2], xa[r][3]};
+        if (sid[r][2] >= 0 || sid[r][3] >= 0)
+            *reinterpret_cast<V2 *>(row_p + (TJ / 2) * 8) = V2{xa[r][2], xa[r][3]};
         count += compact_slot<0>(sid[r][0], id_row, ids_lds + 2u * (unsigned int)count);
         count += compact_slot<4>(sid[r][1], id_row, ids_lds + 2u * (unsigned int)count);
         if (count >= 64) rescan(false);               // count <= 63 + 2 * 64 here
-        count += compact_slot<8>(sid[r][2], id_row, ids_lds + 2u * (unsigned int)count);
-        count += compact_slot<12>(sid[r][3], id_row, ids_lds + 2u * (unsigned int)count);
+        count += compact_slot<0>(sid[r][2], id_row2, ids_lds + 2u * (unsigned int)count);
+        count += compact_slot<4>(sid[r][3], id_row2, ids_lds + 2u * (unsigned int)count);
         if (count >= 64) rescan(false);
     }
     if (count > 0) rescan(true);
@@ -1915,7 +1927,14 @@ static bool small_tiles(int n, int rows, long long thresh = 512)
 // ms, N = 6144 23.3 -> 21.8 ms, N = 8192 unchanged; gpurun_out/r02_run15_tiles.log).
 // After the re-scan rewrite (gpurun_out/r02_run60.log, 64 x 64 against 128 x 64): N = 3072 3.79 / 4.03 ms,
 // 6144 18.56 / 18.88, 8192 39.17 / 38.96, 10240 70.56 / 72.02: level or ahead up to there.
-static bool small_tiles_arg(int n, int rows) { return small_tiles(n, rows, 6500); }
+static bool small_tiles_arg(int n, int rows)
+{
+    static const long long thresh = [] {               // FWX_ARG_SMALL_TILES_BELOW: A/B switch
+        const char *e = getenv("FWX_ARG_SMALL_TILES_BELOW");
+        return e ? atoll(e) : 6500LL;
+    }();
+    return small_tiles(n, rows, thresh);
+}
 
 __global__ __launch_bounds__(256) void nonneg_check_f64(const double *rate, const int32_t *next,
                                                         size_t count, int *flag)
@@ -1999,10 +2018,19 @@ static bool launch_max_form(const FusedArgs<double> &a, dim3 grid, dim3 block, i
         if (ct_vec && general) ct_vec = 2;
         ColWin c2 = cw;
         c2.jt0 = window ? cw.jt0 / 2 : 0;
-        const dim3 g(window ? grid.x / 2 : (unsigned)((a.n + 63) / 64), (unsigned)((a.rows + 63) / 64));
-        hipLaunchKernelGGL((fused_main_arg_f64<2>), g, block, 0, s, a.rate, a.next, a.rows, a.n, a.row0, a.k0,
-                           a.bt, a.w, a.ct, a.cnt, a.ct_ld, ct_vec, skip_lo, skip_hi, last, a.hops, a.cht,
-                           a.wh, c2);
+        // 64 x 64 tiles, two workgroups per CU.  FWX_ARG_F64_SHORT_TILES=1: 32 x 64 tiles, three per CU --
+        // measured SLOWER (N = 16384 + next 485.8 -> 522.0 ms, profiles/r03_experiments_not_adopted.txt
+        // item 4): the third wave per SIMD buys less than the doubled W staging and LDS reads cost
+        static const bool tall = [] { const char *e = getenv("FWX_ARG_F64_SHORT_TILES"); return !(e && *e == '1'); }();
+        const unsigned gx = window ? grid.x / 2 : (unsigned)((a.n + 63) / 64);
+        if (tall)
+            hipLaunchKernelGGL((fused_main_arg_f64<2, 4>), dim3(gx, (unsigned)((a.rows + 63) / 64)), block, 0, s,
+                               a.rate, a.next, a.rows, a.n, a.row0, a.k0, a.bt, a.w, a.ct, a.cnt, a.ct_ld, ct_vec,
+                               skip_lo, skip_hi, last, a.hops, a.cht, a.wh, c2);
+        else
+            hipLaunchKernelGGL((fused_main_arg_f64<3, 2>), dim3(gx, (unsigned)((a.rows + 31) / 32)), block, 0, s,
+                               a.rate, a.next, a.rows, a.n, a.row0, a.k0, a.bt, a.w, a.ct, a.cnt, a.ct_ld, ct_vec,
+                               skip_lo, skip_hi, last, a.hops, a.cht, a.wh, c2);
         return true;
     }
     if (!small) {
