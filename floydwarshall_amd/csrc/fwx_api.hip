@@ -71,21 +71,27 @@ template <typename T> bool fused_ok(int n, const void *rate, const int32_t *)
 // 12288: 117.0 / 117.5, 16384: 266.3 / 262.2; + trace 8192: 46.1 / 45.8, 10240: 84.6 / 83.6, 16384:
 // 316.2 / 305.0; f64 + trace 8192: 137.9 / 132.6.
 // ws: see fused_ws_bytes.
-//   double pass (rates only inside the domain -- the max-form kernels --, 64-aligned blocks, large
+//   double pass (inside the domain -- the max-form and the arg kernels --, 64-aligned blocks, large
 //     matrices): the main kernel applies TWO passes (128 pivots) per launch, which halves the tile
-//     traffic and the per-tile overhead that kept it at 0.75 of its issue bound.  It needs the
+//     traffic and the per-tile overhead that kept it at 0.75 of its issue bound (the arg kernels run
+//     their two passes one after the other on the tile they keep in registers).  It needs the
 //     panels of both passes up front, so the look-ahead is two deep: beside main(P) -- which leaves
 //     the 128 rows and 128 columns of the NEXT pair of blocks alone -- the side stream brings
 //     exactly that cross up to date with the pair being applied (two launches of 128 pivots), runs
 //     the panels of the first block of the next pair, applies that one pass to the rows and columns
 //     of the second block, and runs its panels.  An entry that main(P+1) then folds again with a
 //     pass it has already seen does not move (max is idempotent; the compare form would not move or
-//     count it either), so main(P+1) simply covers everything but the cross after it.
+//     count it either -- and an entry that does not move is no item of the arg re-scan: its next-hop,
+//     path length and trace stay), so main(P+1) simply covers everything but the cross after it.
 constexpr int kLookaheadMinN = INT32_MAX, kLookaheadMinNWithNext = 16384, kLookaheadMinNWithTrace = 8192;
 // crossover (single / double pass, ms; profiles/r03_double_pass_crossover.txt): f32 4096: 4.10 / 4.74,
 // 6144: 10.47 / 10.18, 8192: 21.2 / 20.0, 12288: 68.1 / 61.0, 16384: 152.0 / 135.3; f64 6144: 23.1 / 22.1,
 // 16384: 355 / 324 -- below ~6000 the side chain (five launches per 128 pivots) is the critical path
 constexpr int kDoublePassMinN = 6144;    // FWX_DOUBLE_PASS_MIN_N overrides
+// ... and with next-hops (the arg kernels; + trace, + hops), f32 only: FWX_DOUBLE_PASS_NEXT_MIN_N overrides.
+// (f64: the two-pass fused_main_arg_f64 is SLOWER than two launches, N = 16384 + next 486 -> 499 ms on
+// one box -- tools/runs/r03_run33.sh --, so f64 stays on the single pass unless the variable asks)
+constexpr int kDoublePassNextMinN = 8192;
 // FWX_LOOKAHEAD_MIN_N / FWX_SYMMETRIC_MIN_N override the thresholds (tests force each schedule at
 // small sizes, tuning runs switch one off with a huge value); read on every solve.
 static int env_threshold(const char *name, int dflt)
@@ -180,24 +186,36 @@ int fused_range(T *rate, int32_t *next, int32_t *hops, int n, int k_begin, int k
     };
 
     // ---- double pass: see the header comment ----------------------------------------------------
-    if (!next && nonneg && !d_updates && !rec && k_begin % FWX_FUSED_B == 0 &&
-        n >= env_threshold("FWX_DOUBLE_PASS_MIN_N", kDoublePassMinN) && k_end - k_begin >= 4 * FWX_FUSED_B) {
+    if (nonneg && !d_updates && !rec && k_begin % FWX_FUSED_B == 0 &&
+        n >= (next ? env_threshold("FWX_DOUBLE_PASS_NEXT_MIN_N", sizeof(T) == 4 ? kDoublePassNextMinN : INT32_MAX)
+                   : env_threshold("FWX_DOUBLE_PASS_MIN_N", kDoublePassMinN)) &&
+        k_end - k_begin >= 4 * FWX_FUSED_B) {
         constexpr int Bq = FWX_FUSED_B;
         const int nb = (k_end - k_begin) / Bq;          // full blocks; a ragged tail is handled below
         const int pairs = nb / 2;
         // four panel sets, as two adjacent pairs: block q lives in set q & 3, so a pair (2P, 2P + 1)
-        // is contiguous in W (128 rows) and in Ct (128 lines)
-        T *w4 = (T *)ws;
-        T *ct4 = w4 + (size_t)4 * Bq * n;
+        // is contiguous in W (128 rows), in Ct (128 lines) and likewise in CNt, WH, CHt
+        char *q4 = (char *)ws;
+        T *w4 = (T *)q4;                 q4 += (size_t)4 * Bq * n * sizeof(T);
+        T *ct4 = (T *)q4;                q4 += (size_t)4 * Bq * ld * sizeof(T);
+        int32_t *cnt4 = (int32_t *)q4;   q4 += (size_t)4 * Bq * ld * sizeof(int32_t);
+        int32_t *wh4 = nullptr, *cht4 = nullptr;
+        if (hops) {
+            wh4 = (int32_t *)q4;         q4 += (size_t)4 * Bq * n * sizeof(int32_t);
+            cht4 = (int32_t *)q4;
+        }
         auto set_of = [&](int q) { return q & 3; };
+        auto wh_of = [&](int q) { return wh4 ? wh4 + (size_t)set_of(q) * Bq * n : nullptr; };
         auto bind4 = [&](int q, int blocks) {           // pivots of `blocks` blocks starting at block q
             a.k0 = k_begin + q * Bq; a.bt = blocks * Bq;
-            a.w = w4 + (size_t)set_of(q) * Bq * n; a.wh = nullptr;
-            a.ct = ct4 + (size_t)set_of(q) * Bq * ld; a.cnt = nullptr; a.cht = nullptr;
+            a.w = w4 + (size_t)set_of(q) * Bq * n; a.wh = wh_of(q);
+            a.ct = ct4 + (size_t)set_of(q) * Bq * ld;
+            a.cnt = next ? cnt4 + (size_t)set_of(q) * Bq * ld : nullptr;
+            a.cht = cht4 ? cht4 + (size_t)set_of(q) * Bq * ld : nullptr;
         };
         auto panels4 = [&](int q, hipStream_t st) {
             bind4(q, 1);
-            return fwx::launch_fused_panels<T>(a, w4 + (size_t)set_of(q) * Bq * n, nullptr, st);
+            return fwx::launch_fused_panels<T>(a, w4 + (size_t)set_of(q) * Bq * n, wh_of(q), st);
         };
         // pivots of `blocks` blocks from block q onto the rows [lo, hi) (all columns) and the columns
         // [lo, hi) (the other rows)

@@ -1308,13 +1308,14 @@ __device__ __forceinline__ int compact_slot(int sid, unsigned int id_row, unsign
             : "v"(pa), "v"(pb), "v"(pc_), "v"(pd), "v"(m));                                               \
     } while (0)
 
-template <int MINW, int RI>
+template <int MINW, int RI, int NP>
 __global__ __launch_bounds__(256, MINW) void fused_main_arg(float *rate, int32_t *next, int rows, int n,
-                                                            int row0, int k0, int bt, const float *w,
-                                                            const float *ct, const int32_t *cnt,
-                                                            int ct_ld, int ct_vec, int skip_lo,
-                                                            int skip_hi, int32_t *last, int32_t *hops,
-                                                            const int32_t *cht, const int32_t *wh, ColWin cw)
+                                                            int row0, int k0_all, int bt_all,
+                                                            const float *w_all, const float *ct_all,
+                                                            const int32_t *cnt_all, int ct_ld, int ct_vec,
+                                                            int skip_lo, int skip_hi, int32_t *last,
+                                                            int32_t *hops, const int32_t *cht_all,
+                                                            const int32_t *wh_all, ColWin cw)
 {
     typedef float V4 __attribute__((ext_vector_type(4)));
     // list capacity: a flush point after every second entry slot, 63 carried + 2 * 64 new items
@@ -1327,15 +1328,52 @@ __global__ __launch_bounds__(256, MINW) void fused_main_arg(float *rate, int32_t
     // CN[t*][i], and with hops CHt[t*][i] and WH[t*][j]
     __shared__ int32_t g_next[4][64], g_hc[4][64], g_hw[4][64];
 
-    const int tid = threadIdx.x;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int tid_all = threadIdx.x;
+    const int wave = __builtin_amdgcn_readfirstlane(tid_all >> 6);
     const int i_base = blockIdx.y * TI;
     const int j_base = (blockIdx.x + cw.jt0) * TJ;
     if (cw.cskip_lo <= j_base && j_base + TJ <= cw.cskip_hi) return;   // the whole tile is someone else's
+    const float nanv = qnan<float>();
+
+    // the tile: loaded once (after the first pass's operand strips have been staged: see below),
+    // carried in registers through every pass of the launch
+    V4 xa[RI], xb[RI];
+
+    // NP = 1 or 2 passes of up to B pivots per launch (two: the double-pass schedule of fused_range,
+    // bt_all == 2 B).  A pass is complete in itself -- stage its operand strips, fold, track, re-scan
+    // the moved entries, store the rows that moved -- only the tile stays in registers from one to the
+    // next, which saves the second pass its tile load and the launch its second prologue, tail and gap.
+    // The two passes are two inlined COPIES of the body (a lambda called twice; `#pragma unroll` refuses a
+    // loop with barriers in it), not a run-time loop: around a back-edge the compiler's
+    // wait-count pass sees the re-scan's global -> LDS gathers and the conditional diagonal loads as
+    // pending everywhere -- s_waitcnt vmcnt(0) before every LDS store of the staging (its 12 loads
+    // one at a time) and before every row store: 10 % (f32) to 20 % (f64) slower, measured
+    // (tools/runs/r03_run33.sh).  Inside the body the kernel's operands are the CURRENT pass's.
+    static_assert(NP == 1 || NP == 2, "passes per launch");
+    auto one_pass = [&](const int ps) __attribute__((always_inline)) {
+    // With two passes, everything a pass derives from the thread index is derived again in the second,
+    // from a copy the compiler cannot see through: shared between the copies those values (store
+    // offsets, item ids, LDS addresses -- used after the fold) would be live THROUGH the second fold,
+    // 20 registers above its 148, i.e. spilled.
+    int tid = tid_all;
+    if (NP > 1) {
+        asm volatile("" : "+v"(tid));
+        __builtin_assume(tid >= 0 && tid < 256);
+    }
     const int ti = tid >> 4, tj = tid & 15;
     const int i0 = i_base + ti * RI;
     const bool skip = i0 >= skip_lo && i0 < skip_hi;   // rows done by the look-ahead launch
-    const float nanv = qnan<float>();
+    const int jcol = j_base + tj * 4;
+    const bool jok = jcol < n && !cw.skips(jcol);
+    const int jc = jok ? jcol : n - 4;
+    const int k0 = k0_all + ps * B;
+    const int bt = NP == 1 ? bt_all : B;
+    const float *const w = w_all + (size_t)ps * B * n;
+    const float *const ct = ct_all + (size_t)ps * B * ct_ld;
+    const int32_t *const cnt = cnt_all + (size_t)ps * B * ct_ld;
+    const int32_t *const cht = cht_all ? cht_all + (size_t)ps * B * ct_ld : nullptr;
+    const int32_t *const wh = wh_all ? wh_all + (size_t)ps * B * n : nullptr;
+    if (ps) __syncthreads();          // every wave has finished the re-scan that reads the previous strips
 
     // ---- stage W (NaN at j == k and past the matrix) and C (NaN at i == k, from colpanel) -------
     // A full pass on a tile inside the slab (all but the edge tiles): straight-line copies from two
@@ -1390,18 +1428,18 @@ __global__ __launch_bounds__(256, MINW) void fused_main_arg(float *rate, int32_t
     }
     }
 
-    const int jcol = j_base + tj * 4;
-    const bool jok = jcol < n && !cw.skips(jcol);
-    const int jc = jok ? jcol : n - 4;
-    V4 xa[RI], xb[RI];
+    if (ps == 0) {
+#pragma unroll
+        for (int r = 0; r < RI; ++r) {
+            const int i = min(i0 + r, rows - 1);
+            xa[r] = *reinterpret_cast<const V4 *>(rate + (size_t)i * n + jc);
+        }
+    }
     int sid[RI][4];
 #pragma unroll
-    for (int r = 0; r < RI; ++r) {
-        const int i = min(i0 + r, rows - 1);
-        xa[r] = *reinterpret_cast<const V4 *>(rate + (size_t)i * n + jc);
+    for (int r = 0; r < RI; ++r)
 #pragma unroll
         for (int e = 0; e < 4; ++e) sid[r][e] = -1;
-    }
     __syncthreads();
 
     // ---- 1. the fold: two pivots per v_max3_f32, four stages that ping-pong xa <-> xb -----------
@@ -1593,6 +1631,9 @@ __global__ __launch_bounds__(256, MINW) void fused_main_arg(float *rate, int32_t
     }
     if (count > 0) rescan(true);
     retire();
+    };   // one_pass
+    one_pass(0);
+    if constexpr (NP > 1) one_pass(1);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1605,13 +1646,14 @@ __global__ __launch_bounds__(256, MINW) void fused_main_arg(float *rate, int32_t
 // operands per relaxation -- at the edge of the LDS pipe -- so it is slower than
 // fused_main_max_f64's, and still well ahead of the compare form.
 // ------------------------------------------------------------------------------------------------
-template <int MINW, int RI>
+template <int MINW, int RI, int NP>
 __global__ __launch_bounds__(256, MINW) void fused_main_arg_f64(double *rate, int32_t *next, int rows, int n,
-                                                                int row0, int k0, int bt, const double *w,
-                                                                const double *ct, const int32_t *cnt,
-                                                                int ct_ld, int ct_vec, int skip_lo,
-                                                                int skip_hi, int32_t *last, int32_t *hops,
-                                                                const int32_t *cht, const int32_t *wh, ColWin cw)
+                                                                int row0, int k0_all, int bt_all,
+                                                                const double *w_all, const double *ct_all,
+                                                                const int32_t *cnt_all, int ct_ld, int ct_vec,
+                                                                int skip_lo, int skip_hi, int32_t *last,
+                                                                int32_t *hops, const int32_t *cht_all,
+                                                                const int32_t *wh_all, ColWin cw)
 {
     typedef double V2 __attribute__((ext_vector_type(2)));
     // RI rows per thread: 64 x 64 tiles (RI = 4; 69 KB of LDS, two workgroups per CU: the shipped form)
@@ -1623,15 +1665,36 @@ __global__ __launch_bounds__(256, MINW) void fused_main_arg_f64(double *rate, in
     __shared__ unsigned short l_id[4][LCAP];    // per-wave item lists: row << 8 | column << 2 | stage
     __shared__ int32_t g_next[4][64], g_hc[4][64], g_hw[4][64];   // gathers of the batch in flight
 
-    const int tid = threadIdx.x;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int tid_all = threadIdx.x;
+    const int wave = __builtin_amdgcn_readfirstlane(tid_all >> 6);
     const int i_base = blockIdx.y * TI;
     const int j_base = (blockIdx.x + cw.jt0) * TJ;
     if (cw.cskip_lo <= j_base && j_base + TJ <= cw.cskip_hi) return;   // the whole tile is someone else's
+    const double nanv = qnan<double>();
+
+    // the tile: loaded once, carried in registers through every pass of the launch (see fused_main_arg)
+    double xa[RI][4], xb[RI][4];
+
+    // NP = 1 or 2 passes per launch, two copies of the body; per-pass operands and (with two passes)
+    // everything derived from the thread index are (re)defined inside (see fused_main_arg)
+    static_assert(NP == 1 || NP == 2, "passes per launch");
+    auto one_pass = [&](const int ps) __attribute__((always_inline)) {
+    int tid = tid_all;
+    if (NP > 1) {
+        asm volatile("" : "+v"(tid));
+        __builtin_assume(tid >= 0 && tid < 256);
+    }
     const int ti = tid >> 4, tj = tid & 15;
     const int i0 = i_base + ti * RI;
     const bool skip = i0 >= skip_lo && i0 < skip_hi;   // rows done by the look-ahead launch
-    const double nanv = qnan<double>();
+    const int k0 = k0_all + ps * B;
+    const int bt = NP == 1 ? bt_all : B;
+    const double *const w = w_all + (size_t)ps * B * n;
+    const double *const ct = ct_all + (size_t)ps * B * ct_ld;
+    const int32_t *const cnt = cnt_all + (size_t)ps * B * ct_ld;
+    const int32_t *const cht = cht_all ? cht_all + (size_t)ps * B * ct_ld : nullptr;
+    const int32_t *const wh = wh_all ? wh_all + (size_t)ps * B * n : nullptr;
+    if (ps) __syncthreads();          // every wave has finished the re-scan that reads the previous strips
 
     // ---- stage W (NaN at j == k and past the matrix) and C (NaN at i == k, from colpanel) -------
     // full pass on a tile inside the slab: straight-line copies, the pivot columns poisoned afterwards
@@ -1691,20 +1754,22 @@ __global__ __launch_bounds__(256, MINW) void fused_main_arg_f64(double *rate, in
     const int jcol = j_base + tj * 2, jcol2 = jcol + TJ / 2;
     const bool jok = jcol < n && !cw.skips(jcol);       // n % 2 == 0, window bounds % 4 == 0: whole vectors
     const bool jok2 = jcol2 < n && !cw.skips(jcol2);
-    const int jc = jok ? jcol : n - 2;
-    const int jc2 = jok2 ? jcol2 : n - 2;
     auto col_of = [&](int e) { return e < 2 ? jcol + e : jcol2 + (e - 2); };
-    double xa[RI][4], xb[RI][4];
+    if (ps == 0) {                                  // the tile, once
+        const int jc = jok ? jcol : n - 2, jc2 = jok2 ? jcol2 : n - 2;
+#pragma unroll
+        for (int r = 0; r < RI; ++r) {
+            const int i = min(i0 + r, rows - 1);
+            const V2 a = *reinterpret_cast<const V2 *>(rate + (size_t)i * n + jc);
+            const V2 b = *reinterpret_cast<const V2 *>(rate + (size_t)i * n + jc2);
+            xa[r][0] = a[0]; xa[r][1] = a[1]; xa[r][2] = b[0]; xa[r][3] = b[1];
+        }
+    }
     int sid[RI][4];
 #pragma unroll
-    for (int r = 0; r < RI; ++r) {
-        const int i = min(i0 + r, rows - 1);
-        const V2 a = *reinterpret_cast<const V2 *>(rate + (size_t)i * n + jc);
-        const V2 b = *reinterpret_cast<const V2 *>(rate + (size_t)i * n + jc2);
-        xa[r][0] = a[0]; xa[r][1] = a[1]; xa[r][2] = b[0]; xa[r][3] = b[1];
+    for (int r = 0; r < RI; ++r)
 #pragma unroll
         for (int e = 0; e < 4; ++e) sid[r][e] = -1;
-    }
     __syncthreads();
 
     // ---- 1. the fold: four stages of 16 pivots that ping-pong xa <-> xb --------------------------
@@ -1872,6 +1937,9 @@ __global__ __launch_bounds__(256, MINW) void fused_main_arg_f64(double *rate, in
     }
     if (count > 0) rescan(true);
     retire();
+    };   // one_pass
+    one_pass(0);
+    if constexpr (NP > 1) one_pass(1);
 }
 
 // Domain check (fwx.h "Domain"): clears bit 0 of *flag if any rate has its sign bit set or is NaN,
@@ -1973,17 +2041,19 @@ static bool launch_max_form(const FusedArgs<float> &a, dim3 grid, dim3 block, in
         if (ct_vec && general) ct_vec = 2;
         // rates + next-hops (+ trace, + hops): max-form fold, then arg re-scan of the moved entries
         // (grid.x is the caller's: all 64-column tiles, or the tiles of a column window)
+        // a.bt <= B: one pass; a.bt == 2 B (check_fused_args): the two-pass instantiation
+#define FWX_ARG_LAUNCH(RI_, NP_, G_)                                                                   \
+        hipLaunchKernelGGL((fused_main_arg<3, RI_, NP_>), G_, block, 0, s, a.rate, a.next, a.rows, a.n,  \
+                           a.row0, a.k0, a.bt, a.w, a.ct, a.cnt, a.ct_ld, ct_vec, skip_lo, skip_hi, last, \
+                           a.hops, a.cht, a.wh, cw)
         if (small || small_tiles_arg(a.n, a.rows)) {
             const dim3 g(small ? grid.x : (unsigned)((a.n + 63) / 64), (unsigned)((a.rows + 63) / 64));
-            hipLaunchKernelGGL((fused_main_arg<3, 4>), g, block, 0, s, a.rate, a.next, a.rows, a.n, a.row0,
-                               a.k0, a.bt, a.w, a.ct, a.cnt, a.ct_ld, ct_vec, skip_lo, skip_hi, last,
-                               a.hops, a.cht, a.wh, cw);
+            if (a.bt > B) FWX_ARG_LAUNCH(4, 2, g); else FWX_ARG_LAUNCH(4, 1, g);
         } else {
             const dim3 g((unsigned)((a.n + 63) / 64), (unsigned)((a.rows + 127) / 128));
-            hipLaunchKernelGGL((fused_main_arg<3, 8>), g, block, 0, s, a.rate, a.next, a.rows, a.n, a.row0,
-                               a.k0, a.bt, a.w, a.ct, a.cnt, a.ct_ld, ct_vec, skip_lo, skip_hi, last,
-                               a.hops, a.cht, a.wh, cw);
+            if (a.bt > B) FWX_ARG_LAUNCH(8, 2, g); else FWX_ARG_LAUNCH(8, 1, g);
         }
+#undef FWX_ARG_LAUNCH
         return true;
     }
     if (small) {
@@ -2023,14 +2093,17 @@ static bool launch_max_form(const FusedArgs<double> &a, dim3 grid, dim3 block, i
         // item 4): the third wave per SIMD buys less than the doubled W staging and LDS reads cost
         static const bool tall = [] { const char *e = getenv("FWX_ARG_F64_SHORT_TILES"); return !(e && *e == '1'); }();
         const unsigned gx = window ? grid.x / 2 : (unsigned)((a.n + 63) / 64);
-        if (tall)
-            hipLaunchKernelGGL((fused_main_arg_f64<2, 4>), dim3(gx, (unsigned)((a.rows + 63) / 64)), block, 0, s,
-                               a.rate, a.next, a.rows, a.n, a.row0, a.k0, a.bt, a.w, a.ct, a.cnt, a.ct_ld, ct_vec,
-                               skip_lo, skip_hi, last, a.hops, a.cht, a.wh, c2);
-        else
-            hipLaunchKernelGGL((fused_main_arg_f64<3, 2>), dim3(gx, (unsigned)((a.rows + 31) / 32)), block, 0, s,
-                               a.rate, a.next, a.rows, a.n, a.row0, a.k0, a.bt, a.w, a.ct, a.cnt, a.ct_ld, ct_vec,
-                               skip_lo, skip_hi, last, a.hops, a.cht, a.wh, c2);
+#define FWX_ARG64_LAUNCH(MINW_, RI_, NP_)                                                               \
+        hipLaunchKernelGGL((fused_main_arg_f64<MINW_, RI_, NP_>),                                         \
+                           dim3(gx, (unsigned)((a.rows + 16 * RI_ - 1) / (16 * RI_))), block, 0, s, a.rate,  \
+                           a.next, a.rows, a.n, a.row0, a.k0, a.bt, a.w, a.ct, a.cnt, a.ct_ld, ct_vec,      \
+                           skip_lo, skip_hi, last, a.hops, a.cht, a.wh, c2)
+        if (tall) {
+            if (a.bt > B) FWX_ARG64_LAUNCH(2, 4, 2); else FWX_ARG64_LAUNCH(2, 4, 1);
+        } else {
+            if (a.bt > B) FWX_ARG64_LAUNCH(3, 2, 2); else FWX_ARG64_LAUNCH(3, 2, 1);
+        }
+#undef FWX_ARG64_LAUNCH
         return true;
     }
     if (!small) {
@@ -2080,8 +2153,9 @@ hipError_t launch_nonneg_check(const float *rate, const int32_t *next, size_t co
 template <typename T> static hipError_t check_fused_args(const FusedArgs<T> &a)
 {
     constexpr int VW = Vec16<T>::W;
-    // (a double pass, 2 * B pivots: only the rates-only max-form kernels, whose LDS stages do not grow with bt)
-    const bool two = !a.next && a.nonneg && !a.updates;
+    // (a double pass, 2 * B pivots: the max-form and arg kernels -- inside the domain, no update count)
+    const bool two = a.nonneg && !a.updates;
+    if (a.next && a.bt > B && a.bt != 2 * B) return hipErrorInvalidValue;   // the arg kernels: one or two FULL passes
     if (a.bt > (two ? 2 * B : B) || a.n % VW != 0 || ((uintptr_t)a.rate % 16) || ((uintptr_t)a.w % 16) ||
         (a.next && ((uintptr_t)a.next % 16)) || a.ct_ld < a.rows)
         return hipErrorInvalidValue;

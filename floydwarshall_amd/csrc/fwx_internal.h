@@ -355,13 +355,11 @@ struct CtxLease {
 inline size_t fused_ws_bytes(int n, size_t es, bool with_hops)
 {
     const size_t ld = ((size_t)n + 3) & ~(size_t)3;
-    // two row panels W and two sets of pivot-column snapshots (Ct, CNt): pass p+1's are produced
-    // while pass p's are read (fused_range)
-    size_t b = (size_t)FWX_FUSED_B * n * 2 * es + (size_t)FWX_FUSED_B * ld * 2 * (es + 4) + 256;
-    // the double-pass schedule of rates-only solves keeps FOUR panel sets (two passes being applied,
-    // two being produced): two more W and Ct panels
-    b += (size_t)FWX_FUSED_B * n * 2 * es + (size_t)FWX_FUSED_B * ld * 2 * es;
-    if (with_hops) b += (size_t)FWX_FUSED_B * n * 2 * 4 + (size_t)FWX_FUSED_B * ld * 2 * 4;
+    // FOUR panel sets -- W, Ct, CNt, and with hops WH, CHt -- of 64 pivots each: the double-pass
+    // schedule (fused_range) applies two passes per main launch while the next two are produced; the
+    // single-pass schedules use the first two sets
+    size_t b = (size_t)4 * FWX_FUSED_B * ((size_t)n * es + ld * (es + 4)) + 256;
+    if (with_hops) b += (size_t)4 * FWX_FUSED_B * ((size_t)n * 4 + ld * 4);
     return b;
 }
 
