@@ -31,6 +31,7 @@
 // Roofline: per pass 4 B read + 4 B written per entry against 1.5*B = 96 VALU lane-ops per entry in
 // the max form (3*B in the compare form): these kernels are VALU-bound, not HBM-bound.
 #include <hip/hip_runtime.h>
+#include <type_traits>
 #include <stdint.h>
 #include <stdlib.h>
 
@@ -1557,9 +1558,12 @@ __global__ __launch_bounds__(256, MINW) void fused_main_arg(float *rate, int32_t
             float p[ARG_SL];
 #pragma unroll
             for (int u = 0; u < ARG_SL; ++u) p[u] = pc[u * TI] * pw[u * TJ];
-            float m = __builtin_fmaxf(p[0], p[1]);
+            // (three levels of v_max3_f32 instead of a chain of eight)
+            float m5[5];
 #pragma unroll
-            for (int u = 2; u < ARG_SL; u += 2) m = __builtin_fmaxf(__builtin_fmaxf(m, p[u]), p[u + 1]);
+            for (int u = 0; u < 5; ++u) m5[u] = __builtin_fmaxf(__builtin_fmaxf(p[3 * u], p[3 * u + 1]), p[3 * u + 2]);
+            const float m = __builtin_fmaxf(__builtin_fmaxf(__builtin_fmaxf(m5[0], m5[1]), m5[2]),
+                                            __builtin_fmaxf(__builtin_fmaxf(m5[3], m5[4]), p[15]));
             int found = -1;                          // descending: the smallest matching pivot wins
             FWX_FIND4("v_cmp_eq_f32", found, m, p[15], 15, p[14], 14, p[13], 13, p[12], 12);
             FWX_FIND4("v_cmp_eq_f32", found, m, p[11], 11, p[10], 10, p[9], 9, p[8], 8);
@@ -1797,6 +1801,37 @@ __global__ __launch_bounds__(256, MINW) void fused_main_arg_f64(double *rate, in
             for (int e = 0; e < 4; ++e) out[r][e] = fmax_t(in[r][e], p[e]);
         }
     };
+    // NPV pivots from t on, in place, all their operand reads issued together (with two waves per SIMD
+    // the LDS latency of every pivot is exposed; this divides the number of waits)
+    auto stepn = [&](auto npv, int t, double (&x)[RI][4]) {
+        constexpr int NPV = decltype(npv)::value;
+        double c[NPV][RI], wv[NPV][4];
+#pragma unroll
+        for (int u = 0; u < NPV; ++u) {
+#pragma unroll
+            for (int q = 0; q < RI / 2; ++q) {
+                const V2 cv = *reinterpret_cast<const V2 *>(&sC[t + u][ti * RI + q * 2]);
+                c[u][q * 2] = cv[0];
+                c[u][q * 2 + 1] = cv[1];
+            }
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                const V2 wq = *reinterpret_cast<const V2 *>(&sW[t + u][tj * 2 + q * (TJ / 2)]);
+                wv[u][q * 2] = wq[0];
+                wv[u][q * 2 + 1] = wq[1];
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < NPV; ++u)
+#pragma unroll
+            for (int r = 0; r < RI; ++r) {
+                double p[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) p[e] = c[u][r] * wv[u][e];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) x[r][e] = fmax_t(x[r][e], p[e]);
+            }
+    };
     int stages = 0;                                  // stages executed (wave-uniform)
 #pragma unroll
     for (int s = 0; s < B / ARG_SL; ++s) {
@@ -1805,8 +1840,10 @@ __global__ __launch_bounds__(256, MINW) void fused_main_arg_f64(double *rate, in
             double (&dst)[RI][4] = (s & 1) ? xa : xb;
             const int t_hi = min(s * ARG_SL + ARG_SL, npiv);
             step(s * ARG_SL, src, dst);
+            int t = s * ARG_SL + 1;
 #pragma unroll 1
-            for (int t = s * ARG_SL + 1; t < t_hi; ++t) step(t, dst, dst);
+            for (; t + 1 < t_hi; t += 2) stepn(std::integral_constant<int, 2>{}, t, dst);   // (4 per trip: level, 226 VGPRs)
+            if (t < t_hi) step(t, dst, dst);
 #pragma unroll
             for (int r = 0; r < RI; ++r)
                 track4(sid[r][0], sid[r][1], sid[r][2], sid[r][3], dst[r][0], dst[r][1], dst[r][2], dst[r][3],
@@ -1867,9 +1904,14 @@ __global__ __launch_bounds__(256, MINW) void fused_main_arg_f64(double *rate, in
             double p[ARG_SL];
 #pragma unroll
             for (int u = 0; u < ARG_SL; ++u) p[u] = pc[u * TI] * pw[u * TJ];
-            double m = p[0];
+            // (a tree: the 15 maxima as a chain are 15 dependent f64 instructions per batch, and with two
+            //  waves per SIMD nobody else fills their latency)
+            double m8[8], m4[4];
 #pragma unroll
-            for (int u = 1; u < ARG_SL; ++u) m = fmax_t(m, p[u]);
+            for (int u = 0; u < 8; ++u) m8[u] = fmax_t(p[2 * u], p[2 * u + 1]);
+#pragma unroll
+            for (int u = 0; u < 4; ++u) m4[u] = fmax_t(m8[2 * u], m8[2 * u + 1]);
+            const double m = fmax_t(fmax_t(m4[0], m4[1]), fmax_t(m4[2], m4[3]));
             int found = -1;                          // descending: the smallest matching pivot wins
             FWX_FIND4("v_cmp_eq_f64", found, m, p[15], 15, p[14], 14, p[13], 13, p[12], 12);
             FWX_FIND4("v_cmp_eq_f64", found, m, p[11], 11, p[10], 10, p[9], 9, p[8], 8);
