@@ -443,8 +443,9 @@ def run_single(args):
                                              "cycles (DESIGN.md 4.2, profiles/r03_sq_arg_main.txt)"},
                    "check": {"rate_digest": digest(got[0]), "next_digest": digest(got[1]),
                              "rates_equal_rates_only_leg": digest(got[0]) == out["check"]["rate_digest"]},
-                   "note": "same workload with the next-hop matrix carried (rates + next, fused_main_arg), "
-                           "best of 2, blocking fwx_matrix_solve calls; not part of `value`"}
+                   "note": "same workload with the next-hop matrix carried (rates + next: fused_main_arg, from N = 8192 "
+                           "two passes = 128 pivots per main launch), best of 2, blocking fwx_matrix_solve calls; "
+                           "not part of `value`"}
             gold = os.path.join(ROOT, "tests", "golden", "config4_n16384_digests.json")
             if n == 16384 and args.dist == "d1" and args.config in (0, 4) and os.path.exists(gold):
                 with open(gold) as f:
