@@ -489,6 +489,33 @@ __global__ __launch_bounds__(PANEL_THREADS) void fused_panels(int row_wgs, const
     }
 }
 
+// The same for f32 rates + next-hops, with or without the path trace (no hops), held to 48 VGPRs.  A
+// 1024-thread workgroup is four waves per SIMD: at 48 registers they take 192, and a retiring
+// fused_main_arg workgroup (three per CU at 152 allocated registers per wave) leaves 512 - 2 * 152 = 208
+// free -- so this launch's workgroups are placed one by one as main workgroups retire.  At the 49 / 54
+// (allocated: 56) the compiler picks by itself they need 224: TWO free main slots on one CU, i.e. the
+// main grid's tail (772 us beside the main launch against 30 us alone, gpurun_out/r03_final_prof_next),
+// and with two passes per main launch the side chain -- two panels per pair -- then ends after it.
+// (amdgpu_num_vgpr counts HALF the unified register file of gfx950: 24 -> 48.)
+template <bool HAS_LAST>
+__global__ __launch_bounds__(PANEL_THREADS) __attribute__((amdgpu_num_vgpr(24)))
+void fused_panels_next_f32(int row_wgs, const float *rate, const int32_t *next, int n, int k0, int bt, float *w_out,
+                           float *ct, int32_t *cnt, int ct_ld, const int32_t *last, int32_t *at_row,
+                           int32_t *at_col)
+{
+    constexpr int RL = rowpanel_lds<float, false>(), CL = colpanel_lds<float, true, false>();
+    __shared__ __attribute__((aligned(16))) char smem[RL > CL ? RL : CL];
+    const size_t prow = (size_t)k0 * n;
+    if ((int)blockIdx.x < row_wgs)                 // workgroup-uniform
+        rowpanel_body<float, HAS_LAST, false, false>(smem, (int)blockIdx.x, rate + prow, n, k0, bt, w_out,
+                                                     HAS_LAST ? last + prow : nullptr,
+                                                     HAS_LAST ? at_row + prow : nullptr, nullptr, nullptr);
+    else
+        colpanel_body<float, true, HAS_LAST, false, true, false>(smem, (int)blockIdx.x - row_wgs, rate, next, n, n, 0,
+                                                                 k0, bt, nullptr, ct, cnt, ct_ld, last, at_col,
+                                                                 nullptr, nullptr, nullptr, rate + prow, nullptr);
+}
+
 // ------------------------------------------------------------------------------------------------
 // BS pivots are staged in LDS at a time (the register tile lives across stages), which keeps a
 // workgroup at 32 KiB of LDS and <= 128 VGPRs: 4 workgroups = 16 waves per CU.  The loop is pure
@@ -2351,6 +2378,19 @@ hipError_t launch_fused_panels(const FusedArgs<T> &a, T *w_out, int32_t *wh_out,
     hipLaunchKernelGGL((fused_panels<T, HN, HL, HH>), grid, block, 0, s, row_wgs, a.rate, a.next, a.n, a.k0, \
                        a.bt, w_out, a.ct, a.cnt, a.ct_ld, a.plog.last, a.plog.at_row, a.plog.at_col,  \
                        a.hops, wh_out, a.cht)
+    // f32 with next-hops, no hops: the form that fits beside two fused_main_arg workgroups (FWX_PANELS_TIGHT=0: A/B)
+    static const bool tight = [] { const char *e = getenv("FWX_PANELS_TIGHT"); return !(e && *e == '0'); }();
+    if constexpr (sizeof(T) == 4) {
+        if (tight && a.next && !a.hops) {
+            if (a.plog.last)
+                hipLaunchKernelGGL(fused_panels_next_f32<true>, grid, block, 0, s, row_wgs, a.rate, a.next, a.n, a.k0,
+                                   a.bt, w_out, a.ct, a.cnt, a.ct_ld, a.plog.last, a.plog.at_row, a.plog.at_col);
+            else
+                hipLaunchKernelGGL(fused_panels_next_f32<false>, grid, block, 0, s, row_wgs, a.rate, a.next, a.n, a.k0,
+                                   a.bt, w_out, a.ct, a.cnt, a.ct_ld, nullptr, nullptr, nullptr);
+            return hipGetLastError();
+        }
+    }
     if (a.plog.last) {
         if (a.hops) FWX_PANELS(true, true, true); else FWX_PANELS(true, true, false);
     } else if (a.next) {
