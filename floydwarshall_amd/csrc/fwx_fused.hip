@@ -16,11 +16,15 @@
 //   fused_colpanel      the B pivot columns of every row i: exports Ct[t][i] (NaN where i == k: skip
 //                       i==k) and CNt[t][i] = next_t[i][k0+t].  Reads the block columns of a finished
 //                       W (partitioned solves), or -- OWN_D -- evolves the diagonal block itself
-//   fused_panels        both of them as ONE launch (single-device solves)
+//   fused_panels        both of them as ONE launch (single-device solves); fused_panels_next_f32: the
+//                       same for f32 + next-hops in 48 VGPRs, so that its 1024-thread workgroups fit
+//                       beside two fused_main_arg workgroups on a CU
 //   fused_main_max      rates only, f32, inside the domain: the fold as max (two pivots per v_max3_f32),
-//                       128 x 128 tile, 8 x 8 entries per thread; fused_main_max_f64 likewise for f64
+//                       128 x 128 tile, 8 x 8 entries per thread, one or two passes (64 / 128 pivots) per
+//                       launch; fused_main_max_f64 likewise for f64
 //   fused_main_arg      rates + next-hops (+ path trace, + hops), f32 inside the domain: max-form fold,
-//                       then an arg re-scan of the entries that moved; fused_main_arg_f64 for f64
+//                       then an arg re-scan of the entries that moved; NP = 1 or 2 complete passes per
+//                       launch on the tile kept in registers; fused_main_arg_f64 for f64
 //   fused_main          compare form (product, compare, selects): update counting and inputs outside
 //                       the domain
 //
