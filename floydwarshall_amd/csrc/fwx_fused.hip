@@ -1515,8 +1515,18 @@ __global__ __launch_bounds__(256, MINW) void fused_main_arg(float *rate, int32_t
             V4 (&dst)[RI] = (s & 1) ? xa : xb;
             const int p_hi = min(s * SP + SP, npairs);
             pair_step(s * SP, src, dst);
+            int tp = s * SP + 1;
+            if (RI == 4) {
+                // the 64 x 64 form (96 VGPRs of 128): two pairs per trip, so that one wait covers the eight
+                // operand reads of four pivots -- its 48-instruction pairs are too short to hide a read
 #pragma unroll 1
-            for (int tp = s * SP + 1; tp < p_hi; ++tp) pair_step(tp, dst, dst);
+                for (; tp + 1 < p_hi; tp += 2) {
+                    pair_step(tp, dst, dst);
+                    pair_step(tp + 1, dst, dst);
+                }
+            }
+#pragma unroll 1
+            for (; tp < p_hi; ++tp) pair_step(tp, dst, dst);
 #pragma unroll
             for (int r = 0; r < RI; ++r)
                 track4(sid[r][0], sid[r][1], sid[r][2], sid[r][3], dst[r][0], dst[r][1], dst[r][2], dst[r][3],
