@@ -110,6 +110,7 @@ private:
     std::vector<int32_t> devices_;   // non-empty: partition the matrix over these from multi_from_ on
     int32_t multi_from_ = 0;
     bool dev_multi_ = false;         // dev_ is a partitioned handle
+    bool dev_padded_ = false;        // dev_ has order n + 1: an isolated vertex pads an odd n (session.cpp)
     ExchRateTimes rates_;
     bool in_sync_ = false;      // what the reference's AppState would be
     uint64_t version_ = 0;      // bumped by every accepted update that changes buildMatrix's output

@@ -230,11 +230,7 @@ def test_incremental_updates_patch_the_kept_input(n_exch, partitioned):
     assert np.array_equal(n1, n2) and np.array_equal(h1, h2)
 
 
-def test_odd_vertex_counts_take_the_fused_engine_through_a_padded_handle():
-    """243 vertices: rows of an f64 matrix of odd order are not a multiple of 16 bytes, which a
-    single-device handle can only solve one launch per pivot; the session uses a ONE-partition handle,
-    whose slab is padded on the device.  Answers and exact paths as a fresh session / the oracle."""
-    rnd = np.random.default_rng(27)
+def _odd_market(rnd, negative=False):
     ccys = ["C%d" % i for i in range(9)]
     price = dict(zip(ccys, 0.5 + 1.5 * rnd.random(len(ccys))))
     log = []
@@ -244,6 +240,35 @@ def test_odd_vertex_counts_take_the_fused_engine_through_a_padded_handle():
             a, b = ccys[i], ccys[(i + 1) % len(ccys)]
             log.append((t, "E%02d" % e, a, b, price[b] / price[a] * (0.97 + 0.03 * rnd.random()),
                         price[a] / price[b] * (0.97 + 0.03 * rnd.random())))
+    if negative:
+        old = log[40]
+        log[40] = (old[0], old[1], old[2], old[3], -old[4], old[5])
+    return log, t
+
+
+def _same_answers(s, log, vs, rnd, queries=8):
+    fresh = host.Session(device=0)
+    for r in log:
+        fresh.update_rates(*r)
+    for _ in range(queries):
+        a, b = (vs[int(x)] for x in rnd.integers(0, len(vs), 2))
+        try:
+            want = fresh.find_best_rate(a, b)
+        except host.AlgoError as err:
+            with pytest.raises(host.AlgoError) as e2:
+                s.find_best_rate(a, b)
+            assert str(e2.value) == str(err)
+            continue
+        assert s.find_best_rate(a, b) == want
+
+
+def test_odd_vertex_counts_are_padded_with_an_isolated_vertex_and_resume():
+    """243 vertices: rows of an f64 matrix of odd order are not a multiple of 16 bytes, which a
+    single-device handle can only solve one launch per pivot.  The session adds ONE vertex without any
+    edge (inert while no rate is negative), so the ordinary handle of order 244 runs the fused engine and
+    resumes after price changes.  Answers and exact paths as a fresh session / the oracle."""
+    rnd = np.random.default_rng(27)
+    log, t = _odd_market(rnd)
     s = host.Session(device=0)
     for r in log:
         assert s.update_rates(*r)
@@ -255,25 +280,46 @@ def test_odd_vertex_counts_take_the_fused_engine_through_a_padded_handle():
     assert_bits_equal(gr, er, "rate")
     assert np.array_equal(gn, en)
     assert s.parts == 1
-    for step in range(4):                                   # price changes: patched, full re-solves
+    for step in range(4):                 # price changes on late exchanges (vertices >= 180): resumed
         t += 1
-        old = log[int(rnd.integers(0, len(log)))]
+        old = log[int(rnd.integers(20 * 9, len(log)))]
         log.append((t, old[1], old[2], old[3], old[4] * 0.99, old[5]))
         assert s.update_rates(*log[-1])
-        fresh = host.Session(device=0)
-        for r in log:
-            fresh.update_rates(*r)
-        for _ in range(8):
-            a, b = (vs[int(x)] for x in rnd.integers(0, len(vs), 2))
-            try:
-                want = fresh.find_best_rate(a, b)
-            except host.AlgoError as err:
-                with pytest.raises(host.AlgoError) as e2:
-                    s.find_best_rate(a, b)
-                assert str(e2.value) == str(err)
-                continue
-            assert s.find_best_rate(a, b) == want
-    assert s.patched_solves == 4 and s.resumed_solves == 0
+        _same_answers(s, log, vs, rnd)
+    assert s.patched_solves == 4 and s.resumed_solves == 4
+    # a NEGATIVE rate arrives: the pad vertex would no longer be inert (0 * 0 beats a negative entry),
+    # so the session rebuilds without it (order 243: the per-k engine, outside the domain anyway) -- same answers
+    t += 1
+    old = log[5]
+    log.append((t, old[1], old[2], old[3], -0.25, old[5]))
+    assert s.update_rates(*log[-1])
+    _same_answers(s, log, vs, rnd)
+    assert s.parts == 1 and s.resumed_solves == 4
+
+
+def test_odd_vertex_counts_with_a_negative_rate_stay_unpadded():
+    """The same market with a negative rate from the start: no isolated vertex (it would not be inert);
+    the matrix is outside the reference's domain, so the per-k engine solves it at its odd order; full
+    re-solves, same answers.  (Round 3 first sent such a session to a one-partition handle, which refuses
+    matrices outside the domain with next-hops: FWX_ERR_UNSUPPORTED.)"""
+    rnd = np.random.default_rng(28)
+    log, t = _odd_market(rnd, negative=True)
+    s = host.Session(device=0)
+    for r in log:
+        assert s.update_rates(*r)
+    vs, rate0, next0 = s.build_matrix()
+    er, en = rate0.copy(), next0.copy()
+    oracle.relax(er, en)
+    gr, gn, _ = s.solved_matrix()
+    assert_bits_equal(gr, er, "rate")
+    assert np.array_equal(gn, en)
+    for step in range(2):
+        t += 1
+        old = log[int(rnd.integers(0, len(log)))]
+        log.append((t, old[1], old[2], old[3], abs(old[4]) * 0.99, old[5]))
+        assert s.update_rates(*log[-1])
+        _same_answers(s, log, vs, rnd)
+    assert s.parts == 1 and s.resumed_solves == 0
 
 
 def test_find_best_rate_unknown_vertices_keep_state_and_cache():

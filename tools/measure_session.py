@@ -41,8 +41,8 @@ def timed_query(s, a, b):
     return time.perf_counter() - t0
 
 
-# (27 x 9 = 243 and 113 x 9 = 1017 vertices: ODD orders, which the session solves through a one-partition
-# handle that pads its slab on the device -- the fused engine instead of one launch per pivot)
+# (27 x 9 = 243 and 113 x 9 = 1017 vertices: ODD orders, which the session pads with one isolated vertex --
+# the fused engine instead of one launch per pivot, and resumable like the even orders)
 for n_exch, n_ccy in ((2, 2), (6, 8), (20, 12), (27, 9), (60, 16), (113, 9), (128, 16), (256, 16)):
     rows = market(n_exch, n_ccy)
     line = {}
