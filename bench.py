@@ -39,15 +39,86 @@ import time
 
 import numpy as np
 
+import threading
+
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 # the host driver of this pool only supports dmabuf IPC; RCCL needs it before HIP initialises
+# (floydwarshall_amd/_lib.py sets the same default for every other binding of the package)
 os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 
 SEGMENTS = 16
 HBM_PEAK_GBPS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
 INFINITY_CACHE_BYTES = 256 << 20
 PMC_PROFILE = os.path.join("profiles", "r03_pmc_traffic.json")
+
+
+class Watchdog:
+    """A hung collective must not end as a driver kill with nothing written.  arm(label) starts the
+    clock for one phase (a step, the handle creation, an extra leg); if the phase is still running
+    `bound_s` seconds later the watchdog thread prints ONE JSON line that says which phase hung, flushes,
+    and ends the process with exit code 3 (os._exit: the main thread is stuck inside a blocking runtime
+    call and cannot be unwound; nothing is re-executed).  Only `emit`-ing ranks print (rank 0)."""
+
+    EXIT_CODE = 3
+
+    def __init__(self, bound_s, base_line, emit=True, out=None, exit_fn=None):
+        self.bound_s, self.base, self.emit = float(bound_s), dict(base_line), emit
+        self.out = out or sys.stdout
+        self.exit_fn = exit_fn or os._exit
+        self._lock = threading.Lock()
+        self._label, self._deadline, self._done = None, None, []
+        self._stop = threading.Event()
+        self._thread = None
+        if self.bound_s > 0:
+            self._thread = threading.Thread(target=self._run, name="bench-watchdog", daemon=True)
+            self._thread.start()
+
+    def arm(self, label):
+        with self._lock:
+            self._label, self._deadline = label, time.monotonic() + self.bound_s
+
+    def disarm(self):
+        with self._lock:
+            if self._label is not None:
+                self._done.append(self._label)
+            self._label = self._deadline = None
+
+    def stop(self):
+        self._stop.set()
+
+    def error_line(self, label):
+        line = dict(self.base)
+        line.update({"value": None, "error": "watchdog: phase %r still running after %.0f s" % (label, self.bound_s),
+                     "hung_phase": label, "phases_completed": list(self._done)})
+        return line
+
+    def _run(self):
+        while not self._stop.wait(0.25):
+            with self._lock:
+                label, deadline = self._label, self._deadline
+            if label is not None and time.monotonic() > deadline:
+                if self.emit:
+                    print(json.dumps(self.error_line(label)), file=self.out, flush=True)
+                self.exit_fn(self.EXIT_CODE)
+                return
+
+
+def create_multi_handle(engine, n, np_dtype, with_next, devs, exchange_name, factory=None):
+    """The partitioned handle of the single-process N > 1 form, fail-soft: with `--exchange auto` a
+    handle that cannot be created over RCCL (FWX_ERR_RCCL: librccl missing, ncclCommInitAll failing -- e.g.
+    without dmabuf IPC) is created again over peer copies, which need neither RCCL nor IPC inside one
+    process, and the line says so.  Returns (handle, {"requested", "rccl_error"})."""
+    factory = factory or engine.DeviceMatrix
+    xchg = {"auto": engine.FWX_XCHG_AUTO, "rccl": engine.FWX_XCHG_RCCL, "peer": engine.FWX_XCHG_PEER}[exchange_name]
+    info = {"requested": exchange_name, "rccl_error": None}
+    try:
+        return factory(n, np_dtype, with_next=with_next, devices=devs, exchange=xchg), info
+    except engine.FwxError as err:
+        if exchange_name != "auto" or err.status != engine.FWX_ERR_RCCL:
+            raise
+        info["rccl_error"] = {"status": int(err.status), "message": str(err), "where": "fwx_matrix_create_multi"}
+    return factory(n, np_dtype, with_next=with_next, devices=devs, exchange=engine.FWX_XCHG_PEER), info
 
 
 def parse_args():
@@ -78,6 +149,9 @@ def parse_args():
                     help="process-group backend for N > 1 (gloo only to rehearse the N > 1 code path "
                          "with several ranks on one GPU; never a performance number)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    ap.add_argument("--step-timeout", type=float, default=240.0,
+                    help="N > 1: seconds one phase (handle creation, a step, an extra leg) may take before the "
+                         "watchdog prints an error line and exits with code 3; 0 = off")
     ap.add_argument("--kslice", type=int, default=0,
                     help="DEBUG: run only this many pivots per step (result flagged invalid)")
     ap.add_argument("--config", type=int, default=0, choices=[0, 2, 3, 4, 5],
@@ -582,29 +656,58 @@ def run_multi(args):
     del rate64
     if args.kslice:
         raise SystemExit("--kslice is a single-GPU debug option")
-    xchg = {"auto": engine.FWX_XCHG_AUTO, "rccl": engine.FWX_XCHG_RCCL, "peer": engine.FWX_XCHG_PEER}[args.exchange]
-    h = engine.DeviceMatrix(n, np_dtype, with_next=args.with_next, devices=devs, exchange=xchg)
-    h.keep_input()
-    h.upload(rate_host, next_host if args.with_next else None)
-    del next_host
-    parts, transport = h.parts()
-    ranks = h.comm_ranks()
-    eng = engine.FWX_ENGINE_PERK if args.engine == "perk" else engine.FWX_ENGINE_FUSED
     serp = not args.no_serpentine
     relax_per_step = float(n) ** 3
+    base_line = {"metric": "edge-relaxations/sec (N^3/t), N=%d %s" % (n, "fp32" if es == 4 else "fp64"),
+                 "unit": "edge-relaxations/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+                 "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": args.dtype,
+                 "data": "synthetic", "config": workload_config(args, n, n, serp, world, "row-block x%d over HIP "
+                                                                "devices %s, ONE process" % (world, devs))}
+    dog = Watchdog(args.step_timeout, base_line)
+    dog.arm("create the partitioned handle (%s exchange) + upload" % args.exchange)
+    h, xinfo = create_multi_handle(engine, n, np_dtype, args.with_next, devs, args.exchange)
+    h.keep_input()
+    h.upload(rate_host, next_host if args.with_next else None)
+    dog.disarm()
+    del next_host
+    eng = engine.FWX_ENGINE_PERK if args.engine == "perk" else engine.FWX_ENGINE_FUSED
 
-    def step(count=False):
+    def step(count=False, which=None):
         h.patch_input([], np.empty(0, dtype=np_dtype))      # restore the kept input on every partition
-        return h.solve(engine=eng, serpentine=serp, count_updates=count)
+        return h.solve(engine=eng if which is None else which, serpentine=serp, count_updates=count)
+
+    def guarded_first_step():
+        """The first solve is where a communicator that initialised but cannot carry a panel shows:
+        FWX_ERR_RCCL here, under `--exchange auto`, rebuilds the handle over peer copies once."""
+        nonlocal h
+        try:
+            return step(count=True)
+        except engine.FwxError as err:
+            if args.exchange != "auto" or err.status != engine.FWX_ERR_RCCL or xinfo["rccl_error"]:
+                raise
+            xinfo["rccl_error"] = {"status": int(err.status), "message": str(err), "where": "first solve"}
+            h.close()
+            h = engine.DeviceMatrix(n, np_dtype, with_next=args.with_next, devices=devs, exchange=engine.FWX_XCHG_PEER)
+            h.keep_input()
+            h.upload(rate_host, make_input(args, n)[1] if args.with_next else None)
+            return step(count=True)
 
     updates = None
-    for w in range(args.warmup):
-        u = step(count=(w == 0))
-        updates = u if w == 0 else updates
+    dog.arm("first solve (counted)")
+    updates = guarded_first_step()          # always one counted solve: U and the transport check
+    dog.disarm()
+    for w in range(1, args.warmup):
+        dog.arm("warm-up step %d" % w)
+        step()
+        dog.disarm()
+    parts, transport = h.parts()
+    ranks = h.comm_ranks()
     hip.synchronize(devs)
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    for i in range(args.steps):
+        dog.arm("timed step %d of %d" % (i + 1, args.steps))
         step()
+        dog.disarm()
     hip.synchronize(devs)
     dt = time.perf_counter() - t0
 
@@ -621,9 +724,57 @@ def run_multi(args):
         "data": "synthetic", "config": workload_config(args, n, n, serp, world, partition),
         "host_runtime": "HIP runtime via ctypes (no torch in the process)",
         "exchange": {"transport": "rccl" if transport == engine.FWX_XCHG_RCCL else "peer",
+                     "requested": xinfo["requested"], "rccl_error": xinfo["rccl_error"],
                      "rccl_ranks_in_communicator": ranks, "partitions": parts,
                      "distinct_devices": len(set(devs))},
     }
+    if args.warmup < 1:
+        out["warmup_note"] = "one counted solve ran before the timed region regardless of --warmup 0"
+
+    def timing_leg(which, label):
+        """One more solve with per-step event timings switched on (two event records per span: kept out
+        of the timed region): is a step bound by the slab sweep or by the panel chain?"""
+        dog.arm("event-timed solve (%s)" % label)
+        h.set_timing(True)
+        step(which=which)
+        t = h.timing()
+        h.set_timing(False)
+        dog.disarm()
+        return {"avg_bulk_us": t["bulk_us"], "avg_bulk_mean_us": t["bulk_mean_us"],
+                "avg_lookahead_us": t["lookahead_us"], "avg_panel_us": t["panel_us"],
+                "avg_exchange_us": t["exchange_us"], "avg_chain_us": t["chain_us"],
+                "chain_over_bulk": t["chain_over_bulk"], "steps": t["steps"],
+                "pivots_per_step": t["pivots_per_step"],
+                "avg_bulk_us_per_block": t["bulk_us"] * 64.0 / max(1, t["pivots_per_step"])}
+
+    if not args.no_extras:
+        out["exchange"].update(timing_leg(None, args.engine))
+        out["exchange"]["timing_note"] = (
+            "HIP events on the streams the work runs on, one extra untimed solve: bulk = the slab sweep of a "
+            "step (mean over steps of the max over partitions), chain = what the next step waits for besides it "
+            "(look-ahead rows + owner's panel kernel + exchange; whole side chain under the pair schedule); "
+            "chain_over_bulk > 1 = bound by the panel chain (DESIGN.md section 5)")
+    if not args.no_extras and not args.no_fused_extra and args.engine == "perk":
+        # Not part of `value`: the same workload on the engine AUTO picks (fused: 128 pivots per main launch
+        # behind a two-deep look-ahead where the partitions allow), same handle, best of 2
+        def fused_step():
+            h.patch_input([], np.empty(0, dtype=np_dtype))
+            t1 = time.perf_counter()
+            h.solve(engine=engine.FWX_ENGINE_FUSED)
+            return time.perf_counter() - t1
+        dog.arm("fused-engine leg")
+        fused_step()
+        ft = min(fused_step(), fused_step())
+        dog.disarm()
+        leg = {"value": relax_per_step / ft, "unit": "edge-relaxations/s", "ms_per_step": 1e3 * ft, "steps": 2,
+               "note": "same workload, same handle, fwx_opts.engine = FUSED (what AUTO runs); solve only (the "
+                       "restore of the kept input is outside this clock); not part of `value`"}
+        got = h.download()
+        leg["check"] = {"rate_digest": digest(got[0])}
+        del got
+        leg["exchange"] = timing_leg(engine.FWX_ENGINE_FUSED, "fused")
+        out["fused_engine"] = leg
+        step()                               # the line's `check` below looks at the per-k result again
     if logical:
         out["INVALID_logical_partitions"] = ("%d partitions time-share %d device(s): a rehearsal of the "
                                              "N > 1 code path, not a scaling number" % (world, len(set(devs))))
@@ -669,7 +820,13 @@ def run_multi(args):
                 (not args.with_next or out["check"]["next_digest"] == g["next_digest"]) and
                 (updates is None or updates == g["U"]))
         del got
+        if "fused_engine" in out:
+            out["fused_engine"]["check"]["equals_timed_engine_bits"] = bool(
+                out["fused_engine"]["check"]["rate_digest"] == out["check"]["rate_digest"])
+    dog.arm("destroy the handle")
     h.close()
+    dog.disarm()
+    dog.stop()
     if not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(rate_host, min(args.cpu_seconds, 8.0))
     print(json.dumps(out), flush=True)
@@ -711,31 +868,68 @@ def run_dist(args, world, rank, local_rank):
     del next_host
     k_end = n
     backend = fwdist.HipBackend(args.engine)
+    relax_per_step = float(k_end) * n * n
+    # every rank runs a watchdog (a hung collective hangs all of them); rank 0 writes the line
+    dog = Watchdog(args.step_timeout,
+                   {"metric": "edge-relaxations/sec (N^3/t), N=%d %s" % (n, "fp32" if es == 4 else "fp64"),
+                    "unit": "edge-relaxations/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+                    "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": args.dtype,
+                    "data": "synthetic", "config": workload_config(args, n, k_end, True, world)},
+                   emit=rank == 0)
 
-    def step():
+    def step(bk=None, timer=None):
         rate.copy_(pristine)
         if nxt is not None:
             nxt.copy_(pristine_next)
-        fwdist.solve_partitioned(rate, n, rank, world, nxt=nxt, block=args.block, backend=backend)
+        fwdist.solve_partitioned(rate, n, rank, world, nxt=nxt, block=args.block, backend=bk or backend,
+                                 timer=timer)
 
     def fence():
         torch.cuda.synchronize()
         dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
+    for w in range(args.warmup):
+        dog.arm("warm-up step %d" % (w + 1))
         step()
+        torch.cuda.synchronize()
+        dog.disarm()
+    dog.arm("barrier before the timed region")
     fence()
+    dog.disarm()
     t0 = time.perf_counter()
+    dog.arm("the %d timed steps" % args.steps)
     for _ in range(args.steps):
         step()
     fence()
+    dog.disarm()
     dt = time.perf_counter() - t0
     t = torch.tensor([dt], dtype=torch.float64, device=dev)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     dt = float(t.item())
 
-    relax_per_step = float(k_end) * n * n
+    def timing_leg(bk, label):
+        """One more, untimed solve with per-step event spans on every rank (dist.StepTimer): bulk and
+        exchange as the MAX over ranks of the rank's mean, look-ahead and panel as the mean over the ranks
+        that owned a block."""
+        dog.arm("event-timed solve (%s)" % label)
+        tm = fwdist.StepTimer(on_gpu=True)
+        step(bk=bk, timer=tm)
+        sm = tm.summary()
+        v = torch.tensor([sm[k][0] for k in fwdist.StepTimer.KINDS] +
+                         [sm[k][0] * sm[k][1] for k in fwdist.StepTimer.KINDS] +
+                         [float(sm[k][1]) for k in fwdist.StepTimer.KINDS], dtype=torch.float64, device=dev)
+        mx, sm_all = v[:4].clone(), v[4:].clone()
+        dist.all_reduce(mx, op=dist.ReduceOp.MAX)
+        dist.all_reduce(sm_all, op=dist.ReduceOp.SUM)
+        dog.disarm()
+        mean = lambda i: float(sm_all[i] / sm_all[4 + i]) if float(sm_all[4 + i]) > 0 else 0.0   # noqa: E731
+        bulk, la, pan, xch = float(mx[0]), mean(1), mean(2), float(mx[3])
+        chain = la + pan + xch
+        return {"avg_bulk_us": bulk, "avg_lookahead_us": la, "avg_panel_us": pan, "avg_exchange_us": xch,
+                "avg_chain_us": chain, "chain_over_bulk": chain / bulk if bulk > 0 else None,
+                "pivots_per_step": args.block, "avg_bulk_us_per_block": bulk * 64.0 / args.block}
+
     out = {
         "metric": "edge-relaxations/sec (N^3/t), N=%d %s" % (n, "fp32" if es == 4 else "fp64"),
         "value": args.steps * relax_per_step / dt, "unit": "edge-relaxations/s", "n_gpus": world,
@@ -770,6 +964,32 @@ def run_dist(args, world, rank, local_rank):
                            "note": "VALU-issue-bound kernel: low HBM fraction by design"}
     out["exchange"] = {"transport": "rccl (torch.distributed)" if args.backend == "nccl" else args.backend,
                        "ranks_in_process_group": dist.get_world_size()}
+    if not args.no_extras:
+        out["exchange"].update(timing_leg(None, args.engine))
+        out["exchange"]["timing_note"] = (
+            "events on the streams the work runs on, one extra untimed solve: bulk = the slab sweep of a step, "
+            "chain = look-ahead rows + owner's panel + broadcast (issue -> side stream released); "
+            "chain_over_bulk > 1 = bound by the panel chain (DESIGN.md section 5)")
+    if not args.no_extras and not args.no_fused_extra and args.engine == "perk":
+        # not part of `value`: the same workload on the fused engine (64 pivots per pass), best of 2
+        fbk = fwdist.HipBackend("fused")
+        times = []
+        dog.arm("fused-engine leg")
+        for i in range(3):
+            fence()
+            t1 = time.perf_counter()
+            step(bk=fbk)
+            fence()
+            times.append(time.perf_counter() - t1)
+        dog.disarm()
+        tt = torch.tensor(times[1:], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        ft = float(tt.min().item())
+        out["fused_engine"] = {"value": relax_per_step / ft, "unit": "edge-relaxations/s", "ms_per_step": 1e3 * ft,
+                               "steps": 2, "exchange": timing_leg(fbk, "fused"),
+                               "note": "same workload on the fused engine (what AUTO runs), restore included, "
+                                       "max over ranks, best of 2; not part of `value`"}
+    dog.stop()
     if rank == 0:
         if not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(make_input(args, n)[0].astype(np_dtype),

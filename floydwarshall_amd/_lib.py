@@ -2,6 +2,13 @@
 import ctypes
 import os
 
+# Multi-process / multi-device GPU work on this pool needs dmabuf IPC: without it RCCL (and any
+# device-memory sharing across processes) fails in hipIpcGetMemHandle ("invalid argument").  The HIP
+# runtime reads the variable when it initialises, so it is set HERE, at import, before the first HIP
+# call any binding of this package can make -- a host that binds libfwx directly (C, Haskell) exports
+# it itself (include/fwx.h FWX_XCHG_RCCL).  setdefault: an explicit setting wins.
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+
 PKG = os.path.dirname(os.path.abspath(__file__))
 # FWX_LIB_PATH: developer override, e.g. an experimental build of the same ABI
 LIB_PATH = os.environ.get("FWX_LIB_PATH") or os.path.join(PKG, "libfwx.so")
@@ -55,6 +62,14 @@ class FwxFusedScratch(ctypes.Structure):
     _fields_ = [("col_rate", c_vp), ("col_next", c_vp), ("col_hops", c_vp)]
 
 
+class FwxMultiTiming(ctypes.Structure):
+    _fields_ = [("struct_size", ctypes.c_uint32), ("steps", c_i32), ("pivots_per_step", c_i32),
+                ("partitions", c_i32), ("bulk_us", ctypes.c_float), ("bulk_mean_us", ctypes.c_float),
+                ("lookahead_us", ctypes.c_float), ("panel_us", ctypes.c_float),
+                ("exchange_us", ctypes.c_float), ("chain_us", ctypes.c_float),
+                ("chain_over_bulk", ctypes.c_float)]
+
+
 class FwxError(RuntimeError):
     def __init__(self, status, what):
         self.status = status
@@ -86,6 +101,9 @@ SIGNATURES = {
     "fwx_matrix_keep_input": (ctypes.c_int, [c_vp]),
     "fwx_matrix_patch_input": (ctypes.c_int, [c_vp, c_i32, c_vp, c_vp, c_vp, c_vp]),
     "fwx_matrix_enable_resume": (ctypes.c_int, [c_vp, c_i32]),
+    "fwx_matrix_resume_bytes": (ctypes.c_int, [c_vp, c_i32, ctypes.POINTER(ctypes.c_uint64)]),
+    "fwx_device_memory": (ctypes.c_int, [c_i32, ctypes.POINTER(ctypes.c_uint64),
+                                         ctypes.POINTER(ctypes.c_uint64)]),
     "fwx_matrix_resolve": (ctypes.c_int, [c_vp, c_i32, c_vp, c_vp, c_vp, c_vp, ctypes.POINTER(FwxOpts),
                                           ctypes.POINTER(c_i32)]),
     "fwx_matrix_enable_path_log": (ctypes.c_int, [c_vp]),
@@ -96,6 +114,8 @@ SIGNATURES = {
     "fwx_matrix_create_multi": (ctypes.c_int, [ctypes.POINTER(c_vp), c_i32, c_i32, c_i32, c_i32, c_i32,
                                                ctypes.POINTER(c_i32), c_i32]),
     "fwx_matrix_parts": (ctypes.c_int, [c_vp, ctypes.POINTER(c_i32)]),
+    "fwx_matrix_set_timing": (ctypes.c_int, [c_vp, c_i32]),
+    "fwx_matrix_get_timing": (ctypes.c_int, [c_vp, ctypes.POINTER(FwxMultiTiming)]),
     "fwx_matrix_comm_ranks": (ctypes.c_int, [c_vp]),
     "fwx_solve_multi_f64": (ctypes.c_int, [c_i32, c_vp, c_vp, c_vp, c_i32, ctypes.POINTER(c_i32), c_i32,
                                            ctypes.POINTER(FwxOpts)]),

@@ -340,32 +340,32 @@ int fused_range(T *rate, int32_t *next, int32_t *hops, int n, int k_begin, int k
 
 // AUTO: the single-launch kernel up to its 64 x 64 form, the fused engine above wherever it applies.
 constexpr int kSmallSolveAutoMax = 64;
-template <typename T> bool pick_fused(int engine, int n, const void *rate, const int32_t *hops)
+template <typename T> bool pick_fused(int engine, int n, int nd, const void *rate, const int32_t *hops)
 {
     if (engine == FWX_ENGINE_PERK) return false;
-    if (!fused_ok<T>(n, rate, hops)) return false;
+    if (!fused_ok<T>(nd, rate, hops)) return false;
     // tools/measure_small.py (profiles/r02_small_sizes.txt): with the serial two-launch schedule
     // the fused engine beats the per-k engine at every order, and the single-launch kernel above
     // its 64 x 64 register form (n = 72 f64 + next: 0.13 ms against 0.20; n = 128: 0.18 / 0.36)
     return engine == FWX_ENGINE_FUSED || n > kSmallSolveAutoMax;
 }
 
-// Which engine runs a solve of pivots [k_begin, k_end) of an order-n matrix (pivots < n only for a
-// matrix padded by the host-buffer path).
+// Which engine runs a solve of pivots [k_begin, k_end) of a matrix of order n held on the device at
+// order (= pitch) nd >= n: the host-buffer path and the handles pad an odd order with inert entries
+// (fwx_matrix::nd), every engine then runs the nd x nd arrays over the real pivots only.
 enum Route { ROUTE_SMALL, ROUTE_PERK, ROUTE_FUSED };
 template <typename T>
-int route_solve(const Opts &op, int n, bool whole, const T *rate, const int32_t *next,
+int route_solve(const Opts &op, int n, int nd, const T *rate, const int32_t *next,
                 const int32_t *hops, bool counting, int *d_flag, hipStream_t s, Route &route,
                 bool &nonneg, fwx_matrix *cache = nullptr)
 {
     nonneg = false;
-    (void)whole;
-    if (op.engine == FWX_ENGINE_FUSED && !fused_ok<T>(n, rate, hops)) return FWX_ERR_UNSUPPORTED;
+    if (op.engine == FWX_ENGINE_FUSED && !fused_ok<T>(nd, rate, hops)) return FWX_ERR_UNSUPPORTED;
     // AUTO below the fused engine's range, or where it cannot read the matrix / the input lies outside
-    // its domain: the single-launch kernel while it fits (n <= FWX_SMALL_N), else one launch per pivot
-    const Route fallback = (op.engine == FWX_ENGINE_AUTO && n <= FWX_SMALL_N) ? ROUTE_SMALL : ROUTE_PERK;
+    // its domain: the single-launch kernel while it fits (nd <= FWX_SMALL_N), else one launch per pivot
+    const Route fallback = (op.engine == FWX_ENGINE_AUTO && nd <= FWX_SMALL_N) ? ROUTE_SMALL : ROUTE_PERK;
     if (op.engine == FWX_ENGINE_AUTO && n <= kSmallSolveAutoMax) { route = ROUTE_SMALL; return FWX_OK; }
-    if (!pick_fused<T>(op.engine, n, rate, hops)) { route = fallback; return FWX_OK; }
+    if (!pick_fused<T>(op.engine, n, nd, rate, hops)) { route = fallback; return FWX_OK; }
     // The fused kernels take next[i][k] as the head of ikPath ++ kjPath (Algorithms.hs:55), which
     // is the reference's list head only while a winning product never has an empty ikPath -- true
     // on the reference's own domain, checked here.  Outside it the per-k engine, which reads the
@@ -378,7 +378,7 @@ int route_solve(const Opts &op, int n, bool whole, const T *rate, const int32_t 
         if (cache && cache->dom_known) {
             bits = cache->dom_bits;
         } else {
-            const int rc = domain_bits<T>(rate, next, (size_t)n * n, d_flag, s, bits);
+            const int rc = domain_bits<T>(rate, next, (size_t)nd * nd, d_flag, s, bits);
             if (rc) return rc;
             if (cache && (next || !cache->next)) { cache->dom_bits = bits; cache->dom_known = 1; }
         }
@@ -408,7 +408,6 @@ int solve_host(int32_t n, T *rate, int32_t *next, int32_t *hops, const fwx_opts 
     // padding entry is never a pivot row or column -- and a +0.0 target is never improved
     // (0 < +-0 and 0 < NaN are false), so U is unchanged too.  The caller's arrays stay n x n.
     constexpr int VW = 16 / (int)sizeof(T);
-    const bool whole = op.k_begin == 0 && op.k_end == n;
     const bool to_fused = op.engine == FWX_ENGINE_FUSED || (op.engine == FWX_ENGINE_AUTO && n > kSmallSolveAutoMax);
     const int nd = (to_fused && n % VW) ? (n + VW - 1) / VW * VW : n;
     const size_t nn = (size_t)nd * (size_t)nd;
@@ -467,18 +466,12 @@ int solve_host(int32_t n, T *rate, int32_t *next, int32_t *hops, const fwx_opts 
     unsigned long long *upd = op.updates_out ? (unsigned long long *)d_upd.p : nullptr;
     Route route;
     bool nonneg = false;
-    // (a padded matrix is routed by its real order n -- the single-launch engine never sees one --
-    // and solved over its real pivots only: the padding is inert)
-    if (nd == n) {
-        if ((rc = route_solve<T>(op, n, whole, dr, dn, dh, upd != nullptr, d_flag, s, route, nonneg))) return rc;
-    } else {
-        Opts opd = op;
-        opd.engine = FWX_ENGINE_FUSED;
-        if ((rc = route_solve<T>(opd, nd, whole, dr, dn, dh, upd != nullptr, d_flag, s, route, nonneg))) return rc;
-    }
+    // (a padded matrix is routed by its real order n and solved over its real pivots only: the padding
+    // is inert)
+    if ((rc = route_solve<T>(op, n, nd, dr, dn, dh, upd != nullptr, d_flag, s, route, nonneg))) return rc;
     if (route == ROUTE_SMALL) {
         // the reference's own regime: the whole solve in one single-workgroup launch
-        FWX_HIP(fwx::launch_small_solve<T>(dr, dn, dh, n, op.k_begin, op.k_end, upd, fwx::PathLog(), s));
+        FWX_HIP(fwx::launch_small_solve<T>(dr, dn, dh, nd, op.k_begin, op.k_end, upd, fwx::PathLog(), s));
     } else if (route == ROUTE_FUSED) {
         void *ws = nullptr;
         if ((rc = cx.reserve(CallCtx::WS, fused_ws_bytes(nd, sizeof(T), dh != nullptr), &ws))) return rc;
@@ -509,13 +502,13 @@ int solve_host(int32_t n, T *rate, int32_t *next, int32_t *hops, const fwx_opts 
 }
 
 // Single-thread device walk of the next-hop matrix (fwx_matrix_query).
-__global__ void follow_path_kernel(const int32_t *next, int n, int src, int dst, int32_t *out,
+__global__ void follow_path_kernel(const int32_t *next, int n, int ld, int src, int dst, int32_t *out,
                                    int cap, int32_t *len_out)
 {
     int len = 0, cur = src;
-    if (next[(size_t)src * n + dst] < 0) { *len_out = 0; return; }
+    if (next[(size_t)src * ld + dst] < 0) { *len_out = 0; return; }
     while (cur != dst || len == 0) {
-        const int nx = next[(size_t)cur * n + dst];
+        const int nx = next[(size_t)cur * ld + dst];
         if (nx < 0 || nx >= n || len >= n) { *len_out = FWX_ERR_CYCLE; return; }
         if (len >= cap) { *len_out = FWX_ERR_CAPACITY; return; }
         out[len++] = nx;
@@ -600,7 +593,7 @@ namespace {
 template <typename T>
 int matrix_solve_typed(fwx_matrix *m, const Opts &op, unsigned long long *upd, hipStream_t s, CallCtx *cx)
 {
-    const int n = m->n;
+    const int n = m->n, nd = m->nd;      // order of the matrix; order (= pitch) of the device arrays
     T *r = (T *)m->rate;
     Route route;
     bool nonneg = false;
@@ -613,19 +606,19 @@ int matrix_solve_typed(fwx_matrix *m, const Opts &op, unsigned long long *upd, h
         d_flag = (int *)((unsigned long long *)small + FWX_UPDATE_SHARDS);
     }
     m->fresh = 0;                        // whatever happens next, the arrays are no longer the upload
-    if ((rc = route_solve<T>(op, n, op.k_begin == 0 && op.k_end == n, r, m->next, m->hops, upd != nullptr,
-                             d_flag, s, route, nonneg, m->flag ? m : nullptr)))
+    if ((rc = route_solve<T>(op, n, nd, r, m->next, m->hops, upd != nullptr, d_flag, s, route, nonneg,
+                             m->flag ? m : nullptr)))
         return rc;
     if (route == ROUTE_SMALL) {
         if (m->resume) { m->resume->valid_upto = 0; m->resume->state_at = -1; }
-        FWX_HIP(fwx::launch_small_solve<T>(r, m->next, m->hops, n, op.k_begin, op.k_end, upd,
+        FWX_HIP(fwx::launch_small_solve<T>(r, m->next, m->hops, nd, op.k_begin, op.k_end, upd,
                                            m->plog, s));
         return FWX_OK;
     }
     if (route == ROUTE_FUSED) {
         // a handle keeps its workspace and look-ahead stream across solves; a view borrows the
         // pooled context's
-        const size_t need = fused_ws_bytes(n, sizeof(T), m->hops != nullptr);
+        const size_t need = fused_ws_bytes(nd, sizeof(T), m->hops != nullptr);
         void *ws = nullptr;
         SideStream *side = nullptr;
         if (m->flag) {
@@ -661,17 +654,17 @@ int matrix_solve_typed(fwx_matrix *m, const Opts &op, unsigned long long *upd, h
             R.state_at = -1;
             if (chain) rec = &R;
         }
-        rc = fused_range<T>(r, m->next, m->hops, n, op.k_begin, op.k_end, ws, upd, s, m->plog, nonneg, side, rec);
+        rc = fused_range<T>(r, m->next, m->hops, nd, op.k_begin, op.k_end, ws, upd, s, m->plog, nonneg, side, rec);
         if (rc) return rc;
         FWX_HIP(hipStreamSynchronize(s));
         if (rec) rec->valid_upto = rec->state_at = op.k_end;
         return FWX_OK;
     }
     if (m->resume) { m->resume->valid_upto = 0; m->resume->state_at = -1; }   // nothing was recorded
-    return relax_range<T>(r, m->next, m->hops, n, n, 0, r + (size_t)op.k_begin * n,
-                          m->hops ? m->hops + (size_t)op.k_begin * n : nullptr, n, op.k_begin,
+    return relax_range<T>(r, m->next, m->hops, nd, nd, 0, r + (size_t)op.k_begin * nd,
+                          m->hops ? m->hops + (size_t)op.k_begin * nd : nullptr, nd, op.k_begin,
                           op.k_end, op.serpentine, upd, s, m->plog, 0, 0,
-                          m->next ? m->next + (size_t)op.k_begin * n : nullptr);
+                          m->next ? m->next + (size_t)op.k_begin * nd : nullptr);
 }
 
 // Solve with the path trace (PathLog): one pass.  `last` starts at -1 everywhere; the kernels set
@@ -685,7 +678,7 @@ int logged_solve(fwx_matrix *m, const Opts &op_in, hipStream_t s, bool resumed =
     if (!resumed && !m->fresh) return FWX_ERR_INVALID;   // a traced solve starts from an uploaded input
     const Opts &op = op_in;                      // engines as for any matrix: single launch, fused
                                                  //   (no hops), per-k -- all three keep the trace
-    const size_t nn = (size_t)m->n * (size_t)m->n;
+    const size_t nn = (size_t)m->nd * (size_t)m->nd;
     if (!resumed) {
         FWX_HIP(hipMemsetAsync(m->plog.last, 0xFF, nn * 4, s));
         FWX_HIP(hipMemsetAsync(m->plog.at_col, 0xFF, nn * 4, s));
@@ -746,8 +739,8 @@ __global__ void exact_path_kernel(fwx::PathLog plog, const int32_t *next0, int n
 
 // Batch form: one thread per (src[q], dst[q]); query q writes its list to paths + q*cap and uses
 // stacks + q*3*cap as its stack.  len_out[q] = length, FWX_ERR_CAPACITY if it does not fit.
-__global__ __launch_bounds__(64) void exact_paths_kernel(fwx::PathLog plog, const int32_t *next0, int n,
-                                                         int count, const int32_t *src,
+__global__ __launch_bounds__(64) void exact_paths_kernel(fwx::PathLog plog, const int32_t *next0, int n_real,
+                                                         int n, int count, const int32_t *src,
                                                          const int32_t *dst, int32_t *paths,
                                                          int32_t *stacks, int cap, int32_t *len_out)
 {
@@ -755,7 +748,7 @@ __global__ __launch_bounds__(64) void exact_paths_kernel(fwx::PathLog plog, cons
     const int qi = blockIdx.x * 64 + threadIdx.x;
     if (qi >= count) return;
     const int s0 = src[qi], d0 = dst[qi];
-    if (s0 < 0 || d0 < 0 || s0 >= n || d0 >= n) { len_out[qi] = FWX_ERR_INVALID; return; }
+    if (s0 < 0 || d0 < 0 || s0 >= n_real || d0 >= n_real) { len_out[qi] = FWX_ERR_INVALID; return; }
     int32_t *out = paths + (size_t)qi * cap;
     int32_t *stack = stacks + (size_t)qi * 3 * cap;
     int sp = 0, len = 0;
@@ -763,7 +756,7 @@ __global__ __launch_bounds__(64) void exact_paths_kernel(fwx::PathLog plog, cons
     while (sp > 0) {
         --sp;
         const int a = stack[3 * sp], b = stack[3 * sp + 1], kind = stack[3 * sp + 2];
-        const size_t off = (size_t)a * n + b;
+        const size_t off = (size_t)a * n + b;                 // n: the pitch of the trace arrays
         const int q = kind == FINAL ? plog.last[off] : kind == AS_COLUMN ? plog.at_col[off] : plog.at_row[off];
         if (q < 0) {
             if (next0[off] >= 0) {
@@ -835,6 +828,40 @@ __global__ __launch_bounds__(64) void replay_entries_kernel(const int64_t *index
     }
 }
 
+// The caller's arrays are n x n; a single-device handle holds them at pitch nd (fwx_matrix::nd).
+// src / dst may be host or device memory (hipMemcpyDefault).
+int copy_in(fwx_matrix *m, void *dev, const void *src, size_t es, hipStream_t s)
+{
+    const size_t n = (size_t)m->n, nd = (size_t)m->nd;
+    if (nd == n) FWX_HIP(hipMemcpyAsync(dev, src, n * n * es, hipMemcpyDefault, s));
+    else FWX_HIP(hipMemcpy2DAsync(dev, nd * es, src, n * es, n * es, n, hipMemcpyDefault, s));
+    return FWX_OK;
+}
+int copy_out(fwx_matrix *m, void *dst, const void *dev, size_t es, hipStream_t s)
+{
+    const size_t n = (size_t)m->n, nd = (size_t)m->nd;
+    if (nd == n) FWX_HIP(hipMemcpyAsync(dst, dev, n * n * es, hipMemcpyDefault, s));
+    else FWX_HIP(hipMemcpy2DAsync(dst, n * es, dev, nd * es, n * es, n, hipMemcpyDefault, s));
+    return FWX_OK;
+}
+// entry index of the caller's n x n view (i * n + j) -> offset in the device arrays
+inline size_t dev_offset(const fwx_matrix *m, int64_t index)
+{
+    return (size_t)(index / m->n) * (size_t)m->nd + (size_t)(index % m->n);
+}
+
+// Element counts behind the memory a resumable handle keeps: `cells` per n x n array and `col_cells`
+// per all-pivot column-panel array, summed over the partitions of a partitioned handle.
+struct MultiDims { uint64_t cells, col_cells; };
+MultiDims resume_dims(const fwx_matrix *m)
+{
+    MultiDims d;
+    const uint64_t nd = (uint64_t)m->nd;
+    d.cells = nd * nd;
+    d.col_cells = nd * ((nd + 3) & ~(uint64_t)3);
+    return d;
+}
+
 void resume_free(Resume *r)
 {
     if (!r) return;
@@ -846,11 +873,12 @@ void resume_free(Resume *r)
     delete r;
 }
 
+// index: entry offsets in the DEVICE arrays (row * nd + column)
 template <typename T>
 int resolve_typed(fwx_matrix *m, int32_t count, const int64_t *index, int c_idx, hipStream_t s)
 {
     Resume &R = *m->resume;
-    const int n = m->n, c = R.pivot[(size_t)c_idx];
+    const int n = m->nd, c = R.pivot[(size_t)c_idx];
     const size_t nn = (size_t)n * n;
     // the state at the start of step c ...
     FWX_HIP(hipMemcpyAsync(m->rate, R.rate[(size_t)c_idx], nn * sizeof(T), hipMemcpyDeviceToDevice, s));
@@ -980,8 +1008,12 @@ int fwx_matrix_create(fwx_matrix **out, int32_t n, int32_t dtype, int32_t with_n
         if (!m) return FWX_ERR_OOM;
         memset(m, 0, sizeof(*m));
         m->n = n; m->dtype = dtype; m->device = dev;
-        const size_t nn = (size_t)n * (size_t)n;
         const size_t es = dtype == FWX_F64 ? 8 : 4;
+        // rows of 16-byte vectors for any n (fwx_matrix::nd): the arrays are nd x nd, the padding is
+        // written here, once -- nothing ever stores a different value into it
+        const int vw = (int)(16 / es);
+        m->nd = (n + vw - 1) / vw * vw;
+        const size_t nn = (size_t)m->nd * (size_t)m->nd;
         hipError_t e = hipMalloc(&m->rate, nn * es ? nn * es : 1);
         if (e == hipSuccess && with_next) e = hipMalloc((void **)&m->next, nn * 4 ? nn * 4 : 1);
         if (e == hipSuccess && with_hops) e = hipMalloc((void **)&m->hops, nn * 4 ? nn * 4 : 1);
@@ -989,6 +1021,12 @@ int fwx_matrix_create(fwx_matrix **out, int32_t n, int32_t dtype, int32_t with_n
         if (e == hipSuccess) e = hipMalloc((void **)&m->upd, FWX_UPDATE_SHARDS * 8);
         if (e == hipSuccess) e = hipMalloc((void **)&m->flag, 16);
         if (e == hipSuccess) e = hipStreamCreateWithFlags(&m->stream, hipStreamNonBlocking);
+        if (e == hipSuccess && m->nd != n) {
+            e = hipMemsetAsync(m->rate, 0, nn * es, m->stream);                                  // +0.0
+            if (e == hipSuccess && m->next) e = hipMemsetAsync(m->next, 0xFF, nn * 4, m->stream);   // -1
+            if (e == hipSuccess && m->hops) e = hipMemsetAsync(m->hops, 0, nn * 4, m->stream);
+            if (e == hipSuccess) e = hipStreamSynchronize(m->stream);
+        }
         if (e != hipSuccess) {
             g_last_hip = (int)e;
             (void)hipGetLastError();
@@ -1050,15 +1088,15 @@ int fwx_matrix_upload(fwx_matrix *m, const void *rate, const int32_t *next, cons
         DeviceGuard g;
         int rc = g.enter(m->device);
         if (rc) return rc;
-        const size_t nn = (size_t)m->n * (size_t)m->n, es = m->dtype == FWX_F64 ? 8 : 4;
+        const size_t nn = (size_t)m->nd * (size_t)m->nd, es = m->dtype == FWX_F64 ? 8 : 4;
         // hipMemcpyDefault: the sources may be host arrays (what an FFI hands over) or device arrays
         // (a caller that keeps its pristine input in HBM, e.g. the benchmark)
         hipStream_t s = m->stream;
         m->dom_known = 0;                  // a new input: the domain check has to look at it
         if (m->resume) m->resume->valid_upto = 0;   // ... and nothing of the old solve can be resumed
-        FWX_HIP(hipMemcpyAsync(m->rate, rate, nn * es, hipMemcpyDefault, s));
-        if (m->next) FWX_HIP(hipMemcpyAsync(m->next, next, nn * 4, hipMemcpyDefault, s));
-        if (m->hops) FWX_HIP(hipMemcpyAsync(m->hops, hops, nn * 4, hipMemcpyDefault, s));
+        if ((rc = copy_in(m, m->rate, rate, es, s))) return rc;
+        if (m->next && (rc = copy_in(m, m->next, next, 4, s))) return rc;
+        if (m->hops && (rc = copy_in(m, m->hops, hops, 4, s))) return rc;
         if (m->plog.last || (m->keep && m->next)) {
             // traced matrix: keep the uploaded next-hops (paths of entries never improved); kept input
             FWX_HIP(hipMemcpyAsync(m->next0, m->next, nn * 4, hipMemcpyDeviceToDevice, s));
@@ -1086,7 +1124,7 @@ int fwx_matrix_enable_path_log(fwx_matrix *m)
         DeviceGuard g;
         int rc = g.enter(m->device);
         if (rc) return rc;
-        const size_t nn = (size_t)m->n * (size_t)m->n;
+        const size_t nn = (size_t)m->nd * (size_t)m->nd;
         FWX_HIP(hipMalloc((void **)&m->plog.at_col, nn * 4));
         FWX_HIP(hipMalloc((void **)&m->plog.at_row, nn * 4));
         if (!m->next0) FWX_HIP(hipMalloc((void **)&m->next0, nn * 4));
@@ -1112,7 +1150,7 @@ int fwx_matrix_keep_input(fwx_matrix *m)
         DeviceGuard g;
         int rc = g.enter(m->device);
         if (rc) return rc;
-        const size_t nn = (size_t)m->n * (size_t)m->n, es = m->dtype == FWX_F64 ? 8 : 4;
+        const size_t nn = (size_t)m->nd * (size_t)m->nd, es = m->dtype == FWX_F64 ? 8 : 4;
         FWX_HIP(hipMalloc(&m->rate0, nn * es));
         if (m->next && !m->next0) FWX_HIP(hipMalloc((void **)&m->next0, nn * 4));
         if (m->hops) FWX_HIP(hipMalloc((void **)&m->hops0, nn * 4));
@@ -1144,7 +1182,7 @@ int fwx_matrix_patch_input(fwx_matrix *m, int32_t count, const int64_t *index, c
         DeviceGuard g;
         int rc = g.enter(m->device);
         if (rc) return rc;
-        const size_t nn = (size_t)nn64, es = m->dtype == FWX_F64 ? 8 : 4;
+        const size_t nn = (size_t)m->nd * (size_t)m->nd, es = m->dtype == FWX_F64 ? 8 : 4;
         hipStream_t s = m->stream;
         if (m->resume) m->resume->valid_upto = 0;   // the kept input changes without a replay
         // the remembered domain answer survives a patch whose values are themselves inside the domain
@@ -1161,7 +1199,7 @@ int fwx_matrix_patch_input(fwx_matrix *m, int32_t count, const int64_t *index, c
             if (!ok || (m->dom_bits & want) != want) m->dom_known = 0;
         }
         for (int32_t q = 0; q < count; ++q) {        // a handful of entries: plain small copies
-            const size_t off = (size_t)index[q];
+            const size_t off = dev_offset(m, index[q]);
             FWX_HIP(hipMemcpyAsync((char *)m->rate0 + off * es, (const char *)rate_vals + (size_t)q * es, es,
                                    hipMemcpyHostToDevice, s));
             if (next_vals) FWX_HIP(hipMemcpyAsync(m->next0 + off, next_vals + q, 4, hipMemcpyHostToDevice, s));
@@ -1178,6 +1216,35 @@ int fwx_matrix_patch_input(fwx_matrix *m, int32_t count, const int64_t *index, c
     });
 }
 
+int fwx_device_memory(int32_t device, uint64_t *free_bytes, uint64_t *total_bytes)
+{
+    return fwxi::guarded([&]() -> int {
+        DeviceGuard g;
+        int rc = g.enter(device);
+        if (rc) return rc;
+        size_t f = 0, t = 0;
+        FWX_HIP(hipMemGetInfo(&f, &t));
+        if (free_bytes) *free_bytes = f;
+        if (total_bytes) *total_bytes = t;
+        return FWX_OK;
+    });
+}
+
+int fwx_matrix_resume_bytes(const fwx_matrix *m, int32_t checkpoints, uint64_t *bytes_out)
+{
+    return fwxi::guarded([&]() -> int {
+        if (!m || !bytes_out || checkpoints < 0 || checkpoints > FWX_MAX_CHECKPOINTS) return FWX_ERR_INVALID;
+        const MultiDims d = resume_dims(m);
+        const uint64_t es = m->dtype == FWX_F64 ? 8 : 4;
+        // per checkpoint: one copy of every array; panels: w + ct (+ cnt) (+ wh + cht) for all pivots
+        const uint64_t per_cp = d.cells * (es + (m->next ? 4 : 0) + (m->hops ? 4 : 0) + (m->plog.last ? 12 : 0));
+        const uint64_t panels = d.cells * es + d.col_cells * es + (m->next ? d.col_cells * 4 : 0) +
+                                (m->hops ? d.cells * 4 + d.col_cells * 4 : 0);
+        *bytes_out = (uint64_t)checkpoints * per_cp + panels + (uint64_t)FWX_MAX_PATCH * 8;
+        return FWX_OK;
+    });
+}
+
 int fwx_matrix_enable_resume(fwx_matrix *m, int32_t checkpoints)
 {
     return fwxi::guarded([&]() -> int {
@@ -1185,10 +1252,10 @@ int fwx_matrix_enable_resume(fwx_matrix *m, int32_t checkpoints)
         if (m->multi) return FWX_ERR_UNSUPPORTED;
         if (m->resume) return FWX_ERR_INVALID;
         if (!m->keep) return FWX_ERR_INVALID;                // replays start from the kept input
-        const int n = m->n;
+        const int n = m->nd;                                 // everything below is sized like the device arrays
         const bool f64 = m->dtype == FWX_F64;
-        // resumable = the fused engine can run the handle's arrays (fwx.h fwx_engine)
-        if (n <= kSmallSolveAutoMax || n % (f64 ? 2 : 4) != 0) return FWX_ERR_UNSUPPORTED;
+        // resumable = AUTO takes the fused engine for this order (fwx.h fwx_engine)
+        if (m->n <= kSmallSolveAutoMax) return FWX_ERR_UNSUPPORTED;
         DeviceGuard g;
         int rc = g.enter(m->device);
         if (rc) return rc;
@@ -1206,8 +1273,8 @@ int fwx_matrix_enable_resume(fwx_matrix *m, int32_t checkpoints)
         R->ld = (n + 3) & ~3;
         // checkpoints at the multiples of 64 closest to q * n / (checkpoints + 1)
         for (int q = 1; q <= checkpoints; ++q) {
-            int p = (int)(((int64_t)n * q / (checkpoints + 1) + 32) / 64 * 64);
-            if (p <= 0 || p >= n || (!R->pivot.empty() && p <= R->pivot.back())) continue;
+            int p = (int)(((int64_t)m->n * q / (checkpoints + 1) + 32) / 64 * 64);
+            if (p <= 0 || p >= m->n || (!R->pivot.empty() && p <= R->pivot.back())) continue;
             R->pivot.push_back(p);
         }
         R->count = (int)R->pivot.size();
@@ -1288,15 +1355,17 @@ int fwx_matrix_resolve(fwx_matrix *m, int32_t count, const int64_t *index, const
         const size_t es = m->dtype == FWX_F64 ? 8 : 4;
         const int keep_valid = R->valid_upto;
         R->valid_upto = 0;                           // until the resumed solve has finished
+        std::vector<int64_t> dindex((size_t)count);  // offsets in the device arrays (pitch nd)
+        for (int32_t q = 0; q < count; ++q) dindex[(size_t)q] = (int64_t)dev_offset(m, index[q]);
         for (int32_t q = 0; q < count; ++q) {        // the kept input first: the replay reads it
-            const size_t off = (size_t)index[q];
+            const size_t off = (size_t)dindex[(size_t)q];
             FWX_HIP(hipMemcpyAsync((char *)m->rate0 + off * es, (const char *)rate_vals + (size_t)q * es, es,
                                    hipMemcpyHostToDevice, s));
             if (next_vals) FWX_HIP(hipMemcpyAsync(m->next0 + off, next_vals + q, 4, hipMemcpyHostToDevice, s));
             if (hops_vals) FWX_HIP(hipMemcpyAsync(m->hops0 + off, hops_vals + q, 4, hipMemcpyHostToDevice, s));
         }
-        rc = m->dtype == FWX_F64 ? resolve_typed<double>(m, count, index, c_idx, s)
-                                 : resolve_typed<float>(m, count, index, c_idx, s);
+        rc = m->dtype == FWX_F64 ? resolve_typed<double>(m, count, dindex.data(), c_idx, s)
+                                 : resolve_typed<float>(m, count, dindex.data(), c_idx, s);
         if (rc) return rc;
         m->fresh = 0;
         m->rec_ready = 0;
@@ -1337,7 +1406,7 @@ int fwx_matrix_query_exact(fwx_matrix *m, int32_t src, int32_t dst, double *rate
         DeviceGuard g;
         int rc = g.enter(m->device);
         if (rc) return rc;
-        const size_t idx = (size_t)src * m->n + dst;
+        const size_t idx = (size_t)src * m->nd + dst;
         hipStream_t s = m->stream;
         float f32_rate = 0;
         if (rate_out) {
@@ -1352,7 +1421,7 @@ int fwx_matrix_query_exact(fwx_matrix *m, int32_t src, int32_t dst, double *rate
             m->walk_cap = cap;
         }
         int32_t *len_dev = m->walk + (size_t)4 * cap;
-        hipLaunchKernelGGL(exact_path_kernel, dim3(1), dim3(1), 0, s, m->plog, m->next0, m->n, src,
+        hipLaunchKernelGGL(exact_path_kernel, dim3(1), dim3(1), 0, s, m->plog, m->next0, m->nd, src,
                            dst, m->walk, cap, len_dev);
         FWX_HIP(hipGetLastError());
         int32_t len = 0;
@@ -1398,7 +1467,7 @@ int fwx_matrix_query_exact_batch(fwx_matrix *m, int32_t count, const int32_t *sr
         FWX_HIP(hipMemcpyAsync(d_src.p, src, c * 4, hipMemcpyHostToDevice, s));
         FWX_HIP(hipMemcpyAsync(d_dst.p, dst, c * 4, hipMemcpyHostToDevice, s));
         hipLaunchKernelGGL(exact_paths_kernel, dim3((unsigned)((c + 63) / 64)), dim3(64), 0, s, m->plog,
-                           m->next0, m->n, count, (const int32_t *)d_src.p, (const int32_t *)d_dst.p,
+                           m->next0, m->n, m->nd, count, (const int32_t *)d_src.p, (const int32_t *)d_dst.p,
                            (int32_t *)d_paths.p, (int32_t *)d_stacks.p, cap, (int32_t *)d_len.p);
         FWX_HIP(hipGetLastError());
         FWX_HIP(hipMemcpyAsync(len_out, d_len.p, c * 4, hipMemcpyDeviceToHost, s));
@@ -1418,11 +1487,11 @@ int fwx_matrix_download(fwx_matrix *m, void *rate, int32_t *next, int32_t *hops)
         DeviceGuard g;
         int rc = g.enter(m->device);
         if (rc) return rc;
-        const size_t nn = (size_t)m->n * (size_t)m->n, es = m->dtype == FWX_F64 ? 8 : 4;
+        const size_t es = m->dtype == FWX_F64 ? 8 : 4;
         hipStream_t s = m->stream;
-        if (rate) FWX_HIP(hipMemcpyAsync(rate, m->rate, nn * es, hipMemcpyDefault, s));
-        if (next) FWX_HIP(hipMemcpyAsync(next, m->next, nn * 4, hipMemcpyDefault, s));
-        if (hops) FWX_HIP(hipMemcpyAsync(hops, m->hops, nn * 4, hipMemcpyDefault, s));
+        if (rate && (rc = copy_out(m, rate, m->rate, es, s))) return rc;
+        if (next && (rc = copy_out(m, next, m->next, 4, s))) return rc;
+        if (hops && (rc = copy_out(m, hops, m->hops, 4, s))) return rc;
         FWX_HIP(hipStreamSynchronize(s));
         return FWX_OK;
     });
@@ -1466,7 +1535,7 @@ int fwx_matrix_query(fwx_matrix *m, int32_t src, int32_t dst, double *rate_out, 
         DeviceGuard g;
         int rc = g.enter(m->device);
         if (rc) return rc;
-        const size_t idx = (size_t)src * m->n + dst;
+        const size_t idx = (size_t)src * m->nd + dst;
         hipStream_t s = m->stream;
         float f32_rate = 0;
         if (rate_out) {
@@ -1481,7 +1550,7 @@ int fwx_matrix_query(fwx_matrix *m, int32_t src, int32_t dst, double *rate_out, 
             return FWX_ERR_INVALID;
         }
         const int dcap = cap < m->n ? cap : m->n;
-        hipLaunchKernelGGL(follow_path_kernel, dim3(1), dim3(1), 0, s, m->next, m->n, src, dst,
+        hipLaunchKernelGGL(follow_path_kernel, dim3(1), dim3(1), 0, s, m->next, m->n, m->nd, src, dst,
                            m->scratch + 1, dcap, m->scratch);
         FWX_HIP(hipGetLastError());
         int32_t len = 0;
@@ -1559,7 +1628,7 @@ int fwx_dev_solve(const fwx_slab *full, const fwx_opts *opts)
         if (device_count() <= 0) return FWX_ERR_NO_DEVICE;
         fwx_matrix m;
         memset(&m, 0, sizeof(m));
-        m.n = full->n; m.dtype = full->dtype;
+        m.n = m.nd = full->n; m.dtype = full->dtype;      // caller-owned memory: pitch n, no padding
         m.rate = full->rate; m.next = full->next; m.hops = full->hops;
         DeviceGuard g;                       // the context belongs to the device the call runs on
         if ((rc = g.enter(op.device))) return rc;

@@ -443,6 +443,11 @@ struct Resume {
 
 struct fwx_matrix {
     int32_t n, dtype, device;
+    int32_t nd;            // device order = pitch of every array below: n rounded up to a multiple of 16
+                           // bytes of rate elements, so that the fused engine reads any n.  The padding
+                           // (rate +0.0, next -1, hops 0, trace -1; written once, at create / enable) is
+                           // inert: a padding index is never a pivot, and a +0.0 target never improves
+                           // (0 < +-0 and 0 < NaN are false) -- as in fwx_solve_* and the partitioned handle
     void *rate;
     int32_t *next, *hops, *scratch;
     unsigned long long *upd;

@@ -137,18 +137,61 @@ struct Part {
     int32_t *next0 = nullptr;
     void *rate0 = nullptr;                  // kept input (fwx_matrix_keep_input)
     int32_t *hops0 = nullptr;
-    void *w[2] = {nullptr, nullptr};        // snapshot panels, 64 x nd
-    int32_t *wh[2] = {nullptr, nullptr};    // their hops (iff hops)
-    void *ct = nullptr;                     // pivot-column snapshots, 64 x ct_ld
+    // FOUR panel sets, each contiguous over the sets (set s of W at w[0] + s * 64 * nd, of Ct at
+    // ct + s * 64 * ct_ld, ...): the single-pass schedules ping-pong between sets 0 and 1, the double
+    // pass keeps block q in set q & 3, so that a pair of blocks (2P, 2P + 1) is one 128-pivot panel
+    void *w[4] = {nullptr, nullptr, nullptr, nullptr};        // snapshot panels, 64 x nd each
+    int32_t *wh[4] = {nullptr, nullptr, nullptr, nullptr};    // their hops (iff hops)
+    void *ct = nullptr;                     // pivot-column snapshots, 4 x 64 x ct_ld
     int32_t *cnt = nullptr, *cht = nullptr; // their next-hops / hops
     int ct_ld = 0;
     unsigned long long *upd = nullptr;
     int *flag = nullptr;
     hipStream_t main = nullptr, side = nullptr;
-    hipEvent_t rows_done = nullptr, w_ready[2] = {nullptr, nullptr}, main_free[2] = {nullptr, nullptr};
+    hipEvent_t rows_done = nullptr, main_done = nullptr, panel_done = nullptr;
+    hipEvent_t w_ready[4] = {nullptr, nullptr, nullptr, nullptr}, main_free[4] = {nullptr, nullptr, nullptr, nullptr};
+};
+
+// Per-step event timings of a partitioned solve (fwx_matrix_set_timing / fwx_matrix_get_timing): what
+// the N > 1 benchmark line reports so that a run on hardware this build never touched explains itself
+// -- is a step bound by the slab sweep (BULK) or by what the next step waits for besides it (the
+// look-ahead rows, the owner's panel kernel, the exchange: the CHAIN)?  Spans are pairs of timing
+// events on the stream the work runs on, created on that stream's device and reused across solves.
+struct MultiTimer {
+    enum Kind { BULK, CHAIN, LOOKAHEAD, PANEL, XCHG, NKIND };
+    struct Span { int kind, part, step; hipEvent_t e0, e1; };
+    bool on = false;
+    std::vector<Span> spans;
+    std::vector<hipEvent_t> pool[FWX_MAX_PARTS];
+    size_t used[FWX_MAX_PARTS] = {0};
+    fwx_multi_timing last;
+    void reset() { spans.clear(); for (size_t &u : used) u = 0; memset(&last, 0, sizeof(last)); }
+    hipEvent_t take(int part)
+    {
+        if (used[part] == pool[part].size()) {
+            hipEvent_t e = nullptr;
+            if (hipEventCreate(&e) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+            pool[part].push_back(e);
+        }
+        return pool[part][used[part]++];
+    }
+    // the device of `part` must be current
+    int begin(int kind, int part, int step, hipStream_t st)
+    {
+        if (!on) return -1;
+        Span sp{kind, part, step, take(part), take(part)};
+        if (!sp.e0 || !sp.e1 || hipEventRecord(sp.e0, st) != hipSuccess) { (void)hipGetLastError(); return -1; }
+        spans.push_back(sp);
+        return (int)spans.size() - 1;
+    }
+    void end(int id, hipStream_t st)
+    {
+        if (id >= 0 && hipEventRecord(spans[(size_t)id].e1, st) != hipSuccess) (void)hipGetLastError();
+    }
 };
 
 struct MultiState {
+    MultiTimer timer;
     int parts = 0;
     int nd = 0;                 // device order: n rounded up to a multiple of 16 bytes of elements
     int exchange = FWX_XCHG_PEER;
@@ -280,12 +323,13 @@ static void multi_free(MultiState *M)
         if (hipSetDevice(q.device) != hipSuccess) continue;
         if (q.main) (void)hipStreamDestroy(q.main);
         if (q.side) (void)hipStreamDestroy(q.side);
-        hipEvent_t evs[] = {q.rows_done, q.w_ready[0], q.w_ready[1], q.main_free[0], q.main_free[1]};
+        for (hipEvent_t e : M->timer.pool[p]) (void)hipEventDestroy(e);
+        hipEvent_t evs[] = {q.rows_done, q.main_done, q.panel_done, q.w_ready[0], q.w_ready[1], q.w_ready[2],
+                            q.w_ready[3], q.main_free[0], q.main_free[1], q.main_free[2], q.main_free[3]};
         for (hipEvent_t e : evs)
             if (e) (void)hipEventDestroy(e);
         void *bufs[] = {q.rate, q.next, q.hops, q.plog.last, q.plog.at_col, q.plog.at_row, q.next0, q.rate0,
-                        q.hops0, q.w[0],
-                        q.w[1], q.wh[0], q.wh[1], q.ct, q.cnt, q.cht, q.upd, q.flag};
+                        q.hops0, q.w[0], q.wh[0], q.ct, q.cnt, q.cht, q.upd, q.flag};
         for (void *b : bufs)
             if (b) (void)hipFree(b);
         if (p == 0 && M->qscratch) (void)hipFree(M->qscratch);
@@ -322,21 +366,23 @@ static int multi_alloc(fwx_matrix *m, int n_parts, const int32_t *devices, int e
         M->slab_bytes += cells * es;
         FWX_HIP(hipMalloc(&q.rate, cells * es ? cells * es : 16));
         if (m->next) FWX_HIP(hipMalloc((void **)&q.next, cells * 4 ? cells * 4 : 16));
-        FWX_HIP(hipMalloc(&q.w[0], (size_t)FWX_FUSED_BLOCK * nd * es));
-        FWX_HIP(hipMalloc(&q.w[1], (size_t)FWX_FUSED_BLOCK * nd * es));
-        FWX_HIP(hipMalloc(&q.ct, (size_t)FWX_FUSED_BLOCK * (q.ct_ld ? q.ct_ld : 4) * es));
-        if (m->next) FWX_HIP(hipMalloc((void **)&q.cnt, (size_t)FWX_FUSED_BLOCK * (q.ct_ld ? q.ct_ld : 4) * 4));
+        const size_t wset = (size_t)FWX_FUSED_BLOCK * nd, cset = (size_t)FWX_FUSED_BLOCK * (q.ct_ld ? q.ct_ld : 4);
+        FWX_HIP(hipMalloc(&q.w[0], 4 * wset * es));
+        for (int b = 1; b < 4; ++b) q.w[b] = (char *)q.w[0] + (size_t)b * wset * es;
+        FWX_HIP(hipMalloc(&q.ct, 4 * cset * es));
+        if (m->next) FWX_HIP(hipMalloc((void **)&q.cnt, 4 * cset * 4));
         if (m->hops) {
             FWX_HIP(hipMalloc((void **)&q.hops, cells * 4 ? cells * 4 : 16));
-            FWX_HIP(hipMalloc((void **)&q.wh[0], (size_t)FWX_FUSED_BLOCK * nd * 4));
-            FWX_HIP(hipMalloc((void **)&q.wh[1], (size_t)FWX_FUSED_BLOCK * nd * 4));
-            FWX_HIP(hipMalloc((void **)&q.cht, (size_t)FWX_FUSED_BLOCK * (q.ct_ld ? q.ct_ld : 4) * 4));
+            FWX_HIP(hipMalloc((void **)&q.wh[0], 4 * wset * 4));
+            for (int b = 1; b < 4; ++b) q.wh[b] = q.wh[0] + (size_t)b * wset;
+            FWX_HIP(hipMalloc((void **)&q.cht, 4 * cset * 4));
         }
         FWX_HIP(hipMalloc((void **)&q.upd, FWX_UPDATE_SHARDS * 8));
         FWX_HIP(hipMalloc((void **)&q.flag, 16));
         FWX_HIP(hipStreamCreateWithFlags(&q.main, hipStreamNonBlocking));
         FWX_HIP(hipStreamCreateWithFlags(&q.side, hipStreamNonBlocking));
-        hipEvent_t *evs[] = {&q.rows_done, &q.w_ready[0], &q.w_ready[1], &q.main_free[0], &q.main_free[1]};
+        hipEvent_t *evs[] = {&q.rows_done, &q.main_done, &q.panel_done, &q.w_ready[0], &q.w_ready[1], &q.w_ready[2],
+                             &q.w_ready[3], &q.main_free[0], &q.main_free[1], &q.main_free[2], &q.main_free[3]};
         for (hipEvent_t *e : evs) FWX_HIP(hipEventCreateWithFlags(e, hipEventDisableTiming));
     }
     // Peer access is wanted, not required: the QUERIES walk every slab from partition 0's device and
@@ -503,9 +549,10 @@ template <typename T> static fwx::FusedArgs<T> part_args(const MultiState &M, co
 // Snapshot panel of block b on its owner's side stream + its exchange into slot b & 1 of every
 // partition.  Precondition: the owner's main stream has recorded rows_done after bringing the
 // block's rows up to time k0.
-template <typename T> static int issue_panel(MultiState &M, const Block &blk, int slot)
+template <typename T> static int issue_panel(MultiState &M, const Block &blk, int slot, int step = 0)
 {
     Part &o = M.part[blk.owner];
+    MultiTimer &tm = M.timer;
     const size_t bytes = (size_t)blk.bt * M.nd * sizeof(T);
     int rc = set_dev(o.device);
     if (rc) return rc;
@@ -516,9 +563,11 @@ template <typename T> static int issue_panel(MultiState &M, const Block &blk, in
             if (r != blk.owner) FWX_HIP(hipStreamWaitEvent(o.side, M.part[r].w_ready[slot], 0));
     const size_t row_off = (size_t)(blk.k0 - o.row0) * M.nd;
     const size_t hbytes = (size_t)blk.bt * M.nd * sizeof(int32_t);
+    const int t_panel = tm.begin(MultiTimer::PANEL, blk.owner, step, o.side);
     FWX_HIP(fwx::launch_fused_panel<T>((const T *)o.rate + row_off, M.nd, blk.k0, blk.bt, (T *)o.w[slot],
                                        o.side, plog_rows(o.plog, row_off),
                                        o.hops ? o.hops + row_off : nullptr, o.wh[slot]));
+    tm.end(t_panel, o.side);
     FWX_HIP(hipEventRecord(o.w_ready[slot], o.side));
     if (M.exchange == FWX_XCHG_PEER) {
         for (int r = 0; r < M.parts; ++r) {
@@ -527,6 +576,7 @@ template <typename T> static int issue_panel(MultiState &M, const Block &blk, in
             if ((rc = set_dev(q.device))) return rc;
             FWX_HIP(hipStreamWaitEvent(q.side, q.main_free[slot], 0));
             FWX_HIP(hipStreamWaitEvent(q.side, o.w_ready[slot], 0));
+            const int t_x = tm.begin(MultiTimer::XCHG, r, step, q.side);
             if (q.device == o.device) {
                 FWX_HIP(hipMemcpyAsync(q.w[slot], o.w[slot], bytes, hipMemcpyDeviceToDevice, q.side));
                 if (o.hops)
@@ -536,6 +586,7 @@ template <typename T> static int issue_panel(MultiState &M, const Block &blk, in
                 if (o.hops)
                     FWX_HIP(hipMemcpyPeerAsync(q.wh[slot], q.device, o.wh[slot], o.device, hbytes, q.side));
             }
+            tm.end(t_x, q.side);
             FWX_HIP(hipEventRecord(q.w_ready[slot], q.side));
         }
     } else {
@@ -544,6 +595,11 @@ template <typename T> static int issue_panel(MultiState &M, const Block &blk, in
             if (r == blk.owner) continue;
             if ((rc = set_dev(M.part[r].device))) return rc;
             FWX_HIP(hipStreamWaitEvent(M.part[r].side, M.part[r].main_free[slot], 0));
+        }
+        int t_x[FWX_MAX_PARTS];
+        for (int r = 0; r < M.parts; ++r) {
+            if ((rc = set_dev(M.part[r].device))) return rc;
+            t_x[r] = tm.begin(MultiTimer::XCHG, r, step, M.part[r].side);
         }
         FWX_NCCL(api.GroupStart());
         for (int r = 0; r < M.parts; ++r) {
@@ -559,9 +615,246 @@ template <typename T> static int issue_panel(MultiState &M, const Block &blk, in
         for (int r = 0; r < M.parts; ++r) {
             Part &q = M.part[r];
             if ((rc = set_dev(q.device))) return rc;
+            tm.end(t_x[r], q.side);
             FWX_HIP(hipEventRecord(q.w_ready[slot], q.side));
         }
     }
+    return FWX_OK;
+}
+
+// Turns the spans of the solve that has just been synchronised into fwx_multi_timing.
+static void summarize_timing(MultiState &M)
+{
+    MultiTimer &tm = M.timer;
+    fwx_multi_timing &t = tm.last;
+    t.struct_size = (uint32_t)sizeof(t);
+    t.partitions = M.parts;
+    if (!tm.on || tm.spans.empty()) return;
+    // per kind: mean over steps of the MAX over partitions (what a step waits for), and the plain mean
+    int steps = 0;
+    for (const MultiTimer::Span &sp : tm.spans) steps = sp.step + 1 > steps ? sp.step + 1 : steps;
+    std::vector<float> mx((size_t)steps * MultiTimer::NKIND, -1.0f);
+    double sum[MultiTimer::NKIND] = {0};
+    long cnt[MultiTimer::NKIND] = {0};
+    for (const MultiTimer::Span &sp : tm.spans) {
+        if (hipSetDevice(M.part[sp.part].device) != hipSuccess) continue;
+        float ms = 0;
+        if (hipEventElapsedTime(&ms, sp.e0, sp.e1) != hipSuccess) { (void)hipGetLastError(); continue; }
+        float &slot = mx[(size_t)sp.step * MultiTimer::NKIND + sp.kind];
+        slot = ms > slot ? ms : slot;
+        sum[sp.kind] += ms;
+        ++cnt[sp.kind];
+    }
+    auto mean_of_max = [&](int kind) -> float {
+        double a = 0; long c = 0;
+        for (int st = 0; st < steps; ++st) {
+            const float v = mx[(size_t)st * MultiTimer::NKIND + kind];
+            if (v >= 0) { a += v; ++c; }
+        }
+        return c ? (float)(1e3 * a / c) : 0.0f;
+    };
+    auto mean = [&](int kind) -> float { return cnt[kind] ? (float)(1e3 * sum[kind] / cnt[kind]) : 0.0f; };
+    t.steps = (int32_t)cnt[MultiTimer::BULK] / (M.parts > 0 ? M.parts : 1);
+    t.bulk_us = mean_of_max(MultiTimer::BULK);
+    t.bulk_mean_us = mean(MultiTimer::BULK);
+    t.lookahead_us = mean(MultiTimer::LOOKAHEAD);
+    t.panel_us = mean(MultiTimer::PANEL);
+    t.exchange_us = mean_of_max(MultiTimer::XCHG);
+    // single pass: the serial chain of a step is look-ahead rows -> panel kernel -> exchange; the double
+    // pass measures it whole, on the side stream (CHAIN), from the moment the previous main launch ends
+    t.chain_us = cnt[MultiTimer::CHAIN] ? mean_of_max(MultiTimer::CHAIN)
+                                        : t.lookahead_us + t.panel_us + t.exchange_us;
+    t.chain_over_bulk = t.bulk_us > 0 ? t.chain_us / t.bulk_us : 0.0f;
+}
+
+static int finish_multi_solve(fwx_matrix *m, bool counting, const Opts &op)
+{
+    MultiState &M = *m->multi;
+    int rc;
+    uint64_t total = 0;
+    for (int p = 0; p < M.parts; ++p) {
+        Part &q = M.part[p];
+        if ((rc = set_dev(q.device))) return rc;
+        FWX_HIP(hipStreamSynchronize(q.side));
+        FWX_HIP(hipStreamSynchronize(q.main));
+        if (counting) {
+            uint64_t u = 0;
+            if ((rc = sum_updates(q.upd, &u, q.main))) return rc;
+            total += u;
+        }
+    }
+    summarize_timing(M);
+    if (counting) *op.updates_out = total;
+    m->last_u = total;
+    return FWX_OK;
+}
+
+// crossover thresholds of the double pass: those of the single-device engine (fwx_api.hip fused_range),
+// same environment overrides
+static int env_threshold_multi(const char *name, int dflt)
+{
+    const char *e = getenv(name);
+    if (e && *e) {
+        char *end = nullptr;
+        const long v = strtol(e, &end, 10);
+        if (end != e && v >= 0 && v <= INT32_MAX) return (int)v;
+    }
+    return dflt;
+}
+
+// The double pass on partitions: fused_range's schedule (fwx_api.hip) with owners and an exchange.
+// Blocks q = 0, 1, ... of 64 pivots; block q lives in panel set q & 3 on EVERY partition, so a pair
+// (2P, 2P + 1) is one contiguous 128-pivot panel and every partition's main kernel applies a pair per
+// launch.  Beside main(P) -- which leaves the rows and the columns of the NEXT pair alone -- every
+// partition's side stream brings its part of that cross up to date with the pair being applied (its
+// local rows of those columns; on the owners also the cross rows themselves), the owner of the first
+// block of the next pair runs its snapshot panel and sends it, every partition forms its column panel
+// from it, applies that one pass to the second block's columns (its owner: and rows), and the same
+// again for the second block.  main(P + 1) waits for its own partition's side chain only.  Nothing
+// orders two partitions but the panels: each exchange has a whole pair's sweep to arrive, twice the
+// single pass's.  Same kernels, operands and order per entry as on one device: bit-identical.
+// Buffer reuse: set s is overwritten every fourth block; a partition's main(P - 1) -- the last reader
+// of the sets chain(P) writes -- precedes its chain(P) in stream order (main_done), and an owner waits
+// for every peer's w_ready[s] before it overwrites a panel peers may still be copying (PEER exchange).
+// done: the number of blocks applied (a multiple of 2 ... or all of them if the count is odd).
+template <typename T>
+static int multi_double_pass(fwx_matrix *m, const std::vector<Block> &blocks, Throttle &thr, int &done)
+{
+    MultiState &M = *m->multi;
+    const int P = M.parts, nd = M.nd;
+    constexpr int Bq = FWX_FUSED_BLOCK;
+    const bool with_next = m->next != nullptr;
+    done = 0;
+    // full 64-aligned blocks from the start of the range; every partition non-empty and 64-aligned
+    int nb = 0;
+    while ((size_t)nb < blocks.size() && blocks[(size_t)nb].bt == Bq && blocks[(size_t)nb].k0 % Bq == 0) ++nb;
+    for (int p = 0; p < P; ++p)
+        if (M.part[p].rows <= 0 || M.part[p].row0 % Bq != 0) return FWX_OK;
+    const int min_n = with_next ? env_threshold_multi("FWX_DOUBLE_PASS_NEXT_MIN_N", sizeof(T) == 4 ? 8192 : INT32_MAX)
+                                : env_threshold_multi("FWX_DOUBLE_PASS_MIN_N", 6144);
+    if (m->n < min_n || nb < 4) return FWX_OK;
+    int rc;
+    MultiTimer &tm = M.timer;
+    tm.last.pivots_per_step = 2 * Bq;
+    auto kq = [&](int q) { return blocks[(size_t)q].k0; };
+    auto args = [&](Part &q, int blk, int nblocks) {
+        fwx::FusedArgs<T> a = part_args<T>(M, q, true, false);
+        const size_t set = (size_t)(blk & 3);
+        a.k0 = kq(blk); a.bt = nblocks * Bq;
+        a.w = (const T *)q.w[0] + set * Bq * nd;
+        a.wh = q.wh[0] ? q.wh[0] + set * Bq * nd : nullptr;
+        a.ct = (T *)q.ct + set * Bq * q.ct_ld;
+        a.cnt = q.cnt ? q.cnt + set * Bq * q.ct_ld : nullptr;
+        a.cht = q.cht ? q.cht + set * Bq * q.ct_ld : nullptr;
+        return a;
+    };
+    auto local = [&](const Part &q, int g) { const int l = g - q.row0; return l < 0 ? 0 : l > q.rows ? q.rows : l; };
+    // pivots of `nblocks` blocks from block blk onto the rows [lo, hi) this partition holds (all columns)
+    // and onto the columns [lo, hi) of its other rows
+    auto cross = [&](Part &q, int blk, int nblocks, int lo, int hi, hipStream_t st) -> int {
+        const fwx::FusedArgs<T> a = args(q, blk, nblocks);
+        const int l_lo = local(q, lo), l_hi = local(q, hi);
+        if (l_hi > l_lo) FWX_HIP(fwx::launch_fused_main<T>(a, l_lo, l_hi, st));
+        FWX_HIP(fwx::launch_fused_main<T>(a, 0, q.rows, st, l_lo, l_hi, fwx::FusedCols::only(lo, hi)));
+        return FWX_OK;
+    };
+    // snapshot panel of block blk on its owner + exchange, then every partition's column panel, all on
+    // the side streams
+    auto produce = [&](int blk, int step) -> int {
+        int rc2 = issue_panel<T>(M, blocks[(size_t)blk], blk & 3, step);
+        if (rc2) return rc2;
+        for (int p = 0; p < P; ++p) {
+            Part &q = M.part[p];
+            if ((rc2 = set_dev(q.device))) return rc2;
+            FWX_HIP(hipStreamWaitEvent(q.side, q.w_ready[blk & 3], 0));
+            FWX_HIP(fwx::launch_fused_colpanel<T>(args(q, blk, 1), q.side));
+        }
+        return FWX_OK;
+    };
+    auto each = [&](auto &&fn) -> int {
+        for (int p = 0; p < P; ++p) {
+            int rc2 = set_dev(M.part[p].device);
+            if (rc2 || (rc2 = fn(p, M.part[p]))) return rc2;
+        }
+        return FWX_OK;
+    };
+    // chain(0): panels of block 0, that pass onto block 1's rows and columns, panels of block 1 -- on the
+    // side streams, behind everything the main streams hold so far
+    if ((rc = each([&](int, Part &q) -> int {
+            FWX_HIP(hipEventRecord(q.main_done, q.main));
+            FWX_HIP(hipStreamWaitEvent(q.side, q.main_done, 0));
+            // (issue_panel orders the owner's panel behind rows_done / main_free: both on the main stream)
+            FWX_HIP(hipEventRecord(q.rows_done, q.main));
+            return FWX_OK;
+        })))
+        return rc;
+    if ((rc = produce(0, 0))) return rc;
+    if ((rc = each([&](int, Part &q) -> int { return cross(q, 0, 1, kq(1), kq(1) + Bq, q.side); }))) return rc;
+    if ((rc = produce(1, 0))) return rc;
+    if ((rc = each([&](int, Part &q) -> int {
+            FWX_HIP(hipEventRecord(q.panel_done, q.side));
+            FWX_HIP(hipStreamWaitEvent(q.main, q.panel_done, 0));
+            return FWX_OK;
+        })))
+        return rc;
+    const int pairs = nb / 2;
+    int t_chain[FWX_MAX_PARTS];
+    for (int pr = 0; pr < pairs; ++pr) {
+        const int q0 = 2 * pr;
+        const int q_lo = q0 + 2, q_hi = q0 + 4 < nb ? q0 + 4 : nb;       // blocks of the next pair (or the odd last one)
+        if (q_hi > q_lo) {
+            const int x_lo = kq(q_lo), x_hi = kq(q_hi - 1) + Bq;
+            if ((rc = each([&](int p, Part &q) -> int {
+                    FWX_HIP(hipEventRecord(q.main_done, q.main));          // main(pr - 1) and chain(pr) precede
+                    FWX_HIP(hipStreamWaitEvent(q.side, q.main_done, 0));
+                    t_chain[p] = tm.begin(MultiTimer::CHAIN, p, pr, q.side);
+                    return cross(q, q0, 2, x_lo, x_hi, q.side);            // the pair being applied onto the next cross
+                })))
+                return rc;
+            if ((rc = produce(q_lo, pr))) return rc;
+            if (q_hi - q_lo == 2) {
+                if ((rc = each([&](int, Part &q) -> int { return cross(q, q_lo, 1, kq(q_lo + 1), x_hi, q.side); })))
+                    return rc;
+                if ((rc = produce(q_lo + 1, pr))) return rc;
+            }
+            if ((rc = each([&](int p, Part &q) -> int {
+                    tm.end(t_chain[p], q.side);
+                    FWX_HIP(hipEventRecord(q.panel_done, q.side));
+                    const int t_bulk = tm.begin(MultiTimer::BULK, p, pr, q.main);
+                    FWX_HIP(fwx::launch_fused_main<T>(args(q, q0, 2), 0, q.rows, q.main, local(q, x_lo), local(q, x_hi),
+                                                      fwx::FusedCols::except(x_lo, x_hi)));
+                    tm.end(t_bulk, q.main);
+                    FWX_HIP(hipStreamWaitEvent(q.main, q.panel_done, 0));
+                    return FWX_OK;
+                })))
+                return rc;
+        } else {
+            if ((rc = each([&](int p, Part &q) -> int {
+                    const int t_bulk = tm.begin(MultiTimer::BULK, p, pr, q.main);
+                    FWX_HIP(fwx::launch_fused_main<T>(args(q, q0, 2), 0, q.rows, q.main));
+                    tm.end(t_bulk, q.main);
+                    return FWX_OK;
+                })))
+                return rc;
+        }
+        if ((rc = set_dev(M.part[0].device))) return rc;
+        if ((rc = thr.tick(M.part[0].main, 10))) return rc;
+    }
+    if (nb & 1) {                                       // the odd last block: its panels are ready
+        if ((rc = each([&](int, Part &q) -> int {
+                FWX_HIP(fwx::launch_fused_main<T>(args(q, nb - 1, 1), 0, q.rows, q.main));
+                return FWX_OK;
+            })))
+            return rc;
+    }
+    // the single-pass loop (a ragged tail) and the final synchronisation follow in stream order: every
+    // main stream has waited for its side chain; the sets 0 / 1 it may reuse are guarded by w_ready
+    if ((rc = each([&](int, Part &q) -> int {
+            for (int sl = 0; sl < 4; ++sl) FWX_HIP(hipEventRecord(q.main_free[sl], q.main));
+            return FWX_OK;
+        })))
+        return rc;
+    done = nb;
     return FWX_OK;
 }
 
@@ -610,7 +903,19 @@ template <typename T> static int multi_solve_typed(fwx_matrix *m, const Opts &op
         }
     }
     if (blocks.empty()) return FWX_OK;
+    M.timer.reset();
+    M.timer.last.pivots_per_step = FWX_FUSED_BLOCK;
     Throttle thr;
+    // double pass (the fused engine inside the domain, 64-aligned partitions, large matrices): the full
+    // blocks in pairs, 128 pivots per main launch behind a two-deep look-ahead; what is left -- an odd
+    // block's worth or a ragged tail -- goes through the single-pass loop below
+    size_t first = 0;
+    if (!perk && nonneg && !counting) {
+        int done = 0;
+        if ((rc = multi_double_pass<T>(m, blocks, thr, done))) return rc;
+        first = (size_t)done;
+        if (first == blocks.size()) return finish_multi_solve(m, counting, op);
+    }
     // per-k engine on several partitions: one enqueueing thread per partition (see SweepWorkers)
     std::unique_ptr<SweepWorkers> workers;
     if (perk && P > 1) {
@@ -618,15 +923,18 @@ template <typename T> static int multi_solve_typed(fwx_matrix *m, const Opts &op
         workers.reset(new SweepWorkers(P));
     }
     {   // the first panel: its rows are at time k0 already
-        Part &o = M.part[blocks[0].owner];
+        Part &o = M.part[blocks[first].owner];
         if ((rc = set_dev(o.device))) return rc;
         FWX_HIP(hipEventRecord(o.rows_done, o.main));
-        if ((rc = issue_panel<T>(M, blocks[0], 0))) return rc;
+        if ((rc = issue_panel<T>(M, blocks[first], 0, (int)first))) return rc;
     }
-    for (size_t b = 0; b < blocks.size(); ++b) {
+    MultiTimer &tm = M.timer;
+    int t_bulk[FWX_MAX_PARTS];
+    for (size_t b = first; b < blocks.size(); ++b) {
         const Block &blk = blocks[b];
-        const int slot = (int)(b & 1);
+        const int slot = (int)((b - first) & 1);
         const bool more = b + 1 < blocks.size();
+        const int step = (int)b;
         // fused engine: pivot-column snapshots on every partition; per-k engine: the pivot column is
         // read from the slab itself by every launch, the main stream just waits for the panel
         for (int p = 0; p < P; ++p) {
@@ -634,6 +942,7 @@ template <typename T> static int multi_solve_typed(fwx_matrix *m, const Opts &op
             if (q.rows == 0) continue;
             if ((rc = set_dev(q.device))) return rc;
             FWX_HIP(hipStreamWaitEvent(q.main, q.w_ready[slot], 0));
+            t_bulk[p] = tm.begin(MultiTimer::BULK, p, step, q.main);
             if (perk) continue;
             fwx::FusedArgs<T> a = part_args<T>(M, q, nonneg, counting);
             a.k0 = blk.k0; a.bt = blk.bt; a.w = (const T *)q.w[slot]; a.wh = q.wh[slot];
@@ -648,6 +957,7 @@ template <typename T> static int multi_solve_typed(fwx_matrix *m, const Opts &op
             if ((rc = set_dev(o.device))) return rc;
             fwx::FusedArgs<T> a = part_args<T>(M, o, nonneg, counting);
             a.k0 = blk.k0; a.bt = blk.bt; a.w = (const T *)o.w[slot]; a.wh = o.wh[slot];
+            const int t_la = tm.begin(MultiTimer::LOOKAHEAD, nb.owner, step, o.main);
             if (!perk) {
                 FWX_HIP(fwx::launch_fused_main<T>(a, la_lo, la_hi, o.main));
             } else {
@@ -660,8 +970,9 @@ template <typename T> static int multi_solve_typed(fwx_matrix *m, const Opts &op
                 a.rows = nb.bt; a.row0 = nb.k0;
                 FWX_HIP(fwx::launch_fused_relax<T>(a, o.main));
             }
+            tm.end(t_la, o.main);
             FWX_HIP(hipEventRecord(o.rows_done, o.main));
-            if ((rc = issue_panel<T>(M, nb, slot ^ 1))) return rc;
+            if ((rc = issue_panel<T>(M, nb, slot ^ 1, step + 1))) return rc;
         }
         for (int p = 0; p < P; ++p) {
             Part &q = M.part[p];
@@ -678,6 +989,7 @@ template <typename T> static int multi_solve_typed(fwx_matrix *m, const Opts &op
                     FWX_HIP(fwx::launch_fused_main<T>(a, 0, la_lo, q.main));
                     FWX_HIP(fwx::launch_fused_main<T>(a, la_hi, q.rows, q.main));
                 }
+                tm.end(t_bulk[p], q.main);
             }
             FWX_HIP(hipEventRecord(q.main_free[slot], q.main));
         }
@@ -713,27 +1025,14 @@ template <typename T> static int multi_solve_typed(fwx_matrix *m, const Opts &op
             for (int p = 0; p < P; ++p) {
                 Part &q = M.part[p];
                 if ((rc = set_dev(q.device))) return rc;
+                if (q.rows > 0) tm.end(t_bulk[p], q.main);
                 FWX_HIP(hipEventRecord(q.main_free[slot], q.main));
             }
         }
         if ((rc = set_dev(M.part[0].device))) return rc;
         if ((rc = thr.tick(M.part[0].main, perk ? blk.bt + 4 : 4))) return rc;
     }
-    uint64_t total = 0;
-    for (int p = 0; p < P; ++p) {
-        Part &q = M.part[p];
-        if ((rc = set_dev(q.device))) return rc;
-        FWX_HIP(hipStreamSynchronize(q.side));
-        FWX_HIP(hipStreamSynchronize(q.main));
-        if (counting) {
-            uint64_t u = 0;
-            if ((rc = sum_updates(q.upd, &u, q.main))) return rc;
-            total += u;
-        }
-    }
-    if (counting) *op.updates_out = total;
-    m->last_u = total;
-    return FWX_OK;
+    return finish_multi_solve(m, counting, op);
 }
 
 // ---- entry points used by fwx_api.hip for handles with m->multi -----------------------------------
@@ -1023,7 +1322,7 @@ int fwx_matrix_create_multi(fwx_matrix **out, int32_t n, int32_t dtype, int32_t 
         fwx_matrix *m = new (std::nothrow) fwx_matrix();
         if (!m) return FWX_ERR_OOM;
         memset(m, 0, sizeof(*m));
-        m->n = n; m->dtype = dtype; m->device = devices[0];
+        m->n = m->nd = n; m->dtype = dtype; m->device = devices[0];   // (the slabs' pitch is MultiState::nd)
         m->next = with_next ? (int32_t *)(uintptr_t)16 : nullptr;   // markers only: the slabs own the arrays
         m->hops = with_hops ? (int32_t *)(uintptr_t)16 : nullptr;
         DevRestore keep;
@@ -1040,11 +1339,34 @@ int fwx_matrix_create_multi(fwx_matrix **out, int32_t n, int32_t dtype, int32_t 
 
 int fwx_matrix_comm_ranks(const fwx_matrix *m)
 {
-    if (!m) return FWX_ERR_INVALID;
-    if (!m->multi || !m->multi->comms) return 0;
-    int ranks = 0;
-    if (rccl().CommCount(m->multi->comms->comm[0], &ranks) != ncclSuccess) return FWX_ERR_RCCL;
-    return ranks;
+    return fwxi::guarded([&]() -> int {
+        if (!m) return FWX_ERR_INVALID;
+        if (!m->multi || !m->multi->comms) return 0;
+        int ranks = 0;
+        if (rccl().CommCount(m->multi->comms->comm[0], &ranks) != ncclSuccess) return FWX_ERR_RCCL;
+        return ranks;
+    });
+}
+
+int fwx_matrix_set_timing(fwx_matrix *m, int32_t on)
+{
+    return fwxi::guarded([&]() -> int {
+        if (!m) return FWX_ERR_INVALID;
+        if (!m->multi) return FWX_ERR_UNSUPPORTED;
+        m->multi->timer.on = on != 0;
+        return FWX_OK;
+    });
+}
+
+int fwx_matrix_get_timing(const fwx_matrix *m, fwx_multi_timing *out)
+{
+    return fwxi::guarded([&]() -> int {
+        if (!m || !out || out->struct_size < sizeof(fwx_multi_timing)) return FWX_ERR_INVALID;
+        if (!m->multi) return FWX_ERR_UNSUPPORTED;
+        *out = m->multi->timer.last;
+        out->struct_size = (uint32_t)sizeof(fwx_multi_timing);
+        return FWX_OK;
+    });
 }
 
 int fwx_matrix_parts(const fwx_matrix *m, int32_t *exchange_out)

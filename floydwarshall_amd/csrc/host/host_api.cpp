@@ -89,6 +89,8 @@ int64_t fwxh_session_resumed_solves(const fwxh_session *s) { return s ? s->impl.
 
 int64_t fwxh_session_resumed_pivots(const fwxh_session *s) { return s ? s->impl.resumed_pivots() : -1; }
 
+int32_t fwxh_session_checkpoints_kept(const fwxh_session *s) { return s ? s->impl.checkpoints_kept() : -1; }
+
 int fwxh_session_set_checkpoints(fwxh_session *s, int32_t checkpoints)
 {
     if (!s || checkpoints < 0 || checkpoints > FWX_MAX_CHECKPOINTS) return FWX_ERR_INVALID;

@@ -91,6 +91,7 @@ public:
     int64_t resumed_pivots() const { return resumed_pivots_; }   // pivots those did NOT have to run, in total
     // checkpoints a resident matrix keeps for resumed re-solves (0 = off); takes effect with the next handle
     void set_checkpoints(int32_t c) { checkpoints_ = c; drop_device(); solved_version_ = ~0ull; }
+    int32_t checkpoints_kept() const { return dev_ ? dev_checkpoints_ : 0; }   // of the resident handle
     const ExchRateTimes &rates() const { return rates_; }
 
     // updateRates (ProcessRequests.hs:89-102) on parsed fields; true if applied
@@ -110,7 +111,7 @@ private:
     std::vector<int32_t> devices_;   // non-empty: partition the matrix over these from multi_from_ on
     int32_t multi_from_ = 0;
     bool dev_multi_ = false;         // dev_ is a partitioned handle
-    bool dev_padded_ = false;        // dev_ has order n + 1: an isolated vertex pads an odd n (session.cpp)
+    int32_t dev_checkpoints_ = 0;    // checkpoints the resident handle really keeps (0: it cannot resume)
     ExchRateTimes rates_;
     bool in_sync_ = false;      // what the reference's AppState would be
     uint64_t version_ = 0;      // bumped by every accepted update that changes buildMatrix's output

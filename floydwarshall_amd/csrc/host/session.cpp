@@ -37,7 +37,6 @@ void Session::drop_device()
         fwx_matrix_destroy(dev_);
         dev_ = nullptr;
     }
-    dev_padded_ = false;
     rebuild_ = true;             // the kept input went with the handle
     patches_.clear();
 }
@@ -96,16 +95,9 @@ int Session::ensure_solved()
         std::vector<int64_t> idx;
         std::vector<double> rate;
         std::vector<int32_t> next, hops;
-        const int64_t n0 = (int64_t)m.n(), dn = n0 + (dev_padded_ ? 1 : 0);
-        bool pad_holds = true;
         for (const Patch &p : patches_) {
-            idx.push_back(p.idx / n0 * dn + p.idx % n0);     // rows of the device matrix are dn long
+            idx.push_back(p.idx);
             rate.push_back(p.rate); next.push_back(p.next); hops.push_back(p.hops);
-            if (dev_padded_ && p.rate < 0.0) pad_holds = false;   // (a +0 pad is inert only without negatives)
-        }
-        if (!pad_holds) {
-            drop_device();                                     // rebuilds below, without the pad vertex
-            goto marshal;
         }
         // runAlgo on the patched input: from the last stored state the changed entries cannot have
         // influenced (fwx_matrix_resolve; bit-identical to runAlgo 0), else from pivot 0
@@ -125,26 +117,12 @@ int Session::ensure_solved()
         }
         drop_device();           // whatever went wrong: marshal from scratch below
     }
-marshal:
     build_matrix_into(rates_, m);
     // The device handle (matrix, pristine copies, log arrays) is kept while the vertex count stays
     // the same -- a rate update between known vertices, the common case -- and only re-uploaded.
-    const bool want_parts = !devices_.empty() && m.n() >= multi_from_;
-    // An ODD vertex count: a single-device handle cannot run the fused engine on rows that are not a
-    // multiple of 16 bytes (fwx.h fwx_engine) and would fall back to one launch per pivot.  The session
-    // pads the matrix itself: ONE more vertex with no edge at all (rate +0, no path -- `isolatedEntry`,
-    // Utils.hs:13-14 -- in its whole row and column) makes the order even, and it is inert while no real
-    // rate is negative: every product through it is +0 (or NaN), which never exceeds an entry >= +0 under
-    // the strict compare of Algorithms.hs:55, and an entry of its own row or column never rises above +0.
-    // Then the ordinary handle runs the fused engine AND resumes.  With a negative rate in the map (outside
-    // the reference's domain: the per-k engine solves it anyway) the matrix stays as it is.
-    const bool odd = !want_parts && m.n() >= kFusedFrom && m.n() % 2 != 0;
-    bool no_negative = true;
-    for (size_t q = 0; odd && no_negative && q < m.rate.size(); ++q) no_negative = !(m.rate[q] < 0.0);
-    const bool pad_host = odd && no_negative;
-    const bool want_multi = want_parts;
-    const int32_t dn = m.n() + (pad_host ? 1 : 0);              // order of the device matrix
-    if (dev_ && (dev_n_ != m.n() || dev_multi_ != want_multi || dev_padded_ != pad_host)) drop_device();
+    // (any vertex count: the handles pad odd orders on the device themselves, fwx.h fwx_engine)
+    const bool want_multi = !devices_.empty() && m.n() >= multi_from_;
+    if (dev_ && (dev_n_ != m.n() || dev_multi_ != want_multi)) drop_device();
     vertices_ = m.vertices;
     if (m.n() > 0) {
         // The solve keeps the path trace (fwx_matrix_enable_path_log), from which
@@ -161,38 +139,36 @@ marshal:
             rc = want_multi ? fwx_matrix_create_multi(&dev_, m.n(), FWX_F64, 1, dev_hops_ ? 1 : 0,
                                                       (int32_t)devices_.size(), devices_.data(),
                                                       FWX_XCHG_AUTO)
-                            : fwx_matrix_create(&dev_, dn, FWX_F64, 1, dev_hops_ ? 1 : 0,
+                            : fwx_matrix_create(&dev_, m.n(), FWX_F64, 1, dev_hops_ ? 1 : 0,
                                                 devices_.empty() ? device_ : devices_[0]);
             if (rc) return rc;
             dev_multi_ = want_multi;
-            dev_padded_ = pad_host;
             dev_n_ = m.n();
             if ((rc = fwx_matrix_enable_path_log(dev_)) || (rc = fwx_matrix_keep_input(dev_))) {
                 drop_device();
                 return rc;
             }
-            // state checkpoints + panels, so that a re-solve after a price change can resume (f3);
-            // where the fused engine cannot run the matrix (small, partitions) it just stays a full solve
-            if (checkpoints_ > 0) {
-                rc = fwx_matrix_enable_resume(dev_, checkpoints_);
-                if (rc < 0 && rc != FWX_ERR_UNSUPPORTED) {
-                    drop_device();
-                    return rc;
-                }
+            // State checkpoints + panels, so that a re-solve after a price change can resume (f3).
+            // Resuming is an optimisation, never a requirement: the count is cut to what fits into half
+            // of the device's free memory (a checkpoint is a copy of every array -- 24 B per entry for
+            // this traced f64 matrix -- and the panels another ~2.5 arrays: 7 checkpoints of a 16384-vertex
+            // market would be 45 GB), and where nothing fits, the allocation fails anyway, or the handle
+            // cannot resume at all (small, partitions: FWX_ERR_UNSUPPORTED) the session carries on with
+            // full solves from the patched input.
+            dev_checkpoints_ = 0;
+            int32_t want = checkpoints_;
+            if (want > 0) {
+                uint64_t free_b = 0, total_b = 0, need = 0;
+                if (fwx_device_memory(devices_.empty() ? device_ : devices_[0], &free_b, &total_b) == FWX_OK)
+                    while (want > 0 && fwx_matrix_resume_bytes(dev_, want, &need) == FWX_OK && need > free_b / 2)
+                        --want;
+            }
+            if (want > 0) {
+                const int placed = fwx_matrix_enable_resume(dev_, want);
+                if (placed > 0) dev_checkpoints_ = placed;        // any failure: no resume, the solve goes on
             }
         }
-        if (pad_host) {                          // (dev_hops_ is false from kFusedFrom vertices on)
-            const size_t n0 = (size_t)m.n(), d = (size_t)dn;
-            std::vector<double> pr(d * d, 0.0);
-            std::vector<int32_t> pn(d * d, -1);
-            for (size_t i = 0; i < n0; ++i) {
-                std::memcpy(&pr[i * d], &m.rate[i * n0], n0 * sizeof(double));
-                std::memcpy(&pn[i * d], &m.next[i * n0], n0 * sizeof(int32_t));
-            }
-            rc = fwx_matrix_upload(dev_, pr.data(), pn.data(), nullptr);
-        } else {
-            rc = fwx_matrix_upload(dev_, m.rate.data(), m.next.data(), dev_hops_ ? m.hops.data() : nullptr);
-        }
+        rc = fwx_matrix_upload(dev_, m.rate.data(), m.next.data(), dev_hops_ ? m.hops.data() : nullptr);
         if (rc || (rc = fwx_matrix_solve(dev_, nullptr))) {         // runAlgo 0, on the GPU
             drop_device();
             return rc;

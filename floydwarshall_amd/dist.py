@@ -132,8 +132,50 @@ class HipBackend:
             self.relax(slab, n, row0, k0, k1, w, wh)
 
 
+class StepTimer:
+    """Per-step spans of one rank's solve_partitioned, from timing events on the stream the work runs on
+    (GPU) or the wall clock (CPU rehearsal): bulk = the slab sweep of a step, lookahead = the owner bringing
+    the next block's rows up to date, panel = the owner's snapshot panel, exchange = from the broadcast's
+    issue to the side stream having waited for it.  A diagnostic (two event records per span): the
+    benchmark runs it in an extra, untimed solve.  summary() -> {kind: (mean microseconds, count)}."""
+
+    KINDS = ("bulk", "lookahead", "panel", "exchange")
+
+    def __init__(self, on_gpu):
+        self.on_gpu = on_gpu
+        self.spans = []           # (kind, e0, e1) or (kind, seconds)
+
+    def begin(self, kind):
+        if self.on_gpu:
+            e0 = torch.cuda.Event(enable_timing=True)
+            e0.record()
+            return (kind, e0)
+        import time
+        return (kind, time.perf_counter())
+
+    def end(self, token):
+        kind, start = token
+        if self.on_gpu:
+            e1 = torch.cuda.Event(enable_timing=True)
+            e1.record()
+            self.spans.append((kind, start, e1))
+        else:
+            import time
+            self.spans.append((kind, time.perf_counter() - start))
+
+    def summary(self):
+        if self.on_gpu:
+            torch.cuda.synchronize()
+        acc = {k: [0.0, 0] for k in self.KINDS}
+        for sp in self.spans:
+            us = 1e3 * sp[1].elapsed_time(sp[2]) if self.on_gpu else 1e6 * sp[1]
+            acc[sp[0]][0] += us
+            acc[sp[0]][1] += 1
+        return {k: ((v[0] / v[1]) if v[1] else 0.0, v[1]) for k, v in acc.items()}
+
+
 def solve_partitioned(rate, n, rank, world, *, nxt=None, hops=None, trace=None, block=64, backend=None,
-                      group=None, lookahead=True, force_collectives=False, skip_launch=True):
+                      group=None, lookahead=True, force_collectives=False, skip_launch=True, timer=None):
     """In-place solve of this rank's slab `rate` (rows row_bounds(n, world)[rank]...), with its
     next-hops `nxt`, path lengths `hops` (needs nxt) and path trace `trace` (an engine.Trace of the
     slab, all -1; needs nxt) if given.
@@ -198,12 +240,19 @@ def solve_partitioned(rate, n, rank, world, *, nxt=None, hops=None, trace=None, 
         wh = hbufs[idx & 1][:b] if hops is not None else None
         works = []
 
+        tok = []
+
         def issue():
             if rank == owner:
                 lo = k0 - row0
+                t = timer.begin("panel") if timer else None
                 backend.panel(slab.rows(lo, lo + b), n, k0, w, wh)
+                if timer:
+                    timer.end(t)
             if collectives:
                 src = owner if group is None else dist.get_global_rank(group, owner)
+                if timer:
+                    tok.append(timer.begin("exchange"))
                 works.append(dist.broadcast(w, src=src, group=group, async_op=True))
                 if wh is not None:
                     works.append(dist.broadcast(wh, src=src, group=group, async_op=True))
@@ -222,19 +271,27 @@ def solve_partitioned(rate, n, rank, world, *, nxt=None, hops=None, trace=None, 
                         work.wait()                # side stream behind the collective
                 else:
                     work.wait()
+            if tok:
+                if on_gpu:
+                    with torch.cuda.stream(side):
+                        timer.end(tok.pop())
+                else:
+                    timer.end(tok.pop())
             if on_gpu:
                 main.wait_stream(side)
         return w, wh, wait
 
     def relax_rows_except(skips, k0, k1, w, wh):
-        if skip_launch and len(skips) == 1 and hasattr(backend, "relax_skipping") and \
-                backend.relax_skipping(slab, n, row0, k0, k1, w, wh, skips[0]):
-            return
+        t = timer.begin("bulk") if timer else None
+        done = skip_launch and len(skips) == 1 and hasattr(backend, "relax_skipping") and \
+            backend.relax_skipping(slab, n, row0, k0, k1, w, wh, skips[0])
         pos = 0
-        for lo, hi in sorted(skips) + [(rows, rows)]:
+        for lo, hi in ([] if done else sorted(skips) + [(rows, rows)]):
             if lo > pos:
                 backend.relax(slab.rows(pos, lo), n, row0 + pos, k0, k1, w, wh)
             pos = max(pos, hi)
+        if timer:
+            timer.end(t)
 
     w, wh, wait = panel_and_broadcast(0)
     for idx, (k0, b, owner) in enumerate(blocks):
@@ -246,8 +303,11 @@ def solve_partitioned(rate, n, rank, world, *, nxt=None, hops=None, trace=None, 
             nk0, nb, nowner = blocks[idx + 1]
             if rank == nowner:
                 nlo = nk0 - row0
+                t = timer.begin("lookahead") if timer else None
                 getattr(backend, "relax_lookahead", backend.relax)(
                     slab.rows(nlo, nlo + nb), n, nk0, k0, k1, w, wh)
+                if timer:
+                    timer.end(t)
                 skips.append((nlo, nlo + nb))
             nxt_panel = panel_and_broadcast(idx + 1)
             relax_rows_except(skips, k0, k1, w, wh)

@@ -15,13 +15,13 @@ import numpy as np
 from . import _lib
 from ._lib import (FWX_ENGINE_AUTO, FWX_ENGINE_FUSED, FWX_ENGINE_PERK, FWX_F32, FWX_F64,
                    FWX_FUSED_BLOCK, FWX_UPDATE_SHARDS, FWX_XCHG_AUTO, FWX_XCHG_PEER, FWX_XCHG_RCCL,
-                   FwxError, FwxOpts, FwxPivots, FwxSlab, check, lib)
+                   FWX_ERR_RCCL, FwxError, FwxOpts, FwxPivots, FwxSlab, check, lib)
 
 __all__ = ["solve", "follow_path", "dev_follow_paths", "dev_check_nonneg", "dev_domain_bits", "dev_solve_fused",
            "dev_solve", "DeviceMatrix", "dev_relax", "dev_panel", "dev_panel_snap",
            "dev_relax_fused", "FusedWorkspace", "Trace", "FWX_FUSED_BLOCK", "device_count",
            "FwxError", "FWX_ENGINE_AUTO", "FWX_ENGINE_PERK", "FWX_ENGINE_FUSED",
-           "FWX_UPDATE_SHARDS", "solve_multi", "FWX_XCHG_AUTO", "FWX_XCHG_PEER", "FWX_XCHG_RCCL"]
+           "FWX_UPDATE_SHARDS", "solve_multi", "FWX_XCHG_AUTO", "FWX_XCHG_PEER", "FWX_XCHG_RCCL", "FWX_ERR_RCCL"]
 
 
 def device_count():
@@ -129,6 +129,18 @@ class DeviceMatrix:
     def comm_ranks(self):
         """Ranks of the RCCL communicator the partitions exchange panels on (0: not RCCL)."""
         return check(lib().fwx_matrix_comm_ranks(self._h), "fwx_matrix_comm_ranks")
+
+    def set_timing(self, on=True):
+        """Per-step event timings of the following solves (partitioned handles; fwx_matrix_set_timing)."""
+        check(lib().fwx_matrix_set_timing(self._h, 1 if on else 0), "fwx_matrix_set_timing")
+
+    def timing(self):
+        """fwx_multi_timing of the last solve as a dict (microseconds; see include/fwx.h)."""
+        from ._lib import FwxMultiTiming
+        t = FwxMultiTiming()
+        t.struct_size = ctypes.sizeof(FwxMultiTiming)
+        check(lib().fwx_matrix_get_timing(self._h, ctypes.byref(t)), "fwx_matrix_get_timing")
+        return {name: getattr(t, name) for name, _ in FwxMultiTiming._fields_ if name != "struct_size"}
 
     def upload(self, rate, nxt=None, hops=None):
         _check_arrays(rate, nxt, hops)

@@ -23,6 +23,7 @@ HOST_SIGNATURES = {
     "fwxh_session_patched_solves": (c_i64, [c_vp]),
     "fwxh_session_resumed_solves": (c_i64, [c_vp]),
     "fwxh_session_resumed_pivots": (c_i64, [c_vp]),
+    "fwxh_session_checkpoints_kept": (c_i32, [c_vp]),
     "fwxh_session_set_checkpoints": (ctypes.c_int, [c_vp, c_i32]),
     "fwxh_session_destroy": (ctypes.c_int, [c_vp]),
     "fwxh_session_state": (ctypes.c_int, [c_vp]),
@@ -167,6 +168,11 @@ class Session:
     @property
     def resumed_pivots(self):
         return hlib().fwxh_session_resumed_pivots(self._h)
+
+    @property
+    def checkpoints_kept(self):
+        """Checkpoints the resident matrix really keeps (0: it cannot resume; re-solves are full solves)."""
+        return hlib().fwxh_session_checkpoints_kept(self._h)
 
     def set_checkpoints(self, checkpoints):
         """State checkpoints the next resident matrix keeps for resumed re-solves (0 = off)."""

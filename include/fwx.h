@@ -78,11 +78,14 @@ typedef enum fwx_dtype { FWX_F32 = 0, FWX_F64 = 1 } fwx_dtype;
 
 /* Which relaxation engine runs the pivots.  All are bit-exact with the reference loop.
  * AUTO: n <= 64 -> the whole solve in one single-workgroup launch; above -> FUSED (two launches
- * per 64 pivots).  Where FUSED does not apply -- an input outside the domain below, or rows that
- * are not a multiple of 16 bytes: fwx_solve_f32/f64 (host buffers) pad an odd-sized matrix on the
- * device, the entry points that work on device memory they do not own (fwx_matrix_*, fwx_dev_*)
- * cannot -- AUTO takes the single-launch kernel up to n = 128 and PERK above; an explicit FUSED is
- * refused there (FWX_ERR_UNSUPPORTED).                                                            */
+ * per 64 pivots).  The fused kernels read rows in 16-byte vectors; buildMatrix (Algorithms.hs:29)
+ * produces any n, so every entry point that OWNS its device memory -- fwx_solve_f32/f64, the handles
+ * of fwx_matrix_create and fwx_matrix_create_multi -- keeps the matrix at a device order rounded up
+ * to 4 (f32) / 2 (f64) with inert padding (rate +0.0, next -1: a padding index is never a pivot and
+ * a +0.0 target never improves) and runs any engine on any n.  Where FUSED does not apply -- an
+ * input outside the domain below, or caller-owned device memory (fwx_dev_*) whose rows are not a
+ * multiple of 16 bytes -- AUTO takes the single-launch kernel up to n = 128 and PERK above; an
+ * explicit FUSED on such caller-owned memory is refused (FWX_ERR_UNSUPPORTED).                     */
 typedef enum fwx_engine {
     FWX_ENGINE_AUTO = 0,
     FWX_ENGINE_PERK = 1,  /* one N x N launch per pivot k (HBM-bound streaming kernel)            */
@@ -181,8 +184,8 @@ int fwx_matrix_patch_input(fwx_matrix *m, int32_t count, const int64_t *index, c
  * enable_resume: after create, enable_path_log (if the trace is wanted: afterwards it is refused) and
  *   keep_input, before the upload whose solve is to be resumable; `checkpoints` in 1..FWX_MAX_CHECKPOINTS, spread evenly over the pivots on multiples
  *   of 64; returns the number placed (n < 128 leaves room for none: 0), or FWX_ERR_UNSUPPORTED where
- *   the fused engine cannot run the handle's arrays (n <= 64, rows not a multiple of 16 bytes,
- *   partitioned handles).  Memory: one copy of every array per checkpoint + ~2.5 more for the panels.
+ *   AUTO does not take the fused engine (n <= 64) and on partitioned handles.  Any other n works
+ *   (the handle pads its rows).  Memory: one copy of every array per checkpoint + ~2.5 more for the panels.
  * resolve: fwx_matrix_patch_input + fwx_matrix_solve in one call, resuming where it can.  Falls back
  *   to exactly that pair (a full solve from the patched kept input, which records afresh) when there
  *   is nothing to resume from: no checkpoint at or below m, the previous solve did not record (other
@@ -191,6 +194,13 @@ int fwx_matrix_patch_input(fwx_matrix *m, int32_t count, const int64_t *index, c
  *   receives the pivot the solve started at (0 = full solve).                                       */
 #define FWX_MAX_CHECKPOINTS 16
 int fwx_matrix_enable_resume(fwx_matrix *m, int32_t checkpoints);
+/* What enable_resume(checkpoints) would allocate on the device(s) for this handle, in bytes (call it
+ * after enable_path_log, like enable_resume itself), and the free / total memory of a device
+ * (hipMemGetInfo; device -1 = the caller's current one): a host sizes its checkpoint count with these
+ * -- the Session mirror keeps the resume memory below half of what is free and carries on WITHOUT
+ * resuming when even one checkpoint does not fit or the allocation fails.                          */
+int fwx_matrix_resume_bytes(const fwx_matrix *m, int32_t checkpoints, uint64_t *bytes_out);
+int fwx_device_memory(int32_t device, uint64_t *free_bytes, uint64_t *total_bytes);
 int fwx_matrix_resolve(fwx_matrix *m, int32_t count, const int64_t *index, const void *rate_vals,
                        const int32_t *next_vals, const int32_t *hops_vals, const fwx_opts *opts,
                        int32_t *resumed_from);
@@ -237,7 +247,11 @@ int fwx_matrix_query_exact_batch(fwx_matrix *m, int32_t count, const int32_t *sr
  * exchange:
  *   FWX_XCHG_RCCL  ncclBroadcast of each panel on RCCL (ncclCommInitAll over the devices, one
  *                  communicator per partition, calls grouped; librccl.so.1 is loaded on first use,
- *                  libfwx does not link it).  Needs pairwise distinct devices.
+ *                  libfwx does not link it).  Needs pairwise distinct devices.  On this pool RCCL needs
+ *                  HSA_ENABLE_IPC_MODE_LEGACY=0 in the environment BEFORE the first HIP call of the
+ *                  process (the host driver only supports dmabuf IPC; otherwise ncclCommInitAll fails
+ *                  in hipIpcGetMemHandle and create_multi returns FWX_ERR_RCCL): a host exports it or
+ *                  falls back to FWX_XCHG_PEER, which needs no IPC inside one process.
  *   FWX_XCHG_PEER  hipMemcpyPeerAsync from the owner's panel into every other partition's panel
  *                  buffer (plain device-to-device copies when the device is the same).
  *   FWX_XCHG_AUTO  RCCL when there are >= 2 partitions on pairwise distinct devices, else PEER.
@@ -263,6 +277,28 @@ int fwx_matrix_query_exact_batch(fwx_matrix *m, int32_t count, const int32_t *sr
 int fwx_matrix_create_multi(fwx_matrix **out, int32_t n, int32_t dtype, int32_t with_next,
                             int32_t with_hops, int32_t n_parts, const int32_t *devices,
                             int32_t exchange);
+/* Per-step timings of the last solve of a partitioned handle, from HIP events on the streams the work
+ * ran on (a diagnostic: each span costs two event records; off by default).  A step is one block of 64
+ * pivots, or a PAIR of blocks where the solve ran two passes per main launch (pivots_per_step = 128).
+ *   bulk_us       what a step costs when nothing else limits it: the slab sweep (column panel + main
+ *                 kernel / the 64 per-k launches) on a partition's main stream -- mean over steps of the
+ *                 MAX over partitions; bulk_mean_us: the plain mean
+ *   lookahead_us  the owner bringing the next block's rows up to date (single pass; main stream)
+ *   panel_us      the owner's snapshot panel kernel (side stream)
+ *   exchange_us   the panel's way to the other partitions: peer copy on each receiver / the RCCL
+ *                 broadcast call on every partition's side stream -- mean over steps of the max
+ *   chain_us      everything the NEXT step waits for besides the sweep.  Single pass: lookahead + panel
+ *                 + exchange.  Double pass: measured whole on each partition's side stream, from the end
+ *                 of the previous main launch to the last column panel of the next pair (cross launches,
+ *                 both panels, both exchanges) -- mean over steps of the max over partitions
+ *   chain_over_bulk > 1: the solve is bound by the panel chain, not by the sweep */
+typedef struct fwx_multi_timing {
+    uint32_t struct_size;
+    int32_t steps, pivots_per_step, partitions;
+    float bulk_us, bulk_mean_us, lookahead_us, panel_us, exchange_us, chain_us, chain_over_bulk;
+} fwx_multi_timing;
+int fwx_matrix_set_timing(fwx_matrix *m, int32_t on);      /* FWX_ERR_UNSUPPORTED on a single-device handle */
+int fwx_matrix_get_timing(const fwx_matrix *m, fwx_multi_timing *out);   /* out->struct_size = sizeof(*out) */
 /* Partitions of a handle (1 for a single-device handle); exchange_out (optional) receives the
  * transport in use (FWX_XCHG_PEER / FWX_XCHG_RCCL).                                              */
 int fwx_matrix_parts(const fwx_matrix *m, int32_t *exchange_out);

@@ -67,6 +67,10 @@ int64_t fwxh_session_patched_solves(const fwxh_session *s);
  * the next resident matrix keeps (default 7, 0 = never resume; drops the resident matrix).         */
 int64_t fwxh_session_resumed_solves(const fwxh_session *s);
 int64_t fwxh_session_resumed_pivots(const fwxh_session *s);
+/* Checkpoints the resident matrix really keeps: the requested count cut to what fits into half of the
+ * device's free memory; 0 = the handle cannot resume (too small, partitioned, nothing fits, or the
+ * allocation failed) and every re-solve is a full solve of the patched input -- never an error.     */
+int32_t fwxh_session_checkpoints_kept(const fwxh_session *s);
 int fwxh_session_set_checkpoints(fwxh_session *s, int32_t checkpoints);
 int32_t fwxh_session_rate_count(const fwxh_session *s);
 

@@ -6,6 +6,11 @@ import pytest
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
+# dmabuf IPC (RCCL between devices and device memory shared across processes need it on this pool): set
+# before the first HIP call of the pytest process and inherited by every rank the tests spawn.  The
+# loader (floydwarshall_amd/_lib.py) sets the same default; here it also covers spawned helpers that
+# import torch first.
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 
 
 def pytest_configure(config):
@@ -23,6 +28,15 @@ def pytest_configure(config):
     # was built against (/opt/rocm) -- tests/test_abi_symbols.py checks exactly that.
     from floydwarshall_amd import _lib
     _lib.lib()
+
+
+@pytest.fixture(autouse=True)
+def _disarm_the_fault_injection_hook():
+    """fwx_test_fail_after arms a thread-local countdown; a test that fails between arming it and its own
+    clean-up must not make later, unrelated tests see FWX_ERR_OOM."""
+    yield
+    from floydwarshall_amd import _lib
+    _lib.lib().fwx_test_fail_after(0)
 
 
 @pytest.fixture(scope="session")

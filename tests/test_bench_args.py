@@ -59,3 +59,99 @@ def test_gpus_2_without_a_launcher_reaches_the_partitioned_path_and_fails_loudly
     assert r.returncode != 0
     assert "torch.distributed.run" not in r.stderr
     assert "no HIP device" in r.stderr or "libfwx" in r.stderr, r.stderr
+
+
+def test_watchdog_prints_an_error_line_and_exits_with_code_3():
+    """A phase that outlives its bound: ONE JSON line naming the phase (and the phases that did finish),
+    flushed, then exit code 3 -- never a silent driver kill.  A phase that finishes in time prints nothing."""
+    import io
+    import json
+    import time
+    import bench
+    out, codes = io.StringIO(), []
+    dog = bench.Watchdog(0.3, {"metric": "m", "n_gpus": 8}, out=out, exit_fn=codes.append)
+    dog.arm("warm-up step 1")
+    dog.disarm()
+    time.sleep(0.5)                                   # disarmed: the clock is not running
+    assert out.getvalue() == "" and codes == []
+    dog.arm("timed step 2 of 5")
+    for _ in range(40):
+        if codes:
+            break
+        time.sleep(0.1)
+    assert codes == [3]
+    lines = out.getvalue().strip().splitlines()
+    assert len(lines) == 1
+    line = json.loads(lines[0])
+    assert line["hung_phase"] == "timed step 2 of 5" and line["value"] is None and "watchdog" in line["error"]
+    assert line["phases_completed"] == ["warm-up step 1"] and line["n_gpus"] == 8
+    # a non-emitting rank (rank != 0 under torchrun) exits the same way without printing
+    out2, codes2 = io.StringIO(), []
+    dog2 = bench.Watchdog(0.2, {}, emit=False, out=out2, exit_fn=codes2.append)
+    dog2.arm("x")
+    for _ in range(40):
+        if codes2:
+            break
+        time.sleep(0.1)
+    assert codes2 == [3] and out2.getvalue() == ""
+    # bound 0 = off: no thread
+    assert bench.Watchdog(0, {})._thread is None
+
+
+def test_watchdog_really_ends_a_hung_process():
+    """End to end in a child process: the main thread blocks for good, the line appears, rc == 3."""
+    import json
+    code = ("import sys, time; sys.path.insert(0, %r); import bench; "
+            "d = bench.Watchdog(0.5, {'metric': 'm'}); d.arm('timed step 1 of 1'); time.sleep(60)" % ROOT)
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=60)
+    assert r.returncode == 3, (r.returncode, r.stderr)
+    assert json.loads(r.stdout.strip())["hung_phase"] == "timed step 1 of 1"
+
+
+def test_rccl_failure_falls_back_to_peer_copies_and_says_so():
+    """`--exchange auto`: FWX_ERR_RCCL from fwx_matrix_create_multi -> one retry over peer copies, recorded;
+    an explicit `--exchange rccl` and any other error are not swallowed."""
+    import numpy as np
+    import bench
+    from floydwarshall_amd import engine
+    made = []
+
+    class Fake:
+        def __init__(self, n, dtype, with_next, devices, exchange):
+            made.append(exchange)
+            if exchange != engine.FWX_XCHG_PEER and fail["status"] is not None:
+                err = engine.FwxError.__new__(engine.FwxError)      # (no library needed for the message)
+                RuntimeError.__init__(err, "fwx_matrix_create_multi: RCCL could not be loaded")
+                err.status = fail["status"]
+                raise err
+
+    fail = {"status": engine.FWX_ERR_RCCL}
+    h, info = bench.create_multi_handle(engine, 256, np.float32, False, [0, 1], "auto", factory=Fake)
+    assert isinstance(h, Fake) and made == [engine.FWX_XCHG_AUTO, engine.FWX_XCHG_PEER]
+    assert info["requested"] == "auto" and info["rccl_error"]["status"] == engine.FWX_ERR_RCCL
+    assert info["rccl_error"]["where"] == "fwx_matrix_create_multi"
+    del made[:]
+    with pytest.raises(engine.FwxError):                                     # asked for RCCL: no fallback
+        bench.create_multi_handle(engine, 256, np.float32, False, [0, 1], "rccl", factory=Fake)
+    assert made == [engine.FWX_XCHG_RCCL]
+    fail["status"] = -3                                                      # FWX_ERR_HIP: not ours to hide
+    with pytest.raises(engine.FwxError):
+        bench.create_multi_handle(engine, 256, np.float32, False, [0, 1], "auto", factory=Fake)
+    fail["status"] = None
+    del made[:]
+    h, info = bench.create_multi_handle(engine, 256, np.float32, False, [0, 1], "auto", factory=Fake)
+    assert made == [engine.FWX_XCHG_AUTO] and info["rccl_error"] is None
+
+
+def test_the_ipc_mode_is_set_before_any_hip_call():
+    """HSA_ENABLE_IPC_MODE_LEGACY=0 (dmabuf IPC: RCCL needs it on this pool) is a default of every binding of
+    the package, not only of bench.py: importing the loader sets it, an explicit setting wins."""
+    code = ("import os, sys; sys.path.insert(0, %r); os.environ.pop('HSA_ENABLE_IPC_MODE_LEGACY', None); "
+            "import floydwarshall_amd._lib; print(os.environ['HSA_ENABLE_IPC_MODE_LEGACY'])" % ROOT)
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=120)
+    assert r.stdout.strip() == "0", r.stderr
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="1")
+    code = ("import os, sys; sys.path.insert(0, %r); import floydwarshall_amd._lib; "
+            "print(os.environ['HSA_ENABLE_IPC_MODE_LEGACY'])" % ROOT)
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=120, env=env)
+    assert r.stdout.strip() == "1", r.stderr

@@ -262,11 +262,11 @@ def _same_answers(s, log, vs, rnd, queries=8):
         assert s.find_best_rate(a, b) == want
 
 
-def test_odd_vertex_counts_are_padded_with_an_isolated_vertex_and_resume():
-    """243 vertices: rows of an f64 matrix of odd order are not a multiple of 16 bytes, which a
-    single-device handle can only solve one launch per pivot.  The session adds ONE vertex without any
-    edge (inert while no rate is negative), so the ordinary handle of order 244 runs the fused engine and
-    resumes after price changes.  Answers and exact paths as a fresh session / the oracle."""
+def test_odd_vertex_counts_run_the_fused_engine_and_resume():
+    """243 vertices: rows of an f64 matrix of odd order are not a multiple of 16 bytes.  The handle pads
+    its rows on the device (fwx.h fwx_engine; round 3 had the SESSION invent a vertex instead), so the
+    ordinary handle of order 243 runs the fused engine and resumes after price changes.  Answers and
+    exact paths as a fresh session / the oracle."""
     rnd = np.random.default_rng(27)
     log, t = _odd_market(rnd)
     s = host.Session(device=0)
@@ -279,7 +279,7 @@ def test_odd_vertex_counts_are_padded_with_an_isolated_vertex_and_resume():
     gr, gn, _ = s.solved_matrix()
     assert_bits_equal(gr, er, "rate")
     assert np.array_equal(gn, en)
-    assert s.parts == 1
+    assert s.parts == 1 and s.checkpoints_kept >= 1
     for step in range(4):                 # price changes on late exchanges (vertices >= 180): resumed
         t += 1
         old = log[int(rnd.integers(20 * 9, len(log)))]
@@ -287,8 +287,8 @@ def test_odd_vertex_counts_are_padded_with_an_isolated_vertex_and_resume():
         assert s.update_rates(*log[-1])
         _same_answers(s, log, vs, rnd)
     assert s.patched_solves == 4 and s.resumed_solves == 4
-    # a NEGATIVE rate arrives: the pad vertex would no longer be inert (0 * 0 beats a negative entry),
-    # so the session rebuilds without it (order 243: the per-k engine, outside the domain anyway) -- same answers
+    # a NEGATIVE rate arrives: the matrix leaves the reference's domain and the per-k engine solves it
+    # (the handle's padding stays inert: it is never a pivot) -- a full solve, same answers
     t += 1
     old = log[5]
     log.append((t, old[1], old[2], old[3], -0.25, old[5]))
@@ -297,11 +297,9 @@ def test_odd_vertex_counts_are_padded_with_an_isolated_vertex_and_resume():
     assert s.parts == 1 and s.resumed_solves == 4
 
 
-def test_odd_vertex_counts_with_a_negative_rate_stay_unpadded():
-    """The same market with a negative rate from the start: no isolated vertex (it would not be inert);
-    the matrix is outside the reference's domain, so the per-k engine solves it at its odd order; full
-    re-solves, same answers.  (Round 3 first sent such a session to a one-partition handle, which refuses
-    matrices outside the domain with next-hops: FWX_ERR_UNSUPPORTED.)"""
+def test_odd_vertex_counts_with_a_negative_rate():
+    """The same market with a negative rate from the start: outside the reference's domain, so the per-k
+    engine solves the padded handle over its 243 real pivots; full re-solves, same answers."""
     rnd = np.random.default_rng(28)
     log, t = _odd_market(rnd, negative=True)
     s = host.Session(device=0)
@@ -320,6 +318,41 @@ def test_odd_vertex_counts_with_a_negative_rate_stay_unpadded():
         assert s.update_rates(*log[-1])
         _same_answers(s, log, vs, rnd)
     assert s.parts == 1 and s.resumed_solves == 0
+
+
+def test_a_failed_resume_allocation_does_not_fail_the_solve():
+    """Resuming is an optimisation: when `fwx_matrix_enable_resume` fails (here: the fault-injection hook
+    makes its first allocation point throw -- what an out-of-memory device does), the session carries on
+    with a handle that cannot resume: the first query is answered, later price changes are full solves of
+    the patched input, every answer as a fresh session gives it."""
+    from floydwarshall_amd._lib import lib
+    rnd = np.random.default_rng(31)
+    log, t = _odd_market(rnd)
+    s = host.Session(device=0)
+    for r in log:
+        assert s.update_rates(*r)
+    vs, _, _ = s.build_matrix()
+    try:
+        lib().fwx_test_fail_after(1)          # the only allocation point on this path is enable_resume's
+        s.solved_matrix()                     # the first solve: creates the resident handle
+    finally:
+        lib().fwx_test_fail_after(0)
+    assert s.solves == 1 and s.checkpoints_kept == 0
+    _same_answers(s, log, vs, rnd, queries=2)
+    for step in range(2):
+        t += 1
+        old = log[int(rnd.integers(20 * 9, len(log)))]
+        log.append((t, old[1], old[2], old[3], old[4] * 0.99, old[5]))
+        assert s.update_rates(*log[-1])
+        _same_answers(s, log, vs, rnd, queries=3)
+    assert s.patched_solves == 2 and s.resumed_solves == 0
+    # ... and a checkpoint count the device cannot hold is cut, not refused
+    big = host.Session(device=0)
+    big.set_checkpoints(16)
+    for r in log:
+        assert big.update_rates(*r)
+    _same_answers(big, log, vs, rnd, queries=2)
+    assert 1 <= big.checkpoints_kept <= 16
 
 
 def test_find_best_rate_unknown_vertices_keep_state_and_cache():

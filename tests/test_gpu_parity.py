@@ -284,10 +284,14 @@ def test_fused_engine_k_range_and_unsupported():
     odd, _, _ = synth.make("d1", 63, np.float32, seed=1)
     with pytest.raises(engine.FwxError):
         engine.dev_solve(dev(odd), engine=engine.FWX_ENGINE_FUSED)
-    with pytest.raises(engine.FwxError):
-        with engine.DeviceMatrix(63, np.float32, with_next=False) as dm:
-            dm.upload(odd)
-            dm.solve(engine=engine.FWX_ENGINE_FUSED)
+    # ... a handle owns its arrays and pads them (next test but one)
+    want = odd.copy()
+    oracle.relax(want)
+    with engine.DeviceMatrix(63, np.float32, with_next=False) as dm:
+        dm.upload(odd)
+        dm.solve(engine=engine.FWX_ENGINE_FUSED)
+        got, _, _ = dm.download()
+    assert_bits_equal(got, want, "rate")
 
 
 @pytest.mark.parametrize("dtype", [np.float64, np.float32])
@@ -302,6 +306,93 @@ def test_host_api_pads_odd_sizes_for_the_fused_engine(n, dtype):
         _solve_and_compare(rate, None, None, engine=engine.FWX_ENGINE_FUSED)
         _solve_and_compare(rate, nxt, None)                                     # AUTO
         _solve_and_compare(rate, None, None, k_begin=n // 3, k_end=n - 1)       # AUTO, pivot range
+
+
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+@pytest.mark.parametrize("n", [243, 1017, 3101])
+def test_single_device_handles_pad_their_rows_for_any_order(n, dtype):
+    """buildMatrix (Algorithms.hs:29) produces any n; `fwx_matrix_create` keeps the arrays at a device
+    order rounded up to 16 bytes of rate elements (inert padding: never a pivot, a +0.0 target never
+    improves), so a plain handle runs the FUSED engine, keeps hops and the path trace, answers queries
+    and RESUMES at every order -- nothing falls back to one launch per pivot.  Everything against the
+    oracle (rates, next, hops, U) and, for the `_path` lists, against their defining properties."""
+    kind = "d2" if n != 1017 else "t1"                      # 1017: tie-heavy, earliest pivot must win
+    rate, nxt, hops = synth.make(kind, n, dtype, seed=4300 + n)
+    er, en, eh = rate.copy(), nxt.copy(), hops.copy()
+    eu = oracle.relax_mt(er, en, hops=eh)
+    it = np.uint64 if dtype == np.float64 else np.uint32
+    # rates only / + next / + next + hops, FUSED and AUTO and PERK, with U
+    for fields in (0, 1, 2):
+        for eng in (engine.FWX_ENGINE_FUSED, engine.FWX_ENGINE_AUTO, engine.FWX_ENGINE_PERK):
+            if eng == engine.FWX_ENGINE_PERK and (fields != 2 or n > 1100):
+                continue
+            with engine.DeviceMatrix(n, dtype, with_next=fields >= 1, with_hops=fields == 2) as dm:
+                dm.upload(rate, nxt if fields >= 1 else None, hops if fields == 2 else None)
+                u = dm.solve(engine=eng, count_updates=True)
+                gr, gn, gh = dm.download()
+                assert u == eu, (fields, eng)
+                assert np.array_equal(gr.view(it), er.view(it)), (fields, eng)
+                if fields >= 1:
+                    assert np.array_equal(gn, en), (fields, eng)
+                    s_, d_ = n - 1, n // 2                   # a query in the last (odd) row
+                    r_, path = dm.query(s_, d_)
+                    assert path == [int(x) for x in engine.follow_path(en, s_, d_)]
+                    assert np.asarray(r_, dtype=dtype).view(it) == er[s_, d_].view(it)
+                if fields == 2:
+                    assert np.array_equal(gh, eh), (fields, eng)
+                # uncounted: the max-form kernels (and the double pass where the order reaches it)
+                dm.upload(rate, nxt if fields >= 1 else None, hops if fields == 2 else None)
+                dm.solve(engine=eng)
+                gr2, gn2, gh2 = dm.download()
+                assert np.array_equal(gr2.view(it), er.view(it)), (fields, eng, "max form")
+                if fields >= 1:
+                    assert np.array_equal(gn2, en)
+                if fields == 2:
+                    assert np.array_equal(gh2, eh)
+    # path trace + kept input + resume: a change of two entries late in the matrix resumes at a checkpoint
+    with engine.DeviceMatrix(n, dtype, with_next=True, with_hops=True) as dm:
+        dm.enable_path_log()
+        dm.keep_input()
+        placed = dm.enable_resume(3)
+        assert placed == 3
+        dm.upload(rate, nxt, hops)
+        dm.solve()
+        gr, gn, gh = dm.download()
+        assert np.array_equal(gr.view(it), er.view(it)) and np.array_equal(gn, en) and np.array_equal(gh, eh)
+        rnd = np.random.default_rng(n)
+        pairs = rnd.integers(0, n, size=(64, 2)).astype(np.int32)
+        pairs[0] = (n - 1, 0)
+        pairs[1] = (0, n - 1)
+        lists = dm.query_exact_batch(pairs[:, 0], pairs[:, 1], cap=4 * n)
+        for q, (a, b) in enumerate(pairs):
+            assert len(lists[q]) == eh[a, b], (a, b)         # length of the reference's list = hops
+            if lists[q]:
+                assert lists[q][-1] == b and lists[q][0] == en[a, b]
+        i, j = n - 2, n - 1                                  # both indices beyond the last checkpoint
+        r2 = rate.copy()
+        idx = np.array([i * n + j, j * n + i], dtype=np.int64)
+        vals = (r2.reshape(-1)[idx] * dtype(0.9)).astype(dtype)
+        r2.reshape(-1)[idx] = vals
+        started = dm.resolve(idx, vals, np.array([j, i], dtype=np.int32), np.array([1, 1], dtype=np.int32))
+        assert started > 0 and started % 64 == 0
+        er2, en2, eh2 = r2.copy(), nxt.copy(), hops.copy()
+        oracle.relax_mt(er2, en2, hops=eh2)
+        gr, gn, gh = dm.download()
+        assert np.array_equal(gr.view(it), er2.view(it)) and np.array_equal(gn, en2) and np.array_equal(gh, eh2)
+        lists = dm.query_exact_batch(pairs[:, 0], pairs[:, 1], cap=4 * n)
+        for q, (a, b) in enumerate(pairs):
+            assert len(lists[q]) == eh2[a, b], (a, b)
+        # patch_input (full solve of the patched kept input) takes the caller's n x n indices too
+        r3 = r2.copy()
+        idx = np.array([(n - 1) * n + 1], dtype=np.int64)
+        vals = (r3.reshape(-1)[idx] * dtype(0.5)).astype(dtype)
+        r3.reshape(-1)[idx] = vals
+        dm.patch_input(idx, vals, np.array([1], dtype=np.int32), np.array([1], dtype=np.int32))
+        dm.solve()
+        er3, en3, eh3 = r3.copy(), nxt.copy(), hops.copy()
+        oracle.relax_mt(er3, en3, hops=eh3)
+        gr, gn, gh = dm.download()
+        assert np.array_equal(gr.view(it), er3.view(it)) and np.array_equal(gn, en3) and np.array_equal(gh, eh3)
 
 
 def test_config3_n8192_fp32_fused_vs_perk_and_oracle_slices():
