@@ -15,6 +15,7 @@
 #include "fwx_guard.h"
 #include "fwx_internal.h"
 #include "fwx_kernels.h"
+#include "fwx_replay.h"
 
 using namespace fwxi;
 
@@ -771,63 +772,6 @@ __global__ __launch_bounds__(64) void exact_paths_kernel(fwx::PathLog plog, cons
     }
     len_out[qi] = len;
 }
-// Replay of patched input entries through the pivots [0, c) they were not part of (Resume in
-// fwx_internal.h).  One wave per entry (i, j): lane l of chunk q forms the candidate of pivot
-// k = 64 q + l from the stored panels, c[k] = ct[k][i] * w[k][j] -- the very operands step k used --
-// and the wave folds the chunk at once: on the reference's domain the strict fold of Algorithms.hs:55
-// ends at max(x, max_k c[k]) (a NaN candidate never wins), and its LAST update is the FIRST pivot that
-// attains that maximum, which gives next = cnt[k*][i], hops = cht[k*][i] + wh[k*][j], last = k*.
-// Checkpoints are multiples of 64, so the value at every checkpoint <= c falls on a chunk boundary
-// and is written into that checkpoint; the value at time c goes to the live arrays.
-struct ReplayTargets {
-    enum { MAX = 20 };
-    int count;
-    int pivot[MAX];
-    void *rate[MAX];
-    int32_t *next[MAX], *hops[MAX], *last[MAX];
-};
-
-template <typename T>
-__global__ __launch_bounds__(64) void replay_entries_kernel(const int64_t *index, int n, int ld, int c,
-                                                            const T *rate0, const int32_t *next0,
-                                                            const int32_t *hops0, const T *w, const T *ct,
-                                                            const int32_t *cnt, const int32_t *wh,
-                                                            const int32_t *cht, ReplayTargets tg)
-{
-    const int64_t idx = index[blockIdx.x];
-    const int i = (int)(idx / n), j = (int)(idx % n), lane = threadIdx.x;
-    T x = rate0[idx];
-    int nx = next0 ? next0[idx] : -1, hp = hops0 ? hops0[idx] : 0, last = -1;
-    int t = 0;
-    for (int k0 = 0; k0 <= c; k0 += 64) {
-        while (t < tg.count && tg.pivot[t] == k0) {
-            if (lane == 0) {
-                ((T *)tg.rate[t])[idx] = x;
-                if (tg.next[t]) tg.next[t][idx] = nx;
-                if (tg.hops[t]) tg.hops[t][idx] = hp;
-                if (tg.last[t]) tg.last[t][idx] = last;
-            }
-            ++t;
-        }
-        if (k0 == c || i == j) continue;                 // a diagonal entry is never a target (:54)
-        const int k = k0 + lane;
-        T v = ct[(size_t)k * ld + i] * w[(size_t)k * n + j];
-        int arg = k;
-        if (!(v == v)) v = -INFINITY;                    // NaN (inf * 0) never wins a strict compare
-        for (int d = 1; d < 64; d <<= 1) {               // max, earliest pivot on ties
-            const T ov = __shfl_xor(v, d);
-            const int oa = __shfl_xor(arg, d);
-            if (ov > v || (ov == v && oa < arg)) { v = ov; arg = oa; }
-        }
-        if (x < v) {
-            x = v;
-            last = arg;
-            if (cnt) nx = cnt[(size_t)arg * ld + i];
-            if (cht) hp = cht[(size_t)arg * ld + i] + wh[(size_t)arg * n + j];
-        }
-    }
-}
-
 // The caller's arrays are n x n; a single-device handle holds them at pitch nd (fwx_matrix::nd).
 // src / dst may be host or device memory (hipMemcpyDefault).
 int copy_in(fwx_matrix *m, void *dev, const void *src, size_t es, hipStream_t s)
@@ -852,12 +796,16 @@ inline size_t dev_offset(const fwx_matrix *m, int64_t index)
 
 // Element counts behind the memory a resumable handle keeps: `cells` per n x n array and `col_cells`
 // per all-pivot column-panel array, summed over the partitions of a partitioned handle.
-struct MultiDims { uint64_t cells, col_cells; };
+struct MultiDims { uint64_t cells, col_cells, w_cells; };
 MultiDims resume_dims(const fwx_matrix *m)
 {
     MultiDims d;
+    if (m->multi) {
+        multi_resume_dims(m, &d.cells, &d.col_cells, &d.w_cells);
+        return d;
+    }
     const uint64_t nd = (uint64_t)m->nd;
-    d.cells = nd * nd;
+    d.cells = d.w_cells = nd * nd;
     d.col_cells = nd * ((nd + 3) & ~(uint64_t)3);
     return d;
 }
@@ -908,7 +856,7 @@ int resolve_typed(fwx_matrix *m, int32_t count, const int64_t *index, int c_idx,
     }
     int64_t *d_index = R.idx;
     FWX_HIP(hipMemcpyAsync(d_index, index, (size_t)count * 8, hipMemcpyHostToDevice, s));
-    hipLaunchKernelGGL(replay_entries_kernel<T>, dim3((unsigned)count), dim3(64), 0, s, d_index, n, R.ld, c,
+    hipLaunchKernelGGL(replay_entries_kernel<T>, dim3((unsigned)count), dim3(64), 0, s, d_index, n, R.ld, 0, c,
                        (const T *)m->rate0, m->next ? m->next0 : nullptr, m->hops ? m->hops0 : nullptr,
                        (const T *)R.w, (const T *)R.ct, m->next ? R.cnt : nullptr, R.wh, R.cht, tg);
     FWX_HIP(hipGetLastError());
@@ -1188,16 +1136,7 @@ int fwx_matrix_patch_input(fwx_matrix *m, int32_t count, const int64_t *index, c
         // the remembered domain answer survives a patch whose values are themselves inside the domain
         // (rate >= +0 and not NaN; a non-zero rate comes with a next-hop >= 0); anything else, or a
         // non-zero rate patched in without its next-hop, sends the next solve through the check again
-        if (m->dom_known) {
-            bool ok = true;
-            for (int32_t q = 0; q < count && ok; ++q) {
-                const double r = m->dtype == FWX_F64 ? ((const double *)rate_vals)[q] : (double)((const float *)rate_vals)[q];
-                ok = !(r != r) && !std::signbit(r);
-                if (ok && m->next && r != 0.0) ok = next_vals && next_vals[q] >= 0;
-            }
-            const int want = m->next ? 3 : 1;
-            if (!ok || (m->dom_bits & want) != want) m->dom_known = 0;
-        }
+        if (m->dom_known && !patch_keeps_domain(m, count, rate_vals, next_vals)) m->dom_known = 0;
         for (int32_t q = 0; q < count; ++q) {        // a handful of entries: plain small copies
             const size_t off = dev_offset(m, index[q]);
             FWX_HIP(hipMemcpyAsync((char *)m->rate0 + off * es, (const char *)rate_vals + (size_t)q * es, es,
@@ -1237,9 +1176,10 @@ int fwx_matrix_resume_bytes(const fwx_matrix *m, int32_t checkpoints, uint64_t *
         const MultiDims d = resume_dims(m);
         const uint64_t es = m->dtype == FWX_F64 ? 8 : 4;
         // per checkpoint: one copy of every array; panels: w + ct (+ cnt) (+ wh + cht) for all pivots
+        // (a partitioned handle: every partition keeps all pivot ROWS, its own part of the columns)
         const uint64_t per_cp = d.cells * (es + (m->next ? 4 : 0) + (m->hops ? 4 : 0) + (m->plog.last ? 12 : 0));
-        const uint64_t panels = d.cells * es + d.col_cells * es + (m->next ? d.col_cells * 4 : 0) +
-                                (m->hops ? d.cells * 4 + d.col_cells * 4 : 0);
+        const uint64_t panels = d.w_cells * es + d.col_cells * es + (m->next ? d.col_cells * 4 : 0) +
+                                (m->hops ? d.w_cells * 4 + d.col_cells * 4 : 0);
         *bytes_out = (uint64_t)checkpoints * per_cp + panels + (uint64_t)FWX_MAX_PATCH * 8;
         return FWX_OK;
     });
@@ -1249,9 +1189,9 @@ int fwx_matrix_enable_resume(fwx_matrix *m, int32_t checkpoints)
 {
     return fwxi::guarded([&]() -> int {
         if (!m || checkpoints < 1 || checkpoints > FWX_MAX_CHECKPOINTS) return FWX_ERR_INVALID;
-        if (m->multi) return FWX_ERR_UNSUPPORTED;
         if (m->resume) return FWX_ERR_INVALID;
         if (!m->keep) return FWX_ERR_INVALID;                // replays start from the kept input
+        if (m->multi) return m->n <= kSmallSolveAutoMax ? FWX_ERR_UNSUPPORTED : multi_enable_resume(m, checkpoints);
         const int n = m->nd;                                 // everything below is sized like the device arrays
         const bool f64 = m->dtype == FWX_F64;
         // resumable = AUTO takes the fused engine for this order (fwx.h fwx_engine)
@@ -1328,33 +1268,46 @@ int fwx_matrix_resolve(fwx_matrix *m, int32_t count, const int64_t *index, const
         // solve of the kept input -- on a handle that records them, on the reference's domain
         // (the fused engine ran and will run again), for a whole-range uncounted solve
         int c_idx = -1;
-        Resume *R = m->multi ? nullptr : m->resume;
+        Resume *R = m->resume;
         if (R && count > 0 && m->dom_known && !op.updates_out && !op.has_stream && op.k_begin == 0 &&
             op.k_end == m->n && op.engine != FWX_ENGINE_PERK)
             for (int q = 0; q < R->count; ++q)
                 if (R->pivot[(size_t)q] <= lowest && R->pivot[(size_t)q] <= R->valid_upto) c_idx = q;
         if (c_idx >= 0) {
             // are the patched values inside the domain?  (fwx_matrix_patch_input keeps dom_known only then)
-            bool ok = true;
-            for (int32_t q = 0; q < count && ok; ++q) {
-                const double r = m->dtype == FWX_F64 ? ((const double *)rate_vals)[q] : (double)((const float *)rate_vals)[q];
-                ok = !(r != r) && !std::signbit(r);
-                if (ok && m->next && r != 0.0) ok = next_vals && next_vals[q] >= 0;
-            }
-            const int want = m->next ? 3 : 1;
-            if (!ok || (m->dom_bits & want) != want) c_idx = -1;
+            if (!patch_keeps_domain(m, count, rate_vals, next_vals)) c_idx = -1;
         }
         if (c_idx < 0) {
             // nothing to resume from: the patched input from pivot 0 (which records anew)
             if ((rc = fwx_matrix_patch_input(m, count, index, rate_vals, next_vals, hops_vals))) return rc;
             return fwx_matrix_solve(m, opts);
         }
+        if (m->multi) {
+            rc = multi_resolve(m, count, index, rate_vals, next_vals, hops_vals, c_idx, op);
+            if (!rc && resumed_from) *resumed_from = R->pivot[(size_t)c_idx];
+            return rc;
+        }
         DeviceGuard g;
         if ((rc = g.enter(m->device))) return rc;
         hipStream_t s = m->stream;
         const size_t es = m->dtype == FWX_F64 ? 8 : 4;
-        const int keep_valid = R->valid_upto;
+        const int c = R->pivot[(size_t)c_idx];
         R->valid_upto = 0;                           // until the resumed solve has finished
+        // Any error return below leaves the handle in a state the next call can start from: nothing of this
+        // call still queued on the stream (the small copies read the caller's arrays), nothing resumable,
+        // the live arrays no known state of the kept input (the next resolve / patch_input restores them).
+        struct Unwind {
+            fwx_matrix *m; hipStream_t s; bool armed = true;
+            ~Unwind()
+            {
+                if (!armed) return;
+                (void)hipStreamSynchronize(s);
+                m->resume->valid_upto = 0;
+                m->resume->state_at = -1;
+                m->fresh = 0;
+                m->rec_ready = 0;
+            }
+        } unwind{m, s};
         std::vector<int64_t> dindex((size_t)count);  // offsets in the device arrays (pitch nd)
         for (int32_t q = 0; q < count; ++q) dindex[(size_t)q] = (int64_t)dev_offset(m, index[q]);
         for (int32_t q = 0; q < count; ++q) {        // the kept input first: the replay reads it
@@ -1369,8 +1322,9 @@ int fwx_matrix_resolve(fwx_matrix *m, int32_t count, const int64_t *index, const
         if (rc) return rc;
         m->fresh = 0;
         m->rec_ready = 0;
-        R->valid_upto = keep_valid;                  // panels < c and checkpoints <= c hold again
-        op.k_begin = R->pivot[(size_t)c_idx];
+        R->valid_upto = c;                           // panels < c and checkpoints <= c hold for the NEW input;
+                                                     // later ones are the old solve's until this one passes them
+        op.k_begin = c;
         R->state_at = op.k_begin;                    // the live arrays: the NEW kept input at time c
         if (m->plog.last) {
             rc = logged_solve(m, op, s, true);
@@ -1379,7 +1333,8 @@ int fwx_matrix_resolve(fwx_matrix *m, int32_t count, const int64_t *index, const
                                      : matrix_solve_typed<float>(m, op, nullptr, s);
             if (!rc) FWX_HIP(hipStreamSynchronize(s));
         }
-        if (rc) { R->valid_upto = 0; return rc; }
+        if (rc) return rc;
+        unwind.armed = false;
         if (resumed_from) *resumed_from = op.k_begin;
         return FWX_OK;
     });

@@ -78,27 +78,65 @@ struct Opts {
 // least EVERY launches are queued behind the one being waited for), but a solve of N = 16384
 // pivots no longer parks 16384 dispatches in the queue: rocprofv3's counter collection, which
 // intercepts every AQL packet, crashed on exactly that.
+// Its events come from a process-wide pool per device and go back there, recorded or not: an event is
+// never destroyed while a command may still reference it (round 3 waited for armed events in the
+// destructor instead, which made the asynchronous entry points -- fwx_dev_relax with 256 or more pivots
+// -- block the host until their last recorded event had completed; fwx.h promises "nothing is
+// synchronised"), and a call creates no event once the pool is warm.  Re-recording a pooled event whose
+// earlier record is still pending is legal HIP; a Throttle only ever waits for records it made itself.
+class ThrottleEvents {
+public:
+    static hipEvent_t take(int dev)
+    {
+        Pool &p = pool();
+        {
+            std::lock_guard<std::mutex> lk(p.mu);
+            if (dev >= 0 && dev < kMaxDev && !p.idle[dev].empty()) {
+                hipEvent_t e = p.idle[dev].back();
+                p.idle[dev].pop_back();
+                return e;
+            }
+        }
+        hipEvent_t e = nullptr;
+        if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) {
+            g_last_hip = (int)hipGetLastError();
+            return nullptr;
+        }
+        return e;
+    }
+    static void give(int dev, hipEvent_t e)
+    {
+        if (!e) return;
+        Pool &p = pool();
+        std::lock_guard<std::mutex> lk(p.mu);
+        if (dev >= 0 && dev < kMaxDev) p.idle[dev].push_back(e);     // (else: leaked, never destroyed pending)
+    }
+
+private:
+    static constexpr int kMaxDev = 64;
+    struct Pool { std::mutex mu; std::vector<hipEvent_t> idle[kMaxDev]; };
+    static Pool &pool() { static Pool *p = new Pool(); return *p; }   // leaked on purpose
+};
+
 struct Throttle {
     static constexpr int EVERY = 256;
     hipEvent_t ev[2] = {nullptr, nullptr};
     bool armed[2] = {false, false};
-    int count = 0, slot = 0;
+    int count = 0, slot = 0, dev = -1;
     ~Throttle()
     {
-        // an event is only destroyed once it has completed (the solve that recorded it synchronises its
-        // stream before it returns; on an error return this wait is what orders the two)
-        for (int i = 0; i < 2; ++i)
-            if (ev[i]) {
-                if (armed[i]) (void)hipEventSynchronize(ev[i]);
-                (void)hipEventDestroy(ev[i]);
-            }
+        for (int i = 0; i < 2; ++i) ThrottleEvents::give(dev, ev[i]);
     }
+    // the stream's device must be current
     int tick(hipStream_t s, int launches = 1)
     {
         count += launches;
         if (count < EVERY) return FWX_OK;
         count = 0;
-        if (!ev[slot]) FWX_HIP(hipEventCreateWithFlags(&ev[slot], hipEventDisableTiming));
+        if (!ev[slot]) {
+            if (dev < 0) FWX_HIP(hipGetDevice(&dev));
+            if (!(ev[slot] = ThrottleEvents::take(dev))) return FWX_ERR_HIP;
+        }
         if (armed[slot]) FWX_HIP(hipEventSynchronize(ev[slot]));
         FWX_HIP(hipEventRecord(ev[slot], s));
         armed[slot] = true;
@@ -486,7 +524,23 @@ struct fwx_matrix {
 namespace fwxi {
 int multi_upload(fwx_matrix *m, const void *rate, const int32_t *next, const int32_t *hops);
 int multi_download(fwx_matrix *m, void *rate, int32_t *next, int32_t *hops);
-int multi_solve(fwx_matrix *m, const Opts &op);
+int multi_solve(fwx_matrix *m, const Opts &op, bool resumed = false);
+int multi_enable_resume(fwx_matrix *m, int32_t checkpoints);
+void multi_resume_dims(const fwx_matrix *m, uint64_t *cells, uint64_t *col_cells, uint64_t *w_cells);
+int multi_resolve(fwx_matrix *m, int32_t count, const int64_t *index, const void *rate_vals,
+                  const int32_t *next_vals, const int32_t *hops_vals, int c_idx, Opts op);
+// Does a patch with these values keep a matrix inside the domain (fwx.h) inside it?  rate >= +0 and not
+// NaN; a non-zero rate comes with a next-hop >= 0 on a handle that carries next-hops.
+inline bool patch_keeps_domain(const fwx_matrix *m, int32_t count, const void *rate_vals, const int32_t *next_vals)
+{
+    for (int32_t q = 0; q < count; ++q) {
+        const double r = m->dtype == FWX_F64 ? ((const double *)rate_vals)[q] : (double)((const float *)rate_vals)[q];
+        if (r != r || r < 0.0 || (r == 0.0 && 1.0 / r < 0.0)) return false;       // NaN, negative, -0.0
+        if (m->next && r != 0.0 && !(next_vals && next_vals[q] >= 0)) return false;
+    }
+    const int want = m->next ? 3 : 1;
+    return (m->dom_bits & want) == want;
+}
 int multi_enable_path_log(fwx_matrix *m);
 int multi_query(fwx_matrix *m, int32_t src, int32_t dst, double *rate_out, int32_t *path_out, int32_t cap);
 int multi_query_exact(fwx_matrix *m, int32_t src, int32_t dst, double *rate_out, int32_t *path_out,

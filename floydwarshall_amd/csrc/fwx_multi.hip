@@ -32,6 +32,7 @@
 #include "fwx_guard.h"
 #include "fwx_internal.h"
 #include "fwx_kernels.h"
+#include "fwx_replay.h"
 
 namespace fwxi {
 
@@ -44,6 +45,7 @@ struct RcclApi {
     decltype(&ncclGroupStart) GroupStart = nullptr;
     decltype(&ncclGroupEnd) GroupEnd = nullptr;
     decltype(&ncclCommCount) CommCount = nullptr;
+    decltype(&ncclCommAbort) CommAbort = nullptr;     // optional: used for communicators in an error state
     bool ok = false;
 };
 
@@ -61,15 +63,21 @@ static RcclApi &rccl()
         api.GroupStart = (decltype(api.GroupStart))dlsym(api.lib, "ncclGroupStart");
         api.GroupEnd = (decltype(api.GroupEnd))dlsym(api.lib, "ncclGroupEnd");
         api.CommCount = (decltype(api.CommCount))dlsym(api.lib, "ncclCommCount");
+        api.CommAbort = (decltype(api.CommAbort))dlsym(api.lib, "ncclCommAbort");
         api.ok = api.CommInitAll && api.CommDestroy && api.Broadcast && api.GroupStart && api.GroupEnd &&
                  api.CommCount;
     });
     return api;
 }
 
+// (used where a MultiState `M` with a communicator set is in scope: a failure marks the set, see
+// CommCache::release)
 #define FWX_NCCL(call)                                                                             \
     do {                                                                                           \
-        if ((call) != ncclSuccess) return FWX_ERR_RCCL;                                            \
+        if ((call) != ncclSuccess) {                                                               \
+            if (M.comms) M.comms->poisoned = true;                                                 \
+            return FWX_ERR_RCCL;                                                                   \
+        }                                                                                          \
     } while (0)
 
 // ---- communicators, cached -------------------------------------------------------------------------
@@ -78,6 +86,7 @@ static RcclApi &rccl()
 // creates one) and puts it back when it is destroyed.  Like the per-call contexts the cache is never
 // torn down (no RCCL / HIP calls from static destructors).
 struct CommSet {
+    bool poisoned = false;   // an RCCL call on it has failed: never handed to another handle
     int parts = 0;
     int devs[FWX_MAX_PARTS];
     ncclComm_t comm[FWX_MAX_PARTS];
@@ -113,12 +122,19 @@ public:
     static void release(CommSet *cs)
     {
         if (!cs) return;
-        Cache &c = cache();
-        {
+        if (!cs->poisoned) {
+            Cache &c = cache();
             std::lock_guard<std::mutex> lk(c.mu);
             if (c.idle.size() < kMaxIdle) { c.idle.push_back(cs); return; }
         }
-        for (int p = 0; p < cs->parts; ++p) (void)rccl().CommDestroy(cs->comm[p]);
+        // not cached: more idle sets than the cache keeps, or a communicator on which a call has failed --
+        // it may be in an error or half-aborted state, and handing it to the next handle with the same
+        // device list would make every later create_multi / solve_multi on those devices fail too
+        RcclApi &api = rccl();
+        for (int p = 0; p < cs->parts; ++p) {
+            if (cs->poisoned && api.CommAbort) (void)api.CommAbort(cs->comm[p]);
+            else (void)api.CommDestroy(cs->comm[p]);
+        }
         delete cs;
     }
 
@@ -147,6 +163,23 @@ struct Part {
     int ct_ld = 0;
     unsigned long long *upd = nullptr;
     int *flag = nullptr;
+    // the panel a slot holds right now: w[slot] / wh[slot], or -- on a handle that records for resumed
+    // solves -- the block's own rows of the all-pivot arrays below (bind_slot)
+    void *wp[4] = {nullptr, nullptr, nullptr, nullptr};
+    int32_t *whp[4] = {nullptr, nullptr, nullptr, nullptr};
+    // Resumable solves (fwx_matrix_enable_resume on a partitioned handle; Resume in fwx_internal.h holds
+    // the pivots and the validity marks): checkpoints = copies of this slab's arrays at the start of a
+    // checkpoint pivot; all-pivot panels = what the passes produce anyway, kept for every pivot --
+    // rw[k][j] = pivot row k at time k (EVERY partition keeps all of them: it receives them anyway, and the
+    // replay of a changed entry (i, j) needs rw[k][j] for all k beside its own rct[k][i]), rct[k][i] = pivot
+    // column k at time k for the local rows (NaN at i == k), rcnt / rwh / rcht likewise
+    struct {
+        std::vector<void *> rate;
+        std::vector<int32_t *> next, hops, last, at_col, at_row;
+        void *rw = nullptr, *rct = nullptr;
+        int32_t *rcnt = nullptr, *rwh = nullptr, *rcht = nullptr;
+        int64_t *idx = nullptr;
+    } R;
     hipStream_t main = nullptr, side = nullptr;
     hipEvent_t rows_done = nullptr, main_done = nullptr, panel_done = nullptr;
     hipEvent_t w_ready[4] = {nullptr, nullptr, nullptr, nullptr}, main_free[4] = {nullptr, nullptr, nullptr, nullptr};
@@ -304,6 +337,22 @@ struct DevRestore {
     ~DevRestore() { if (prev >= 0) (void)hipSetDevice(prev); }
 };
 
+// (the partition's device must be current)
+static void part_resume_free(Part &q)
+{
+    auto drop = [](void *p) { if (p) (void)hipFree(p); };
+    for (void *p : q.R.rate) drop(p);
+    for (auto *v : {&q.R.next, &q.R.hops, &q.R.last, &q.R.at_col, &q.R.at_row}) {
+        for (int32_t *p : *v) drop(p);
+        v->clear();
+    }
+    q.R.rate.clear();
+    drop(q.R.rw); drop(q.R.rct); drop(q.R.rcnt); drop(q.R.rwh); drop(q.R.rcht); drop(q.R.idx);
+    q.R.rw = q.R.rct = nullptr;
+    q.R.rcnt = q.R.rwh = q.R.rcht = nullptr;
+    q.R.idx = nullptr;
+}
+
 static void multi_free(MultiState *M)
 {
     if (!M) return;
@@ -332,6 +381,7 @@ static void multi_free(MultiState *M)
                         q.hops0, q.w[0], q.wh[0], q.ct, q.cnt, q.cht, q.upd, q.flag};
         for (void *b : bufs)
             if (b) (void)hipFree(b);
+        part_resume_free(q);
         if (p == 0 && M->qscratch) (void)hipFree(M->qscratch);
     }
     delete M;
@@ -369,12 +419,14 @@ static int multi_alloc(fwx_matrix *m, int n_parts, const int32_t *devices, int e
         const size_t wset = (size_t)FWX_FUSED_BLOCK * nd, cset = (size_t)FWX_FUSED_BLOCK * (q.ct_ld ? q.ct_ld : 4);
         FWX_HIP(hipMalloc(&q.w[0], 4 * wset * es));
         for (int b = 1; b < 4; ++b) q.w[b] = (char *)q.w[0] + (size_t)b * wset * es;
+        for (int b = 0; b < 4; ++b) q.wp[b] = q.w[b];
         FWX_HIP(hipMalloc(&q.ct, 4 * cset * es));
         if (m->next) FWX_HIP(hipMalloc((void **)&q.cnt, 4 * cset * 4));
         if (m->hops) {
             FWX_HIP(hipMalloc((void **)&q.hops, cells * 4 ? cells * 4 : 16));
             FWX_HIP(hipMalloc((void **)&q.wh[0], 4 * wset * 4));
             for (int b = 1; b < 4; ++b) q.wh[b] = q.wh[0] + (size_t)b * wset;
+            for (int b = 0; b < 4; ++b) q.whp[b] = q.wh[b];
             FWX_HIP(hipMalloc((void **)&q.cht, 4 * cset * 4));
         }
         FWX_HIP(hipMalloc((void **)&q.upd, FWX_UPDATE_SHARDS * 8));
@@ -564,9 +616,9 @@ template <typename T> static int issue_panel(MultiState &M, const Block &blk, in
     const size_t row_off = (size_t)(blk.k0 - o.row0) * M.nd;
     const size_t hbytes = (size_t)blk.bt * M.nd * sizeof(int32_t);
     const int t_panel = tm.begin(MultiTimer::PANEL, blk.owner, step, o.side);
-    FWX_HIP(fwx::launch_fused_panel<T>((const T *)o.rate + row_off, M.nd, blk.k0, blk.bt, (T *)o.w[slot],
+    FWX_HIP(fwx::launch_fused_panel<T>((const T *)o.rate + row_off, M.nd, blk.k0, blk.bt, (T *)o.wp[slot],
                                        o.side, plog_rows(o.plog, row_off),
-                                       o.hops ? o.hops + row_off : nullptr, o.wh[slot]));
+                                       o.hops ? o.hops + row_off : nullptr, o.whp[slot]));
     tm.end(t_panel, o.side);
     FWX_HIP(hipEventRecord(o.w_ready[slot], o.side));
     if (M.exchange == FWX_XCHG_PEER) {
@@ -578,13 +630,13 @@ template <typename T> static int issue_panel(MultiState &M, const Block &blk, in
             FWX_HIP(hipStreamWaitEvent(q.side, o.w_ready[slot], 0));
             const int t_x = tm.begin(MultiTimer::XCHG, r, step, q.side);
             if (q.device == o.device) {
-                FWX_HIP(hipMemcpyAsync(q.w[slot], o.w[slot], bytes, hipMemcpyDeviceToDevice, q.side));
+                FWX_HIP(hipMemcpyAsync(q.wp[slot], o.wp[slot], bytes, hipMemcpyDeviceToDevice, q.side));
                 if (o.hops)
-                    FWX_HIP(hipMemcpyAsync(q.wh[slot], o.wh[slot], hbytes, hipMemcpyDeviceToDevice, q.side));
+                    FWX_HIP(hipMemcpyAsync(q.whp[slot], o.whp[slot], hbytes, hipMemcpyDeviceToDevice, q.side));
             } else {
-                FWX_HIP(hipMemcpyPeerAsync(q.w[slot], q.device, o.w[slot], o.device, bytes, q.side));
+                FWX_HIP(hipMemcpyPeerAsync(q.wp[slot], q.device, o.wp[slot], o.device, bytes, q.side));
                 if (o.hops)
-                    FWX_HIP(hipMemcpyPeerAsync(q.wh[slot], q.device, o.wh[slot], o.device, hbytes, q.side));
+                    FWX_HIP(hipMemcpyPeerAsync(q.whp[slot], q.device, o.whp[slot], o.device, hbytes, q.side));
             }
             tm.end(t_x, q.side);
             FWX_HIP(hipEventRecord(q.w_ready[slot], q.side));
@@ -605,10 +657,10 @@ template <typename T> static int issue_panel(MultiState &M, const Block &blk, in
         for (int r = 0; r < M.parts; ++r) {
             Part &q = M.part[r];
             if ((rc = set_dev(q.device))) return rc;
-            FWX_NCCL(api.Broadcast(q.w[slot], q.w[slot], (size_t)blk.bt * M.nd,
+            FWX_NCCL(api.Broadcast(q.wp[slot], q.wp[slot], (size_t)blk.bt * M.nd,
                                    sizeof(T) == 8 ? ncclFloat64 : ncclFloat32, blk.owner, M.comms->comm[r], q.side));
             if (q.hops)     // the hops of the pivot rows travel with their rates
-                FWX_NCCL(api.Broadcast(q.wh[slot], q.wh[slot], (size_t)blk.bt * M.nd, ncclInt32, blk.owner,
+                FWX_NCCL(api.Broadcast(q.whp[slot], q.whp[slot], (size_t)blk.bt * M.nd, ncclInt32, blk.owner,
                                        M.comms->comm[r], q.side));
         }
         FWX_NCCL(api.GroupEnd());
@@ -858,7 +910,8 @@ static int multi_double_pass(fwx_matrix *m, const std::vector<Block> &blocks, Th
     return FWX_OK;
 }
 
-template <typename T> static int multi_solve_typed(fwx_matrix *m, const Opts &op)
+// resumed: the slabs AND their trace hold a restored checkpoint at time op.k_begin (multi_resolve)
+template <typename T> static int multi_solve_typed(fwx_matrix *m, const Opts &op, bool resumed = false)
 {
     MultiState &M = *m->multi;
     const int nd = M.nd, P = M.parts;
@@ -866,23 +919,61 @@ template <typename T> static int multi_solve_typed(fwx_matrix *m, const Opts &op
     const bool with_next = m->next != nullptr;
     const bool perk = op.engine == FWX_ENGINE_PERK;
     int rc;
-    // domain (fwx.h "Domain"), every slab
+    // domain (fwx.h "Domain"), every slab; the handle remembers the answer for what its arrays hold (the
+    // domain is closed under the algorithm: only an upload or a patch outside it can change the answer)
     int bits = 3;
-    for (int p = 0; p < P; ++p) {
-        Part &q = M.part[p];
-        if (q.rows == 0) continue;
-        if ((rc = set_dev(q.device))) return rc;
-        int b = 3;
-        if ((rc = domain_bits<T>((const T *)q.rate, q.next, (size_t)q.rows * nd, q.flag, q.main, b))) return rc;
-        bits &= b;
+    if (m->dom_known) {
+        bits = m->dom_bits;
+    } else {
+        for (int p = 0; p < P; ++p) {
+            Part &q = M.part[p];
+            if (q.rows == 0) continue;
+            if ((rc = set_dev(q.device))) return rc;
+            int b = 3;
+            if ((rc = domain_bits<T>((const T *)q.rate, q.next, (size_t)q.rows * nd, q.flag, q.main, b))) return rc;
+            bits &= b;
+        }
+        m->dom_bits = bits;
+        m->dom_known = 1;
     }
     if (with_next && bits != 3) return FWX_ERR_UNSUPPORTED;   // see fwx.h: solved on one device
     const bool nonneg = !counting && (with_next ? bits == 3 : (bits & 1) != 0);   // max-form kernels
+    // A resumable handle records the panels of every pass and the checkpoints it walks over -- if this
+    // solve continues the kept input's own solve (the slabs are that input at time k_begin) on the fused
+    // engine inside the domain; what it holds beyond k_begin belongs to an older solve until this one ends
+    Resume *rec = nullptr;
+    if (m->resume) {
+        Resume &R = *m->resume;
+        const bool chain = !perk && m->kept_valid && R.state_at == op.k_begin && op.k_begin % FWX_FUSED_BLOCK == 0 &&
+                           op.k_begin <= R.valid_upto && (with_next ? bits == 3 : (bits & 1) != 0);
+        R.valid_upto = chain ? op.k_begin : 0;
+        R.state_at = -1;
+        if (chain) rec = &R;
+    }
+    for (int p = 0; p < P; ++p) {
+        Part &q = M.part[p];
+        for (int sl = 0; sl < 4; ++sl) { q.wp[sl] = q.w[sl]; q.whp[sl] = q.wh[sl]; }
+    }
+    // pass (k0, ...) reads / writes its own rows of the all-pivot arrays on a recording handle
+    auto bind_slot = [&](const Block &blk, int slot) {
+        if (!rec) return;
+        for (int p = 0; p < P; ++p) {
+            Part &q = M.part[p];
+            q.wp[slot] = (char *)q.R.rw + (size_t)blk.k0 * nd * sizeof(T);
+            q.whp[slot] = q.R.rwh ? q.R.rwh + (size_t)blk.k0 * nd : nullptr;
+        }
+    };
+    auto bind_cols = [&](fwx::FusedArgs<T> &a, const Part &q, const Block &blk) {
+        if (!rec) return;
+        a.ct = (T *)q.R.rct + (size_t)blk.k0 * q.ct_ld;
+        a.cnt = q.R.rcnt ? q.R.rcnt + (size_t)blk.k0 * q.ct_ld : nullptr;
+        a.cht = q.R.rcht ? q.R.rcht + (size_t)blk.k0 * q.ct_ld : nullptr;
+    };
     for (int p = 0; p < P; ++p) {
         Part &q = M.part[p];
         if ((rc = set_dev(q.device))) return rc;
         const size_t cells = (size_t)q.rows * nd;
-        if (q.plog.last) {
+        if (q.plog.last && !resumed) {
             FWX_HIP(hipMemsetAsync(q.plog.last, 0xFF, cells * 4, q.main));
             FWX_HIP(hipMemsetAsync(q.plog.at_col, 0xFF, cells * 4, q.main));
             FWX_HIP(hipMemsetAsync(q.plog.at_row, 0xFF, cells * 4, q.main));
@@ -910,12 +1001,35 @@ template <typename T> static int multi_solve_typed(fwx_matrix *m, const Opts &op
     // blocks in pairs, 128 pivots per main launch behind a two-deep look-ahead; what is left -- an odd
     // block's worth or a ragged tail -- goes through the single-pass loop below
     size_t first = 0;
-    if (!perk && nonneg && !counting) {
+    if (!perk && nonneg && !counting && !rec) {
         int done = 0;
         if ((rc = multi_double_pass<T>(m, blocks, thr, done))) return rc;
         first = (size_t)done;
         if (first == blocks.size()) return finish_multi_solve(m, counting, op);
     }
+    // the state of every slab at the START of a checkpoint pivot (a block start), on a recording handle
+    auto checkpoint = [&](int k0) -> int {
+        if (!rec) return FWX_OK;
+        for (size_t c = 0; c < rec->pivot.size(); ++c) {
+            if (rec->pivot[c] != k0) continue;
+            for (int p = 0; p < P; ++p) {
+                Part &q = M.part[p];
+                if (q.rows == 0) continue;
+                int rc2 = set_dev(q.device);
+                if (rc2) return rc2;
+                const size_t cells = (size_t)q.rows * nd;
+                FWX_HIP(hipMemcpyAsync(q.R.rate[c], q.rate, cells * sizeof(T), hipMemcpyDeviceToDevice, q.main));
+                if (q.next) FWX_HIP(hipMemcpyAsync(q.R.next[c], q.next, cells * 4, hipMemcpyDeviceToDevice, q.main));
+                if (q.hops) FWX_HIP(hipMemcpyAsync(q.R.hops[c], q.hops, cells * 4, hipMemcpyDeviceToDevice, q.main));
+                if (q.plog.last) {
+                    FWX_HIP(hipMemcpyAsync(q.R.last[c], q.plog.last, cells * 4, hipMemcpyDeviceToDevice, q.main));
+                    FWX_HIP(hipMemcpyAsync(q.R.at_col[c], q.plog.at_col, cells * 4, hipMemcpyDeviceToDevice, q.main));
+                    FWX_HIP(hipMemcpyAsync(q.R.at_row[c], q.plog.at_row, cells * 4, hipMemcpyDeviceToDevice, q.main));
+                }
+            }
+        }
+        return FWX_OK;
+    };
     // per-k engine on several partitions: one enqueueing thread per partition (see SweepWorkers)
     std::unique_ptr<SweepWorkers> workers;
     if (perk && P > 1) {
@@ -926,6 +1040,7 @@ template <typename T> static int multi_solve_typed(fwx_matrix *m, const Opts &op
         Part &o = M.part[blocks[first].owner];
         if ((rc = set_dev(o.device))) return rc;
         FWX_HIP(hipEventRecord(o.rows_done, o.main));
+        bind_slot(blocks[first], 0);
         if ((rc = issue_panel<T>(M, blocks[first], 0, (int)first))) return rc;
     }
     MultiTimer &tm = M.timer;
@@ -935,6 +1050,9 @@ template <typename T> static int multi_solve_typed(fwx_matrix *m, const Opts &op
         const int slot = (int)((b - first) & 1);
         const bool more = b + 1 < blocks.size();
         const int step = (int)b;
+        // everything queued on the main streams so far precedes these copies: the previous block's sweep,
+        // the look-ahead on this block's rows; this block's panel (side stream) only READS the slab
+        if (b > first && (rc = checkpoint(blk.k0))) return rc;
         // fused engine: pivot-column snapshots on every partition; per-k engine: the pivot column is
         // read from the slab itself by every launch, the main stream just waits for the panel
         for (int p = 0; p < P; ++p) {
@@ -945,7 +1063,8 @@ template <typename T> static int multi_solve_typed(fwx_matrix *m, const Opts &op
             t_bulk[p] = tm.begin(MultiTimer::BULK, p, step, q.main);
             if (perk) continue;
             fwx::FusedArgs<T> a = part_args<T>(M, q, nonneg, counting);
-            a.k0 = blk.k0; a.bt = blk.bt; a.w = (const T *)q.w[slot]; a.wh = q.wh[slot];
+            a.k0 = blk.k0; a.bt = blk.bt; a.w = (const T *)q.wp[slot]; a.wh = q.whp[slot];
+            bind_cols(a, q, blk);
             FWX_HIP(fwx::launch_fused_colpanel<T>(a, q.main));
         }
         int la_lo = 0, la_hi = 0, la_owner = -1;
@@ -956,7 +1075,8 @@ template <typename T> static int multi_solve_typed(fwx_matrix *m, const Opts &op
             la_owner = nb.owner; la_lo = nb.k0 - o.row0; la_hi = la_lo + nb.bt;
             if ((rc = set_dev(o.device))) return rc;
             fwx::FusedArgs<T> a = part_args<T>(M, o, nonneg, counting);
-            a.k0 = blk.k0; a.bt = blk.bt; a.w = (const T *)o.w[slot]; a.wh = o.wh[slot];
+            a.k0 = blk.k0; a.bt = blk.bt; a.w = (const T *)o.wp[slot]; a.wh = o.whp[slot];
+            bind_cols(a, o, blk);
             const int t_la = tm.begin(MultiTimer::LOOKAHEAD, nb.owner, step, o.main);
             if (!perk) {
                 FWX_HIP(fwx::launch_fused_main<T>(a, la_lo, la_hi, o.main));
@@ -972,6 +1092,7 @@ template <typename T> static int multi_solve_typed(fwx_matrix *m, const Opts &op
             }
             tm.end(t_la, o.main);
             FWX_HIP(hipEventRecord(o.rows_done, o.main));
+            bind_slot(nb, slot ^ 1);
             if ((rc = issue_panel<T>(M, nb, slot ^ 1, step + 1))) return rc;
         }
         for (int p = 0; p < P; ++p) {
@@ -980,7 +1101,8 @@ template <typename T> static int multi_solve_typed(fwx_matrix *m, const Opts &op
             if (perk) continue;                       // the per-k sweeps: below, all partitions at once
             if (q.rows > 0) {
                 fwx::FusedArgs<T> a = part_args<T>(M, q, nonneg, counting);
-                a.k0 = blk.k0; a.bt = blk.bt; a.w = (const T *)q.w[slot]; a.wh = q.wh[slot];
+                a.k0 = blk.k0; a.bt = blk.bt; a.w = (const T *)q.wp[slot]; a.wh = q.whp[slot];
+                bind_cols(a, q, blk);
                 if (p != la_owner) {
                     FWX_HIP(fwx::launch_fused_main<T>(a, 0, q.rows, q.main));
                 } else if (la_lo % 8 == 0 && la_hi % 8 == 0) {
@@ -1009,7 +1131,7 @@ template <typename T> static int multi_solve_typed(fwx_matrix *m, const Opts &op
                         const size_t off = (size_t)lo * nd;
                         return relax_range<T>((T *)q.rate + off, q.next ? q.next + off : nullptr,
                                               q.hops ? q.hops + off : nullptr, hi - lo, nd, q.row0 + lo,
-                                              (const T *)q.w[slot], q.wh[slot], nd, blk.k0, blk.k0 + blk.bt,
+                                              (const T *)q.wp[slot], q.whp[slot], nd, blk.k0, blk.k0 + blk.bt,
                                               op.serpentine, counting ? q.upd : nullptr, q.main, fwx::PathLog(),
                                               skip_lo, skip_hi);
                     };
@@ -1032,7 +1154,9 @@ template <typename T> static int multi_solve_typed(fwx_matrix *m, const Opts &op
         if ((rc = set_dev(M.part[0].device))) return rc;
         if ((rc = thr.tick(M.part[0].main, perk ? blk.bt + 4 : 4))) return rc;
     }
-    return finish_multi_solve(m, counting, op);
+    if ((rc = finish_multi_solve(m, counting, op))) return rc;
+    if (rec) rec->valid_upto = rec->state_at = op.k_end;
+    return FWX_OK;
 }
 
 // ---- entry points used by fwx_api.hip for handles with m->multi -----------------------------------
@@ -1045,6 +1169,11 @@ int multi_upload(fwx_matrix *m, const void *rate, const int32_t *next, const int
     if (m->plog.last) m->rec_ready = 0;
     if (m->keep) m->kept_valid = 1;
     m->fresh = 1;
+    m->dom_known = 0;                  // a new input: the domain check has to look at it
+    if (m->resume) {                   // ... and nothing of the old solve can be resumed
+        m->resume->valid_upto = 0;
+        m->resume->state_at = m->keep ? 0 : -1;
+    }
     return FWX_OK;
 }
 
@@ -1054,19 +1183,194 @@ int multi_download(fwx_matrix *m, void *rate, int32_t *next, int32_t *hops)
     return multi_copy(m, rate, next, hops, false);
 }
 
-int multi_solve(fwx_matrix *m, const Opts &op)
+int multi_solve(fwx_matrix *m, const Opts &op, bool resumed)
 {
-    if (m->plog.last && (op.k_begin != 0 || op.k_end != m->n))
+    if (m->plog.last && ((!resumed && op.k_begin != 0) || op.k_end != m->n))
         return FWX_ERR_UNSUPPORTED;      // the trace covers whole solves (as on one device)
     if (op.engine == FWX_ENGINE_PERK && m->plog.last)
         return FWX_ERR_UNSUPPORTED;      // the per-k kernel keeps no path trace on slabs: AUTO / FUSED do
-    if (m->plog.last && !m->fresh) return FWX_ERR_INVALID;   // a traced solve starts from an upload
+    if (m->plog.last && !m->fresh && !resumed) return FWX_ERR_INVALID;   // a traced solve starts from an upload
     DevRestore keep;
     m->fresh = 0;
-    const int rc = m->dtype == FWX_F64 ? multi_solve_typed<double>(m, op) : multi_solve_typed<float>(m, op);
-    if (rc) return rc;
+    const int rc = m->dtype == FWX_F64 ? multi_solve_typed<double>(m, op, resumed)
+                                       : multi_solve_typed<float>(m, op, resumed);
+    if (rc) {
+        if (m->resume) { m->resume->valid_upto = 0; m->resume->state_at = -1; }
+        return rc;
+    }
     if (m->plog.last) m->rec_ready = 1;
     return FWX_OK;
+}
+
+// ---- resumable solves on a partitioned handle (fwx_matrix_enable_resume / fwx_matrix_resolve) -------
+void multi_resume_dims(const fwx_matrix *m, uint64_t *cells, uint64_t *col_cells, uint64_t *w_cells)
+{
+    const MultiState &M = *m->multi;
+    *cells = *col_cells = *w_cells = 0;
+    for (int p = 0; p < M.parts; ++p) {
+        const Part &q = M.part[p];
+        *cells += (uint64_t)q.rows * M.nd;
+        *col_cells += (uint64_t)M.nd * (q.ct_ld ? q.ct_ld : 4);
+        *w_cells += (uint64_t)M.nd * M.nd;                   // every partition keeps all pivot rows
+    }
+}
+
+int multi_enable_resume(fwx_matrix *m, int32_t checkpoints)
+{
+    MultiState &M = *m->multi;
+    DevRestore keep;
+    const int n = m->n, nd = M.nd;
+    const size_t es = m->dtype == FWX_F64 ? 8 : 4;
+    fail_point();
+    struct Holder {
+        Resume *r = new Resume();
+        MultiState *M;
+        ~Holder()
+        {
+            if (!r) return;
+            for (int p = 0; p < M->parts; ++p)
+                if (hipSetDevice(M->part[p].device) == hipSuccess) part_resume_free(M->part[p]);
+            delete r;
+        }
+    } hold;
+    hold.M = &M;
+    Resume *R = hold.r;
+    R->ld = 0;
+    // checkpoints at the multiples of 64 closest to q * n / (checkpoints + 1) that are block starts: a
+    // block never straddles two partitions, so inside partition p blocks start at row0 + 64 t
+    for (int q = 1; q <= checkpoints; ++q) {
+        const int c = (int)(((int64_t)n * q / (checkpoints + 1) + 32) / 64 * 64);
+        if (c <= 0 || c >= n || (!R->pivot.empty() && c <= R->pivot.back())) continue;
+        int p = 0;
+        while (p + 1 < M.parts && c >= M.part[p + 1].row0) ++p;
+        if ((c - M.part[p].row0) % FWX_FUSED_BLOCK != 0) continue;
+        R->pivot.push_back(c);
+    }
+    R->count = (int)R->pivot.size();
+    auto alloc = [&](void **ptr, size_t bytes) -> int { FWX_HIP(hipMalloc(ptr, bytes ? bytes : 16)); return FWX_OK; };
+    for (int p = 0; p < M.parts; ++p) {
+        Part &q = M.part[p];
+        int rc = set_dev(q.device);
+        if (rc) return rc;
+        const size_t cells = (size_t)q.rows * nd, pan = (size_t)nd * (q.ct_ld ? q.ct_ld : 4);
+        for (int c = 0; c < R->count; ++c) {
+            void *ptr = nullptr;
+            if ((rc = alloc(&ptr, cells * es))) return rc;
+            q.R.rate.push_back(ptr);
+            if (q.next) { if ((rc = alloc(&ptr, cells * 4))) return rc; q.R.next.push_back((int32_t *)ptr); }
+            if (q.hops) { if ((rc = alloc(&ptr, cells * 4))) return rc; q.R.hops.push_back((int32_t *)ptr); }
+            if (q.plog.last)
+                for (auto *v : {&q.R.last, &q.R.at_col, &q.R.at_row}) {
+                    if ((rc = alloc(&ptr, cells * 4))) return rc;
+                    v->push_back((int32_t *)ptr);
+                }
+        }
+        if ((rc = alloc(&q.R.rw, (size_t)nd * nd * es)) || (rc = alloc(&q.R.rct, pan * es))) return rc;
+        if (q.next && (rc = alloc((void **)&q.R.rcnt, pan * 4))) return rc;
+        if (q.hops && ((rc = alloc((void **)&q.R.rwh, (size_t)nd * nd * 4)) || (rc = alloc((void **)&q.R.rcht, pan * 4))))
+            return rc;
+        if ((rc = alloc((void **)&q.R.idx, (size_t)FWX_MAX_PATCH * 8))) return rc;
+    }
+    R->state_at = (m->fresh && m->kept_valid) ? 0 : -1;
+    m->resume = R;
+    hold.r = nullptr;
+    return R->count;
+}
+
+void multi_resume_free(fwx_matrix *m)
+{
+    if (!m->resume) return;
+    delete m->resume;          // (the partitions' arrays go with the partitions: multi_free)
+    m->resume = nullptr;
+}
+
+// The resumed path of fwx_matrix_resolve: patch the kept input, restore checkpoint c_idx on every
+// partition, replay the changed entries through pivots [0, c) from the stored panels (each on the
+// partition that owns its row: its column snapshots are local, the pivot rows are the exchanged copies
+// every partition keeps), then run pivots [c, n).
+template <typename T>
+static int multi_resolve_typed(fwx_matrix *m, int32_t count, const int64_t *index, const void *rate_vals,
+                               const int32_t *next_vals, const int32_t *hops_vals, int c_idx)
+{
+    MultiState &M = *m->multi;
+    Resume &R = *m->resume;
+    const int nd = M.nd, c = R.pivot[(size_t)c_idx];
+    int rc;
+    std::vector<int64_t> local[FWX_MAX_PARTS];
+    for (int32_t e = 0; e < count; ++e) {
+        const int row = (int)(index[e] / m->n), col = (int)(index[e] % m->n);
+        int p = 0;
+        while (p + 1 < M.parts && row >= M.part[p + 1].row0) ++p;
+        Part &q = M.part[p];
+        if ((rc = set_dev(q.device))) return rc;
+        const size_t off = (size_t)(row - q.row0) * nd + col;
+        local[p].push_back((int64_t)off);
+        FWX_HIP(hipMemcpyAsync((T *)q.rate0 + off, (const T *)rate_vals + e, sizeof(T), hipMemcpyHostToDevice, q.main));
+        if (next_vals) FWX_HIP(hipMemcpyAsync(q.next0 + off, next_vals + e, 4, hipMemcpyHostToDevice, q.main));
+        if (hops_vals) FWX_HIP(hipMemcpyAsync(q.hops0 + off, hops_vals + e, 4, hipMemcpyHostToDevice, q.main));
+    }
+    for (int p = 0; p < M.parts; ++p) {
+        Part &q = M.part[p];
+        if (q.rows == 0) continue;
+        if ((rc = set_dev(q.device))) return rc;
+        const size_t cells = (size_t)q.rows * nd, ci = (size_t)c_idx;
+        FWX_HIP(hipMemcpyAsync(q.rate, q.R.rate[ci], cells * sizeof(T), hipMemcpyDeviceToDevice, q.main));
+        if (q.next) FWX_HIP(hipMemcpyAsync(q.next, q.R.next[ci], cells * 4, hipMemcpyDeviceToDevice, q.main));
+        if (q.hops) FWX_HIP(hipMemcpyAsync(q.hops, q.R.hops[ci], cells * 4, hipMemcpyDeviceToDevice, q.main));
+        if (q.plog.last) {
+            FWX_HIP(hipMemcpyAsync(q.plog.last, q.R.last[ci], cells * 4, hipMemcpyDeviceToDevice, q.main));
+            FWX_HIP(hipMemcpyAsync(q.plog.at_col, q.R.at_col[ci], cells * 4, hipMemcpyDeviceToDevice, q.main));
+            FWX_HIP(hipMemcpyAsync(q.plog.at_row, q.R.at_row[ci], cells * 4, hipMemcpyDeviceToDevice, q.main));
+        }
+        if (local[p].empty()) continue;
+        ReplayTargets tg;
+        memset(&tg, 0, sizeof(tg));
+        for (int t = 0; t <= c_idx; ++t) {
+            const int k = tg.count++;
+            tg.pivot[k] = R.pivot[(size_t)t];
+            tg.rate[k] = q.R.rate[(size_t)t];
+            tg.next[k] = q.next ? q.R.next[(size_t)t] : nullptr;
+            tg.hops[k] = q.hops ? q.R.hops[(size_t)t] : nullptr;
+            tg.last[k] = q.plog.last ? q.R.last[(size_t)t] : nullptr;
+        }
+        {
+            const int k = tg.count++;
+            tg.pivot[k] = c;
+            tg.rate[k] = q.rate; tg.next[k] = q.next; tg.hops[k] = q.hops; tg.last[k] = q.plog.last;
+        }
+        FWX_HIP(hipMemcpyAsync(q.R.idx, local[p].data(), local[p].size() * 8, hipMemcpyHostToDevice, q.main));
+        hipLaunchKernelGGL(replay_entries_kernel<T>, dim3((unsigned)local[p].size()), dim3(64), 0, q.main, q.R.idx, nd,
+                           q.ct_ld, q.row0, c, (const T *)q.rate0, q.next ? q.next0 : nullptr,
+                           q.hops ? q.hops0 : nullptr, (const T *)q.R.rw, (const T *)q.R.rct, q.next ? q.R.rcnt : nullptr,
+                           q.R.rwh, q.R.rcht, tg);
+        FWX_HIP(hipGetLastError());
+        FWX_HIP(hipStreamSynchronize(q.main));      // (local[p] is read by the copy above)
+    }
+    return FWX_OK;
+}
+
+int multi_resolve(fwx_matrix *m, int32_t count, const int64_t *index, const void *rate_vals,
+                  const int32_t *next_vals, const int32_t *hops_vals, int c_idx, Opts op)
+{
+    DevRestore keep;
+    Resume &R = *m->resume;
+    const int c = R.pivot[(size_t)c_idx];
+    R.valid_upto = 0;
+    int rc = m->dtype == FWX_F64
+                 ? multi_resolve_typed<double>(m, count, index, rate_vals, next_vals, hops_vals, c_idx)
+                 : multi_resolve_typed<float>(m, count, index, rate_vals, next_vals, hops_vals, c_idx);
+    if (rc) {
+        R.state_at = -1;
+        m->fresh = 0;
+        m->rec_ready = 0;
+        return rc;
+    }
+    m->fresh = 0;
+    m->rec_ready = 0;
+    R.valid_upto = c;
+    R.state_at = c;
+    op.k_begin = c;
+    return multi_solve(m, op, true);
 }
 
 int multi_enable_path_log(fwx_matrix *m)
@@ -1258,6 +1562,8 @@ int multi_patch_input(fwx_matrix *m, int32_t count, const int64_t *index, const 
     DevRestore keep;
     const size_t es = m->dtype == FWX_F64 ? 8 : 4;
     int rc;
+    if (m->resume) m->resume->valid_upto = 0;      // the kept input changes without a replay
+    if (m->dom_known && !patch_keeps_domain(m, count, rate_vals, next_vals)) m->dom_known = 0;
     for (int32_t e = 0; e < count; ++e) {
         const int row = (int)(index[e] / m->n), col = (int)(index[e] % m->n);
         int p = 0;
@@ -1284,6 +1590,7 @@ int multi_patch_input(fwx_matrix *m, int32_t count, const int64_t *index, const 
     }
     m->fresh = 1;
     m->rec_ready = 0;
+    if (m->resume) m->resume->state_at = 0;        // the patched kept input, unsolved
     return FWX_OK;
 }
 
@@ -1291,6 +1598,7 @@ void multi_destroy(fwx_matrix *m)
 {
     multi_free(m->multi);
     m->multi = nullptr;
+    multi_resume_free(m);
 }
 
 }  // namespace fwxi

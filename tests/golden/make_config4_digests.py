@@ -5,8 +5,13 @@ next-hop matrix, and the same solve on every GPU engine, bit for bit.  The fixtu
 oracle's side only -- xxh64 of the solved rates, of the solved next-hops, and U -- so that `-m gpu`
 tests can tie any engine, any partitioning, to the whole oracle solve in seconds.
 
-    python3 tests/golden/make_config4_digests.py profiles/full_parity.json [n] [--next]
+    python3 tests/golden/make_config4_digests.py profiles/full_parity.json [n] [--next] [--f64]
     python3 tests/golden/make_config4_digests.py --write-fixture rates.json next.json
+    python3 tests/golden/make_config4_digests.py --write-fixture-f64 next_f64.json
+
+--f64: the same matrix BEFORE rounding to f32 (synth.d1_uniform(n, float64, BASE_SEED + 3): what
+bench.py's `f64` leg solves), the reference's own precision (Types.hs:26); with --next one run gives the
+rate digest, the next-hop digest and U -> tests/golden/config4_n16384_f64_digests.json (round 4).
 
 (round 2 ran it twice on an MI355X box: profiles/r02_full_parity_n16384.json and
 profiles/r02_full_parity_n16384_next.json; --write-fixture merges two such records.)
@@ -43,14 +48,32 @@ def write_fixture(rates_json, next_json):
     print(json.dumps(fix))
 
 
+def write_fixture_f64(next_json):
+    b = json.load(open(next_json))
+    assert b["ok"] and b["dtype"] == "f64" and b["with_next"]
+    fix = {"n": b["n"], "dtype": "f64",
+           "input": "synth.d1_uniform(n, float64, BASE_SEED + 3): bench.py's matrix before rounding to f32",
+           "oracle": "oracle.relax_mt, whole solve with next-hops (%.0f s)" % b["oracle_seconds"],
+           "U": b["U"], "rate_digest": b["rate_digest_oracle"], "next_digest": b["next_digest_oracle"],
+           "made_by": "tests/golden/make_config4_digests.py --f64 --next"}
+    with open(os.path.join(ROOT, "tests", "golden", "config4_n16384_f64_digests.json"), "w") as f:
+        json.dump(fix, f, indent=1)
+    print(json.dumps(fix))
+
+
 def main():
     if len(sys.argv) > 3 and sys.argv[1] == "--write-fixture":
         write_fixture(sys.argv[2], sys.argv[3])
         return 0
+    if len(sys.argv) > 2 and sys.argv[1] == "--write-fixture-f64":
+        write_fixture_f64(sys.argv[2])
+        return 0
     out_path = sys.argv[1] if len(sys.argv) > 1 else None
-    n = int(sys.argv[2]) if len(sys.argv) > 2 else 16384
+    n = int(sys.argv[2]) if len(sys.argv) > 2 and sys.argv[2].isdigit() else 16384
     with_next = "--next" in sys.argv
-    rate, nxt = synth.d1_uniform(n, np.float32, synth.BASE_SEED + 3)      # bench.py's matrix
+    f64 = "--f64" in sys.argv
+    np_t, it = (np.float64, np.uint64) if f64 else (np.float32, np.uint32)
+    rate, nxt = synth.d1_uniform(n, np_t, synth.BASE_SEED + 3)            # bench.py's matrix
     if not with_next:
         nxt = None
     cores = host_cores()
@@ -62,8 +85,8 @@ def main():
         u += oracle.relax_mt(er, en, k0, min(n, k0 + 1024), threads=cores)
         print("oracle: pivots [0,%d) done, %.0f s" % (min(n, k0 + 1024), time.perf_counter() - t0), flush=True)
     t_cpu = time.perf_counter() - t0
-    rec = {"n": n, "dtype": "f32", "input": "D1, seed BASE_SEED+3 (bench.py's matrix)",
-           "with_next": with_next, "oracle": "oracle.relax_mt (fwo_relax_mt_f32), %d threads" % cores,
+    rec = {"n": n, "dtype": "f64" if f64 else "f32", "input": "D1, seed BASE_SEED+3 (bench.py's matrix)",
+           "with_next": with_next, "oracle": "oracle.relax_mt (fwo_relax_mt_%s), %d threads" % ("f64" if f64 else "f32", cores),
            "oracle_seconds": t_cpu, "oracle_relax_per_s": float(n) ** 3 / t_cpu, "U": u,
            "rate_digest_oracle": digest(er)}
     if en is not None:
@@ -81,7 +104,7 @@ def main():
             gu = u
         rec[name] = {"seconds_incl_pcie": time.perf_counter() - t1, "U": gu, "counted": count,
                      "rate_digest": digest(gr),
-                     "rate_bits_equal_oracle": bool(np.array_equal(gr.view(np.uint32), er.view(np.uint32)))}
+                     "rate_bits_equal_oracle": bool(np.array_equal(gr.view(it), er.view(it)))}
         if gn is not None:
             rec[name]["next_equal_oracle"] = bool(np.array_equal(gn, en))
         print(name, json.dumps(rec[name]), flush=True)

@@ -135,3 +135,71 @@ def path_from_trace(last, at_col, at_row, next0, a, b):
             stack.append((int(q), y, 2))
             stack.append((x, int(q), 1))
     return out
+
+
+# ---- BASELINE config 5 (N = 32768 f32, rate + next + hops): oracle slices around launch boundaries -----
+CONFIG5_SLICES = ((0, 256), (16256, 16512), (32512, 32768))
+
+
+def config5_solve_with_oracle_slices(dm, n, threads=None):
+    """Solves the matrix uploaded into the handle `dm` (rate + next + hops) over all n pivots, and pins
+    three 256-pivot stretches to the oracle: the first pivots (from the input itself), a stretch across the
+    middle of the matrix (pivot 16384 = a partition boundary at P = 8; the stretch starts 128 before it, so
+    a 128-pivot launch ends exactly there) and the last 256 pivots (ending at the solved matrix).  Every
+    stretch is a pivot range of its own on the GPU -- four full blocks: two 128-pivot launches of the double
+    pass, panels across a launch boundary -- and is continued on the oracle (relax_mt with next + hops,
+    ~20 s each) from the state the GPU held before it.  Returns the solved (rate, next, hops)."""
+    import oracle
+    pos = 0
+    for a, b in CONFIG5_SLICES:
+        if a > pos:
+            dm.solve(k_begin=pos, k_end=a)
+        er, en, eh = dm.download()
+        oracle.relax_mt(er, en, a, b, threads=threads, hops=eh)     # the oracle continues from the GPU state
+        dm.solve(k_begin=a, k_end=b)
+        gr, gn, gh = dm.download()
+        assert_bits_equal(gr, er, "rate after pivots [%d, %d)" % (a, b))
+        assert_bits_equal(gn, en, "next after pivots [%d, %d)" % (a, b))
+        assert_bits_equal(gh, eh, "hops after pivots [%d, %d)" % (a, b))
+        del er, en, eh
+        pos = b
+    assert pos == n
+    return gr, gn, gh
+
+
+def check_walks_and_exact_lists(rate0, rate, nxt, hops, src, dst, walk_len, walk_prod, exact_lists_of):
+    """What path reconstruction must satisfy at config 5's size, stated exactly:
+    (1) every walk of the FINAL next-hops from src ends at dst (length >= 1 iff src != dst: D1 is dense);
+    (2) its product of INPUT edge rates is the solved rate up to the fp32 roundings of the two routes
+        involved: |walk product - rate| <= (len + hops) * 2^-24 * rate  (each of the multiplications that
+        formed the stored rate, and each the walk's own route would take, rounds by at most 2^-24);
+    (3) `hops` is the length of the list the reference concatenated when the entry last improved
+        (Algorithms.hs:55).  The walk may be a different route of equal rank (sub-routes re-routed later),
+        so len(walk) == hops is NOT a property -- but for EVERY sampled pair where they differ (and a
+        sample of those where they agree) the exact list rebuilt from the path trace has length `hops`,
+        ends at dst, starts with the stored next-hop, and the f64 product of the input edges along it
+        equals the stored rate up to its own hops - 1 fp32 multiplications: <= (hops - 1) * 2^-24 * 1.001."""
+    u = 2.0 ** -24
+    same = src == dst
+    assert bool((walk_len[same] == 0).all()) and bool((walk_len[~same] >= 1).all())
+    solved = rate[src, dst].astype(np.float64)
+    h = hops[src, dst].astype(np.int64)
+    rel = np.abs(walk_prod - solved) / np.maximum(solved, 1e-300)
+    bound = (walk_len.astype(np.int64) + h) * u
+    worst = int(np.argmax((rel - bound)[~same]))
+    assert bool((rel[~same] <= bound[~same]).all()), (float(rel[~same][worst]), float(bound[~same][worst]))
+    differ = np.flatnonzero((walk_len != h) & ~same)
+    agree = np.flatnonzero((walk_len == h) & ~same)[:2000]
+    pick = np.concatenate([differ, agree])
+    lists = exact_lists_of(src[pick], dst[pick])
+    for q, i in enumerate(pick):
+        s_, d_, path = int(src[i]), int(dst[i]), lists[q]
+        assert len(path) == hops[s_, d_], (s_, d_, len(path), int(hops[s_, d_]), int(walk_len[i]))
+        assert path[-1] == d_ and path[0] == nxt[s_, d_]
+        p, cur = 1.0, s_
+        for v in path:
+            p *= float(rate0[cur, v])
+            cur = v
+        r = float(rate[s_, d_])
+        assert abs(p - r) <= (len(path) - 1) * u * 1.001 * r, (s_, d_, p, r, len(path))
+    return len(differ)

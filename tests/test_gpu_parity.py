@@ -500,41 +500,42 @@ def test_batch_path_follow_matches_host_walk():
 
 
 def test_config5_n32768_fp32_with_next_hop_matrix():
-    """BASELINE.json configs[4] size on one GPU: N=32768 fp32 with the predecessor (next-hop)
-    matrix, full solve (fused engine), then full best-rate path reconstruction for 10^6 sampled
-    (src, dst) pairs on the device: every path ends at dst, and the product of the INPUT edge rates
-    along it equals the solved rate to fp32 rounding.  Oracle parity on a mid-solve pivot slice."""
+    """BASELINE.json configs[4] size on ONE GPU: N = 32768 fp32 with the predecessor (next-hop) matrix and
+    path lengths, through a plain handle (fused engine; two passes per main launch).  Three 256-pivot
+    stretches pinned to the oracle (helpers.config5_solve_with_oracle_slices: first pivots, middle, last
+    pivots -- rate, next AND hops), then full best-rate path reconstruction for 10^6 sampled (src, dst)
+    pairs on the device and the exact `_path` lists of a traced solve of the same input
+    (helpers.check_walks_and_exact_lists)."""
+    from helpers import check_walks_and_exact_lists, config5_solve_with_oracle_slices
     n = 32768
     rate_h, next_h = synth.d1_uniform(n, np.float32, synth.BASE_SEED + 4)
-    rate0 = dev(rate_h)
-    rate = rate0.clone()
-    nxt = dev(next_h)
-    del next_h
-    ws = engine.dev_solve_fused(rate, n, 0, 4096, next_t=nxt)
-    # oracle slice: pivots [4096, 4098) from the GPU state
-    er, en = host(rate), host(nxt)
-    oracle.relax_mt(er, en, 4096, 4098)
-    engine.dev_solve_fused(rate, n, 4096, 4098, next_t=nxt, ws=ws)
-    assert_bits_equal(host(rate), er, "rate after slice")
-    assert_bits_equal(host(nxt), en, "next after slice")
-    del er, en
-    engine.dev_solve_fused(rate, n, 4098, n, next_t=nxt, ws=ws)
-    solved_h = host(rate)
+    hops_h = (next_h >= 0).astype(np.int32)
+    with engine.DeviceMatrix(n, np.float32, with_next=True, with_hops=True) as dm:
+        dm.upload(rate_h, next_h, hops_h)
+        solved_h, nxt_h, hops = config5_solve_with_oracle_slices(dm, n)
+    del hops_h
     assert bool((solved_h >= rate_h).all())
     rnd = np.random.default_rng(7)
     src = rnd.integers(0, n, 1000000).astype(np.int32)
     dst = rnd.integers(0, n, 1000000).astype(np.int32)
+    rate0, nxt = dev(rate_h), dev(nxt_h)
     ln, prod, paths = engine.dev_follow_paths(nxt, dev(src), dev(dst), edge_rate_t=rate0, path_cap=4)
     ln, prod, paths = host(ln), host(prod), host(paths)
-    same = src == dst
-    assert bool((ln[same] == 0).all()) and bool((ln[~same] >= 1).all())
-    solved = solved_h[src, dst].astype(np.float64)
-    rel = (np.abs(prod - solved) / np.maximum(solved, 1e-30))[~same]
-    assert float(rel.max()) < 2e-5, float(rel.max())
+    del rate0, nxt
     assert int(ln.max()) < 64
     short = (ln >= 1) & (ln <= 4)
     last = paths[short, ln[short] - 1]
     assert bool((last == dst[short]).all())
+    with engine.DeviceMatrix(n, np.float32, with_next=True) as dm:
+        dm.enable_path_log()
+        dm.upload(rate_h, next_h)
+        dm.solve()
+        tr, tn, _ = dm.download()
+        assert_bits_equal(tr, solved_h, "traced rates vs the ranged solve")
+        assert_bits_equal(tn, nxt_h, "traced next-hops vs the ranged solve")
+        del tr, tn
+        check_walks_and_exact_lists(rate_h, solved_h, nxt_h, hops, src, dst, ln, prod,
+                                    lambda a, b: dm.query_exact_batch(a, b, cap=256))
 
 
 # ---------------------------------------------------------------------------------------------

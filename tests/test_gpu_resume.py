@@ -28,13 +28,17 @@ def _fresh_lists(n, dtype, rate, nxt, src, dst):
         return dm.query_exact_batch(src, dst, cap=16 * n)
 
 
+@pytest.mark.parametrize("devices", [None, [0, 0], [0, 0, 0, 0]], ids=["one-device", "P2", "P4"])
 @pytest.mark.parametrize("dtype,with_hops,traced", [(np.float64, True, True), (np.float32, False, True),
                                                     (np.float32, True, False), (np.float64, False, False)])
-def test_resolve_equals_a_from_scratch_solve(dtype, with_hops, traced):
+def test_resolve_equals_a_from_scratch_solve(dtype, with_hops, traced, devices):
+    """devices: the same on a ROW-PARTITIONED handle (round 4): checkpoints and all-pivot panels per slab,
+    every partition keeps the exchanged pivot rows, the changed entries are replayed on the partition
+    that owns their row."""
     n, cps = 512, 3
     rnd = np.random.default_rng(77)
     rate, nxt, hops = synth.make("d2", n, dtype, seed=5)
-    with engine.DeviceMatrix(n, dtype, with_next=True, with_hops=with_hops) as dm:
+    with engine.DeviceMatrix(n, dtype, with_next=True, with_hops=with_hops, devices=devices) as dm:
         if traced:
             dm.enable_path_log()
         with pytest.raises(engine.FwxError) as e:
@@ -81,6 +85,8 @@ def test_resolve_equals_a_from_scratch_solve(dtype, with_hops, traced):
                 dst = rnd.integers(0, n, 200).astype(np.int32)
                 src[:4], dst[:4] = (u, v, u, 5), (v, u, 7, v)
                 assert dm.query_exact_batch(src, dst, cap=16 * n) == _fresh_lists(n, dtype, cur_r, cur_n, src, dst)
+        if devices is not None:
+            return          # (a partitioned handle refuses matrices outside the domain with next-hops)
         # outside the reference's domain nothing is resumed (the per-k engine runs the full solve) ...
         idx = np.array([300 * n + 301], dtype=np.int64)
         bad = np.array([-0.5], dtype=dtype)
@@ -167,15 +173,29 @@ def test_what_invalidates_a_recording():
         with engine.DeviceMatrix(odd_n, dtype, with_next=True) as dm:
             dm.keep_input()
             assert dm.enable_resume(2) >= 1
-    with engine.DeviceMatrix(256, np.float32, with_next=True, devices=[0, 0]) as dm:
+    # partitions that do not start on a multiple of 64 (512 rows over 3: 0, 170, 341): a checkpoint must be a
+    # block start, so only pivot 128 (inside partition 0) qualifies -- and it works
+    rate, nxt, _ = synth.make("d1", 512, np.float32, seed=10)
+    with engine.DeviceMatrix(512, np.float32, with_next=True, devices=[0, 0, 0]) as dm:
         dm.keep_input()
-        with pytest.raises(engine.FwxError) as e:
-            dm.enable_resume(2)
-        assert e.value.status == FWX_ERR_UNSUPPORTED
+        assert dm.enable_resume(3) == 1
+        dm.upload(rate, nxt)
+        dm.solve()
+        idx = np.array([400 * 512 + 300], dtype=np.int64)
+        v = (rate.reshape(-1)[idx] * np.float32(0.9)).astype(np.float32)
+        rate.reshape(-1)[idx] = v
+        assert dm.resolve(idx, v, np.array([300], dtype=np.int32)) == 128
+        er, en = rate.copy(), nxt.copy()
+        oracle.relax(er, en)
+        gr, gn, _ = dm.download()
+        assert_bits_equal(gr, er, "rate")
+        assert_bits_equal(gn, en, "next")
 
 
-def test_session_resumes_after_price_changes_and_answers_like_a_fresh_session():
-    """The AppState trigger on top (Types.hs:35-37, ProcessRequests.hs:82-85): 32 exchanges x 8
+@pytest.mark.parametrize("devices", [None, [0, 0, 0, 0]], ids=["one-device", "P4"])
+def test_session_resumes_after_price_changes_and_answers_like_a_fresh_session(devices):
+    """(devices: the session behind `fwx_cli --devices`, the resident matrix row-partitioned -- it resumes
+    like the single-device one.)  The AppState trigger on top (Types.hs:35-37, ProcessRequests.hs:82-85): 32 exchanges x 8
     currencies = 256 vertices; a feed of price changes between known vertices, a best-rate request
     after each.  The session's re-solves resume at a checkpoint whenever the changed vertices allow;
     every answer (rate and the reference's exact `_path`) equals that of a session that never resumes
@@ -197,6 +217,8 @@ def test_session_resumes_after_price_changes_and_answers_like_a_fresh_session():
                 log.append(quote("E%02d" % e, ccys[i], ccys[(i + 3) % len(ccys)], t))
     s, plain = host.Session(device=0), host.Session(device=0)
     plain.set_checkpoints(0)
+    if devices is not None:
+        s.set_devices(devices, min_vertices=0)
     for r in log:
         assert s.update_rates(*r) and plain.update_rates(*r)
     vs = sorted({(r[1], c) for r in log for c in (r[2], r[3])})
@@ -219,7 +241,7 @@ def test_session_resumes_after_price_changes_and_answers_like_a_fresh_session():
                 continue
             assert s.find_best_rate(a, b) == want
     assert s.solves == plain.solves == 25 and s.patched_solves == 24
-    assert plain.resumed_solves == 0
+    assert plain.resumed_solves == 0 and s.parts == (1 if devices is None else len(devices))
     assert s.resumed_solves >= 12, s.resumed_solves            # changes below the first checkpoint cannot
     assert s.resumed_pivots >= 32 * s.resumed_solves
     fresh = host.Session(device=0)

@@ -26,11 +26,22 @@ for parts in (0, 1, 2, 4, 8):
         t0 = time.perf_counter()
         h.solve()
         ts.append(time.perf_counter() - t0)
+    timing = None
+    if parts:
+        # one more solve with per-step event spans (round 4): chain vs bulk per 128-pivot launch
+        h.set_timing(True)
+        h.upload(rate, nxt if with_next else None)
+        h.solve()
+        timing = {k: (round(v, 2) if isinstance(v, float) else v) for k, v in h.timing().items()}
+        h.set_timing(False)
     r = h.download()[0]
     if ref is None:
         ref = r
+        single_ms = 1e3 * min(ts)
     print(json.dumps({"n": n, "next": with_next, "partitions": parts or "single-device handle",
                       "best_ms": round(1e3 * min(ts), 2), "ms": [round(1e3 * t, 2) for t in ts],
+                      "overhead_over_single_device": round(1e3 * min(ts) / single_ms - 1.0, 4),
+                      "timing": timing,
                       "bits_equal_single": bool(np.array_equal(r.view(np.uint32), ref.view(np.uint32)))}),
           flush=True)
     h.close()
