@@ -550,7 +550,7 @@ def run_single(args):
             stream_s = relax_per_step / 2.0 * 3 * 1.104e-9 / 64.0 / 1024.0
             leg = {"value": relax_per_step / nt, "unit": "edge-relaxations/s", "ms_per_step": 1e3 * nt, "steps": 2,
                    "valu_roofline": {"bound": "valu-issue", "bound_ms_per_step": 1e3 * stream_s,
-                                     "frac": stream_s / nt,
+                                     "frac": stream_s / nt, "own_scheme": arg_kernel_own_bound(n, nt),
                                      "note": "against ONE fold at the sustained stream rate (the rates-only bound); "
                                              "the kernel's own scheme -- fold + stage tracking + compaction + "
                                              "re-scan of the moved entries -- issues ~1.45 x the fold's vector "
@@ -578,6 +578,37 @@ def run_single(args):
     if not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(rate_host, args.cpu_seconds)
     print(json.dumps(out), flush=True)
+
+
+def arg_kernel_own_bound(n, measured_s):
+    """The minimum of fused_main_arg's OWN scheme in vector-issue cycles, from the instruction mix of the
+    compiled kernel (tools/isa_mix.py over `hipcc -S`, profiles/r04_arg_isa_mix.txt) priced at the issue costs
+    measured on gfx950 (profiles/r02_valu_issue_rates.txt: v_mul_f32 2.15 cycles, v_max3 / v_cmp / v_cndmask and
+    every other VOP3 4.1, saturated SIMD), per wave and 128 x 64 tile (8 x 4 entries per lane, 64 pivots):
+      fold        32 pivot pairs x (64 v_mul_f32 + 32 v_max3_f32 + 5 loop instructions)
+      tracking    4 stages x 8 rows x (4 v_cmp + 4 v_cndmask)
+      compaction  32 entry slots x (5 vector + ~8 scalar instructions)
+      re-scan     one batch of 64 items = 16 products, 7 v_max3, 17 v_cmp + 17 v_cndmask, address arithmetic;
+                  batches per wave and tile = moved entries / 64 (11 % of 2048 entries on this solve)
+      rest        staging, addressing, row stores, prologue
+    against the wall time of the solve: how close the kernel runs to what its scheme can do at best (the
+    `frac` beside this one is against ONE fold at the stream rate, a bound no next-hop scheme reaches)."""
+    fold = 32 * (64 * 2.15 + 32 * 4.1 + 5 * 2.0)
+    tracking = 4 * 8 * 8 * 4.1
+    compaction = 32 * (5 * 4.1 + 8 * 1.0)
+    moved = 0.11
+    rescan = 260.0 * (moved * 2048 / 64.0)
+    rest = 600.0
+    cycles = fold + tracking + compaction + rescan + rest
+    wave_tiles_per_simd = (n / 128.0) * (n / 64.0) * 4 / 1024.0
+    passes = n / 64.0
+    clock = 2.33e9                                     # held under VALU load (profiles/r02_valu_sustained.txt)
+    bound_s = passes * wave_tiles_per_simd * cycles / clock
+    return {"cycles_per_wave_tile": {"fold": round(fold), "tracking": round(tracking), "compaction": round(compaction),
+                                     "rescan_at_11pct_moved": round(rescan), "rest": round(rest), "total": round(cycles)},
+            "clock_GHz": 2.33, "bound_ms_per_step": 1e3 * bound_s, "frac": bound_s / measured_s,
+            "fold_share_of_own_bound": fold / cycles,
+            "source": "tools/isa_mix.py, profiles/r04_arg_isa_mix.txt, profiles/r02_valu_issue_rates.txt"}
 
 
 def reference_regime_leg(engine, with_cpu):

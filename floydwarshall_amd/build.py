@@ -113,5 +113,32 @@ def build_cli(hipcc, verbose=False):
     return CLI
 
 
+def build_variant(name, defines):
+    """An experimental build of the same ABI with extra -D switches: build/variants/libfwx_<name>.so, selected
+    at run time with FWX_LIB_PATH (floydwarshall_amd/_lib.py) -- how two kernel variants are measured
+    against each other on ONE GPU box in one gpurun call.  Never shipped: build/ is git-ignored."""
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    outdir = os.path.join(ROOT, "build", "variants")
+    objdir = os.path.join(outdir, "obj_" + name)
+    os.makedirs(objdir, exist_ok=True)
+    compile_flags = [f for f in HIPCC_FLAGS if f != "-shared"] + list(defines)
+    objs, jobs = [], []
+    for src in _sources():
+        obj = os.path.join(objdir, os.path.basename(src) + ".o")
+        objs.append(obj)
+        jobs.append([hipcc] + compile_flags + ["-x", "hip", "-c", src, "-o", obj])
+    from concurrent.futures import ThreadPoolExecutor
+    with ThreadPoolExecutor(max_workers=min(len(jobs), os.cpu_count() or 4)) as ex:
+        list(ex.map(lambda c: subprocess.run(c, check=True), jobs))
+    lib = os.path.join(outdir, "libfwx_%s.so" % name)
+    subprocess.run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-fno-gpu-rdc"] + objs + ["-o", lib, "-ldl"],
+                   check=True)
+    return lib
+
+
 if __name__ == "__main__":
-    print(build_lib(force="-f" in sys.argv, verbose=True))
+    if "--variant" in sys.argv:
+        i = sys.argv.index("--variant")
+        print(build_variant(sys.argv[i + 1], [a for a in sys.argv[i + 2:] if a.startswith("-D")]))
+    else:
+        print(build_lib(force="-f" in sys.argv, verbose=True))
