@@ -1274,14 +1274,6 @@ __global__ __launch_bounds__(256, MINW) void fused_main_max_f64(double *rate, in
 // (8-pivot stages halve the re-scan's products and double the tracking compares: no difference,
 // 257.3 vs 259.3 ms at N = 16384, gpurun_out/r02_run30.log)
 constexpr int ARG_SL = 16;         // pivots per tracking stage of fused_main_arg (even, divides B)
-// build-time experiment switches (python -m floydwarshall_amd.build --variant NAME -DFWX_EXP_...=1 makes
-// build/variants/libfwx_NAME.so; FWX_LIB_PATH selects it for an A/B on one box)
-#ifndef FWX_EXP_PRIO
-#define FWX_EXP_PRIO 0
-#endif
-#ifndef FWX_EXP_LATE_STORES
-#define FWX_EXP_LATE_STORES 0
-#endif
 
 // gfx950 needs two wait states between a vector instruction that writes a scalar register (a compare)
 // and a vector instruction that reads it as a lane mask (a select), and it does not interlock.  Written
@@ -1400,9 +1392,6 @@ __global__ __launch_bounds__(256, MINW) void fused_main_arg(float *rate, int32_t
         asm volatile("" : "+v"(tid));
         __builtin_assume(tid >= 0 && tid < 256);
     }
-#if FWX_EXP_PRIO
-    __builtin_amdgcn_s_setprio(FWX_EXP_PRIO);
-#endif
     const int ti = tid >> 4, tj = tid & 15;
     const int i0 = i_base + ti * RI;
     const bool skip = i0 >= skip_lo && i0 < skip_hi;   // rows done by the look-ahead launch
@@ -1490,9 +1479,6 @@ __global__ __launch_bounds__(256, MINW) void fused_main_arg(float *rate, int32_t
     // that do are simply never stored, see row_ok below) -- a per-lane bound would put the loop
     // counter in a vector register and the loop under an exec mask
     const int npairs = __builtin_amdgcn_ballot_w64(!skip) ? (bt + 1) / 2 : 0;
-#if FWX_EXP_PRIO
-    __builtin_amdgcn_s_setprio(0);
-#endif
     auto pair_step = [&](int tp, const V4 (&in)[RI], V4 (&out)[RI]) {
         float c[RI][2], wv[4][2];
 #pragma unroll
@@ -1552,9 +1538,6 @@ __global__ __launch_bounds__(256, MINW) void fused_main_arg(float *rate, int32_t
 #pragma unroll
         for (int r = 0; r < RI; ++r) xa[r] = xb[r];
     }
-#if FWX_EXP_PRIO
-    __builtin_amdgcn_s_setprio(FWX_EXP_PRIO);
-#endif
 
     // ---- 2. + 3. moved entries -> items -> t* -> next (and last) ---------------------------------
     const int gi_lo = row0 + i_base;
@@ -1678,21 +1661,12 @@ __global__ __launch_bounds__(256, MINW) void fused_main_arg(float *rate, int32_t
     }
     const unsigned int lane_offb = (unsigned int)__umul24((unsigned int)(ti * RI), n4) + (unsigned int)(tj * 16);
     const unsigned int id_lane = ((unsigned int)(ti * RI) << 8) | ((unsigned int)(tj * 4) << 2);
-#if FWX_EXP_LATE_STORES
-    // the rows that moved are stored AFTER the re-scans: every retire() waits for vmcnt(0), and a row
-    // store issued between two of them puts its write latency on the gathers' wait
-    int keep[RI];
-#pragma unroll
-    for (int r = 0; r < RI; ++r) keep[r] = (sid[r][0] & sid[r][1]) & (sid[r][2] & sid[r][3]);   // -1: nothing moved
-#endif
 #pragma unroll
     for (int r = 0; r < RI; ++r) {
         const unsigned int id_row = id_lane | ((unsigned int)r << 8);
         // (a moved entry => the row and the columns are inside: jc == jcol)
-#if !FWX_EXP_LATE_STORES
         if (sid[r][0] >= 0 || sid[r][1] >= 0 || sid[r][2] >= 0 || sid[r][3] >= 0)
             *reinterpret_cast<V4 *>(rate_t + (size_t)r * n4 + lane_offb) = xa[r];
-#endif
         count += compact_slot<0>(sid[r][0], id_row, ids_lds + 2u * (unsigned int)count);
         count += compact_slot<4>(sid[r][1], id_row, ids_lds + 2u * (unsigned int)count);
         if (count >= 64) rescan(false);               // count <= 63 + 2 * 64 here
@@ -1702,11 +1676,6 @@ __global__ __launch_bounds__(256, MINW) void fused_main_arg(float *rate, int32_t
     }
     if (count > 0) rescan(true);
     retire();
-#if FWX_EXP_LATE_STORES
-#pragma unroll
-    for (int r = 0; r < RI; ++r)
-        if (keep[r] != -1) *reinterpret_cast<V4 *>(rate_t + (size_t)r * n4 + lane_offb) = xa[r];
-#endif
     };   // one_pass
     one_pass(0);
     if constexpr (NP > 1) one_pass(1);
