@@ -679,7 +679,10 @@ def f64_leg(engine, hip, rate64, n, stream):
         h.solve()
         times.append(time.perf_counter() - t1)
     ft = min(times)
-    same = bool(np.array_equal(h.download()[0].view(np.uint64), rate.numpy(stream).view(np.uint64)))
+    fused_host = h.download()[0]
+    same = bool(np.array_equal(fused_host.view(np.uint64), rate.numpy(stream).view(np.uint64)))
+    f64_digest = digest(fused_host)
+    del fused_host
     # f64 max form: v_mul_f64 + v_max_f64; the pair SUSTAINS 1.907 ns per instruction per SIMD over a
     # 0.2 s burst at 2-3 waves per SIMD, 2.38 GHz held (profiles/r02_valu_sustained.txt)
     cyc = float(n) ** 3 * 8.7 / 64.0 / 1024.0
@@ -693,6 +696,13 @@ def f64_leg(engine, hip, rate64, n, stream):
                                       "at_nominal_clock": {"clock_GHz": 2.4, "frac": cyc / 2.4e9 / ft}},
                     "per_k_equals_fused_bits": same}
     h.close()
+    res["check"] = {"rate_digest": f64_digest}
+    gold = os.path.join(ROOT, "tests", "golden", "config4_n16384_f64_digests.json")
+    if n == 16384 and os.path.exists(gold):
+        with open(gold) as f:
+            g = json.load(f)
+        # (the committed digest is of ONE WHOLE f64 oracle solve of this matrix: 265 s on 16 host threads)
+        res["check"]["equals_whole_oracle_solve"] = bool(f64_digest == g["rate_digest"])
     res["note"] = "not part of `value`; same D1 matrix before rounding to f32; 1 solve per engine"
     return res
 
