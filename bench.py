@@ -50,7 +50,7 @@ os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 SEGMENTS = 16
 HBM_PEAK_GBPS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
 INFINITY_CACHE_BYTES = 256 << 20
-PMC_PROFILE = os.path.join("profiles", "r03_pmc_traffic.json")
+PMC_PROFILE = os.path.join("profiles", "r04_pmc_traffic.json")
 
 
 class Watchdog:
@@ -232,7 +232,7 @@ def cpu_baseline(rate_host, cpu_seconds):
 def pmc_traffic(n, args):
     """HBM bytes per relax_k launch from the rocprofv3 PMC passes over THIS command (`rocprofv3 --pmc
     FETCH_SIZE -- python3 bench.py --steps 1 --warmup 0 --no-extras --no-cpu-baseline`, then
-    WRITE_SIZE; tools/pmc_summary.py turns the counter CSVs into profiles/r03_pmc_traffic.json).
+    WRITE_SIZE; tools/pmc_summary.py turns the counter CSVs into profiles/r04_pmc_traffic.json).
     Counters cannot be read from inside the process, so the line quotes the committed summary, and
     only for the exact configuration it was measured on; otherwise null."""
     path = os.path.join(ROOT, PMC_PROFILE)

@@ -225,6 +225,15 @@ struct MultiTimer {
 
 struct MultiState {
     MultiTimer timer;
+    // self >= 0: ONE partition of `parts` lives in this process (fwx_matrix_create_part: one process per
+    // GPU); only part[self] has arrays, streams and events -- the others are row bounds -- and the panel
+    // exchange is the host's callback (a broadcast among the processes), called once per panel in the
+    // same order on every rank.  The schedules below are the same code either way.
+    int self = -1;
+    fwx_exchange_fn xfn = nullptr;
+    void *xctx = nullptr;
+    bool here(int p) const { return self < 0 || p == self; }
+    int first_here() const { return self < 0 ? 0 : self; }
     int parts = 0;
     int nd = 0;                 // device order: n rounded up to a multiple of 16 bytes of elements
     int exchange = FWX_XCHG_PEER;
@@ -387,7 +396,8 @@ static void multi_free(MultiState *M)
     delete M;
 }
 
-static int multi_alloc(fwx_matrix *m, int n_parts, const int32_t *devices, int exchange)
+static int multi_alloc(fwx_matrix *m, int n_parts, const int32_t *devices, int exchange, int self = -1,
+                       fwx_exchange_fn xfn = nullptr, void *xctx = nullptr)
 {
     const size_t es = m->dtype == FWX_F64 ? 8 : 4;
     const int vw = (int)(16 / es);
@@ -395,12 +405,16 @@ static int multi_alloc(fwx_matrix *m, int n_parts, const int32_t *devices, int e
     if (!M) return FWX_ERR_OOM;
     m->multi = M;
     M->parts = n_parts;
+    M->self = self;
+    M->xfn = xfn;
+    M->xctx = xctx;
     M->nd = (m->n + vw - 1) / vw * vw;
     bool distinct = true;
     for (int p = 0; p < n_parts; ++p)
         for (int q = 0; q < p; ++q) distinct = distinct && devices[p] != devices[q];
     if (exchange == FWX_XCHG_AUTO) exchange = (distinct && n_parts >= 2) ? FWX_XCHG_RCCL : FWX_XCHG_PEER;
     if (exchange == FWX_XCHG_RCCL && !distinct) return FWX_ERR_INVALID;
+    if ((exchange == FWX_XCHG_CALLBACK) != (M->self >= 0)) return FWX_ERR_INVALID;
     M->exchange = exchange;
     const int nd = M->nd;
     for (int p = 0; p < n_parts; ++p) {
@@ -410,6 +424,7 @@ static int multi_alloc(fwx_matrix *m, int n_parts, const int32_t *devices, int e
         const int r1 = p + 1 == n_parts ? nd : (int)((int64_t)m->n * (p + 1) / n_parts);   // padding rows: last
         q.rows = r1 - q.row0;
         q.ct_ld = (q.rows + 3) & ~3;
+        if (!M->here(p)) continue;                 // (another process holds it)
         int rc = set_dev(q.device);
         if (rc) return rc;
         const size_t cells = (size_t)q.rows * nd;
@@ -440,7 +455,7 @@ static int multi_alloc(fwx_matrix *m, int n_parts, const int32_t *devices, int e
     // Peer access is wanted, not required: the QUERIES walk every slab from partition 0's device and
     // need it (they say so when it is missing); the exchange does not -- RCCL has its own transports
     // and hipMemcpyPeerAsync stages through the host when two devices are not peers.
-    for (int p = 0; p < n_parts; ++p)
+    for (int p = 0; p < n_parts && M->self < 0; ++p)
         for (int q = 0; q < n_parts; ++q) {
             if (devices[p] == devices[q]) continue;
             int rc = set_dev(devices[p]);
@@ -468,6 +483,7 @@ static int multi_copy(fwx_matrix *m, void *host_rate, int32_t *host_next, int32_
     const int n = m->n, nd = M.nd;
     for (int p = 0; p < M.parts; ++p) {
         Part &q = M.part[p];
+        if (!M.here(p)) continue;
         int rc = set_dev(q.device);
         if (rc) return rc;
         const int real = (q.row0 + q.rows <= n ? q.rows : n - q.row0);   // rows that exist in the caller's arrays
@@ -479,7 +495,7 @@ static int multi_copy(fwx_matrix *m, void *host_rate, int32_t *host_next, int32_
         if (real <= 0) continue;
         auto copy = [&](void *dev, char *host, size_t e) -> int {
             if (!host) return FWX_OK;
-            host += (size_t)q.row0 * n * e;
+            if (M.self < 0) host += (size_t)q.row0 * n * e;      // (one partition per process: the caller's arrays ARE the slab)
             if (to_device)
                 FWX_HIP(hipMemcpy2DAsync(dev, (size_t)nd * e, host, (size_t)n * e, (size_t)n * e, (size_t)real,
                                          hipMemcpyDefault, q.main));
@@ -500,6 +516,7 @@ static int multi_copy(fwx_matrix *m, void *host_rate, int32_t *host_next, int32_
         }
     }
     for (int p = 0; p < M.parts; ++p) {
+        if (!M.here(p)) continue;
         int rc = set_dev(M.part[p].device);
         if (rc) return rc;
         FWX_HIP(hipStreamSynchronize(M.part[p].main));
@@ -606,22 +623,37 @@ template <typename T> static int issue_panel(MultiState &M, const Block &blk, in
     Part &o = M.part[blk.owner];
     MultiTimer &tm = M.timer;
     const size_t bytes = (size_t)blk.bt * M.nd * sizeof(T);
-    int rc = set_dev(o.device);
-    if (rc) return rc;
-    FWX_HIP(hipStreamWaitEvent(o.side, o.rows_done, 0));
-    FWX_HIP(hipStreamWaitEvent(o.side, o.main_free[slot], 0));       // own main kernels are done with this slot
-    if (M.exchange == FWX_XCHG_PEER)
-        for (int r = 0; r < M.parts; ++r)      // nobody is still copying the previous panel out of this slot
-            if (r != blk.owner) FWX_HIP(hipStreamWaitEvent(o.side, M.part[r].w_ready[slot], 0));
-    const size_t row_off = (size_t)(blk.k0 - o.row0) * M.nd;
     const size_t hbytes = (size_t)blk.bt * M.nd * sizeof(int32_t);
-    const int t_panel = tm.begin(MultiTimer::PANEL, blk.owner, step, o.side);
-    FWX_HIP(fwx::launch_fused_panel<T>((const T *)o.rate + row_off, M.nd, blk.k0, blk.bt, (T *)o.wp[slot],
-                                       o.side, plog_rows(o.plog, row_off),
-                                       o.hops ? o.hops + row_off : nullptr, o.whp[slot]));
-    tm.end(t_panel, o.side);
-    FWX_HIP(hipEventRecord(o.w_ready[slot], o.side));
-    if (M.exchange == FWX_XCHG_PEER) {
+    int rc;
+    if (M.here(blk.owner)) {
+        if ((rc = set_dev(o.device))) return rc;
+        FWX_HIP(hipStreamWaitEvent(o.side, o.rows_done, 0));
+        FWX_HIP(hipStreamWaitEvent(o.side, o.main_free[slot], 0));       // own main kernels are done with this slot
+        if (M.exchange == FWX_XCHG_PEER)
+            for (int r = 0; r < M.parts; ++r)      // nobody is still copying the previous panel out of this slot
+                if (r != blk.owner) FWX_HIP(hipStreamWaitEvent(o.side, M.part[r].w_ready[slot], 0));
+        const size_t row_off = (size_t)(blk.k0 - o.row0) * M.nd;
+        const int t_panel = tm.begin(MultiTimer::PANEL, blk.owner, step, o.side);
+        FWX_HIP(fwx::launch_fused_panel<T>((const T *)o.rate + row_off, M.nd, blk.k0, blk.bt, (T *)o.wp[slot],
+                                           o.side, plog_rows(o.plog, row_off),
+                                           o.hops ? o.hops + row_off : nullptr, o.whp[slot]));
+        tm.end(t_panel, o.side);
+        FWX_HIP(hipEventRecord(o.w_ready[slot], o.side));
+    }
+    if (M.exchange == FWX_XCHG_CALLBACK) {
+        // one partition per process: the host broadcasts the panel among the processes, ordered on this
+        // partition's side stream (behind the panel kernel on the owner, behind the last reader of the
+        // slot elsewhere); every rank gets here for every panel, in the same order
+        Part &q = M.part[M.self];
+        if ((rc = set_dev(q.device))) return rc;
+        if (M.self != blk.owner) FWX_HIP(hipStreamWaitEvent(q.side, q.main_free[slot], 0));
+        const int t_x = tm.begin(MultiTimer::XCHG, M.self, step, q.side);
+        if (M.xfn(M.xctx, blk.k0, blk.bt, blk.owner, q.wp[slot], q.hops ? q.whp[slot] : nullptr,
+                  (int64_t)blk.bt * M.nd, q.side) != 0)
+            return FWX_ERR_RCCL;
+        tm.end(t_x, q.side);
+        FWX_HIP(hipEventRecord(q.w_ready[slot], q.side));
+    } else if (M.exchange == FWX_XCHG_PEER) {
         for (int r = 0; r < M.parts; ++r) {
             if (r == blk.owner) continue;
             Part &q = M.part[r];
@@ -726,6 +758,7 @@ static int finish_multi_solve(fwx_matrix *m, bool counting, const Opts &op)
     uint64_t total = 0;
     for (int p = 0; p < M.parts; ++p) {
         Part &q = M.part[p];
+        if (!M.here(p)) continue;
         if ((rc = set_dev(q.device))) return rc;
         FWX_HIP(hipStreamSynchronize(q.side));
         FWX_HIP(hipStreamSynchronize(q.main));
@@ -817,6 +850,7 @@ static int multi_double_pass(fwx_matrix *m, const std::vector<Block> &blocks, Th
         if (rc2) return rc2;
         for (int p = 0; p < P; ++p) {
             Part &q = M.part[p];
+            if (!M.here(p)) continue;
             if ((rc2 = set_dev(q.device))) return rc2;
             FWX_HIP(hipStreamWaitEvent(q.side, q.w_ready[blk & 3], 0));
             FWX_HIP(fwx::launch_fused_colpanel<T>(args(q, blk, 1), q.side));
@@ -825,6 +859,7 @@ static int multi_double_pass(fwx_matrix *m, const std::vector<Block> &blocks, Th
     };
     auto each = [&](auto &&fn) -> int {
         for (int p = 0; p < P; ++p) {
+            if (!M.here(p)) continue;
             int rc2 = set_dev(M.part[p].device);
             if (rc2 || (rc2 = fn(p, M.part[p]))) return rc2;
         }
@@ -889,8 +924,8 @@ static int multi_double_pass(fwx_matrix *m, const std::vector<Block> &blocks, Th
                 })))
                 return rc;
         }
-        if ((rc = set_dev(M.part[0].device))) return rc;
-        if ((rc = thr.tick(M.part[0].main, 10))) return rc;
+        if ((rc = set_dev(M.part[M.first_here()].device))) return rc;
+        if ((rc = thr.tick(M.part[M.first_here()].main, 10))) return rc;
     }
     if (nb & 1) {                                       // the odd last block: its panels are ready
         if ((rc = each([&](int, Part &q) -> int {
@@ -924,6 +959,8 @@ template <typename T> static int multi_solve_typed(fwx_matrix *m, const Opts &op
     int bits = 3;
     if (m->dom_known) {
         bits = m->dom_bits;
+    } else if (M.self >= 0) {
+        return FWX_ERR_INVALID;     // one partition per process: the host combines the ranks' bits (fwx_matrix_set_domain)
     } else {
         for (int p = 0; p < P; ++p) {
             Part &q = M.part[p];
@@ -954,11 +991,13 @@ template <typename T> static int multi_solve_typed(fwx_matrix *m, const Opts &op
         Part &q = M.part[p];
         for (int sl = 0; sl < 4; ++sl) { q.wp[sl] = q.w[sl]; q.whp[sl] = q.wh[sl]; }
     }
+    auto here = [&](int p) { return M.here(p); };
     // pass (k0, ...) reads / writes its own rows of the all-pivot arrays on a recording handle
     auto bind_slot = [&](const Block &blk, int slot) {
         if (!rec) return;
         for (int p = 0; p < P; ++p) {
             Part &q = M.part[p];
+            if (!here(p)) continue;
             q.wp[slot] = (char *)q.R.rw + (size_t)blk.k0 * nd * sizeof(T);
             q.whp[slot] = q.R.rwh ? q.R.rwh + (size_t)blk.k0 * nd : nullptr;
         }
@@ -971,6 +1010,7 @@ template <typename T> static int multi_solve_typed(fwx_matrix *m, const Opts &op
     };
     for (int p = 0; p < P; ++p) {
         Part &q = M.part[p];
+        if (!here(p)) continue;
         if ((rc = set_dev(q.device))) return rc;
         const size_t cells = (size_t)q.rows * nd;
         if (q.plog.last && !resumed) {
@@ -1014,7 +1054,7 @@ template <typename T> static int multi_solve_typed(fwx_matrix *m, const Opts &op
             if (rec->pivot[c] != k0) continue;
             for (int p = 0; p < P; ++p) {
                 Part &q = M.part[p];
-                if (q.rows == 0) continue;
+                if (q.rows == 0 || !here(p)) continue;
                 int rc2 = set_dev(q.device);
                 if (rc2) return rc2;
                 const size_t cells = (size_t)q.rows * nd;
@@ -1032,14 +1072,16 @@ template <typename T> static int multi_solve_typed(fwx_matrix *m, const Opts &op
     };
     // per-k engine on several partitions: one enqueueing thread per partition (see SweepWorkers)
     std::unique_ptr<SweepWorkers> workers;
-    if (perk && P > 1) {
+    if (perk && P > 1 && M.self < 0) {
         fail_point();
         workers.reset(new SweepWorkers(P));
     }
     {   // the first panel: its rows are at time k0 already
         Part &o = M.part[blocks[first].owner];
-        if ((rc = set_dev(o.device))) return rc;
-        FWX_HIP(hipEventRecord(o.rows_done, o.main));
+        if (here(blocks[first].owner)) {
+            if ((rc = set_dev(o.device))) return rc;
+            FWX_HIP(hipEventRecord(o.rows_done, o.main));
+        }
         bind_slot(blocks[first], 0);
         if ((rc = issue_panel<T>(M, blocks[first], 0, (int)first))) return rc;
     }
@@ -1057,7 +1099,7 @@ template <typename T> static int multi_solve_typed(fwx_matrix *m, const Opts &op
         // read from the slab itself by every launch, the main stream just waits for the panel
         for (int p = 0; p < P; ++p) {
             Part &q = M.part[p];
-            if (q.rows == 0) continue;
+            if (q.rows == 0 || !here(p)) continue;
             if ((rc = set_dev(q.device))) return rc;
             FWX_HIP(hipStreamWaitEvent(q.main, q.w_ready[slot], 0));
             t_bulk[p] = tm.begin(MultiTimer::BULK, p, step, q.main);
@@ -1073,6 +1115,7 @@ template <typename T> static int multi_solve_typed(fwx_matrix *m, const Opts &op
             const Block &nb = blocks[b + 1];
             Part &o = M.part[nb.owner];
             la_owner = nb.owner; la_lo = nb.k0 - o.row0; la_hi = la_lo + nb.bt;
+            if (here(nb.owner)) {
             if ((rc = set_dev(o.device))) return rc;
             fwx::FusedArgs<T> a = part_args<T>(M, o, nonneg, counting);
             a.k0 = blk.k0; a.bt = blk.bt; a.w = (const T *)o.wp[slot]; a.wh = o.whp[slot];
@@ -1092,11 +1135,13 @@ template <typename T> static int multi_solve_typed(fwx_matrix *m, const Opts &op
             }
             tm.end(t_la, o.main);
             FWX_HIP(hipEventRecord(o.rows_done, o.main));
+            }
             bind_slot(nb, slot ^ 1);
             if ((rc = issue_panel<T>(M, nb, slot ^ 1, step + 1))) return rc;
         }
         for (int p = 0; p < P; ++p) {
             Part &q = M.part[p];
+            if (!here(p)) continue;
             if ((rc = set_dev(q.device))) return rc;
             if (perk) continue;                       // the per-k sweeps: below, all partitions at once
             if (q.rows > 0) {
@@ -1120,7 +1165,7 @@ template <typename T> static int multi_solve_typed(fwx_matrix *m, const Opts &op
             // "row-partitioned, pivot-row broadcast per k" -- 64 rows per message)
             for (int p = 0; p < P; ++p) {
                 Part *qp = &M.part[p];
-                if (qp->rows == 0) continue;
+                if (qp->rows == 0 || !here(p)) continue;
                 const bool owner = p == la_owner;
                 auto job = [=, &op]() -> int {
                     Part &q = *qp;
@@ -1146,13 +1191,14 @@ template <typename T> static int multi_solve_typed(fwx_matrix *m, const Opts &op
             if (workers && (rc = workers->run_all())) return rc;
             for (int p = 0; p < P; ++p) {
                 Part &q = M.part[p];
+                if (!here(p)) continue;
                 if ((rc = set_dev(q.device))) return rc;
                 if (q.rows > 0) tm.end(t_bulk[p], q.main);
                 FWX_HIP(hipEventRecord(q.main_free[slot], q.main));
             }
         }
-        if ((rc = set_dev(M.part[0].device))) return rc;
-        if ((rc = thr.tick(M.part[0].main, perk ? blk.bt + 4 : 4))) return rc;
+        if ((rc = set_dev(M.part[M.first_here()].device))) return rc;
+        if ((rc = thr.tick(M.part[M.first_here()].main, perk ? blk.bt + 4 : 4))) return rc;
     }
     if ((rc = finish_multi_solve(m, counting, op))) return rc;
     if (rec) rec->valid_upto = rec->state_at = op.k_end;
@@ -1209,6 +1255,7 @@ void multi_resume_dims(const fwx_matrix *m, uint64_t *cells, uint64_t *col_cells
     *cells = *col_cells = *w_cells = 0;
     for (int p = 0; p < M.parts; ++p) {
         const Part &q = M.part[p];
+        if (!M.here(p)) continue;
         *cells += (uint64_t)q.rows * M.nd;
         *col_cells += (uint64_t)M.nd * (q.ct_ld ? q.ct_ld : 4);
         *w_cells += (uint64_t)M.nd * M.nd;                   // every partition keeps all pivot rows
@@ -1229,7 +1276,7 @@ int multi_enable_resume(fwx_matrix *m, int32_t checkpoints)
         {
             if (!r) return;
             for (int p = 0; p < M->parts; ++p)
-                if (hipSetDevice(M->part[p].device) == hipSuccess) part_resume_free(M->part[p]);
+                if (M->here(p) && hipSetDevice(M->part[p].device) == hipSuccess) part_resume_free(M->part[p]);
             delete r;
         }
     } hold;
@@ -1250,6 +1297,7 @@ int multi_enable_resume(fwx_matrix *m, int32_t checkpoints)
     auto alloc = [&](void **ptr, size_t bytes) -> int { FWX_HIP(hipMalloc(ptr, bytes ? bytes : 16)); return FWX_OK; };
     for (int p = 0; p < M.parts; ++p) {
         Part &q = M.part[p];
+        if (!M.here(p)) continue;
         int rc = set_dev(q.device);
         if (rc) return rc;
         const size_t cells = (size_t)q.rows * nd, pan = (size_t)nd * (q.ct_ld ? q.ct_ld : 4);
@@ -1302,6 +1350,7 @@ static int multi_resolve_typed(fwx_matrix *m, int32_t count, const int64_t *inde
         int p = 0;
         while (p + 1 < M.parts && row >= M.part[p + 1].row0) ++p;
         Part &q = M.part[p];
+        if (!M.here(p)) continue;
         if ((rc = set_dev(q.device))) return rc;
         const size_t off = (size_t)(row - q.row0) * nd + col;
         local[p].push_back((int64_t)off);
@@ -1311,7 +1360,7 @@ static int multi_resolve_typed(fwx_matrix *m, int32_t count, const int64_t *inde
     }
     for (int p = 0; p < M.parts; ++p) {
         Part &q = M.part[p];
-        if (q.rows == 0) continue;
+        if (q.rows == 0 || !M.here(p)) continue;
         if ((rc = set_dev(q.device))) return rc;
         const size_t cells = (size_t)q.rows * nd, ci = (size_t)c_idx;
         FWX_HIP(hipMemcpyAsync(q.rate, q.R.rate[ci], cells * sizeof(T), hipMemcpyDeviceToDevice, q.main));
@@ -1379,6 +1428,7 @@ int multi_enable_path_log(fwx_matrix *m)
     DevRestore keep;
     for (int p = 0; p < M.parts; ++p) {
         Part &q = M.part[p];
+        if (!M.here(p)) continue;
         int rc = set_dev(q.device);
         if (rc) return rc;
         const size_t bytes = (size_t)q.rows * M.nd * 4;
@@ -1391,7 +1441,7 @@ int multi_enable_path_log(fwx_matrix *m)
             FWX_HIP(hipStreamSynchronize(q.main));
         }
     }
-    m->plog.last = M.part[0].plog.last;     // "enabled" marker for the shared handle logic
+    m->plog.last = M.part[M.first_here()].plog.last;     // "enabled" marker for the shared handle logic
     m->rec_ready = 0;
     return FWX_OK;
 }
@@ -1459,6 +1509,7 @@ static int host_walk(fwx_matrix *m, int32_t src, int32_t dst, int32_t *path_out,
 int multi_query(fwx_matrix *m, int32_t src, int32_t dst, double *rate_out, int32_t *path_out, int32_t cap)
 {
     MultiState &M = *m->multi;
+    if (M.self >= 0) return FWX_ERR_UNSUPPORTED;   // one partition per process: a walk crosses the ranks' slabs
     DevRestore keep;
     int rc;
     if (rate_out && (rc = read_rate(m, src, dst, rate_out))) return rc;
@@ -1485,7 +1536,7 @@ int multi_query_exact_batch(fwx_matrix *m, int32_t count, const int32_t *src, co
                             int32_t *len_out, int32_t *path_out, int32_t cap)
 {
     MultiState &M = *m->multi;
-    if (!M.peer_all) return FWX_ERR_UNSUPPORTED;   // the walk reads every slab from one device
+    if (!M.peer_all || M.self >= 0) return FWX_ERR_UNSUPPORTED;   // the walk reads every slab from one device
     DevRestore keep;
     Part &z = M.part[0];
     int rc = set_dev(z.device);
@@ -1521,6 +1572,7 @@ int multi_query_exact(fwx_matrix *m, int32_t src, int32_t dst, double *rate_out,
                       int32_t cap)
 {
     int rc;
+    if (m->multi->self >= 0) return FWX_ERR_UNSUPPORTED;
     {
         DevRestore keep;
         if (rate_out && (rc = read_rate(m, src, dst, rate_out))) return rc;
@@ -1537,6 +1589,7 @@ int multi_keep_input(fwx_matrix *m)
     const size_t es = m->dtype == FWX_F64 ? 8 : 4;
     for (int p = 0; p < M.parts; ++p) {
         Part &q = M.part[p];
+        if (!M.here(p)) continue;
         int rc = set_dev(q.device);
         if (rc) return rc;
         const size_t cells = (size_t)q.rows * M.nd;
@@ -1569,6 +1622,7 @@ int multi_patch_input(fwx_matrix *m, int32_t count, const int64_t *index, const 
         int p = 0;
         while (p + 1 < M.parts && row >= M.part[p + 1].row0) ++p;
         Part &q = M.part[p];
+        if (!M.here(p)) continue;                  // (an entry of a row another process holds)
         if ((rc = set_dev(q.device))) return rc;
         const size_t off = (size_t)(row - q.row0) * M.nd + col;
         FWX_HIP(hipMemcpyAsync((char *)q.rate0 + off * es, (const char *)rate_vals + (size_t)e * es, es,
@@ -1578,6 +1632,7 @@ int multi_patch_input(fwx_matrix *m, int32_t count, const int64_t *index, const 
     }
     for (int p = 0; p < M.parts; ++p) {
         Part &q = M.part[p];
+        if (!M.here(p)) continue;
         if ((rc = set_dev(q.device))) return rc;
         const size_t cells = (size_t)q.rows * M.nd;
         FWX_HIP(hipMemcpyAsync(q.rate, q.rate0, cells * es, hipMemcpyDeviceToDevice, q.main));
@@ -1585,6 +1640,7 @@ int multi_patch_input(fwx_matrix *m, int32_t count, const int64_t *index, const 
         if (q.hops) FWX_HIP(hipMemcpyAsync(q.hops, q.hops0, cells * 4, hipMemcpyDeviceToDevice, q.main));
     }
     for (int p = 0; p < M.parts; ++p) {
+        if (!M.here(p)) continue;
         if ((rc = set_dev(M.part[p].device))) return rc;
         FWX_HIP(hipStreamSynchronize(M.part[p].main));
     }
@@ -1653,6 +1709,70 @@ int fwx_matrix_comm_ranks(const fwx_matrix *m)
         int ranks = 0;
         if (rccl().CommCount(m->multi->comms->comm[0], &ranks) != ncclSuccess) return FWX_ERR_RCCL;
         return ranks;
+    });
+}
+
+int fwx_matrix_create_part(fwx_matrix **out, int32_t n, int32_t dtype, int32_t with_next, int32_t with_hops,
+                           int32_t rank, int32_t world, int32_t device, fwx_exchange_fn exchange, void *ctx)
+{
+    return fwxi::guarded([&]() -> int {
+        if (!out || n < 0 || (dtype != FWX_F32 && dtype != FWX_F64) || world < 1 || world > FWX_MAX_PARTS ||
+            rank < 0 || rank >= world || !exchange || (with_hops && !with_next))
+            return FWX_ERR_INVALID;
+        *out = nullptr;
+        const int cnt = device_count();
+        if (cnt <= 0) return FWX_ERR_NO_DEVICE;
+        int cur = 0;
+        FWX_HIP(hipGetDevice(&cur));
+        const int dev = device == -1 ? cur : device;
+        if (dev < 0 || dev >= cnt) return FWX_ERR_INVALID;
+        int32_t devices[FWX_MAX_PARTS];
+        for (int p = 0; p < world; ++p) devices[p] = dev;          // (only devices[rank] is ever used)
+        fwx_matrix *m = new (std::nothrow) fwx_matrix();
+        if (!m) return FWX_ERR_OOM;
+        memset(m, 0, sizeof(*m));
+        m->n = m->nd = n; m->dtype = dtype; m->device = dev;
+        m->next = with_next ? (int32_t *)(uintptr_t)16 : nullptr;   // markers only: the slab owns the arrays
+        m->hops = with_hops ? (int32_t *)(uintptr_t)16 : nullptr;
+        DevRestore keep;
+        const int rc = multi_alloc(m, world, devices, FWX_XCHG_CALLBACK, rank, exchange, ctx);
+        if (rc) {
+            multi_destroy(m);
+            delete m;
+            return rc;
+        }
+        *out = m;
+        return FWX_OK;
+    });
+}
+
+int fwx_matrix_domain_bits(fwx_matrix *m, int32_t *bits_out)
+{
+    return fwxi::guarded([&]() -> int {
+        if (!m || !bits_out || !m->multi || m->multi->self < 0) return FWX_ERR_INVALID;
+        MultiState &M = *m->multi;
+        Part &q = M.part[M.self];
+        *bits_out = 3;
+        if (q.rows == 0 || m->n == 0) return FWX_OK;
+        DevRestore keep;
+        int rc = set_dev(q.device), b = 3;
+        if (rc) return rc;
+        rc = m->dtype == FWX_F64
+                 ? domain_bits<double>((const double *)q.rate, q.next, (size_t)q.rows * M.nd, q.flag, q.main, b)
+                 : domain_bits<float>((const float *)q.rate, q.next, (size_t)q.rows * M.nd, q.flag, q.main, b);
+        if (rc) return rc;
+        *bits_out = b;
+        return FWX_OK;
+    });
+}
+
+int fwx_matrix_set_domain(fwx_matrix *m, int32_t bits)
+{
+    return fwxi::guarded([&]() -> int {
+        if (!m || !m->multi || m->multi->self < 0 || bits < 0 || bits > 3) return FWX_ERR_INVALID;
+        m->dom_bits = bits;
+        m->dom_known = 1;
+        return FWX_OK;
     });
 }
 

@@ -273,10 +273,39 @@ int fwx_matrix_query_exact_batch(fwx_matrix *m, int32_t count, const int32_t *sr
 #define FWX_XCHG_AUTO 0
 #define FWX_XCHG_PEER 1
 #define FWX_XCHG_RCCL 2
+#define FWX_XCHG_CALLBACK 3   /* fwx_matrix_create_part only */
 #define FWX_MAX_PARTS 32
 int fwx_matrix_create_multi(fwx_matrix **out, int32_t n, int32_t dtype, int32_t with_next,
                             int32_t with_hops, int32_t n_parts, const int32_t *devices,
                             int32_t exchange);
+/* ---- the same partitioned solve, ONE PARTITION PER PROCESS (one process per GPU) -----------------
+ * fwx_matrix_create_part builds the handle of partition `rank` of `world` row blocks: only that slab
+ * lives in this process, and the one exchange of the algorithm -- the 64-pivot snapshot panel, from the
+ * rank that owns those rows to every other -- is the host's: `exchange` is called on the solving thread
+ * once per panel, in the same order on every rank, and must make `w` (count elements of the handle's
+ * dtype) and, if not NULL, `wh` (count int32: the hops of the pivot rows) hold rank `owner`'s copy ON
+ * EVERY RANK, ordered on `stream` (a hipStream_t: enqueue a broadcast on it -- RCCL, or MPI with the
+ * stream synchronised around it; floydwarshall_amd/dist.py uses torch.distributed).  Return 0, or non-zero
+ * to fail the solve (FWX_ERR_RCCL).  Everything else is the code the one-process handle runs -- same
+ * schedules (single pass, the 128-pivot pair schedule, the per-k engine), same kernels, path trace, kept
+ * input, resume -- and so the same bits.  What differs for the caller:
+ *   upload / download  take THIS RANK'S row block: rows [n*rank/world, n*(rank+1)/world) x n
+ *   the domain check   is per slab; the host combines the ranks' answers: fwx_matrix_domain_bits (local
+ *                      bits: 1 = every rate >= +0 and not NaN, 2 = no positive rate without a path), an
+ *                      all-reduce AND among the ranks, fwx_matrix_set_domain -- before the first solve of
+ *                      every upload (a solve without it: FWX_ERR_INVALID)
+ *   updates_out        receives this rank's share of U
+ *   patch / resolve    take the caller's n x n entry indices on every rank; each rank applies its rows'
+ *   queries            walk other ranks' slabs: FWX_ERR_UNSUPPORTED (download the slab instead)
+ * Every rank must issue the same calls with the same options (the schedule is a function of n, world,
+ * the options and the FWX_* environment), or the exchanges do not pair up.                           */
+typedef int (*fwx_exchange_fn)(void *ctx, int32_t k0, int32_t bt, int32_t owner, void *w, int32_t *wh,
+                               int64_t count, void *stream);
+int fwx_matrix_create_part(fwx_matrix **out, int32_t n, int32_t dtype, int32_t with_next, int32_t with_hops,
+                           int32_t rank, int32_t world, int32_t device, fwx_exchange_fn exchange, void *ctx);
+int fwx_matrix_domain_bits(fwx_matrix *m, int32_t *bits_out);
+int fwx_matrix_set_domain(fwx_matrix *m, int32_t bits);
+
 /* Per-step timings of the last solve of a partitioned handle, from HIP events on the streams the work
  * ran on (a diagnostic: each span costs two event records; off by default).  A step is one block of 64
  * pivots, or a PAIR of blocks where the solve ran two passes per main launch (pivots_per_step = 128).

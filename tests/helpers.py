@@ -155,16 +155,30 @@ def config5_solve_with_oracle_slices(dm, n, threads=None):
         if a > pos:
             dm.solve(k_begin=pos, k_end=a)
         er, en, eh = dm.download()
-        oracle.relax_mt(er, en, a, b, threads=threads, hops=eh)     # the oracle continues from the GPU state
+        # Two tests (the plain handle, P = 8 partitions) walk the same input through the same stretches.
+        # The oracle's continuation is a function of the state it starts from, so the second one to arrive
+        # reuses the first one's answer IF its own state before the stretch has the same bits (digests of
+        # all three arrays) -- 20 s of CPU less per stretch; otherwise the oracle runs again.
+        before = (digest(er), digest(en), digest(eh))
+        cached = _CONFIG5_ORACLE.get((n, a, b))
         dm.solve(k_begin=a, k_end=b)
         gr, gn, gh = dm.download()
-        assert_bits_equal(gr, er, "rate after pivots [%d, %d)" % (a, b))
-        assert_bits_equal(gn, en, "next after pivots [%d, %d)" % (a, b))
-        assert_bits_equal(gh, eh, "hops after pivots [%d, %d)" % (a, b))
+        if cached is not None and cached[0] == before:
+            assert (digest(gr), digest(gn), digest(gh)) == cached[1], \
+                "state after pivots [%d, %d) differs from the oracle's continuation" % (a, b)
+        else:
+            oracle.relax_mt(er, en, a, b, threads=threads, hops=eh)     # the oracle continues from the GPU state
+            assert_bits_equal(gr, er, "rate after pivots [%d, %d)" % (a, b))
+            assert_bits_equal(gn, en, "next after pivots [%d, %d)" % (a, b))
+            assert_bits_equal(gh, eh, "hops after pivots [%d, %d)" % (a, b))
+            _CONFIG5_ORACLE[(n, a, b)] = (before, (digest(er), digest(en), digest(eh)))
         del er, en, eh
         pos = b
     assert pos == n
     return gr, gn, gh
+
+
+_CONFIG5_ORACLE = {}     # (n, a, b) -> (digests of the state before the stretch, digests of the oracle's state after it)
 
 
 def check_walks_and_exact_lists(rate0, rate, nxt, hops, src, dst, walk_len, walk_prod, exact_lists_of):
