@@ -68,6 +68,7 @@ class Watchdog:
         self.exit_fn = exit_fn or os._exit
         self._lock = threading.Lock()
         self._label, self._deadline, self._done = None, None, []
+        self._valid = None
         self._stop = threading.Event()
         self._thread = None
         if self.bound_s > 0:
@@ -87,6 +88,14 @@ class Watchdog:
     def stop(self):
         self._stop.set()
 
+    def set_valid_line(self, line):
+        """From here on the run HAS its result: `line` (the dict the caller keeps filling) carries `value`
+        from the completed timed region.  If an optional leg hangs after this point the watchdog prints that
+        line as it stands, plus `extras_aborted`, and exits with code 0 -- a diagnostic leg must not cost the
+        measurement."""
+        with self._lock:
+            self._valid = line
+
     def error_line(self, label):
         line = dict(self.base)
         line.update({"value": None, "error": "watchdog: phase %r still running after %.0f s" % (label, self.bound_s),
@@ -98,6 +107,20 @@ class Watchdog:
             with self._lock:
                 label, deadline = self._label, self._deadline
             if label is not None and time.monotonic() > deadline:
+                with self._lock:
+                    valid = self._valid
+                if valid is not None:
+                    line = dict(valid)
+                    line["extras_aborted"] = {"hung_phase": label, "after_s": self.bound_s,
+                                              "phases_completed": list(self._done)}
+                    try:
+                        text = json.dumps(line)
+                    except (TypeError, ValueError, RuntimeError):
+                        text = json.dumps({k: v for k, v in line.items() if isinstance(v, (int, float, str, bool, type(None)))})
+                    if self.emit:
+                        print(text, file=self.out, flush=True)
+                    self.exit_fn(0)
+                    return
                 if self.emit:
                     print(json.dumps(self.error_line(label)), file=self.out, flush=True)
                 self.exit_fn(self.EXIT_CODE)
@@ -809,6 +832,7 @@ def run_multi(args):
                      "rccl_ranks_in_communicator": ranks, "partitions": parts,
                      "distinct_devices": len(set(devs))},
     }
+    dog.set_valid_line(out)         # `value` stands: whatever hangs from here on cannot cost the line
     if args.warmup < 1:
         out["warmup_note"] = "one counted solve ran before the timed region regardless of --warmup 0"
 
@@ -1045,6 +1069,7 @@ def run_dist(args, world, rank, local_rank):
                            "note": "VALU-issue-bound kernel: low HBM fraction by design"}
     out["exchange"] = {"transport": "rccl (torch.distributed)" if args.backend == "nccl" else args.backend,
                        "ranks_in_process_group": dist.get_world_size()}
+    dog.set_valid_line(out)         # `value` stands: whatever hangs from here on cannot cost the line
     if not args.no_extras:
         out["exchange"].update(timing_leg(None, args.engine))
         out["exchange"]["timing_note"] = (
@@ -1052,24 +1077,49 @@ def run_dist(args, world, rank, local_rank):
             "chain = look-ahead rows + owner's panel + broadcast (issue -> side stream released); "
             "chain_over_bulk > 1 = bound by the panel chain (DESIGN.md section 5)")
     if not args.no_extras and not args.no_fused_extra and args.engine == "perk":
-        # not part of `value`: the same workload on the fused engine (64 pivots per pass), best of 2
-        fbk = fwdist.HipBackend("fused")
+        # Not part of `value`: the same workload on the engine AUTO picks, through the C ABI's own partitioned
+        # handle -- one partition per process (fwx_matrix_create_part), its schedules (the 128-pivot pair
+        # schedule where the partitions start on multiples of 64) and event timings, the panel broadcast handed
+        # back to torch.distributed (dist.PartMatrix).  Best of 2, max over ranks.
+        dog.arm("fused-engine leg (one partition per process behind the C ABI)")
+        ph = fwdist.PartMatrix(n, np_dtype, rank, world, with_next=args.with_next, device=dev_index)
         times = []
-        dog.arm("fused-engine leg")
         for i in range(3):
+            ph.upload_dev(pristine, pristine_next)
             fence()
             t1 = time.perf_counter()
-            step(bk=fbk)
+            ph.solve(engine=fwdist.engine.FWX_ENGINE_FUSED)
             fence()
             times.append(time.perf_counter() - t1)
-        dog.disarm()
         tt = torch.tensor(times[1:], dtype=torch.float64, device=dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         ft = float(tt.min().item())
+        ph.set_timing(True)
+        ph.upload_dev(pristine, pristine_next)
+        ph.solve(engine=fwdist.engine.FWX_ENGINE_FUSED)
+        tm = ph.timing()
+        v = torch.tensor([tm["bulk_us"], tm["chain_us"], tm["exchange_us"], tm["panel_us"], tm["lookahead_us"]],
+                         dtype=torch.float64, device=dev)
+        dist.all_reduce(v, op=dist.ReduceOp.MAX)
+        bulk, chain, xch, pan, la = (float(x) for x in v.tolist())
+        # the result of this engine against the per-k engine's, slab by slab (bit for bit: same digest on every rank)
+        step()                                   # `rate` = the timed engine's result again
+        torch.cuda.synchronize()
+        same = torch.tensor([1 if torch.equal(torch.from_numpy(ph.download()[0]).to(dev), rate) else 0],
+                            dtype=torch.int32, device=dev)
+        dist.all_reduce(same, op=dist.ReduceOp.MIN)
+        ph.close()
+        dog.disarm()
         out["fused_engine"] = {"value": relax_per_step / ft, "unit": "edge-relaxations/s", "ms_per_step": 1e3 * ft,
-                               "steps": 2, "exchange": timing_leg(fbk, "fused"),
-                               "note": "same workload on the fused engine (what AUTO runs), restore included, "
-                                       "max over ranks, best of 2; not part of `value`"}
+                               "steps": 2, "equals_timed_engine_bits": bool(int(same.item())),
+                               "exchange": {"avg_bulk_us": bulk, "avg_chain_us": chain, "avg_exchange_us": xch,
+                                            "avg_panel_us": pan, "avg_lookahead_us": la,
+                                            "chain_over_bulk": chain / bulk if bulk > 0 else None,
+                                            "pivots_per_step": tm["pivots_per_step"], "steps": tm["steps"],
+                                            "avg_bulk_us_per_block": bulk * 64.0 / max(1, tm["pivots_per_step"])},
+                               "note": "same workload, fwx_opts.engine = FUSED on the one-partition-per-process "
+                                       "handle (fwx_matrix_create_part; panels by torch.distributed.broadcast from "
+                                       "libfwx's callback); solve only, max over ranks, best of 2; not part of `value`"}
     dog.stop()
     if rank == 0:
         if not args.no_cpu_baseline:

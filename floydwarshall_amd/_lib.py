@@ -31,10 +31,13 @@ FWX_UPDATE_SHARDS = 256
 FWX_FUSED_BLOCK = 64
 FWX_FLAG_NONNEG = 1
 FWX_XCHG_AUTO, FWX_XCHG_PEER, FWX_XCHG_RCCL = 0, 1, 2
+FWX_XCHG_CALLBACK = 3
 FWX_MAX_PARTS = 32
 
 c_i32 = ctypes.c_int32
 c_vp = ctypes.c_void_p
+# int exchange(void *ctx, int32 k0, int32 bt, int32 owner, void *w, int32 *wh, int64 count, void *stream)
+EXCHANGE_FN = ctypes.CFUNCTYPE(ctypes.c_int, c_vp, c_i32, c_i32, c_i32, c_vp, c_vp, ctypes.c_int64, c_vp)
 
 
 class FwxOpts(ctypes.Structure):
@@ -113,6 +116,10 @@ SIGNATURES = {
     "fwx_matrix_query_exact_batch": (ctypes.c_int, [c_vp, c_i32, c_vp, c_vp, c_vp, c_vp, c_i32]),
     "fwx_matrix_create_multi": (ctypes.c_int, [ctypes.POINTER(c_vp), c_i32, c_i32, c_i32, c_i32, c_i32,
                                                ctypes.POINTER(c_i32), c_i32]),
+    "fwx_matrix_create_part": (ctypes.c_int, [ctypes.POINTER(c_vp), c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32,
+                                              c_vp, c_vp]),
+    "fwx_matrix_domain_bits": (ctypes.c_int, [c_vp, ctypes.POINTER(c_i32)]),
+    "fwx_matrix_set_domain": (ctypes.c_int, [c_vp, c_i32]),
     "fwx_matrix_parts": (ctypes.c_int, [c_vp, ctypes.POINTER(c_i32)]),
     "fwx_matrix_set_timing": (ctypes.c_int, [c_vp, c_i32]),
     "fwx_matrix_get_timing": (ctypes.c_int, [c_vp, ctypes.POINTER(FwxMultiTiming)]),

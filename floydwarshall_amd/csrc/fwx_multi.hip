@@ -738,7 +738,8 @@ static void summarize_timing(MultiState &M)
         return c ? (float)(1e3 * a / c) : 0.0f;
     };
     auto mean = [&](int kind) -> float { return cnt[kind] ? (float)(1e3 * sum[kind] / cnt[kind]) : 0.0f; };
-    t.steps = (int32_t)cnt[MultiTimer::BULK] / (M.parts > 0 ? M.parts : 1);
+    const int held = M.self >= 0 ? 1 : (M.parts > 0 ? M.parts : 1);      // partitions whose spans this process has
+    t.steps = (int32_t)cnt[MultiTimer::BULK] / held;
     t.bulk_us = mean_of_max(MultiTimer::BULK);
     t.bulk_mean_us = mean(MultiTimer::BULK);
     t.lookahead_us = mean(MultiTimer::LOOKAHEAD);

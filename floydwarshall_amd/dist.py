@@ -18,6 +18,9 @@ Look-ahead: while a rank relaxes its slab with panel b, the owner of panel b+1 f
 those B rows up to date, runs their panel phase and starts the broadcast, so the exchange of
 panel b+1 overlaps the bulk of step b.
 """
+import ctypes
+
+import numpy as np
 import torch
 import torch.distributed as dist
 
@@ -319,3 +322,133 @@ def solve_partitioned(rate, n, rank, world, *, nxt=None, hops=None, trace=None, 
             w, wh, wait = nxt_panel
     if on_gpu:
         main.wait_stream(side)
+
+
+# ------------------------------------------------------------------------------------------------------
+# One partition per process behind the C ABI: fwx_matrix_create_part + a torch.distributed exchange
+# ------------------------------------------------------------------------------------------------------
+class _DevPtr:
+    """A device buffer libfwx owns, seen by torch through the CUDA array interface (no copy)."""
+
+    def __init__(self, ptr, count, typestr):
+        self.__cuda_array_interface__ = {"shape": (int(count),), "typestr": typestr, "data": (int(ptr), False),
+                                         "version": 2}
+
+
+class PartMatrix(engine.DeviceMatrix):
+    """Partition `rank` of `world` row blocks as an fwx_matrix in THIS process (fwx_matrix_create_part): the
+    schedules, kernels, path trace, kept input and resume are libfwx's own -- the very code the one-process
+    partitioned handle runs, incl. the 128-pivot pair schedule --, and the one exchange of the algorithm, the
+    snapshot panel of 64 pivot rows, is a `torch.distributed.broadcast` issued from libfwx's callback on the
+    partition's side stream (RCCL over xGMI in production; gloo for rehearsals with several ranks on one GPU).
+
+    upload / download work on this rank's row block (rows row_bounds(n, world)[rank] ... x n).  solve() first
+    combines the ranks' domain bits (an all-reduce), as the C header asks; count_updates returns this rank's
+    share of U.  Every rank must make the same calls with the same options."""
+
+    def __init__(self, n, dtype, rank, world, with_next=True, with_hops=False, device=-1, group=None):
+        from ._lib import EXCHANGE_FN
+        self.n, self.dtype = int(n), np.dtype(dtype)
+        self.with_next, self.with_hops = bool(with_next), bool(with_hops)
+        self.rank, self.world, self.group = int(rank), int(world), group
+        b = row_bounds(self.n, self.world)
+        self.row0, self.rows = b[self.rank], b[self.rank + 1] - b[self.rank]
+        self._views = {}
+        self._error = None
+        self._cb = EXCHANGE_FN(self._exchange)            # (kept alive with the handle)
+        h = ctypes.c_void_p()
+        code = engine.FWX_F64 if self.dtype == np.float64 else engine.FWX_F32
+        engine.check(engine.lib().fwx_matrix_create_part(ctypes.byref(h), self.n, code, int(self.with_next),
+                                                         int(self.with_hops), self.rank, self.world, device,
+                                                         ctypes.cast(self._cb, ctypes.c_void_p), None),
+                     "fwx_matrix_create_part")
+        self._h = h
+        self._domain_fresh = False
+
+    # -- the exchange: called by libfwx on the solving thread, once per panel, same order on every rank --
+    def _view(self, ptr, count, typestr, torch_dtype):
+        key = (int(ptr), int(count), typestr)
+        t = self._views.get(key)
+        if t is None:
+            t = torch.as_tensor(_DevPtr(ptr, count, typestr), device="cuda")
+            assert t.dtype == torch_dtype and t.data_ptr() == int(ptr)
+            if len(self._views) > 4096:
+                self._views.clear()
+            self._views[key] = t
+        return t
+
+    def _exchange(self, ctx, k0, bt, owner, w, wh, count, stream):
+        try:
+            src = owner if self.group is None else dist.get_global_rank(self.group, owner)
+            ts = "<f8" if self.dtype == np.float64 else "<f4"
+            tdt = torch.float64 if self.dtype == np.float64 else torch.float32
+            with torch.cuda.stream(torch.cuda.ExternalStream(int(stream))):
+                work = [dist.broadcast(self._view(w, count, ts, tdt), src=src, group=self.group, async_op=True)]
+                if wh:
+                    work.append(dist.broadcast(self._view(wh, count, "<i4", torch.int32), src=src, group=self.group,
+                                               async_op=True))
+                for x in work:
+                    x.wait()                      # the side stream waits for the collective, not the host
+            return 0
+        except Exception as err:                  # never let an exception unwind into C
+            self._error = err
+            return -1
+
+    # -- slab-shaped transfers ------------------------------------------------------------------------------
+    def upload(self, rate, nxt=None, hops=None):
+        for a in (rate, nxt, hops):
+            assert a is None or (a.shape == (self.rows, self.n) and a.flags.c_contiguous)
+        assert rate.dtype == self.dtype
+        engine.check(engine.lib().fwx_matrix_upload(self._h, rate.ctypes.data_as(ctypes.c_void_p),
+                                                    None if nxt is None else nxt.ctypes.data_as(ctypes.c_void_p),
+                                                    None if hops is None else hops.ctypes.data_as(ctypes.c_void_p)),
+                     "fwx_matrix_upload")
+        self._domain_fresh = False
+
+    def upload_dev(self, rate_d, next_d=None, hops_d=None):
+        super().upload_dev(rate_d, next_d, hops_d)
+        self._domain_fresh = False
+
+    def download(self):
+        rate = np.empty((self.rows, self.n), dtype=self.dtype)
+        nxt = np.empty((self.rows, self.n), dtype=np.int32) if self.with_next else None
+        hops = np.empty((self.rows, self.n), dtype=np.int32) if self.with_hops else None
+        ptr = lambda a: None if a is None else a.ctypes.data_as(ctypes.c_void_p)  # noqa: E731
+        engine.check(engine.lib().fwx_matrix_download(self._h, ptr(rate), ptr(nxt), ptr(hops)), "fwx_matrix_download")
+        return rate, nxt, hops
+
+    def patch_input(self, index, rate_vals, next_vals=None, hops_vals=None):
+        super().patch_input(index, rate_vals, next_vals, hops_vals)
+        self._domain_fresh = False
+
+    def _vote(self):
+        """The domain must hold on EVERY rank (fwx.h "Domain"): local bits -> all-reduce AND -> set."""
+        if self._domain_fresh:
+            return
+        bits = ctypes.c_int32(3)
+        engine.check(engine.lib().fwx_matrix_domain_bits(self._h, ctypes.byref(bits)), "fwx_matrix_domain_bits")
+        ok = torch.tensor([bits.value & 1, (bits.value >> 1) & 1], dtype=torch.int32, device="cuda")
+        if self.world > 1:
+            dist.all_reduce(ok, op=dist.ReduceOp.MIN, group=self.group)
+        d1, d2 = (int(v) for v in ok.tolist())
+        engine.check(engine.lib().fwx_matrix_set_domain(self._h, d1 | (d2 << 1)), "fwx_matrix_set_domain")
+        self._domain_fresh = True
+
+    def solve(self, **kw):
+        self._vote()
+        self._error = None
+        try:
+            return super().solve(**kw)
+        except engine.FwxError:
+            if self._error is not None:
+                raise self._error
+            raise
+
+    def resolve(self, index, rate_vals, next_vals=None, hops_vals=None, **kw):
+        self._error = None
+        try:
+            return super().resolve(index, rate_vals, next_vals, hops_vals, **kw)
+        except engine.FwxError:
+            if self._error is not None:
+                raise self._error
+            raise

@@ -155,3 +155,29 @@ def test_the_ipc_mode_is_set_before_any_hip_call():
             "print(os.environ['HSA_ENABLE_IPC_MODE_LEGACY'])" % ROOT)
     r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=120, env=env)
     assert r.stdout.strip() == "1", r.stderr
+
+
+def test_a_hung_extra_leg_does_not_cost_the_measurement():
+    """Once the timed region has produced `value`, a leg that hangs (the event-timed solve, the fused-engine
+    leg) makes the watchdog print THAT line as it stands, flagged `extras_aborted`, and exit with code 0."""
+    import io
+    import json
+    import time
+    import bench
+    out, codes = io.StringIO(), []
+    dog = bench.Watchdog(0.3, {"metric": "m"}, out=out, exit_fn=codes.append)
+    line = {"metric": "m", "value": 1.5e12, "n_gpus": 8, "exchange": {"transport": "rccl"}}
+    dog.arm("the 2 timed steps")
+    dog.disarm()
+    dog.set_valid_line(line)
+    line["exchange"]["avg_bulk_us"] = 1300.0          # the caller keeps filling the same dict
+    dog.arm("fused-engine leg")
+    for _ in range(40):
+        if codes:
+            break
+        time.sleep(0.1)
+    assert codes == [0]
+    got = json.loads(out.getvalue().strip())
+    assert got["value"] == 1.5e12 and got["exchange"]["avg_bulk_us"] == 1300.0 and "error" not in got
+    assert got["extras_aborted"]["hung_phase"] == "fused-engine leg"
+    assert got["extras_aborted"]["phases_completed"] == ["the 2 timed steps"]
