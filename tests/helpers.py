@@ -148,37 +148,43 @@ def config5_solve_with_oracle_slices(dm, n, threads=None):
     a 128-pivot launch ends exactly there) and the last 256 pivots (ending at the solved matrix).  Every
     stretch is a pivot range of its own on the GPU -- four full blocks: two 128-pivot launches of the double
     pass, panels across a launch boundary -- and is continued on the oracle (relax_mt with next + hops,
-    ~20 s each) from the state the GPU held before it.  Returns the solved (rate, next, hops)."""
+    ~20 s each) from the state the GPU held before it.  Returns the solved (rate, next, hops).
+
+    Two tests (the plain handle, P = 8 partitions) walk the same input through the same stretches.  The
+    first to run does the above and records the digests of the oracle's state after each stretch; the
+    second only has to reach THOSE states: equal digests after a stretch mean its matrix equals one the
+    oracle produced from a verified predecessor -- no second oracle run, no download before the stretch.
+    The oracle runs on a thread of its own (ctypes releases the GIL) while the GPU solves the stretch and the
+    result comes back over PCIe."""
+    import threading
     import oracle
     pos = 0
     for a, b in CONFIG5_SLICES:
         if a > pos:
             dm.solve(k_begin=pos, k_end=a)
-        er, en, eh = dm.download()
-        # Two tests (the plain handle, P = 8 partitions) walk the same input through the same stretches.
-        # The oracle's continuation is a function of the state it starts from, so the second one to arrive
-        # reuses the first one's answer IF its own state before the stretch has the same bits (digests of
-        # all three arrays) -- 20 s of CPU less per stretch; otherwise the oracle runs again.
-        before = (digest(er), digest(en), digest(eh))
         cached = _CONFIG5_ORACLE.get((n, a, b))
+        if cached is None:
+            er, en, eh = dm.download()
+            t = threading.Thread(target=oracle.relax_mt, args=(er, en, a, b), kwargs={"threads": threads, "hops": eh})
+            t.start()                                # the oracle continues from the GPU state, beside the GPU
         dm.solve(k_begin=a, k_end=b)
         gr, gn, gh = dm.download()
-        if cached is not None and cached[0] == before:
-            assert (digest(gr), digest(gn), digest(gh)) == cached[1], \
-                "state after pivots [%d, %d) differs from the oracle's continuation" % (a, b)
-        else:
-            oracle.relax_mt(er, en, a, b, threads=threads, hops=eh)     # the oracle continues from the GPU state
+        if cached is None:
+            t.join()
             assert_bits_equal(gr, er, "rate after pivots [%d, %d)" % (a, b))
             assert_bits_equal(gn, en, "next after pivots [%d, %d)" % (a, b))
             assert_bits_equal(gh, eh, "hops after pivots [%d, %d)" % (a, b))
-            _CONFIG5_ORACLE[(n, a, b)] = (before, (digest(er), digest(en), digest(eh)))
-        del er, en, eh
+            _CONFIG5_ORACLE[(n, a, b)] = (digest(er), digest(en), digest(eh))
+            del er, en, eh
+        else:
+            assert (digest(gr), digest(gn), digest(gh)) == cached, \
+                "state after pivots [%d, %d) differs from the oracle's continuation" % (a, b)
         pos = b
     assert pos == n
     return gr, gn, gh
 
 
-_CONFIG5_ORACLE = {}     # (n, a, b) -> (digests of the state before the stretch, digests of the oracle's state after it)
+_CONFIG5_ORACLE = {}     # (n, a, b) -> digests (rate, next, hops) of the oracle's state after the stretch
 
 
 def check_walks_and_exact_lists(rate0, rate, nxt, hops, src, dst, walk_len, walk_prod, exact_lists_of):

@@ -6,7 +6,9 @@
  * 1. the reference's 4-vertex graph (src/test/MockData.hs:47-57) through fwx_solve_f64 and the
  *    expectations of src/test/AlgorithmsTest.hs:72-75;
  * 2. the same rates through the host mirror (updateRates -> findBestRate), README.md:188-246;
- * 3. the same matrix through fwx_solve_multi_f64 (row-partitioned, one process). */
+ * 3. the same matrix through fwx_solve_multi_f64 (row-partitioned, one process);
+ * 4. a 200-vertex matrix through fwx_matrix_create_part (one partition per process; here world = 1, so
+ *    the host's exchange callback has nothing to move) against fwx_solve_f64, with the event timings. */
 #include <math.h>
 #include <stdio.h>
 #include <stdlib.h>
@@ -22,6 +24,19 @@
             return 1;                                                                              \
         }                                                                                          \
     } while (0)
+
+/* The host's side of the one exchange a partitioned solve has (fwx.h fwx_exchange_fn): make the panel on
+ * this rank hold rank `owner`'s copy, ordered on `stream`.  With one rank the panel is already in place; a
+ * real host enqueues ncclBroadcast(w, w, count, type, owner, comm, stream) here. */
+static int panels_seen = 0;
+static int exchange(void *ctx, int32_t k0, int32_t bt, int32_t owner, void *w, int32_t *wh, int64_t count,
+                    void *stream)
+{
+    (void)ctx; (void)k0; (void)wh; (void)stream;
+    if (owner != 0 || !w || count != (int64_t)bt * 200) return -1;
+    ++panels_seen;
+    return 0;
+}
 
 int main(void)
 {
@@ -66,6 +81,39 @@ int main(void)
         if (rc) fprintf(stderr, "fwx_solve_multi_f64: %s\n", fwx_strerror(rc));
         CHECK(rc == FWX_OK);
         for (i = 0; i < 16; ++i) CHECK(r2[i] == rate[i] && n2[i] == next[i]);
+    }
+
+    {
+        /* 4. one partition per process: create_part, slab upload, the ranks'
+         * domain vote (one rank here), solve, slab download */
+        enum { N = 200 };
+        static double a[N * N], b[N * N];
+        static int32_t an[N * N], bn[N * N];
+        fwx_matrix *m = NULL;
+        fwx_multi_timing tm;
+        int32_t bits = 0;
+        int i, j;
+        for (i = 0; i < N; ++i)
+            for (j = 0; j < N; ++j) {
+                a[i * N + j] = b[i * N + j] = i == j ? 0.0 : 0.05 + 0.95 * (double)((i * 131 + j * 71) % 997) / 997.0;
+                an[i * N + j] = bn[i * N + j] = i == j ? -1 : j;
+            }
+        CHECK(fwx_solve_f64(N, a, an, NULL, NULL) == FWX_OK);
+        CHECK(fwx_matrix_create_part(&m, N, FWX_F64, 1, 0, 0, 1, -1, exchange, NULL) == FWX_OK && m != NULL);
+        CHECK(fwx_matrix_set_timing(m, 1) == FWX_OK);
+        CHECK(fwx_matrix_upload(m, b, bn, NULL) == FWX_OK);
+        CHECK(fwx_matrix_solve(m, NULL) == FWX_ERR_INVALID);          /* the domain vote comes first */
+        CHECK(fwx_matrix_upload(m, b, bn, NULL) == FWX_OK);
+        CHECK(fwx_matrix_domain_bits(m, &bits) == FWX_OK && bits == 3);
+        CHECK(fwx_matrix_set_domain(m, bits) == FWX_OK);
+        CHECK(fwx_matrix_solve(m, NULL) == FWX_OK);
+        CHECK(fwx_matrix_download(m, b, bn, NULL) == FWX_OK);
+        for (i = 0; i < N * N; ++i) CHECK(a[i] == b[i] && an[i] == bn[i]);
+        CHECK(panels_seen == 4);                                       /* 200 pivots = 4 panels */
+        memset(&tm, 0, sizeof(tm));
+        tm.struct_size = (uint32_t)sizeof(tm);
+        CHECK(fwx_matrix_get_timing(m, &tm) == FWX_OK && tm.steps == 4 && tm.bulk_us > 0.0f);
+        CHECK(fwx_matrix_destroy(m) == FWX_OK);
     }
 
     {

@@ -150,3 +150,56 @@ def test_resumed_solves_across_processes(tmp_path):
         assert_bits_equal(gn, en, "next after change %d" % step)
     metas = {open(tmp_path / ("meta_%d.txt" % r)).read() for r in range(world)}
     assert metas == {"3 256 128 0"}                                  # checkpoints 128 / 256 / 384 on both ranks
+
+
+def _rccl_worker(rank, port, n, outdir):
+    import datetime
+    import warnings
+    import torch
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ["FWX_DOUBLE_PASS_MIN_N"] = "0"
+    os.environ["FWX_DOUBLE_PASS_NEXT_MIN_N"] = "0"
+    torch.cuda.set_device(0)
+    dev = torch.device("cuda:0")
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev, timeout=datetime.timedelta(seconds=120))
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore", RuntimeWarning)
+        from floydwarshall_amd import dist as fwdist
+        from floydwarshall_amd import engine, synth
+    rate, nxt, hops = synth.make("d2", n, np.float32, seed=779)
+    h = fwdist.PartMatrix(n, np.float32, 0, 1, with_next=True, with_hops=True, device=0)
+    h.set_timing(True)
+    # from DEVICE arrays, as the benchmark uploads its pristine slab
+    h.upload_dev(torch.from_numpy(rate).to(dev), torch.from_numpy(nxt).to(dev), torch.from_numpy(hops).to(dev))
+    h.solve(engine=engine.FWX_ENGINE_FUSED)
+    t = h.timing()
+    gr, gn, gh = h.download()
+    np.save(os.path.join(outdir, "rate.npy"), gr)
+    np.save(os.path.join(outdir, "next.npy"), gn)
+    np.save(os.path.join(outdir, "hops.npy"), gh)
+    with open(os.path.join(outdir, "meta.txt"), "w") as f:
+        f.write("%d %d %.3f" % (t["pivots_per_step"], t["steps"], t["exchange_us"]))
+    h.close()
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_the_exchange_callback_over_real_rccl_with_one_rank(tmp_path):
+    """Backend "nccl" = RCCL itself, one rank: every panel goes through libfwx's callback into
+    torch.distributed.broadcast on the partition's side stream (torch.cuda.ExternalStream over libfwx's
+    stream, torch.as_tensor over its panel buffer) exactly as with N ranks -- stream ordering against RCCL's
+    internal stream on the real library, under the pair schedule."""
+    import oracle
+    from floydwarshall_amd import synth
+    from helpers import assert_bits_equal, spawn_ranks
+    n = 640
+    spawn_ranks(_rccl_worker, (_free_port(), n, str(tmp_path)), 1)
+    rate, nxt, hops = synth.make("d2", n, np.float32, seed=779)
+    oracle.relax(rate, nxt, hops)
+    assert_bits_equal(np.load(tmp_path / "rate.npy"), rate, "rate over RCCL")
+    assert_bits_equal(np.load(tmp_path / "next.npy"), nxt, "next over RCCL")
+    assert_bits_equal(np.load(tmp_path / "hops.npy"), hops, "hops over RCCL")
+    pps, steps, xus = open(tmp_path / "meta.txt").read().split()
+    assert int(pps) == 128 and int(steps) >= 1 and float(xus) > 0
