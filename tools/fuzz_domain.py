@@ -95,23 +95,55 @@ with np.errstate(all="ignore"):
             if gh is not None:
                 assert_bits_equal(gh, eh, "hops n=%d" % n)
             assert not count or u == eu
-        # partitioned handle, random P, with hops and the trace; exact lists against the per-k trace
+        # partitioned handle, random P, with hops and the trace; exact lists against the per-k trace.  Round 4:
+        # the plain handle also on AUTO (any n: the handle pads its rows), the pair schedule forced at random
+        # (FWX_DOUBLE_PASS_*: read on every solve), and one price change RESUMED on each resumable handle
         parts = int(rnd.integers(1, 9))
         src = rnd.integers(0, n, 64).astype(np.int32)
         dst = rnd.integers(0, n, 64).astype(np.int32)
         lists = []
-        for kw in (dict(devices=[0] * parts), dict(device=0)):
+        for var in ("FWX_DOUBLE_PASS_MIN_N", "FWX_DOUBLE_PASS_NEXT_MIN_N"):
+            if rnd.random() < 0.5:
+                os.environ[var] = "0"
+            else:
+                os.environ.pop(var, None)
+        # the price change: one entry of a late row scaled down (stays inside the domain, no new arbitrage)
+        pi, pj = int(rnd.integers(n // 2, n)), int(rnd.integers(0, n))
+        patch = pi != pj and n > 64 and bool(rate[pi, pj] > 0) and bool(np.isfinite(rate[pi, pj]))
+        if patch:
+            r2 = rate.copy()
+            r2[pi, pj] = dtype(r2[pi, pj] * dtype(0.75))
+            er2, en2, eh2 = r2.copy(), nxt.copy(), hops.copy()
+            note("case %d: n=%d %s oracle of the patched input" % (cases, n, dtype.__name__))
+            if n > 256:
+                oracle.relax_mt(er2, en2, hops=eh2, threads=8)
+            else:
+                oracle.relax(er2, en2, eh2)
+        for kw in (dict(devices=[0] * parts), dict(device=0), dict(device=0, auto=True)):
             note("case %d: n=%d %s handle %s" % (cases, n, dtype.__name__, kw))
+            auto = kw.pop("auto", False)
             with engine.DeviceMatrix(n, dtype, with_next=True, with_hops=True, **kw) as dm:
                 dm.enable_path_log()
+                resumable = patch and ("devices" in kw or auto)
+                if resumable:
+                    dm.keep_input()
+                    dm.enable_resume(3)
                 dm.upload(rate, nxt, hops)
-                dm.solve(engine=engine.FWX_ENGINE_AUTO if "devices" in kw else engine.FWX_ENGINE_PERK)
+                dm.solve(engine=engine.FWX_ENGINE_AUTO if ("devices" in kw or auto) else engine.FWX_ENGINE_PERK)
                 gr, gn, gh = dm.download()
                 assert_bits_equal(gr, er, "handle rate n=%d P=%s" % (n, kw))
                 assert_bits_equal(gn, en, "handle next")
                 assert_bits_equal(gh, eh, "handle hops")
                 lists.append(dm.query_exact_batch(src, dst, cap=16 * n + 64))
-        assert lists[0] == lists[1], "exact lists: partitioned fused trace vs per-k trace, n=%d P=%d" % (n, parts)
+                if resumable:
+                    note("case %d: n=%d %s resolve (%d,%d) %s" % (cases, n, dtype.__name__, pi, pj, kw))
+                    dm.resolve(np.array([pi * n + pj], dtype=np.int64), np.array([r2[pi, pj]], dtype=dtype),
+                               np.array([pj], dtype=np.int32), np.array([1], dtype=np.int32))
+                    gr, gn, gh = dm.download()
+                    assert_bits_equal(gr, er2, "resumed rate n=%d %s" % (n, kw))
+                    assert_bits_equal(gn, en2, "resumed next")
+                    assert_bits_equal(gh, eh2, "resumed hops")
+        assert lists[0] == lists[1] == lists[2], "exact lists: partitioned / plain fused trace vs per-k trace, n=%d P=%d" % (n, parts)
         cases += 1
         if cases % 20 == 0:
             print("%d cases, %.0f s" % (cases, time.time() - t0), flush=True)
