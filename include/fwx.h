@@ -184,8 +184,12 @@ int fwx_matrix_patch_input(fwx_matrix *m, int32_t count, const int64_t *index, c
  * enable_resume: after create, enable_path_log (if the trace is wanted: afterwards it is refused) and
  *   keep_input, before the upload whose solve is to be resumable; `checkpoints` in 1..FWX_MAX_CHECKPOINTS, spread evenly over the pivots on multiples
  *   of 64; returns the number placed (n < 128 leaves room for none: 0), or FWX_ERR_UNSUPPORTED where
- *   AUTO does not take the fused engine (n <= 64) and on partitioned handles.  Any other n works
- *   (the handle pads its rows).  Memory: one copy of every array per checkpoint + ~2.5 more for the panels.
+ *   AUTO does not take the fused engine (n <= 64).  Any other n works (the handle pads its rows), on one
+ *   device and on partitioned handles alike -- there every partition keeps the checkpoints of its slab, its
+ *   own part of the pivot-column snapshots and ALL pivot rows (it receives them anyway), a changed entry is
+ *   replayed on the partition that owns its row, and a checkpoint must be a block start: with partitions
+ *   that do not start on a multiple of 64 fewer are placed.  Memory: one copy of every array per checkpoint
+ *   + ~2.5 more for the panels (fwx_matrix_resume_bytes gives the figure).
  * resolve: fwx_matrix_patch_input + fwx_matrix_solve in one call, resuming where it can.  Falls back
  *   to exactly that pair (a full solve from the patched kept input, which records afresh) when there
  *   is nothing to resume from: no checkpoint at or below m, the previous solve did not record (other
