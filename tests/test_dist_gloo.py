@@ -84,8 +84,17 @@ def _worker(rank, world, port, n, block, lookahead, kind, with_next, outdir):
     slab = torch.from_numpy(rate[b[rank]:b[rank + 1]].copy())
     nslab = torch.from_numpy(nxt[b[rank]:b[rank + 1]].copy()) if with_next else None
     hslab = torch.from_numpy(hops[b[rank]:b[rank + 1]].copy()) if with_next else None
+    # (with the per-step spans the benchmark's N > 1 line reports -- wall clock on the CPU; they must not
+    #  change the schedule)
+    timer = fwdist.StepTimer(on_gpu=False)
     fwdist.solve_partitioned(slab, n, rank, world, nxt=nslab, hops=hslab, block=block,
-                             backend=OracleBackend(), lookahead=lookahead)
+                             backend=OracleBackend(), lookahead=lookahead, timer=timer)
+    sm = timer.summary()
+    blocks = fwdist.pivot_blocks(n, world, block)
+    mine = sum(1 for i, bk in enumerate(blocks) if bk[2] == rank)
+    assert sm["bulk"][1] == len(blocks) and sm["exchange"][1] == len(blocks) and sm["panel"][1] == mine
+    assert sm["lookahead"][1] == (sum(1 for i, bk in enumerate(blocks) if i > 0 and bk[2] == rank) if lookahead else 0)
+    assert all(v[0] >= 0.0 for v in sm.values())
     np.save(os.path.join(outdir, "rate_%d.npy" % rank), slab.numpy())
     if with_next:
         np.save(os.path.join(outdir, "next_%d.npy" % rank), nslab.numpy())
