@@ -118,6 +118,7 @@ SIGNATURES = {
                                                ctypes.POINTER(c_i32), c_i32]),
     "fwx_matrix_create_part": (ctypes.c_int, [ctypes.POINTER(c_vp), c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32,
                                               c_vp, c_vp]),
+    "fwx_matrix_part_rows": (ctypes.c_int, [c_vp, c_i32, ctypes.POINTER(c_i32), ctypes.POINTER(c_i32)]),
     "fwx_matrix_domain_bits": (ctypes.c_int, [c_vp, ctypes.POINTER(c_i32)]),
     "fwx_matrix_set_domain": (ctypes.c_int, [c_vp, c_i32]),
     "fwx_matrix_parts": (ctypes.c_int, [c_vp, ctypes.POINTER(c_i32)]),

@@ -396,6 +396,18 @@ static void multi_free(MultiState *M)
     delete M;
 }
 
+// First row of partition p of P: balanced row blocks, n * p / P -- rounded down to a multiple of 64 once every
+// partition holds at least two blocks (n >= 128 P).  A pivot block never straddles two partitions, so with
+// aligned partitions every block is a full, aligned 64 whatever n is: the pair schedule (128 pivots per main
+// launch) and the checkpoints of resumable solves (block starts) then apply to ANY matrix order, not only to
+// multiples of 64 P.  The imbalance is below one block per partition.  fwx_matrix_part_rows reports the bounds.
+static int part_bound(int n, int parts, int p)
+{
+    if (p >= parts) return n;
+    const int b = (int)((int64_t)n * p / parts);
+    return n >= 2 * FWX_FUSED_BLOCK * parts ? b / FWX_FUSED_BLOCK * FWX_FUSED_BLOCK : b;
+}
+
 static int multi_alloc(fwx_matrix *m, int n_parts, const int32_t *devices, int exchange, int self = -1,
                        fwx_exchange_fn xfn = nullptr, void *xctx = nullptr)
 {
@@ -420,8 +432,8 @@ static int multi_alloc(fwx_matrix *m, int n_parts, const int32_t *devices, int e
     for (int p = 0; p < n_parts; ++p) {
         Part &q = M->part[p];
         q.device = devices[p];
-        q.row0 = (int)((int64_t)m->n * p / n_parts);
-        const int r1 = p + 1 == n_parts ? nd : (int)((int64_t)m->n * (p + 1) / n_parts);   // padding rows: last
+        q.row0 = part_bound(m->n, n_parts, p);
+        const int r1 = p + 1 == n_parts ? nd : part_bound(m->n, n_parts, p + 1);   // padding rows: last
         q.rows = r1 - q.row0;
         q.ct_ld = (q.rows + 3) & ~3;
         if (!M->here(p)) continue;                 // (another process holds it)
@@ -1743,6 +1755,26 @@ int fwx_matrix_create_part(fwx_matrix **out, int32_t n, int32_t dtype, int32_t w
             return rc;
         }
         *out = m;
+        return FWX_OK;
+    });
+}
+
+int fwx_matrix_part_rows(const fwx_matrix *m, int32_t part, int32_t *row0_out, int32_t *rows_out)
+{
+    return fwxi::guarded([&]() -> int {
+        if (!m || part < 0) return FWX_ERR_INVALID;
+        int row0 = 0, rows = m->n;
+        if (m->multi) {
+            if (part >= m->multi->parts) return FWX_ERR_INVALID;
+            const Part &q = m->multi->part[part];
+            row0 = q.row0;
+            rows = q.row0 + q.rows <= m->n ? q.rows : m->n - q.row0;      // (the last slab also holds the padding rows)
+            if (rows < 0) rows = 0;
+        } else if (part != 0) {
+            return FWX_ERR_INVALID;
+        }
+        if (row0_out) *row0_out = row0;
+        if (rows_out) *rows_out = rows;
         return FWX_OK;
     });
 }

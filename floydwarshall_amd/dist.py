@@ -342,7 +342,8 @@ class PartMatrix(engine.DeviceMatrix):
     snapshot panel of 64 pivot rows, is a `torch.distributed.broadcast` issued from libfwx's callback on the
     partition's side stream (RCCL over xGMI in production; gloo for rehearsals with several ranks on one GPU).
 
-    upload / download work on this rank's row block (rows row_bounds(n, world)[rank] ... x n).  solve() first
+    upload / download work on this rank's row block: rows [row0, row0 + rows) x n, as the LIBRARY places them
+    (self.row0 / self.rows, bounds(): 64-aligned for n >= 128 * world; not row_bounds()).  solve() first
     combines the ranks' domain bits (an all-reduce), as the C header asks; count_updates returns this rank's
     share of U.  Every rank must make the same calls with the same options."""
 
@@ -351,8 +352,6 @@ class PartMatrix(engine.DeviceMatrix):
         self.n, self.dtype = int(n), np.dtype(dtype)
         self.with_next, self.with_hops = bool(with_next), bool(with_hops)
         self.rank, self.world, self.group = int(rank), int(world), group
-        b = row_bounds(self.n, self.world)
-        self.row0, self.rows = b[self.rank], b[self.rank + 1] - b[self.rank]
         self._views = {}
         self._error = None
         self._cb = EXCHANGE_FN(self._exchange)            # (kept alive with the handle)
@@ -364,6 +363,9 @@ class PartMatrix(engine.DeviceMatrix):
                      "fwx_matrix_create_part")
         self._h = h
         self._domain_fresh = False
+        # the library places the partitions (64-aligned for n >= 128 * world, so that the pair schedule and
+        # resume checkpoints apply to any n): ask it, do not assume row_bounds()
+        self.row0, self.rows = self.part_rows(self.rank)
 
     # -- the exchange: called by libfwx on the solving thread, once per panel, same order on every rank --
     def _view(self, ptr, count, typestr, torch_dtype):
@@ -393,6 +395,10 @@ class PartMatrix(engine.DeviceMatrix):
         except Exception as err:                  # never let an exception unwind into C
             self._error = err
             return -1
+
+    def bounds(self):
+        """[first row of partition 0, ..., of partition world - 1, n]: where the library cut the matrix."""
+        return [self.part_rows(p)[0] for p in range(self.world)] + [self.n]
 
     # -- slab-shaped transfers ------------------------------------------------------------------------------
     def upload(self, rate, nxt=None, hops=None):

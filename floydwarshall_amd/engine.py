@@ -126,6 +126,12 @@ class DeviceMatrix:
         p = check(lib().fwx_matrix_parts(self._h, ctypes.byref(x)), "fwx_matrix_parts")
         return p, int(x.value)
 
+    def part_rows(self, part):
+        """(row0, rows) of partition `part` (fwx_matrix_part_rows)."""
+        r0, rs = ctypes.c_int32(0), ctypes.c_int32(0)
+        check(lib().fwx_matrix_part_rows(self._h, int(part), ctypes.byref(r0), ctypes.byref(rs)), "fwx_matrix_part_rows")
+        return int(r0.value), int(rs.value)
+
     def comm_ranks(self):
         """Ranks of the RCCL communicator the partitions exchange panels on (0: not RCCL)."""
         return check(lib().fwx_matrix_comm_ranks(self._h), "fwx_matrix_comm_ranks")

@@ -239,7 +239,7 @@ int fwx_matrix_query_exact_batch(fwx_matrix *m, int32_t count, const int32_t *sr
  * The reference has one call site, ProcessRequests.hs:82-84 -> floydWarshall (Algorithms.hs:19-20);
  * a host bound to that one call gets the whole node through these entry points.  The matrix is cut
  * into n_parts contiguous row blocks (partition p holds rows [n*p/P, n*(p+1)/P) of rate / next and
- * of the path trace); step k needs, besides local values, only pivot row k AS IT STANDS AT THE
+ * of the path trace -- the bounds rounded down to multiples of 64 for n >= 128 P, fwx_matrix_part_rows); step k needs, besides local values, only pivot row k AS IT STANDS AT THE
  * START OF STEP k, so pivots travel FWX_FUSED_BLOCK at a time as one snapshot panel per block,
  * produced by the partition that owns those rows and sent to all others, with look-ahead (the
  * owner of the next block relaxes those rows first and runs their panel + the exchange on a side
@@ -293,7 +293,7 @@ int fwx_matrix_create_multi(fwx_matrix **out, int32_t n, int32_t dtype, int32_t 
  * to fail the solve (FWX_ERR_RCCL).  Everything else is the code the one-process handle runs -- same
  * schedules (single pass, the 128-pivot pair schedule, the per-k engine), same kernels, path trace, kept
  * input, resume -- and so the same bits.  What differs for the caller:
- *   upload / download  take THIS RANK'S row block: rows [n*rank/world, n*(rank+1)/world) x n
+ *   upload / download  take THIS RANK'S row block (fwx_matrix_part_rows(m, rank, &row0, &rows)): rows x n
  *   the domain check   is per slab; the host combines the ranks' answers: fwx_matrix_domain_bits (local
  *                      bits: 1 = every rate >= +0 and not NaN, 2 = no positive rate without a path), an
  *                      all-reduce AND among the ranks, fwx_matrix_set_domain -- before the first solve of
@@ -332,6 +332,12 @@ typedef struct fwx_multi_timing {
 } fwx_multi_timing;
 int fwx_matrix_set_timing(fwx_matrix *m, int32_t on);      /* FWX_ERR_UNSUPPORTED on a single-device handle */
 int fwx_matrix_get_timing(const fwx_matrix *m, fwx_multi_timing *out);   /* out->struct_size = sizeof(*out) */
+/* Rows partition `part` holds: [*row0_out, *row0_out + *rows_out).  Balanced row blocks, n * p / P, rounded
+ * down to a multiple of 64 once every partition holds two pivot blocks (n >= 128 P): blocks of 64 pivots never
+ * straddle two partitions, so aligned partitions make every block full and aligned for ANY n, which is what
+ * the 128-pivot pair schedule and the checkpoints of resumable solves need.  A host that feeds slabs
+ * (fwx_matrix_create_part) asks here instead of computing the bounds itself.                        */
+int fwx_matrix_part_rows(const fwx_matrix *m, int32_t part, int32_t *row0_out, int32_t *rows_out);
 /* Partitions of a handle (1 for a single-device handle); exchange_out (optional) receives the
  * transport in use (FWX_XCHG_PEER / FWX_XCHG_RCCL).                                              */
 int fwx_matrix_parts(const fwx_matrix *m, int32_t *exchange_out);

@@ -73,16 +73,17 @@ def test_partitioned_double_pass_distributions(kind, dtype):
 def test_partitioned_double_pass_pivot_ranges_and_fallbacks(dtype):
     """Aligned ranges of at least four full blocks take the pairs -- a ragged end then goes through the
     single-pass loop in the same solve --, anything else the single pass from the start: ranges that do
-    not start on a block, fewer than four blocks, partitions that do not start on a multiple of 64, a
-    counted solve (U: the compare form)."""
+    not start on a block, fewer than four blocks, a counted solve (U: the compare form).  Partitions are cut
+    on multiples of 64 (n >= 128 P), so the order of the matrix does not matter."""
     rate, nxt, _ = synth.make("d2", 1024, dtype, seed=9)
     for kb, ke, pairs in ((0, 1024, True), (0, 500, True), (128, 900, True), (64, 333, True), (512, 1024, True),
                           (37, 611, False), (0, 200, False), (960, 1024, False)):
         _solve_and_check(rate, nxt, None, 2, took_pairs=pairs, k_begin=kb, k_end=ke)
         _solve_and_check(rate, None, None, 4, took_pairs=pairs, k_begin=kb, k_end=ke)
-    odd, onx, _ = synth.make("d1", 1156, dtype, seed=10)             # 1156 / 2 = 578: not 64-aligned
-    _solve_and_check(odd, onx, None, 2, took_pairs=False)
-    _solve_and_check(odd, None, None, 1, took_pairs=True)            # one partition starts at row 0
+    odd, onx, _ = synth.make("d1", 1156, dtype, seed=10)             # 1156 / 2 = 578: the library cuts at 576
+    _solve_and_check(odd, onx, None, 2, took_pairs=True)             # (64-aligned partitions for n >= 128 P: any n)
+    _solve_and_check(odd, None, None, 3, took_pairs=True)            # 0, 384, 768
+    _solve_and_check(odd, None, None, 1, took_pairs=True)
     er, en = rate.copy(), nxt.copy()
     eu = oracle.relax(er, en)
     gr, gn = rate.copy(), nxt.copy()

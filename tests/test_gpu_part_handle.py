@@ -48,10 +48,10 @@ def _solve_worker(rank, world, port, n, dtype_name, kind, fields, eng_name, env,
     dist, fwdist, engine, synth = _init(rank, world, port, env)
     dtype = np.dtype(dtype_name).type
     rate, nxt, hops = synth.make(kind, n, dtype, seed=4242)
-    b = fwdist.row_bounds(n, world)
-    lo, hi = b[rank], b[rank + 1]
     with_next, with_hops, traced = fields >= 1, fields >= 2, fields >= 3
     h = fwdist.PartMatrix(n, dtype, rank, world, with_next=with_next, with_hops=with_hops, device=0)
+    lo, hi = h.row0, h.row0 + h.rows            # where the LIBRARY cut the matrix (64-aligned for n >= 128 * world)
+    assert h.bounds()[rank] == lo and h.bounds()[-1] == n
     if traced:
         h.enable_path_log()
     h.set_timing(True)
@@ -78,7 +78,8 @@ def _solve_worker(rank, world, port, n, dtype_name, kind, fields, eng_name, env,
     (2, 640, "float32", "t1", 1, "fused", True),       # ties + next-hops, pair schedule forced
     (4, 1024, "float64", "d2", 2, "fused", True),      # f64 + next + hops over four ranks, pairs
     (3, 576, "float32", "t2", 3, "auto", True),        # sparse + the path trace, pairs straddling owners
-    (3, 500, "float64", "d1", 1, "fused", False),      # partitions that do not start on a multiple of 64
+    (3, 500, "float64", "d1", 1, "fused", True),       # n no multiple of anything: aligned partitions (0, 128, 320), pairs
+    (3, 300, "float64", "d1", 1, "fused", False),      # n < 128 * world: balanced, unaligned partitions (0, 100, 200)
     (2, 512, "float32", "d2", 2, "perk", False),       # the per-k engine, U per rank
 ])
 def test_one_partition_per_process_equals_the_oracle(tmp_path, world, n, dtype_name, kind, fields, eng_name, pairs):
@@ -107,9 +108,8 @@ def test_one_partition_per_process_equals_the_oracle(tmp_path, world, n, dtype_n
 def _resume_worker(rank, world, port, n, outdir):
     dist, fwdist, engine, synth = _init(rank, world, port, {})
     rate, nxt, _ = synth.make("d2", n, np.float32, seed=99)
-    b = fwdist.row_bounds(n, world)
-    lo, hi = b[rank], b[rank + 1]
     h = fwdist.PartMatrix(n, np.float32, rank, world, with_next=True, device=0)
+    lo, hi = h.row0, h.row0 + h.rows
     h.keep_input()
     placed = h.enable_resume(3)
     h.upload(np.ascontiguousarray(rate[lo:hi]), np.ascontiguousarray(nxt[lo:hi]))

@@ -173,18 +173,37 @@ def test_what_invalidates_a_recording():
         with engine.DeviceMatrix(odd_n, dtype, with_next=True) as dm:
             dm.keep_input()
             assert dm.enable_resume(2) >= 1
-    # partitions that do not start on a multiple of 64 (512 rows over 3: 0, 170, 341): a checkpoint must be a
-    # block start, so only pivot 128 (inside partition 0) qualifies -- and it works
+    # partitions are cut on multiples of 64 once n >= 128 P (512 rows over 3: 0, 128, 320), so every checkpoint
+    # is a block start ...
     rate, nxt, _ = synth.make("d1", 512, np.float32, seed=10)
     with engine.DeviceMatrix(512, np.float32, with_next=True, devices=[0, 0, 0]) as dm:
+        assert [dm.part_rows(p) for p in range(3)] == [(0, 128), (128, 192), (320, 192)]
         dm.keep_input()
-        assert dm.enable_resume(3) == 1
+        assert dm.enable_resume(3) == 3
         dm.upload(rate, nxt)
         dm.solve()
         idx = np.array([400 * 512 + 300], dtype=np.int64)
         v = (rate.reshape(-1)[idx] * np.float32(0.9)).astype(np.float32)
         rate.reshape(-1)[idx] = v
-        assert dm.resolve(idx, v, np.array([300], dtype=np.int32)) == 128
+        assert dm.resolve(idx, v, np.array([300], dtype=np.int32)) == 256
+        er, en = rate.copy(), nxt.copy()
+        oracle.relax(er, en)
+        gr, gn, _ = dm.download()
+        assert_bits_equal(gr, er, "rate")
+        assert_bits_equal(gn, en, "next")
+    # ... below that the partitions are balanced and unaligned (300 rows over 3: 0, 100, 200) and a checkpoint
+    # must still be a block start: only pivot 64 (inside partition 0) qualifies -- and it works
+    rate, nxt, _ = synth.make("d1", 300, np.float32, seed=11)
+    with engine.DeviceMatrix(300, np.float32, with_next=True, devices=[0, 0, 0]) as dm:
+        assert [dm.part_rows(p)[0] for p in range(3)] == [0, 100, 200]
+        dm.keep_input()
+        assert dm.enable_resume(3) == 1
+        dm.upload(rate, nxt)
+        dm.solve()
+        idx = np.array([250 * 300 + 150], dtype=np.int64)
+        v = (rate.reshape(-1)[idx] * np.float32(0.9)).astype(np.float32)
+        rate.reshape(-1)[idx] = v
+        assert dm.resolve(idx, v, np.array([150], dtype=np.int32)) == 64
         er, en = rate.copy(), nxt.copy()
         oracle.relax(er, en)
         gr, gn, _ = dm.download()
@@ -192,7 +211,6 @@ def test_what_invalidates_a_recording():
         assert_bits_equal(gn, en, "next")
 
 
-@pytest.mark.parametrize("devices", [None, [0, 0, 0, 0]], ids=["one-device", "P4"])
 def test_session_resumes_after_price_changes_and_answers_like_a_fresh_session(devices):
     """(devices: the session behind `fwx_cli --devices`, the resident matrix row-partitioned -- it resumes
     like the single-device one.)  The AppState trigger on top (Types.hs:35-37, ProcessRequests.hs:82-85): 32 exchanges x 8
