@@ -7,7 +7,8 @@ fallback: it fails loudly when the HIP library is missing.
 Contents
   fw_oracle.c / libfworacle.so   dense in-place restatement of runAlgo
                                  (/root/reference/src/lib/Algorithms.hs:42-61), f64 and f32,
-                                 single- and multi-threaded; copy-per-k literal form.
+                                 single- and multi-threaded (the latter also with a chunk pre-check
+                                 for the big continuation tests); copy-per-k literal form.
   list_faithful.py               entry-for-entry restatement with whole `_path` lists of
                                  buildMatrix / runAlgo / floydWarshall / optimum
                                  (Algorithms.hs:19-78).
@@ -43,7 +44,7 @@ def lib():
         for name in ("fwo_relax_f64", "fwo_relax_f32"):
             getattr(L, name).restype = u64
             getattr(L, name).argtypes = [i32, vp, vp, vp, i32, i32]
-        for name in ("fwo_relax_mt_f64", "fwo_relax_mt_f32"):
+        for name in ("fwo_relax_mt_f64", "fwo_relax_mt_f32", "fwo_relax_mt_fast_f64", "fwo_relax_mt_fast_f32"):
             getattr(L, name).restype = u64
             getattr(L, name).argtypes = [i32, vp, vp, vp, i32, i32, i32]
         for name in ("fwo_copy_per_k_f64", "fwo_copy_per_k_f32"):
@@ -77,15 +78,18 @@ def relax(rate, nxt=None, hops=None, k_begin=0, k_end=None):
                                                   k_begin, k_end))
 
 
-def relax_mt(rate, nxt=None, k_begin=0, k_end=None, threads=None, hops=None):
-    """Same result as relax(), rows of each pivot step split over `threads` host threads."""
+def relax_mt(rate, nxt=None, k_begin=0, k_end=None, threads=None, hops=None, fast=False):
+    """Same result as relax(), rows of each pivot step split over `threads` host threads.  fast: the same loop
+    with a side-effect-free pre-check that skips 64-column chunks in which the compare of Algorithms.hs:55 holds
+    for no entry (fwo_relax_mt_fast_*; pinned to the plain loop by tests/test_oracle_golden.py) -- for the tests
+    that continue solves at N = 8192 ... 32768."""
     sfx = _check(rate, nxt, hops)
     assert hops is None or nxt is not None
     n = rate.shape[0]
     k_end = n if k_end is None else k_end
     threads = threads or len(os.sched_getaffinity(0))
-    return int(getattr(lib(), "fwo_relax_mt_" + sfx)(n, _ptr(rate), _ptr(nxt), _ptr(hops), k_begin,
-                                                     k_end, threads))
+    name = ("fwo_relax_mt_fast_" if fast else "fwo_relax_mt_") + sfx
+    return int(getattr(lib(), name)(n, _ptr(rate), _ptr(nxt), _ptr(hops), k_begin, k_end, threads))
 
 
 def copy_per_k(rate, nxt, hops):

@@ -211,3 +211,52 @@ def test_k_range_is_resumable():
     oracle.relax(*b, k_begin=17, k_end=50)
     assert_bits_equal(a[0], b[0])
     assert np.array_equal(a[1], b[1]) and np.array_equal(a[2], b[2])
+
+
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+def test_the_chunk_pre_check_loop_equals_the_plain_loop(dtype):
+    """oracle/fw_oracle_fast.c (relax_mt(..., fast=True): the loop the big continuation tests use) against the
+    plain restatement fwo_relax_*: every input kind -- ordinary, market-like, ties, sparse, arbitrage / inf / NaN,
+    overflow --, sizes around the 64-column chunk, with and without next / hops, pivot ranges, thread counts;
+    rates, next, hops and U, bit for bit.  And the reference's own golden 4 x 4."""
+    for kind in ("d1", "d2", "t1", "t2", "t3", "t4"):
+        for n in (1, 2, 63, 64, 65, 130, 257):
+            rate, nxt, hops = synth.make(kind, n, dtype, seed=700 + n)
+            for fields in (0, 1, 2):
+                a = [rate.copy(), nxt.copy() if fields >= 1 else None, hops.copy() if fields >= 2 else None]
+                b = [rate.copy(), nxt.copy() if fields >= 1 else None, hops.copy() if fields >= 2 else None]
+                ua = oracle.relax(*a)
+                ub = oracle.relax_mt(b[0], b[1], hops=b[2], threads=1 + (n + fields) % 5, fast=True)
+                assert ua == ub, (kind, n, fields)
+                assert_bits_equal(a[0], b[0], "rate %s n=%d" % (kind, n))
+                if fields >= 1:
+                    assert np.array_equal(a[1], b[1])
+                if fields >= 2:
+                    assert np.array_equal(a[2], b[2])
+    rate, nxt, hops = synth.make("d2", 200, dtype, seed=77)
+    a, b = (rate.copy(), nxt.copy(), hops.copy()), (rate.copy(), nxt.copy(), hops.copy())
+    ua = oracle.relax(*a, k_begin=37, k_end=150)
+    ub = oracle.relax_mt(b[0], b[1], 37, 90, threads=3, hops=b[2], fast=True)
+    ub += oracle.relax_mt(b[0], b[1], 90, 150, threads=7, hops=b[2], fast=True)
+    assert ua == ub
+    assert_bits_equal(a[0], b[0], "ranged rate")
+    assert np.array_equal(a[1], b[1]) and np.array_equal(a[2], b[2])
+    from hostile_inputs import hostile_matrix
+    rnd = np.random.default_rng(199)
+    for case in range(60):
+        n = int(rnd.integers(2, 91))
+        r, nx, hp = hostile_matrix(rnd, n, dtype)
+        a, b = (r.copy(), nx.copy(), hp.copy()), (r.copy(), nx.copy(), hp.copy())
+        with np.errstate(all="ignore"):
+            ua = oracle.relax(*a)
+            ub = oracle.relax_mt(b[0], b[1], hops=b[2], threads=2, fast=True)
+        assert ua == ub, case
+        assert_bits_equal(a[0], b[0], "hostile rate, case %d" % case)
+        assert np.array_equal(a[1], b[1]) and np.array_equal(a[2], b[2])
+    g = load_golden("algorithms_4x4.json")
+    rate, nxt, hops, _ = golden_dense(g["initial"], dtype)
+    oracle.relax_mt(rate, nxt, hops=hops, threads=2, fast=True)
+    erate, enext, ehops, _ = golden_dense(g["solved"], dtype)
+    if dtype == np.float64:
+        assert_bits_equal(rate, erate, "golden solved 4x4")
+    assert np.array_equal(nxt, enext) and np.array_equal(hops, ehops)
