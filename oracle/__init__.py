@@ -47,6 +47,9 @@ def lib():
         for name in ("fwo_relax_mt_f64", "fwo_relax_mt_f32", "fwo_relax_mt_fast_f64", "fwo_relax_mt_fast_f32"):
             getattr(L, name).restype = u64
             getattr(L, name).argtypes = [i32, vp, vp, vp, i32, i32, i32]
+        for name in ("fwo_relax_mt_tiled_f64", "fwo_relax_mt_tiled_f32"):
+            getattr(L, name).restype = ctypes.c_int64
+            getattr(L, name).argtypes = [i32, vp, vp, vp, i32, i32, i32, i32]
         for name in ("fwo_copy_per_k_f64", "fwo_copy_per_k_f32"):
             getattr(L, name).restype = ctypes.c_int
             getattr(L, name).argtypes = [i32, vp, vp, vp]
@@ -90,6 +93,23 @@ def relax_mt(rate, nxt=None, k_begin=0, k_end=None, threads=None, hops=None, fas
     threads = threads or len(os.sched_getaffinity(0))
     name = ("fwo_relax_mt_fast_" if fast else "fwo_relax_mt_") + sfx
     return int(getattr(lib(), name)(n, _ptr(rate), _ptr(nxt), _ptr(hops), k_begin, k_end, threads))
+
+
+def relax_mt_tiled(rate, nxt=None, k_begin=0, k_end=None, threads=None, hops=None, tile=16):
+    """Same result and U as relax(): the multi-threaded loop tiled over `tile` pivots (each row takes the pivots
+    of a tile in one visit, from snapshots of the pivot rows taken at their own time; fwo_relax_mt_tiled_*,
+    pinned to the plain loop by tests/test_oracle_golden.py) -- for the stretches of a solve at N = 32768, where
+    every pivot step of the plain loop streams the whole matrix through host memory."""
+    sfx = _check(rate, nxt, hops)
+    assert hops is None or nxt is not None
+    n = rate.shape[0]
+    k_end = n if k_end is None else k_end
+    threads = threads or len(os.sched_getaffinity(0))
+    u = int(getattr(lib(), "fwo_relax_mt_tiled_" + sfx)(n, _ptr(rate), _ptr(nxt), _ptr(hops), k_begin, k_end,
+                                                        threads, int(tile)))
+    if u < 0:
+        raise MemoryError("fwo_relax_mt_tiled: snapshot buffers")
+    return u
 
 
 def copy_per_k(rate, nxt, hops):

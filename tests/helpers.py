@@ -147,9 +147,9 @@ def config5_solve_with_oracle_slices(dm, n, threads=None):
     middle of the matrix (pivot 16384 = a partition boundary at P = 8; the stretch starts 128 before it, so
     a 128-pivot launch ends exactly there) and the last 256 pivots (ending at the solved matrix).  Every
     stretch is a pivot range of its own on the GPU -- four full blocks: two 128-pivot launches of the double
-    pass, panels across a launch boundary -- and is continued on the oracle (relax_mt with next + hops; its
-    chunk pre-check form, pinned to the plain loop by tests/test_oracle_golden.py) from the state the GPU
-    held before it.  Returns the solved (rate, next, hops).
+    pass, panels across a launch boundary -- and is continued on the oracle (rate + next + hops; the loop tiled
+    over 16 pivots, oracle.relax_mt_tiled, which tests/test_oracle_golden.py pins to the plain loop: the plain
+    loop streams 12 GiB through host memory per pivot) from the state the GPU held before it.  Returns the solved (rate, next, hops).
 
     Two tests (the plain handle, P = 8 partitions) walk the same input through the same stretches.  The
     first to run does the above and records the digests of the oracle's state after each stretch; the
@@ -166,7 +166,8 @@ def config5_solve_with_oracle_slices(dm, n, threads=None):
         cached = _CONFIG5_ORACLE.get((n, a, b))
         if cached is None:
             er, en, eh = dm.download()
-            t = threading.Thread(target=oracle.relax_mt, args=(er, en, a, b), kwargs={"threads": threads, "hops": eh, "fast": True})
+            t = threading.Thread(target=oracle.relax_mt_tiled, args=(er, en, a, b),
+                                 kwargs={"threads": threads, "hops": eh, "tile": 16})
             t.start()                                # the oracle continues from the GPU state, beside the GPU
         dm.solve(k_begin=a, k_end=b)
         gr, gn, gh = dm.download()

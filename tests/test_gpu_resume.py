@@ -211,6 +211,7 @@ def test_what_invalidates_a_recording():
         assert_bits_equal(gn, en, "next")
 
 
+@pytest.mark.parametrize("devices", [None, [0, 0, 0, 0]], ids=["one-device", "P4"])
 def test_session_resumes_after_price_changes_and_answers_like_a_fresh_session(devices):
     """(devices: the session behind `fwx_cli --devices`, the resident matrix row-partitioned -- it resumes
     like the single-device one.)  The AppState trigger on top (Types.hs:35-37, ProcessRequests.hs:82-85): 32 exchanges x 8

@@ -215,8 +215,8 @@ def test_k_range_is_resumable():
 
 @pytest.mark.parametrize("dtype", [np.float64, np.float32])
 def test_the_chunk_pre_check_loop_equals_the_plain_loop(dtype):
-    """oracle/fw_oracle_fast.c (relax_mt(..., fast=True): the loop the big continuation tests use) against the
-    plain restatement fwo_relax_*: every input kind -- ordinary, market-like, ties, sparse, arbitrage / inf / NaN,
+    """oracle/fw_oracle_fast.c (relax_mt(..., fast=True) and relax_mt_tiled: the loops the big continuation tests
+    use) against the plain restatement fwo_relax_*: every input kind -- ordinary, market-like, ties, sparse, arbitrage / inf / NaN,
     overflow --, sizes around the 64-column chunk, with and without next / hops, pivot ranges, thread counts;
     rates, next, hops and U, bit for bit.  And the reference's own golden 4 x 4."""
     for kind in ("d1", "d2", "t1", "t2", "t3", "t4"):
@@ -225,14 +225,19 @@ def test_the_chunk_pre_check_loop_equals_the_plain_loop(dtype):
             for fields in (0, 1, 2):
                 a = [rate.copy(), nxt.copy() if fields >= 1 else None, hops.copy() if fields >= 2 else None]
                 b = [rate.copy(), nxt.copy() if fields >= 1 else None, hops.copy() if fields >= 2 else None]
+                c = [rate.copy(), nxt.copy() if fields >= 1 else None, hops.copy() if fields >= 2 else None]
                 ua = oracle.relax(*a)
                 ub = oracle.relax_mt(b[0], b[1], hops=b[2], threads=1 + (n + fields) % 5, fast=True)
-                assert ua == ub, (kind, n, fields)
+                # ... and the loop tiled over pivots (oracle.relax_mt_tiled: ragged tiles, tile 1 = the plain order)
+                uc = oracle.relax_mt_tiled(c[0], c[1], hops=c[2], threads=1 + (n + 2 * fields) % 4,
+                                           tile=(1, 5, 16, 64)[(n + fields) % 4])
+                assert ua == ub == uc, (kind, n, fields)
                 assert_bits_equal(a[0], b[0], "rate %s n=%d" % (kind, n))
+                assert_bits_equal(a[0], c[0], "tiled rate %s n=%d" % (kind, n))
                 if fields >= 1:
-                    assert np.array_equal(a[1], b[1])
+                    assert np.array_equal(a[1], b[1]) and np.array_equal(a[1], c[1])
                 if fields >= 2:
-                    assert np.array_equal(a[2], b[2])
+                    assert np.array_equal(a[2], b[2]) and np.array_equal(a[2], c[2])
     rate, nxt, hops = synth.make("d2", 200, dtype, seed=77)
     a, b = (rate.copy(), nxt.copy(), hops.copy()), (rate.copy(), nxt.copy(), hops.copy())
     ua = oracle.relax(*a, k_begin=37, k_end=150)
@@ -241,6 +246,12 @@ def test_the_chunk_pre_check_loop_equals_the_plain_loop(dtype):
     assert ua == ub
     assert_bits_equal(a[0], b[0], "ranged rate")
     assert np.array_equal(a[1], b[1]) and np.array_equal(a[2], b[2])
+    c = (rate.copy(), nxt.copy(), hops.copy())
+    uc = oracle.relax_mt_tiled(c[0], c[1], 37, 101, threads=4, hops=c[2], tile=16)     # ragged: 64 = 4 tiles, then
+    uc += oracle.relax_mt_tiled(c[0], c[1], 101, 150, threads=2, hops=c[2], tile=20)   # 49 = 20 + 20 + 9
+    assert ua == uc
+    assert_bits_equal(a[0], c[0], "ranged tiled rate")
+    assert np.array_equal(a[1], c[1]) and np.array_equal(a[2], c[2])
     from hostile_inputs import hostile_matrix
     rnd = np.random.default_rng(199)
     for case in range(60):
@@ -250,9 +261,13 @@ def test_the_chunk_pre_check_loop_equals_the_plain_loop(dtype):
         with np.errstate(all="ignore"):
             ua = oracle.relax(*a)
             ub = oracle.relax_mt(b[0], b[1], hops=b[2], threads=2, fast=True)
-        assert ua == ub, case
+            c = (r.copy(), nx.copy(), hp.copy())
+            uc = oracle.relax_mt_tiled(c[0], c[1], hops=c[2], threads=3, tile=1 + case % 9)
+        assert ua == ub == uc, case
         assert_bits_equal(a[0], b[0], "hostile rate, case %d" % case)
         assert np.array_equal(a[1], b[1]) and np.array_equal(a[2], b[2])
+        assert_bits_equal(a[0], c[0], "hostile tiled rate, case %d" % case)
+        assert np.array_equal(a[1], c[1]) and np.array_equal(a[2], c[2])
     g = load_golden("algorithms_4x4.json")
     rate, nxt, hops, _ = golden_dense(g["initial"], dtype)
     oracle.relax_mt(rate, nxt, hops=hops, threads=2, fast=True)
