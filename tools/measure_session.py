@@ -41,13 +41,19 @@ def timed_query(s, a, b):
     return time.perf_counter() - t0
 
 
-# (27 x 9 = 243 and 113 x 9 = 1017 vertices: ODD orders, which the session pads with one isolated vertex --
-# the fused engine instead of one launch per pivot, and resumable like the even orders)
+# (27 x 9 = 243 and 113 x 9 = 1017 vertices: ODD orders -- the handle pads its rows on the device: the fused
+# engine instead of one launch per pivot, and resumable like the even orders)
+# usage: measure_session.py [--devices 0,0,0,0]   (the resident matrix row-partitioned: it resumes too)
+DEVICES = None
+if "--devices" in sys.argv:
+    DEVICES = [int(x) for x in sys.argv[sys.argv.index("--devices") + 1].split(",")]
 for n_exch, n_ccy in ((2, 2), (6, 8), (20, 12), (27, 9), (60, 16), (113, 9), (128, 16), (256, 16)):
     rows = market(n_exch, n_ccy)
     line = {}
     for label, cps in (("full", 0), ("resumable", 7)):
         s = host.Session(device=0)
+        if DEVICES:
+            s.set_devices(DEVICES, min_vertices=65)
         s.set_checkpoints(cps)
         for r in rows:
             s.update_rates(*r)
