@@ -168,6 +168,9 @@ def parse_args():
                     help="only the timed region: no fused / f64 / serpentine-off / cross-check legs")
     ap.add_argument("--no-fused-extra", action="store_true")
     ap.add_argument("--no-f64-extra", action="store_true")
+    ap.add_argument("--driver", default="part", choices=["part", "legacy"],
+                    help="torchrun form: part = one partition per process behind the C ABI (libfwx's own schedule, "
+                         "panels broadcast by torch.distributed from its callback); legacy = dist.solve_partitioned")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="process-group backend for N > 1 (gloo only to rehearse the N > 1 code path "
                          "with several ranks on one GPU; never a performance number)")
@@ -941,6 +944,12 @@ def run_multi(args):
 # N > 1: one process per GPU, torch.distributed over RCCL
 # ------------------------------------------------------------------------------------------------
 def run_dist(args, world, rank, local_rank):
+    """One process per GPU under torch.distributed.run.  Driver "part" (default): every rank holds ONE partition
+    of libfwx's own partitioned handle (fwx_matrix_create_part) -- the schedule, kernels and event timings are
+    the library's, exactly the code the one-process form runs, and the panel broadcast is handed back to
+    torch.distributed from libfwx's exchange callback (floydwarshall_amd.dist.PartMatrix).  Driver "legacy":
+    the older Python schedule over the device-pointer entry points (dist.solve_partitioned); with the "part"
+    driver it still runs once, untimed, as a cross-check and for comparison (`legacy_driver`)."""
     import datetime
     import torch
     import torch.distributed as dist
@@ -960,20 +969,9 @@ def run_dist(args, world, rank, local_rank):
     n = args.n
     np_dtype = np.float32 if args.dtype == "f32" else np.float64
     es = np.dtype(np_dtype).itemsize
-    rate64, next_host = make_input(args, n)
-    bounds = fwdist.row_bounds(n, world)
-    r0, r1 = bounds[rank], bounds[rank + 1]
-    pristine = torch.from_numpy(rate64[r0:r1].astype(np_dtype)).to(dev)
-    del rate64
-    rate = torch.empty_like(pristine)
-    pristine_next = nxt = None
-    if args.with_next:
-        pristine_next = torch.from_numpy(next_host[r0:r1]).to(dev)
-        nxt = torch.empty_like(pristine_next)
-    del next_host
     k_end = n
-    backend = fwdist.HipBackend(args.engine)
     relax_per_step = float(k_end) * n * n
+    ENG = {"perk": fwdist.engine.FWX_ENGINE_PERK, "fused": fwdist.engine.FWX_ENGINE_FUSED}
     # every rank runs a watchdog (a hung collective hangs all of them); rank 0 writes the line
     dog = Watchdog(args.step_timeout,
                    {"metric": "edge-relaxations/sec (N^3/t), N=%d %s" % (n, "fp32" if es == 4 else "fp64"),
@@ -982,12 +980,38 @@ def run_dist(args, world, rank, local_rank):
                     "data": "synthetic", "config": workload_config(args, n, k_end, True, world)},
                    emit=rank == 0)
 
-    def step(bk=None, timer=None):
+    driver, driver_note, ph = args.driver, None, None
+    if driver == "part":
+        try:        # (fails the same way on every rank, before any collective: an old library, no device)
+            ph = fwdist.PartMatrix(n, np_dtype, rank, world, with_next=args.with_next, device=dev_index)
+        except Exception as err:          # noqa: BLE001 -- whatever it is, the legacy driver can still run
+            driver, driver_note = "legacy", "PartMatrix could not be created (%s): legacy driver" % err
+    legacy_bounds = fwdist.row_bounds(n, world)
+    bounds = ph.bounds() if ph is not None else legacy_bounds
+    r0, r1 = bounds[rank], bounds[rank + 1]
+    same_cut = bounds == legacy_bounds      # (the library cuts on multiples of 64: N = 16384 at 2 / 4 / 8 ranks agree)
+    rate64, next_host = make_input(args, n)
+    pristine = torch.from_numpy(rate64[r0:r1].astype(np_dtype)).to(dev)
+    pristine_next = torch.from_numpy(next_host[r0:r1]).to(dev) if args.with_next else None
+    del rate64, next_host
+    rate = torch.empty_like(pristine)                       # the legacy driver solves in place, in torch tensors
+    nxt = torch.empty_like(pristine_next) if args.with_next else None
+    backend = fwdist.HipBackend(args.engine)
+
+    def legacy_step(bk=None, timer=None):
         rate.copy_(pristine)
         if nxt is not None:
             nxt.copy_(pristine_next)
         fwdist.solve_partitioned(rate, n, rank, world, nxt=nxt, block=args.block, backend=bk or backend,
                                  timer=timer)
+
+    def step(engine_name=None):
+        """Restore the pristine slab (device to device) + one full solve, both inside whatever clock runs."""
+        if ph is not None:
+            ph.upload_dev(pristine, pristine_next)
+            ph.solve(engine=ENG[engine_name or args.engine])
+        else:
+            legacy_step(bk=None if engine_name in (None, args.engine) else fwdist.HipBackend(engine_name))
 
     def fence():
         torch.cuda.synchronize()
@@ -1013,27 +1037,33 @@ def run_dist(args, world, rank, local_rank):
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     dt = float(t.item())
 
-    def timing_leg(bk, label):
-        """One more, untimed solve with per-step event spans on every rank (dist.StepTimer): bulk and
-        exchange as the MAX over ranks of the rank's mean, look-ahead and panel as the mean over the ranks
-        that owned a block."""
-        dog.arm("event-timed solve (%s)" % label)
-        tm = fwdist.StepTimer(on_gpu=True)
-        step(bk=bk, timer=tm)
-        sm = tm.summary()
-        v = torch.tensor([sm[k][0] for k in fwdist.StepTimer.KINDS] +
-                         [sm[k][0] * sm[k][1] for k in fwdist.StepTimer.KINDS] +
-                         [float(sm[k][1]) for k in fwdist.StepTimer.KINDS], dtype=torch.float64, device=dev)
-        mx, sm_all = v[:4].clone(), v[4:].clone()
-        dist.all_reduce(mx, op=dist.ReduceOp.MAX)
-        dist.all_reduce(sm_all, op=dist.ReduceOp.SUM)
+    def max_over_ranks(values):
+        v = torch.tensor(values, dtype=torch.float64, device=dev)
+        dist.all_reduce(v, op=dist.ReduceOp.MAX)
+        return [float(x) for x in v.tolist()]
+
+    def timing_leg(engine_name):
+        """One more, untimed solve with per-step event spans on every rank: the slab sweep of a step against
+        what the next step waits for besides it, each as the MAX over ranks of the rank's figure."""
+        dog.arm("event-timed solve (%s)" % engine_name)
+        if ph is not None:
+            ph.set_timing(True)
+            step(engine_name)
+            tm = ph.timing()
+            ph.set_timing(False)
+            bulk, chain, xch, pan, la = max_over_ranks([tm["bulk_us"], tm["chain_us"], tm["exchange_us"],
+                                                        tm["panel_us"], tm["lookahead_us"]])
+            pps, steps = tm["pivots_per_step"], tm["steps"]
+        else:
+            tm = fwdist.StepTimer(on_gpu=True)
+            legacy_step(bk=None if engine_name == args.engine else fwdist.HipBackend(engine_name), timer=tm)
+            sm = tm.summary()
+            bulk, la, pan, xch = max_over_ranks([sm[k][0] for k in fwdist.StepTimer.KINDS])
+            chain, pps, steps = la + pan + xch, args.block, sm["bulk"][1]
         dog.disarm()
-        mean = lambda i: float(sm_all[i] / sm_all[4 + i]) if float(sm_all[4 + i]) > 0 else 0.0   # noqa: E731
-        bulk, la, pan, xch = float(mx[0]), mean(1), mean(2), float(mx[3])
-        chain = la + pan + xch
         return {"avg_bulk_us": bulk, "avg_lookahead_us": la, "avg_panel_us": pan, "avg_exchange_us": xch,
                 "avg_chain_us": chain, "chain_over_bulk": chain / bulk if bulk > 0 else None,
-                "pivots_per_step": args.block, "avg_bulk_us_per_block": bulk * 64.0 / args.block}
+                "pivots_per_step": pps, "steps": steps, "avg_bulk_us_per_block": bulk * 64.0 / max(1, pps)}
 
     out = {
         "metric": "edge-relaxations/sec (N^3/t), N=%d %s" % (n, "fp32" if es == 4 else "fp64"),
@@ -1041,13 +1071,17 @@ def run_dist(args, world, rank, local_rank):
         "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps,
         "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": args.dtype,
         "data": "synthetic", "config": workload_config(args, n, k_end, True, world),
+        "driver": {"name": driver, "note": driver_note,
+                   "what": "part: one partition per process behind the C ABI (fwx_matrix_create_part), libfwx's own "
+                           "schedule, panels broadcast by torch.distributed from its exchange callback; legacy: "
+                           "dist.solve_partitioned, the Python schedule over the device-pointer entry points"},
     }
     if args.backend != "nccl":
         out["INVALID_rehearsal_backend"] = args.backend
     # Aggregate HBM figure: every rank streams its slab once per pivot (per-k engine) -- algorithmic
     # bytes of the whole solve over the wall time of the step (exchange and look-ahead included),
     # against world x 8 TB/s.  A slab that fits the Infinity Cache is served from it: "effective".
-    slab_bytes = es * n * (bounds[1] - bounds[0])
+    slab_bytes = es * n * max(bounds[p + 1] - bounds[p] for p in range(world))
     if args.engine == "perk":
         alg_total = es * relax_per_step + 2.0 * es * n * n
         achieved = alg_total * args.steps / dt / 1e9
@@ -1059,7 +1093,7 @@ def run_dist(args, world, rank, local_rank):
                            if slab_bytes <= INFINITY_CACHE_BYTES else "aggregate over ranks",
                            "note": "algorithmic bytes of the solve (s*N^3 + 2*s*N^2; the s*U term, "
                                    "~0.2 %, is left out) / wall time per step, all ranks; includes the "
-                                   "panel exchange"}
+                                   "device-to-device restore and the panel exchange"}
     else:
         pass_bytes = 2.0 * es * n * n + 2 * 64 * es * n * world
         achieved = pass_bytes * ((k_end + 63) // 64) * args.steps / dt / 1e9
@@ -1071,64 +1105,58 @@ def run_dist(args, world, rank, local_rank):
                        "ranks_in_process_group": dist.get_world_size()}
     dog.set_valid_line(out)         # `value` stands: whatever hangs from here on cannot cost the line
     if not args.no_extras:
-        out["exchange"].update(timing_leg(None, args.engine))
+        out["exchange"].update(timing_leg(args.engine))
         out["exchange"]["timing_note"] = (
             "events on the streams the work runs on, one extra untimed solve: bulk = the slab sweep of a step, "
-            "chain = look-ahead rows + owner's panel + broadcast (issue -> side stream released); "
-            "chain_over_bulk > 1 = bound by the panel chain (DESIGN.md section 5)")
+            "chain = what the next step waits for besides it (look-ahead rows + owner's panel + broadcast; the "
+            "whole side chain under the pair schedule); chain_over_bulk > 1 = bound by the panel chain "
+            "(DESIGN.md section 5)")
     if not args.no_extras and not args.no_fused_extra and args.engine == "perk":
-        # Not part of `value`: the same workload on the engine AUTO picks, through the C ABI's own partitioned
-        # handle -- one partition per process (fwx_matrix_create_part), its schedules (the 128-pivot pair
-        # schedule where the partitions start on multiples of 64) and event timings, the panel broadcast handed
-        # back to torch.distributed (dist.PartMatrix).  Best of 2, max over ranks.
-        dog.arm("fused-engine leg (one partition per process behind the C ABI)")
-        ph = fwdist.PartMatrix(n, np_dtype, rank, world, with_next=args.with_next, device=dev_index)
-        # the library cuts the matrix itself (64-aligned partitions, so that the pair schedule applies to any
-        # n); for N = 16384 at 2 / 4 / 8 ranks that is row_bounds() and the rank's pristine slab serves both
-        same_cut = (ph.row0, ph.rows) == (r0, r1 - r0)
-        if not same_cut:
-            r64, nx_h = make_input(args, n)
-            pristine = torch.from_numpy(r64[ph.row0:ph.row0 + ph.rows].astype(np_dtype)).to(dev)
-            pristine_next = torch.from_numpy(nx_h[ph.row0:ph.row0 + ph.rows]).to(dev) if args.with_next else None
-            del r64, nx_h
+        # Not part of `value`: the same workload on the engine AUTO picks (fused; the 128-pivot pair schedule
+        # under the "part" driver), same handle, solve only, best of 2, max over ranks
+        dog.arm("fused-engine leg")
         times = []
         for i in range(3):
-            ph.upload_dev(pristine, pristine_next)
+            if ph is not None:
+                ph.upload_dev(pristine, pristine_next)
             fence()
             t1 = time.perf_counter()
-            ph.solve(engine=fwdist.engine.FWX_ENGINE_FUSED)
+            if ph is not None:
+                ph.solve(engine=ENG["fused"])
+            else:
+                legacy_step(bk=fwdist.HipBackend("fused"))
             fence()
             times.append(time.perf_counter() - t1)
-        tt = torch.tensor(times[1:], dtype=torch.float64, device=dev)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        ft = float(tt.min().item())
-        ph.set_timing(True)
-        ph.upload_dev(pristine, pristine_next)
-        ph.solve(engine=fwdist.engine.FWX_ENGINE_FUSED)
-        tm = ph.timing()
-        v = torch.tensor([tm["bulk_us"], tm["chain_us"], tm["exchange_us"], tm["panel_us"], tm["lookahead_us"]],
-                         dtype=torch.float64, device=dev)
-        dist.all_reduce(v, op=dist.ReduceOp.MAX)
-        bulk, chain, xch, pan, la = (float(x) for x in v.tolist())
-        # the result of this engine against the per-k engine's, slab by slab (bit for bit: same digest on every rank)
-        same = torch.tensor([1], dtype=torch.int32, device=dev)
-        if same_cut:
-            step()                               # `rate` = the timed engine's result again
-            torch.cuda.synchronize()
-            same[0] = 1 if torch.equal(torch.from_numpy(ph.download()[0]).to(dev), rate) else 0
-        dist.all_reduce(same, op=dist.ReduceOp.MIN)
-        ph.close()
+        ft = min(max_over_ranks(times[1:]))
         dog.disarm()
         out["fused_engine"] = {"value": relax_per_step / ft, "unit": "edge-relaxations/s", "ms_per_step": 1e3 * ft,
-                               "steps": 2, "equals_timed_engine_bits": bool(int(same.item())) if same_cut else None,
-                               "exchange": {"avg_bulk_us": bulk, "avg_chain_us": chain, "avg_exchange_us": xch,
-                                            "avg_panel_us": pan, "avg_lookahead_us": la,
-                                            "chain_over_bulk": chain / bulk if bulk > 0 else None,
-                                            "pivots_per_step": tm["pivots_per_step"], "steps": tm["steps"],
-                                            "avg_bulk_us_per_block": bulk * 64.0 / max(1, tm["pivots_per_step"])},
-                               "note": "same workload, fwx_opts.engine = FUSED on the one-partition-per-process "
-                                       "handle (fwx_matrix_create_part; panels by torch.distributed.broadcast from "
-                                       "libfwx's callback); solve only, max over ranks, best of 2; not part of `value`"}
+                               "steps": 2, "exchange": timing_leg("fused"),
+                               "note": "same workload, engine = FUSED (what AUTO runs), same driver; %s; max over "
+                                       "ranks, best of 2; not part of `value`"
+                                       % ("solve only" if ph is not None else "restore included")}
+    if not args.no_extras and ph is not None and same_cut:
+        # the older Python driver once, untimed region of its own: a cross-check of the two schedules (bit for
+        # bit, every rank's slab) and their per-k times side by side
+        dog.arm("legacy driver leg (dist.solve_partitioned)")
+        step()                                   # the timed engine's result again, in the handle
+        mine = torch.from_numpy(ph.download()[0]).to(dev)
+        lt = []
+        for i in range(2):
+            fence()
+            t1 = time.perf_counter()
+            legacy_step()
+            fence()
+            lt.append(time.perf_counter() - t1)
+        same = torch.tensor([1 if torch.equal(mine, rate) else 0], dtype=torch.int32, device=dev)
+        dist.all_reduce(same, op=dist.ReduceOp.MIN)
+        ls = max_over_ranks([lt[1]])[0]
+        dog.disarm()
+        out["legacy_driver"] = {"value": relax_per_step / ls, "ms_per_step": 1e3 * ls, "steps": 1,
+                                "equals_timed_driver_bits": bool(int(same.item())),
+                                "note": "dist.solve_partitioned, same engine, restore included; not part of `value`"}
+        del mine
+    if ph is not None:
+        ph.close()
     dog.stop()
     if rank == 0:
         if not args.no_cpu_baseline:
