@@ -77,11 +77,12 @@ newSolver m = do
   fp <- newForeignPtr h (c_destroy h >> return ())
   ok "keep_input" =<< c_keep_input h                 -- the uploaded input stays on the device
   ok "enable_path_log" =<< c_enable_log h            -- exact `_path` lists (must precede enable_resume)
-  -- 7 checkpoints + the panels of every pivot.  Returns the number of checkpoints (>= 0), or
-  -- FWX_ERR_UNSUPPORTED for orders the fused engine does not run (n <= 64, odd n): such a solver still
-  -- works, every update just re-solves from pivot 0.
-  rc <- c_enable_resume h 7
-  when (rc < 0 && rc /= fwxErrUnsupported) $ ok "enable_resume" rc
+  -- 7 checkpoints + the panels of every pivot.  Returns the number of checkpoints (>= 0), or a negative
+  -- status: FWX_ERR_UNSUPPORTED for n <= 64 (solved in one launch; any larger n works, odd ones included: the
+  -- handle pads its rows), FWX_ERR_OOM when the device cannot hold them.  Resuming is an optimisation: whatever
+  -- the status, the solver works, every update just re-solves from pivot 0 (fwx.h: fwx_matrix_resume_bytes /
+  -- fwx_device_memory size the count to the device beforehand).
+  _ <- c_enable_resume h 7
   S.unsafeWith rate $ \pr -> S.unsafeWith next $ \pn -> ok "upload" =<< c_upload h pr pn nullPtr
   ok "solve" =<< c_solve h nullPtr
   return (Solver fp vertices)
