@@ -223,9 +223,11 @@ int fused_range(T *rate, int32_t *next, int32_t *hops, int n, int k_begin, int k
         auto cross = [&](int q, int blocks, int lo, int hi, hipStream_t st) -> hipError_t {
             if (hi <= lo) return hipSuccess;
             bind4(q, blocks);
+            a.side = true;
             hipError_t e = fwx::launch_fused_main<T>(a, lo, hi, st);
-            if (e != hipSuccess) return e;
-            return fwx::launch_fused_main<T>(a, 0, n, st, lo, hi, fwx::FusedCols::only(lo, hi));
+            if (e == hipSuccess) e = fwx::launch_fused_main<T>(a, 0, n, st, lo, hi, fwx::FusedCols::only(lo, hi));
+            a.side = false;
+            return e;
         };
         auto rows_of = [&](int q) { return k_begin + q * Bq; };
         // chain(0): panels of block 0, that pass onto block 1's rows and columns, panels of block 1
@@ -299,9 +301,12 @@ int fused_range(T *rate, int32_t *next, int32_t *hops, int n, int k_begin, int k
                 FWX_HIP(hipStreamWaitEvent(side.s, side.main_done, 0));
                 // side: pass b on the next block's rows (all columns), then on its columns (the
                 // other rows) ...
-                FWX_HIP(fwx::launch_fused_main<T>(a, k1, k1 + bt1, side.s));
-                FWX_HIP(fwx::launch_fused_main<T>(a, 0, n, side.s, k1, k1 + bt1,
-                                                  fwx::FusedCols::only(k1, k1 + bt1)));
+                a.side = true;
+                hipError_t se = fwx::launch_fused_main<T>(a, k1, k1 + bt1, side.s);
+                if (se == hipSuccess)
+                    se = fwx::launch_fused_main<T>(a, 0, n, side.s, k1, k1 + bt1, fwx::FusedCols::only(k1, k1 + bt1));
+                a.side = false;
+                FWX_HIP(se);
                 // ... then the next pass's panels (one launch) into the other buffer set
                 FWX_HIP(panels(k1, bt1, bi ^ 1, side.s));
                 FWX_HIP(hipEventRecord(side.panel_done, side.s));

@@ -94,6 +94,7 @@ constexpr int B = FWX_FUSED_B;
 // [cskip_lo, cskip_hi) (multiples of 4) are left alone -- another launch of the same pass owns them.
 struct ColWin {
     int jt0, cskip_lo, cskip_hi;
+    int prio = 0;          // FusedArgs::side: the launch's waves issue ahead of the main launch's on a shared SIMD
     __host__ __device__ bool skips(int j) const { return j >= cskip_lo && j < cskip_hi; }
     __host__ __device__ bool clear_of(int j_lo, int j_hi) const { return j_hi <= cskip_lo || j_lo >= cskip_hi; }
 };
@@ -171,6 +172,7 @@ __device__ __forceinline__ void rowpanel_body(char *smem, int bid, const T *rows
 {
     typedef T line_t[64];
     typedef int32_t iline_t[64];
+    __builtin_amdgcn_s_setprio(3);                 // the panels ARE the serial chain: first in line on their SIMD
     line_t *s_dline = (line_t *)smem;              // published pivot rows, diagonal-block part (time t)
     line_t *s_sline = s_dline + B;                 // ... strip part
     iline_t *s_dh = (iline_t *)(s_sline + B);      // their hops (HAS_HOPS)
@@ -313,6 +315,7 @@ __device__ __forceinline__ void colpanel_body(char *smem, int bid, const T *rate
 {
     typedef T line_t[64];
     typedef int32_t iline_t[64];
+    __builtin_amdgcn_s_setprio(3);                 // the panels ARE the serial chain: first in line on their SIMD
     line_t *s_line = (line_t *)smem;               // published pivot columns (time-t, NaN at i==k)
     line_t *s_wd = s_line + B;                     // s_wd[t][c] = D_t[k0+t][k0+c]
     iline_t *s_nline = (iline_t *)(s_wd + B);      // (HAS_NEXT)
@@ -539,6 +542,7 @@ __global__ __launch_bounds__(256, MINW) void fused_main(T *rate, int32_t *next, 
                                                         int32_t *hops, const int32_t *cht,
                                                         const int32_t *wh, ColWin cw)
 {
+    if (cw.prio) __builtin_amdgcn_s_setprio(2);    // a launch of the look-ahead chain (FusedArgs::side)
     constexpr bool HAS_LAST = TRACK;
     static_assert(!HAS_LAST || HAS_NEXT, "the path trace and hops ride on the next-hop variant");
     using V = typename Vec16<T>::type;
@@ -880,6 +884,7 @@ __global__ __launch_bounds__(256, MINW) void fused_main_max(float *rate, int row
                                                             const float *ct, int ct_ld, int ct_vec,
                                                             int skip_lo, int skip_hi, ColWin cw)
 {
+    if (cw.prio) __builtin_amdgcn_s_setprio(2);    // a launch of the look-ahead chain (FusedArgs::side)
     typedef float V4 __attribute__((ext_vector_type(4)));
     // 16 pivots (8 pairs) per LDS stage, two stages resident: while stage s is being folded the
     // operands of stage s+1 are already in flight from L2 into registers.
@@ -1123,6 +1128,7 @@ __global__ __launch_bounds__(256, MINW) void fused_main_max_f64(double *rate, in
                                                                 const double *ct, int ct_ld, int ct_vec,
                                                                 int skip_lo, int skip_hi, ColWin cw)
 {
+    if (cw.prio) __builtin_amdgcn_s_setprio(2);    // a launch of the look-ahead chain (FusedArgs::side)
     typedef double V2 __attribute__((ext_vector_type(2)));
     constexpr int RI = 8, NH = 4, TI = 128, TJ = 128, HJ = 32, BS = 8;
     constexpr int NST = BS / 8;                  // staging rounds per stage (8 pivots per round)
@@ -1349,6 +1355,7 @@ __global__ __launch_bounds__(256, MINW) void fused_main_arg(float *rate, int32_t
                                                             int32_t *hops, const int32_t *cht_all,
                                                             const int32_t *wh_all, ColWin cw)
 {
+    if (cw.prio) __builtin_amdgcn_s_setprio(2);    // a launch of the look-ahead chain (FusedArgs::side)
     typedef float V4 __attribute__((ext_vector_type(4)));
     // list capacity: a flush point after every second entry slot, 63 carried + 2 * 64 new items
     constexpr int TI = 16 * RI, TJ = 64, LCAP = 192;
@@ -1700,6 +1707,7 @@ __global__ __launch_bounds__(256, MINW) void fused_main_arg_f64(double *rate, in
                                                                 int32_t *hops, const int32_t *cht_all,
                                                                 const int32_t *wh_all, ColWin cw)
 {
+    if (cw.prio) __builtin_amdgcn_s_setprio(2);    // a launch of the look-ahead chain (FusedArgs::side)
     typedef double V2 __attribute__((ext_vector_type(2)));
     // RI rows per thread: 64 x 64 tiles (RI = 4; 69 KB of LDS, two workgroups per CU: the shipped form)
     // or 32 x 64 (RI = 2; 52.5 KB, three: kept as an A/B switch, slower -- see launch_max_form)
@@ -2295,6 +2303,7 @@ hipError_t launch_fused_main(const FusedArgs<T> &full, int r_lo, int r_hi, hipSt
         return hipErrorInvalidValue;
     ColWin cw;
     cw.jt0 = 0;
+    cw.prio = full.side ? 1 : 0;
     cw.cskip_lo = cols.skip_hi > cols.skip_lo ? cols.skip_lo : 0;
     cw.cskip_hi = cols.skip_hi > cols.skip_lo ? cols.skip_hi : 0;
     skip_lo -= r_lo;                    // kernel sees rows relative to its own slab

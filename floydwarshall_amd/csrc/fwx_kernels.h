@@ -80,6 +80,9 @@ template <typename T> struct FusedArgs {
                            // and not NaN and, if next is carried, no positive rate lacks a path:
                            // the max-form kernels may run (f32: rates only, or rates + next + trace)
     PathLog plog = PathLog();   // path trace (needs next): rows x n like rate / next, LOCAL rows
+    bool side = false;     // launch_fused_main: a launch of the look-ahead chain beside a main launch (the next
+                           // blocks' rows and columns) -- its waves run at raised priority (s_setprio 2; the
+                           // panel kernels always run at 3), because the chain, not the sweep, bounds mid sizes
 };
 
 // Domain check (fwx.h "Domain").  *flag is a device int preset to 3; bit 0 is cleared if any of the

@@ -850,7 +850,8 @@ static int multi_double_pass(fwx_matrix *m, const std::vector<Block> &blocks, Th
     // pivots of `nblocks` blocks from block blk onto the rows [lo, hi) this partition holds (all columns)
     // and onto the columns [lo, hi) of its other rows
     auto cross = [&](Part &q, int blk, int nblocks, int lo, int hi, hipStream_t st) -> int {
-        const fwx::FusedArgs<T> a = args(q, blk, nblocks);
+        fwx::FusedArgs<T> a = args(q, blk, nblocks);
+        a.side = true;
         const int l_lo = local(q, lo), l_hi = local(q, hi);
         if (l_hi > l_lo) FWX_HIP(fwx::launch_fused_main<T>(a, l_lo, l_hi, st));
         FWX_HIP(fwx::launch_fused_main<T>(a, 0, q.rows, st, l_lo, l_hi, fwx::FusedCols::only(lo, hi)));
@@ -1135,6 +1136,7 @@ template <typename T> static int multi_solve_typed(fwx_matrix *m, const Opts &op
             bind_cols(a, o, blk);
             const int t_la = tm.begin(MultiTimer::LOOKAHEAD, nb.owner, step, o.main);
             if (!perk) {
+                a.side = true;                     // the look-ahead rows head the owner's chain
                 FWX_HIP(fwx::launch_fused_main<T>(a, la_lo, la_hi, o.main));
             } else {
                 // these few rows sit on the owner's critical path: one fused launch (column snapshots of
