@@ -249,7 +249,17 @@ int fused_range(T *rate, int32_t *next, int32_t *hops, int n, int k_begin, int k
                 }
                 FWX_HIP(hipEventRecord(side.panel_done, side.s));
                 bind4(q, 2);
-                FWX_HIP(fwx::launch_fused_main<T>(a, 0, n, s, x_lo, x_hi, fwx::FusedCols::except(x_lo, x_hi)));
+                // a main launch whose retiring workgroups leave no room for a panel workgroup goes out as two
+                // halves: the chain's panels get in at each half's tail instead of at the end of the whole launch
+                // (N = 8192 + next-hops: gap between main launches 77 -> 20 us; FWX_SPLIT_MAIN=0: A/B)
+                static const bool split_ok = [] { const char *e = getenv("FWX_SPLIT_MAIN"); return !(e && *e == '0'); }();
+                const int h = n / 2 / 128 * 128;
+                if (split_ok && h > 0 && fwx::fused_main_starves_panels<T>(a)) {
+                    FWX_HIP(fwx::launch_fused_main<T>(a, 0, h, s, x_lo, x_hi, fwx::FusedCols::except(x_lo, x_hi)));
+                    FWX_HIP(fwx::launch_fused_main<T>(a, h, n, s, x_lo, x_hi, fwx::FusedCols::except(x_lo, x_hi)));
+                } else {
+                    FWX_HIP(fwx::launch_fused_main<T>(a, 0, n, s, x_lo, x_hi, fwx::FusedCols::except(x_lo, x_hi)));
+                }
                 FWX_HIP(hipStreamWaitEvent(s, side.panel_done, 0));
             } else {
                 bind4(q, 2);

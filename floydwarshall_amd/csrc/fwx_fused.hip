@@ -2120,6 +2120,12 @@ hipError_t launch_nonneg_check(const double *rate, const int32_t *next, size_t c
     return hipGetLastError();
 }
 
+template <> bool fused_main_starves_panels<float>(const FusedArgs<float> &a)
+{
+    return a.nonneg && !a.updates && a.next && small_tiles_arg(a.n, a.rows);
+}
+template <> bool fused_main_starves_panels<double>(const FusedArgs<double> &) { return false; }
+
 // f32, rates only, no update counting, domain verified by the caller: the max3 kernel.
 static bool launch_max_form(const FusedArgs<float> &a, dim3 grid, dim3 block, int skip_lo,
                             int skip_hi, hipStream_t s, int32_t *last, bool small, ColWin cw, bool)

@@ -107,6 +107,12 @@ struct FusedCols {
     static FusedCols only(int lo, int hi) { FusedCols c; c.c_lo = lo; c.c_hi = hi; return c; }
     static FusedCols except(int lo, int hi) { FusedCols c; c.skip_lo = lo; c.skip_hi = hi; return c; }
 };
+// True if the main launch these arguments select leaves no room for a panel workgroup when ONE of its own
+// workgroups retires (f32 with next-hops on 64 x 64 tiles: four workgroups per CU at 128 registers free 128 per
+// SIMD, a panel workgroup is four waves per SIMD at 48): the panels of the look-ahead chain then wait for the
+// launch's tail.  A double-pass schedule issues such a main launch as two halves -- the first one's tail lets the
+// chain's first panel in, the second one's the other (fused_range in fwx_api.hip, profiles/r04_timeline_*).
+template <typename T> bool fused_main_starves_panels(const FusedArgs<T> &a);
 template <typename T>
 hipError_t launch_fused_main(const FusedArgs<T> &a, int r_lo, int r_hi, hipStream_t s,
                              int skip_lo = 0, int skip_hi = 0, FusedCols cols = FusedCols());

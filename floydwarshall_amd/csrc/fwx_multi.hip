@@ -922,8 +922,18 @@ static int multi_double_pass(fwx_matrix *m, const std::vector<Block> &blocks, Th
                     tm.end(t_chain[p], q.side);
                     FWX_HIP(hipEventRecord(q.panel_done, q.side));
                     const int t_bulk = tm.begin(MultiTimer::BULK, p, pr, q.main);
-                    FWX_HIP(fwx::launch_fused_main<T>(args(q, q0, 2), 0, q.rows, q.main, local(q, x_lo), local(q, x_hi),
-                                                      fwx::FusedCols::except(x_lo, x_hi)));
+                    // (two halves where a retiring main workgroup leaves no room for a panel workgroup: fused_range)
+                    const fwx::FusedArgs<T> am = args(q, q0, 2);
+                    const int h = q.rows / 2 / 128 * 128;
+                    if (h > 0 && fwx::fused_main_starves_panels<T>(am)) {
+                        FWX_HIP(fwx::launch_fused_main<T>(am, 0, h, q.main, local(q, x_lo), local(q, x_hi),
+                                                          fwx::FusedCols::except(x_lo, x_hi)));
+                        FWX_HIP(fwx::launch_fused_main<T>(am, h, q.rows, q.main, local(q, x_lo), local(q, x_hi),
+                                                          fwx::FusedCols::except(x_lo, x_hi)));
+                    } else {
+                        FWX_HIP(fwx::launch_fused_main<T>(am, 0, q.rows, q.main, local(q, x_lo), local(q, x_hi),
+                                                          fwx::FusedCols::except(x_lo, x_hi)));
+                    }
                     tm.end(t_bulk, q.main);
                     FWX_HIP(hipStreamWaitEvent(q.main, q.panel_done, 0));
                     return FWX_OK;
