@@ -544,6 +544,13 @@ def run_single(args):
                     "source": "tools/valu_rate.hip: profiles/r02_valu_sustained.txt (0.3 s bursts: 2.33 GHz "
                               "held), profiles/r02_valu_issue_rates.txt, profiles/r02_clocks.txt; whole solve "
                               "(panels and look-ahead launches included), not the main kernel alone"}
+            kclk = kernel_clock_ghz("float32", False)
+            if kclk:
+                # the clock measured INSIDE fused_main_max on this solve shape (valu_rate's register stream holds
+                # 2.33 GHz, the real kernel with its LDS operand reads less): the issue bound at that clock
+                valu["at_kernel_clock"] = {"clock_GHz": kclk, "bound_ms_per_step": 1e3 * cyc / (kclk * 1e9),
+                                           "frac": cyc / (kclk * 1e9) / ft,
+                                           "source": "profiles/r04_shader_clock.json (tools/measure_clock.py)"}
         out["fused_engine"] = {"value": relax_per_step / ft, "unit": "edge-relaxations/s",
                                "ms_per_step": 1e3 * ft, "steps": 2, "valu_roofline": valu,
                                "note": "same workload on the default (AUTO) engine: fused (from N = 6144 a "
@@ -606,6 +613,19 @@ def run_single(args):
     print(json.dumps(out), flush=True)
 
 
+def kernel_clock_ghz(dtype_name, with_next, n=16384):
+    """Shader clock measured INSIDE the fused main kernels (profiles/r04_shader_clock.json, a -DFWX_CLOCK_PROBE
+    build; tools/measure_clock.py), or None."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "r04_shader_clock.json")) as f:
+            for r in json.load(f)["runs"]:
+                if r["n"] == n and r["dtype"] == dtype_name and r["next"] == with_next:
+                    return float(r["shader_clock_GHz"])
+    except (OSError, ValueError, KeyError):
+        pass
+    return None
+
+
 def arg_kernel_own_bound(n, measured_s):
     """The minimum of fused_main_arg's OWN scheme in vector-issue cycles, from the instruction mix of the
     compiled kernel (tools/isa_mix.py over `hipcc -S`, profiles/r04_arg_isa_mix.txt) priced at the issue costs
@@ -630,11 +650,17 @@ def arg_kernel_own_bound(n, measured_s):
     passes = n / 64.0
     clock = 2.33e9                                     # held under VALU load (profiles/r02_valu_sustained.txt)
     bound_s = passes * wave_tiles_per_simd * cycles / clock
-    return {"cycles_per_wave_tile": {"fold": round(fold), "tracking": round(tracking), "compaction": round(compaction),
-                                     "rescan_at_11pct_moved": round(rescan), "rest": round(rest), "total": round(cycles)},
-            "clock_GHz": 2.33, "bound_ms_per_step": 1e3 * bound_s, "frac": bound_s / measured_s,
-            "fold_share_of_own_bound": fold / cycles,
-            "source": "tools/isa_mix.py, profiles/r04_arg_isa_mix.txt, profiles/r02_valu_issue_rates.txt"}
+    out = {"cycles_per_wave_tile": {"fold": round(fold), "tracking": round(tracking), "compaction": round(compaction),
+                                    "rescan_at_11pct_moved": round(rescan), "rest": round(rest), "total": round(cycles)},
+           "clock_GHz": 2.33, "bound_ms_per_step": 1e3 * bound_s, "frac": bound_s / measured_s,
+           "fold_share_of_own_bound": fold / cycles,
+           "source": "tools/isa_mix.py, profiles/r04_arg_isa_mix.txt, profiles/r02_valu_issue_rates.txt"}
+    kclk = kernel_clock_ghz("float32", True)
+    if kclk:                                           # the clock measured inside the kernel itself
+        at = passes * wave_tiles_per_simd * cycles / (kclk * 1e9)
+        out["at_kernel_clock"] = {"clock_GHz": kclk, "bound_ms_per_step": 1e3 * at, "frac": at / measured_s,
+                                  "source": "profiles/r04_shader_clock.json (tools/measure_clock.py)"}
+    return out
 
 
 def reference_regime_leg(engine, with_cpu):
@@ -721,6 +747,10 @@ def f64_leg(engine, hip, rate64, n, stream):
                                       "at_round1_clock": {"clock_GHz": 1.92, "frac": cyc / 1.92e9 / ft},
                                       "at_nominal_clock": {"clock_GHz": 2.4, "frac": cyc / 2.4e9 / ft}},
                     "per_k_equals_fused_bits": same}
+    kclk = kernel_clock_ghz("float64", False)
+    if kclk:                                           # the clock measured inside fused_main_max_f64 (profiles/r04_shader_clock.json)
+        res["fused"]["valu_roofline"]["at_kernel_clock"] = {"clock_GHz": kclk, "bound_ms_per_step": 1e3 * cyc / (kclk * 1e9),
+                                                           "frac": cyc / (kclk * 1e9) / ft}
     h.close()
     res["check"] = {"rate_digest": f64_digest}
     gold = os.path.join(ROOT, "tests", "golden", "config4_n16384_f64_digests.json")

@@ -89,6 +89,28 @@ constexpr int B = FWX_FUSED_B;
 // all vector-memory loads have returned, the other counters untouched.
 #define FWX_WAIT_VMCNT0 0x0F70
 
+// -DFWX_CLOCK_PROBE (a variant build, never shipped): the shader clock the chip holds while the main kernels run --
+// every workgroup adds its s_memtime cycles and its s_memrealtime ticks (100 MHz) to two counters that
+// fwx_debug_clock reads (tools/measure_clock.py).
+#ifdef FWX_CLOCK_PROBE
+__device__ unsigned long long g_clk[3];
+struct ClockProbe {
+    unsigned long long t0, r0;
+    __device__ ClockProbe() : t0(__builtin_amdgcn_s_memtime()), r0(__builtin_amdgcn_s_memrealtime()) {}
+    __device__ ~ClockProbe()
+    {
+        if (threadIdx.x == 0) {
+            atomicAdd(&g_clk[0], __builtin_amdgcn_s_memtime() - t0);
+            atomicAdd(&g_clk[1], __builtin_amdgcn_s_memrealtime() - r0);
+            atomicAdd(&g_clk[2], 1ull);
+        }
+    }
+};
+#define FWX_PROBE ClockProbe probe_
+#else
+#define FWX_PROBE do { } while (0)
+#endif
+
 // Column controls of a main-kernel launch (symmetric look-ahead, fused_range in fwx_api.hip):
 // the grid's column tiles start at tile jt0 (a launch over a window of columns), and columns
 // [cskip_lo, cskip_hi) (multiples of 4) are left alone -- another launch of the same pass owns them.
@@ -884,6 +906,7 @@ __global__ __launch_bounds__(256, MINW) void fused_main_max(float *rate, int row
                                                             const float *ct, int ct_ld, int ct_vec,
                                                             int skip_lo, int skip_hi, ColWin cw)
 {
+    FWX_PROBE;
     if (cw.prio) __builtin_amdgcn_s_setprio(2);    // a launch of the look-ahead chain (FusedArgs::side)
     typedef float V4 __attribute__((ext_vector_type(4)));
     // 16 pivots (8 pairs) per LDS stage, two stages resident: while stage s is being folded the
@@ -1128,6 +1151,7 @@ __global__ __launch_bounds__(256, MINW) void fused_main_max_f64(double *rate, in
                                                                 const double *ct, int ct_ld, int ct_vec,
                                                                 int skip_lo, int skip_hi, ColWin cw)
 {
+    FWX_PROBE;
     if (cw.prio) __builtin_amdgcn_s_setprio(2);    // a launch of the look-ahead chain (FusedArgs::side)
     typedef double V2 __attribute__((ext_vector_type(2)));
     constexpr int RI = 8, NH = 4, TI = 128, TJ = 128, HJ = 32, BS = 8;
@@ -1355,6 +1379,7 @@ __global__ __launch_bounds__(256, MINW) void fused_main_arg(float *rate, int32_t
                                                             int32_t *hops, const int32_t *cht_all,
                                                             const int32_t *wh_all, ColWin cw)
 {
+    FWX_PROBE;
     if (cw.prio) __builtin_amdgcn_s_setprio(2);    // a launch of the look-ahead chain (FusedArgs::side)
     typedef float V4 __attribute__((ext_vector_type(4)));
     // list capacity: a flush point after every second entry slot, 63 carried + 2 * 64 new items
@@ -1707,6 +1732,7 @@ __global__ __launch_bounds__(256, MINW) void fused_main_arg_f64(double *rate, in
                                                                 int32_t *hops, const int32_t *cht_all,
                                                                 const int32_t *wh_all, ColWin cw)
 {
+    FWX_PROBE;
     if (cw.prio) __builtin_amdgcn_s_setprio(2);    // a launch of the look-ahead chain (FusedArgs::side)
     typedef double V2 __attribute__((ext_vector_type(2)));
     // RI rows per thread: 64 x 64 tiles (RI = 4; 69 KB of LDS, two workgroups per CU: the shipped form)
@@ -2451,3 +2477,16 @@ template hipError_t launch_fused_panel<double>(const double *, int, int, int, do
                                                PathLog, const int32_t *, int32_t *);
 
 }  // namespace fwx
+
+#ifdef FWX_CLOCK_PROBE
+extern "C" __attribute__((visibility("default"))) int fwx_debug_clock(unsigned long long *out, int reset)
+{
+    if (out && hipMemcpyFromSymbol(out, HIP_SYMBOL(fwx::g_clk), 24) != hipSuccess) return -1;
+    if (reset) {
+        const unsigned long long z[3] = {0, 0, 0};
+        if (hipMemcpyToSymbol(HIP_SYMBOL(fwx::g_clk), z, 24) != hipSuccess) return -1;
+    }
+    return 0;
+}
+#endif
+
