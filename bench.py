@@ -271,19 +271,23 @@ def pmc_traffic(n, args):
 
 
 def digest(a):
-    """64-bit digest of an array's bytes (xxhash if present, else crc32 of 64 MiB chunks)."""
-    buf = memoryview(np.ascontiguousarray(a)).cast("B")
+    """64-bit digest of an array's bytes (xxhash if present, else crc32 of 64 MiB chunks); a list / tuple of
+    arrays is digested as their concatenation (row slabs of one matrix, in order)."""
+    parts = a if isinstance(a, (list, tuple)) else [a]
+    bufs = [memoryview(np.ascontiguousarray(x)).cast("B") for x in parts]
     try:
         import xxhash
         h = xxhash.xxh64()
-        for off in range(0, len(buf), 1 << 26):
-            h.update(buf[off:off + (1 << 26)])
+        for buf in bufs:
+            for off in range(0, len(buf), 1 << 26):
+                h.update(buf[off:off + (1 << 26)])
         return "xxh64:" + h.hexdigest()
     except ImportError:
         import zlib
         c = 0
-        for off in range(0, len(buf), 1 << 26):
-            c = zlib.crc32(buf[off:off + (1 << 26)], c)
+        for buf in bufs:
+            for off in range(0, len(buf), 1 << 26):
+                c = zlib.crc32(buf[off:off + (1 << 26)], c)
         return "crc32:%08x" % c
 
 
@@ -1164,6 +1168,46 @@ def run_dist(args, world, rank, local_rank):
                                "note": "same workload, engine = FUSED (what AUTO runs), same driver; %s; max over "
                                        "ranks, best of 2; not part of `value`"
                                        % ("solve only" if ph is not None else "restore included")}
+    if not args.no_extras:
+        # What the ranks computed, checked on rank 0: every rank's slab of the last timed step's result gathered
+        # (device tensors over RCCL; host tensors under the gloo rehearsal), digested in row order, and -- for the
+        # headline matrix -- compared with the digest of the whole CPU-oracle solve (tests/golden/)
+        dog.arm("result check (gather of the slabs on rank 0)")
+        if ph is not None:
+            got = ph.download()
+            mine, mine_next = torch.from_numpy(got[0]), (torch.from_numpy(got[1]) if args.with_next else None)
+            del got
+        else:
+            mine, mine_next = rate.cpu(), (nxt.cpu() if nxt is not None else None)
+        rows_max = max(bounds[p + 1] - bounds[p] for p in range(world))
+
+        def gather_rows(t):
+            buf = torch.zeros((rows_max, n), dtype=t.dtype)
+            buf[:r1 - r0] = t
+            if args.backend == "nccl":
+                buf = buf.to(dev)
+            parts = [torch.empty_like(buf) for _ in range(world)] if rank == 0 else None
+            dist.gather(buf, parts, dst=0)
+            if rank != 0:
+                return None
+            return [parts[p][:bounds[p + 1] - bounds[p]].cpu().numpy() for p in range(world)]
+
+        slabs = gather_rows(mine)
+        slabs_next = gather_rows(mine_next) if mine_next is not None else None
+        if rank == 0:
+            chk = {"rate_digest": digest(slabs), "what": "the ranks' slabs of the timed engine's result, gathered on "
+                                                           "rank 0 and digested in row order"}
+            if slabs_next is not None:
+                chk["next_digest"] = digest(slabs_next)
+            gold = os.path.join(ROOT, "tests", "golden", "config4_n16384_digests.json")
+            if n == 16384 and es == 4 and args.dist == "d1" and args.config in (0, 4) and os.path.exists(gold):
+                with open(gold) as f:
+                    g = json.load(f)
+                chk["equals_whole_oracle_solve"] = bool(chk["rate_digest"] == g["rate_digest"] and
+                                                        (slabs_next is None or chk["next_digest"] == g["next_digest"]))
+            out["check"] = chk
+        del slabs, slabs_next, mine, mine_next
+        dog.disarm()
     if not args.no_extras and ph is not None and same_cut:
         # the older Python driver once, untimed region of its own: a cross-check of the two schedules (bit for
         # bit, every rank's slab) and their per-k times side by side
