@@ -69,6 +69,7 @@ class Watchdog:
         self._lock = threading.Lock()
         self._label, self._deadline, self._done = None, None, []
         self._valid = None
+        self._quiet = False
         self._stop = threading.Event()
         self._thread = None
         if self.bound_s > 0:
@@ -96,6 +97,12 @@ class Watchdog:
         with self._lock:
             self._valid = line
 
+    def line_printed(self):
+        """The line is out.  A phase that hangs from here on (the final barrier with a rank gone) only ends the
+        process, with code 0 and nothing more written."""
+        with self._lock:
+            self._quiet = True
+
     def error_line(self, label):
         line = dict(self.base)
         line.update({"value": None, "error": "watchdog: phase %r still running after %.0f s" % (label, self.bound_s),
@@ -108,7 +115,10 @@ class Watchdog:
                 label, deadline = self._label, self._deadline
             if label is not None and time.monotonic() > deadline:
                 with self._lock:
-                    valid = self._valid
+                    valid, quiet = self._valid, self._quiet
+                if quiet:
+                    self.exit_fn(0)
+                    return
                 if valid is not None:
                     line = dict(valid)
                     line["extras_aborted"] = {"hung_phase": label, "after_s": self.bound_s,
@@ -1139,106 +1149,129 @@ def run_dist(args, world, rank, local_rank):
                        "ranks_in_process_group": dist.get_world_size()}
     dog.set_valid_line(out)         # `value` stands: whatever hangs from here on cannot cost the line
     if not args.no_extras:
-        out["exchange"].update(timing_leg(args.engine))
-        out["exchange"]["timing_note"] = (
-            "events on the streams the work runs on, one extra untimed solve: bulk = the slab sweep of a step, "
-            "chain = what the next step waits for besides it (look-ahead rows + owner's panel + broadcast; the "
-            "whole side chain under the pair schedule); chain_over_bulk > 1 = bound by the panel chain "
-            "(DESIGN.md section 5)")
+        try:
+            out["exchange"].update(timing_leg(args.engine))
+            out["exchange"]["timing_note"] = (
+                "events on the streams the work runs on, one extra untimed solve: bulk = the slab sweep of a step, "
+                "chain = what the next step waits for besides it (look-ahead rows + owner's panel + broadcast; the "
+                "whole side chain under the pair schedule); chain_over_bulk > 1 = bound by the panel chain "
+                "(DESIGN.md section 5)")
+        except Exception as err:      # noqa: BLE001 -- an optional leg must not cost the line
+            out.setdefault("extras_failed", []).append({"leg": dog._label, "error": repr(err)[:400]})
+            dog.disarm()
     if not args.no_extras and not args.no_fused_extra and args.engine == "perk":
-        # Not part of `value`: the same workload on the engine AUTO picks (fused; the 128-pivot pair schedule
-        # under the "part" driver), same handle, solve only, best of 2, max over ranks
-        dog.arm("fused-engine leg")
-        times = []
-        for i in range(3):
-            if ph is not None:
-                ph.upload_dev(pristine, pristine_next)
-            fence()
-            t1 = time.perf_counter()
-            if ph is not None:
-                ph.solve(engine=ENG["fused"])
-            else:
-                legacy_step(bk=fwdist.HipBackend("fused"))
-            fence()
-            times.append(time.perf_counter() - t1)
-        ft = min(max_over_ranks(times[1:]))
-        dog.disarm()
-        out["fused_engine"] = {"value": relax_per_step / ft, "unit": "edge-relaxations/s", "ms_per_step": 1e3 * ft,
-                               "steps": 2, "exchange": timing_leg("fused"),
-                               "note": "same workload, engine = FUSED (what AUTO runs), same driver; %s; max over "
-                                       "ranks, best of 2; not part of `value`"
-                                       % ("solve only" if ph is not None else "restore included")}
+        try:
+            # Not part of `value`: the same workload on the engine AUTO picks (fused; the 128-pivot pair schedule
+            # under the "part" driver), same handle, solve only, best of 2, max over ranks
+            dog.arm("fused-engine leg")
+            times = []
+            for i in range(3):
+                if ph is not None:
+                    ph.upload_dev(pristine, pristine_next)
+                fence()
+                t1 = time.perf_counter()
+                if ph is not None:
+                    ph.solve(engine=ENG["fused"])
+                else:
+                    legacy_step(bk=fwdist.HipBackend("fused"))
+                fence()
+                times.append(time.perf_counter() - t1)
+            ft = min(max_over_ranks(times[1:]))
+            dog.disarm()
+            out["fused_engine"] = {"value": relax_per_step / ft, "unit": "edge-relaxations/s", "ms_per_step": 1e3 * ft,
+                                   "steps": 2, "exchange": timing_leg("fused"),
+                                   "note": "same workload, engine = FUSED (what AUTO runs), same driver; %s; max over "
+                                           "ranks, best of 2; not part of `value`"
+                                           % ("solve only" if ph is not None else "restore included")}
+        except Exception as err:      # noqa: BLE001 -- an optional leg must not cost the line
+            out.setdefault("extras_failed", []).append({"leg": dog._label, "error": repr(err)[:400]})
+            dog.disarm()
     if not args.no_extras:
-        # What the ranks computed, checked on rank 0: every rank's slab of the last timed step's result gathered
-        # (device tensors over RCCL; host tensors under the gloo rehearsal), digested in row order, and -- for the
-        # headline matrix -- compared with the digest of the whole CPU-oracle solve (tests/golden/)
-        dog.arm("result check (gather of the slabs on rank 0)")
-        if ph is not None:
-            got = ph.download()
-            mine, mine_next = torch.from_numpy(got[0]), (torch.from_numpy(got[1]) if args.with_next else None)
-            del got
-        else:
-            mine, mine_next = rate.cpu(), (nxt.cpu() if nxt is not None else None)
-        rows_max = max(bounds[p + 1] - bounds[p] for p in range(world))
+        try:
+            # What the ranks computed, checked on rank 0: every rank's slab of the last timed step's result gathered
+            # (device tensors over RCCL; host tensors under the gloo rehearsal), digested in row order, and -- for the
+            # headline matrix -- compared with the digest of the whole CPU-oracle solve (tests/golden/)
+            dog.arm("result check (gather of the slabs on rank 0)")
+            step()                                   # the timed engine's result again
+            torch.cuda.synchronize()
+            if ph is not None:
+                got = ph.download()
+                mine, mine_next = torch.from_numpy(got[0]), (torch.from_numpy(got[1]) if args.with_next else None)
+                del got
+            else:
+                mine, mine_next = rate.cpu(), (nxt.cpu() if nxt is not None else None)
+            rows_max = max(bounds[p + 1] - bounds[p] for p in range(world))
 
-        def gather_rows(t):
-            buf = torch.zeros((rows_max, n), dtype=t.dtype)
-            buf[:r1 - r0] = t
-            if args.backend == "nccl":
-                buf = buf.to(dev)
-            parts = [torch.empty_like(buf) for _ in range(world)] if rank == 0 else None
-            dist.gather(buf, parts, dst=0)
-            if rank != 0:
-                return None
-            return [parts[p][:bounds[p + 1] - bounds[p]].cpu().numpy() for p in range(world)]
+            def gather_rows(t):
+                buf = torch.zeros((rows_max, n), dtype=t.dtype)
+                buf[:r1 - r0] = t
+                if args.backend == "nccl":
+                    buf = buf.to(dev)
+                parts = [torch.empty_like(buf) for _ in range(world)] if rank == 0 else None
+                dist.gather(buf, parts, dst=0)
+                if rank != 0:
+                    return None
+                return [parts[p][:bounds[p + 1] - bounds[p]].cpu().numpy() for p in range(world)]
 
-        slabs = gather_rows(mine)
-        slabs_next = gather_rows(mine_next) if mine_next is not None else None
-        if rank == 0:
-            chk = {"rate_digest": digest(slabs), "what": "the ranks' slabs of the timed engine's result, gathered on "
-                                                           "rank 0 and digested in row order"}
-            if slabs_next is not None:
-                chk["next_digest"] = digest(slabs_next)
-            gold = os.path.join(ROOT, "tests", "golden", "config4_n16384_digests.json")
-            if n == 16384 and es == 4 and args.dist == "d1" and args.config in (0, 4) and os.path.exists(gold):
-                with open(gold) as f:
-                    g = json.load(f)
-                chk["equals_whole_oracle_solve"] = bool(chk["rate_digest"] == g["rate_digest"] and
-                                                        (slabs_next is None or chk["next_digest"] == g["next_digest"]))
-            out["check"] = chk
-        del slabs, slabs_next, mine, mine_next
-        dog.disarm()
+            slabs = gather_rows(mine)
+            slabs_next = gather_rows(mine_next) if mine_next is not None else None
+            if rank == 0:
+                chk = {"rate_digest": digest(slabs), "what": "the ranks' slabs of the timed engine's result, gathered on "
+                                                               "rank 0 and digested in row order"}
+                if slabs_next is not None:
+                    chk["next_digest"] = digest(slabs_next)
+                gold = os.path.join(ROOT, "tests", "golden", "config4_n16384_digests.json")
+                if n == 16384 and es == 4 and args.dist == "d1" and args.config in (0, 4) and os.path.exists(gold):
+                    with open(gold) as f:
+                        g = json.load(f)
+                    chk["equals_whole_oracle_solve"] = bool(chk["rate_digest"] == g["rate_digest"] and
+                                                            (slabs_next is None or chk["next_digest"] == g["next_digest"]))
+                out["check"] = chk
+            del slabs, slabs_next, mine, mine_next
+            dog.disarm()
+        except Exception as err:      # noqa: BLE001 -- an optional leg must not cost the line
+            out.setdefault("extras_failed", []).append({"leg": dog._label, "error": repr(err)[:400]})
+            dog.disarm()
     if not args.no_extras and ph is not None and same_cut:
-        # the older Python driver once, untimed region of its own: a cross-check of the two schedules (bit for
-        # bit, every rank's slab) and their per-k times side by side
-        dog.arm("legacy driver leg (dist.solve_partitioned)")
-        step()                                   # the timed engine's result again, in the handle
-        mine = torch.from_numpy(ph.download()[0]).to(dev)
-        lt = []
-        for i in range(2):
-            fence()
-            t1 = time.perf_counter()
-            legacy_step()
-            fence()
-            lt.append(time.perf_counter() - t1)
-        same = torch.tensor([1 if torch.equal(mine, rate) else 0], dtype=torch.int32, device=dev)
-        dist.all_reduce(same, op=dist.ReduceOp.MIN)
-        ls = max_over_ranks([lt[1]])[0]
-        dog.disarm()
-        out["legacy_driver"] = {"value": relax_per_step / ls, "ms_per_step": 1e3 * ls, "steps": 1,
-                                "equals_timed_driver_bits": bool(int(same.item())),
-                                "note": "dist.solve_partitioned, same engine, restore included; not part of `value`"}
-        del mine
+        try:
+            # the older Python driver once, untimed region of its own: a cross-check of the two schedules (bit for
+            # bit, every rank's slab) and their per-k times side by side
+            dog.arm("legacy driver leg (dist.solve_partitioned)")
+            step()                                   # the timed engine's result again, in the handle
+            mine = torch.from_numpy(ph.download()[0]).to(dev)
+            lt = []
+            for i in range(2):
+                fence()
+                t1 = time.perf_counter()
+                legacy_step()
+                fence()
+                lt.append(time.perf_counter() - t1)
+            same = torch.tensor([1 if torch.equal(mine, rate) else 0], dtype=torch.int32, device=dev)
+            dist.all_reduce(same, op=dist.ReduceOp.MIN)
+            ls = max_over_ranks([lt[1]])[0]
+            dog.disarm()
+            out["legacy_driver"] = {"value": relax_per_step / ls, "ms_per_step": 1e3 * ls, "steps": 1,
+                                    "equals_timed_driver_bits": bool(int(same.item())),
+                                    "note": "dist.solve_partitioned, same engine, restore included; not part of `value`"}
+            del mine
+        except Exception as err:      # noqa: BLE001 -- an optional leg must not cost the line
+            out.setdefault("extras_failed", []).append({"leg": dog._label, "error": repr(err)[:400]})
+            dog.disarm()
     if ph is not None:
         ph.close()
-    dog.stop()
+    dog.disarm()
     if rank == 0:
         if not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(make_input(args, n)[0].astype(np_dtype),
                                                min(args.cpu_seconds, 8.0))
         print(json.dumps(out), flush=True)
+    # the line is out: a rank that is gone (its own watchdog ended it during an optional leg) must not leave the
+    # others in this barrier for ever
+    dog.line_printed()
+    dog.arm("final barrier")
     dist.barrier()
     dist.destroy_process_group()
+    dog.stop()
 
 
 def main():

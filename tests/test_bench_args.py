@@ -181,3 +181,22 @@ def test_a_hung_extra_leg_does_not_cost_the_measurement():
     assert got["value"] == 1.5e12 and got["exchange"]["avg_bulk_us"] == 1300.0 and "error" not in got
     assert got["extras_aborted"]["hung_phase"] == "fused-engine leg"
     assert got["extras_aborted"]["phases_completed"] == ["the 2 timed steps"]
+
+
+def test_after_the_line_is_printed_a_hung_final_barrier_only_ends_the_process():
+    """run_dist prints its line, then waits in a last barrier: if a rank is gone (its own watchdog ended it during an
+    optional leg) that barrier never returns -- the watchdog then ends the process with code 0 and writes NOTHING
+    more (the driver parses ONE line)."""
+    import io
+    import time
+    import bench
+    out, codes = io.StringIO(), []
+    dog = bench.Watchdog(0.3, {"metric": "m"}, out=out, exit_fn=codes.append)
+    dog.set_valid_line({"metric": "m", "value": 2.0e12})
+    dog.line_printed()
+    dog.arm("final barrier")
+    for _ in range(40):
+        if codes:
+            break
+        time.sleep(0.1)
+    assert codes == [0] and out.getvalue() == ""
