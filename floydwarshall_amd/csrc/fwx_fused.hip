@@ -129,6 +129,36 @@ __device__ __forceinline__ void lds_barrier()
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
 }
 
+// Synchronisation of the panel chain (round 4).  FWX_PANEL_FLAGS=1 (default): no workgroup barrier in the loop --
+// the wave on its serial phase raises ONE LDS FLAG PER PIVOT right after publishing that pivot's line, and a later
+// wave applies a pivot as soon as its flag is up: the wave that goes serial next has applied all but the last pivot
+// of the sub-block before its predecessor is done, so the chain per sub-block is one serial phase + one pivot's
+// apply instead of serial phase + barrier + four pivots' apply.  Older sub-blocks are waited for with one flag
+// (their last pivot's: lines and flags of a wave go through the LDS queue in order).  =0: the barrier form.
+#ifndef FWX_PANEL_FLAGS
+#define FWX_PANEL_FLAGS 1
+#endif
+constexpr int PANEL_FLAG_BYTES = B * 4;
+__device__ __forceinline__ void panel_flags_init(int *flag)
+{
+    if (threadIdx.x < B) flag[threadIdx.x] = 0;
+}
+__device__ __forceinline__ void panel_flag_raise(int *flag, int t)
+{
+    // A wave's LDS operations are executed in issue order (one queue per CU; that is what lgkmcnt counts on), so a
+    // plain store issued AFTER the lines' stores is seen after them: no wait for their completion on the chain --
+    // a release store puts s_waitcnt lgkmcnt(0) in front, ~4 x 64 cycles per sub-block.  The compiler must not
+    // move it up: signal fences on both sides.
+    __atomic_signal_fence(__ATOMIC_SEQ_CST);
+    __hip_atomic_store(&flag[t], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    __atomic_signal_fence(__ATOMIC_SEQ_CST);
+}
+__device__ __forceinline__ void panel_flag_wait(int *flag, int t)
+{
+    while (__builtin_amdgcn_readfirstlane(__hip_atomic_load(&flag[t], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP)) == 0)
+        __builtin_amdgcn_s_sleep(1);
+}
+
 // ------------------------------------------------------------------------------------------------
 // Panel kernels.  One wave per SUB-BLOCK of SB = 4 pivots: 16 waves = 1024 threads per workgroup.
 // Wave b owns SB of the 64 panel lines (rows for the row panel, block columns for the column
@@ -182,12 +212,12 @@ template <> __device__ __forceinline__ int readlane<int>(int v, int lane)
 // fused_panels below)
 template <typename T, bool HAS_HOPS> constexpr int rowpanel_lds()
 {
-    return 2 * B * 64 * (int)sizeof(T) + (HAS_HOPS ? 2 * B * 64 * 4 : 0);
+    return 2 * B * 64 * (int)sizeof(T) + (HAS_HOPS ? 2 * B * 64 * 4 : 0) + PANEL_FLAG_BYTES;
 }
 // MAXF (rates only, domain verified by the caller): x <- max(x, c * w) instead of compare + select --
 // the same bits on that domain (see fused_main_max; the NaN operands that encode the skip set are
 // ignored by max exactly as `x < NaN` is false), one instruction less on the serial chain.
-template <typename T, bool HAS_LAST, bool HAS_HOPS, bool MAXF = false>
+template <typename T, bool HAS_LAST, bool HAS_HOPS, bool MAXF = false, bool FLAGS = FWX_PANEL_FLAGS != 0>
 __device__ __forceinline__ void rowpanel_body(char *smem, int bid, const T *rows, int n, int k0, int bt,
                                               T *w_out, const int32_t *last_rows, int32_t *at_rows,
                                               const int32_t *hops_rows, int32_t *wh_out)
@@ -239,64 +269,96 @@ __device__ __forceinline__ void rowpanel_body(char *smem, int bid, const T *rows
         if (HAS_HOPS) hs[q] = us ? (int32_t)((uint32_t)ch + (uint32_t)hws) : hs[q];
     };
 
+    // the serial phase of this wave's sub-block b: pivot by pivot, each line published (and, with flags, announced)
+    // before the wave's other rows take the pivot
+    auto serial_phase = [&](int b, int *flag) {
+#pragma unroll
+        for (int tq = 0; tq < SB; ++tq) {
+            const int t = b * SB + tq;
+            if (t >= bt) continue;
+            // the pivot row at time t: every earlier pivot has been applied, pivot t leaves it alone
+            T wd = pd[tq];
+            if (lane == t) wd = qnan<T>();     // skip j == k (also hides the stale diagonal)
+            T ws = ps[tq];
+            if (j == k0 + t) ws = dorig;
+            const int32_t hwd = HAS_HOPS ? hd[tq] : 0;
+            const int32_t hws = HAS_HOPS ? (j == k0 + t ? hdorig : hs[tq]) : 0;
+            const T snap = ws;                                    // the snapshot (stored below)
+            if (j == k0 + t) ws = qnan<T>();                      // skip j == k
+            s_dline[t][lane] = wd;
+            s_sline[t][lane] = ws;
+            if (HAS_HOPS) { s_dh[t][lane] = hwd; s_sh[t][lane] = hws; }
+            if (flag) panel_flag_raise(flag, t);
+            if (valid) {
+                w_out[(size_t)t * n + j] = snap;
+                if (HAS_LAST) at_rows[(size_t)t * n + j] = j == k0 + t ? -1 : lp[tq];
+                if (HAS_HOPS) wh_out[(size_t)t * n + j] = hws;
+            }
+            // column t of this wave's rows: SB independent cross-lane reads first
+            T cv[SB];
+            int32_t ch[SB];
+#pragma unroll
+            for (int q = 0; q < SB; ++q) {
+                cv[q] = readlane<T>(pd[q], t);
+                ch[q] = HAS_HOPS ? readlane<int>(hd[q], t) : 0;
+            }
+#pragma unroll
+            for (int q = 0; q < SB; ++q) {
+                if (q == tq) continue;                        // skip i == k
+                relax_row(q, cv[q], ch[q], wd, ws, hwd, hws, t);
+            }
+        }
+    };
+    // published pivot t onto this wave's rows
+    auto apply_pivot = [&](int t) {
+        const T wd = s_dline[t][lane], ws = s_sline[t][lane];
+        const int32_t hwd = HAS_HOPS ? s_dh[t][lane] : 0, hws = HAS_HOPS ? s_sh[t][lane] : 0;
+        T cv[SB];
+        int32_t ch[SB];
+#pragma unroll
+        for (int q = 0; q < SB; ++q) {
+            cv[q] = readlane<T>(pd[q], t);
+            ch[q] = HAS_HOPS ? readlane<int>(hd[q], t) : 0;
+        }
+#pragma unroll
+        for (int q = 0; q < SB; ++q) relax_row(q, cv[q], ch[q], wd, ws, hwd, hws, t);
+    };
+    if constexpr (FLAGS) {
+    int *flag = reinterpret_cast<int *>(smem + rowpanel_lds<T, HAS_HOPS>() - PANEL_FLAG_BYTES);
+    panel_flags_init(flag);
+    __syncthreads();
+    // sub-blocks long done: one wait each (the flag of their last pivot), four pivots per trip
+#pragma unroll 1
+    for (int b = 0; b + 1 < wave; ++b) {
+        if (b * SB >= bt) break;                   // uniform
+        panel_flag_wait(flag, min(b * SB + SB, bt) - 1);
+#pragma unroll
+        for (int tq = 0; tq < SB; ++tq)
+            if (b * SB + tq < bt) apply_pivot(b * SB + tq);
+    }
+    // the sub-block right before this wave's: pivot by pivot, as its owner announces them
+    if (wave > 0 && (wave - 1) * SB < bt) {
+#pragma unroll
+        for (int tq = 0; tq < SB; ++tq) {
+            const int t = (wave - 1) * SB + tq;
+            if (t >= bt) continue;
+            panel_flag_wait(flag, t);
+            apply_pivot(t);
+        }
+    }
+    if (wave * SB < bt) serial_phase(wave, flag);
+    } else {
 #pragma unroll 1                                   // code size: keep the panel inside the I-cache
     for (int b = 0; b < B / SB; ++b) {
         if (b * SB >= bt) continue;                // uniform
-        if (wave == b) {
-#pragma unroll
-            for (int tq = 0; tq < SB; ++tq) {
-                const int t = b * SB + tq;
-                if (t >= bt) continue;
-                // the pivot row at time t: every earlier pivot has been applied, pivot t leaves it alone
-                T wd = pd[tq];
-                if (lane == t) wd = qnan<T>();     // skip j == k (also hides the stale diagonal)
-                T ws = ps[tq];
-                if (j == k0 + t) ws = dorig;
-                const int32_t hwd = HAS_HOPS ? hd[tq] : 0;
-                const int32_t hws = HAS_HOPS ? (j == k0 + t ? hdorig : hs[tq]) : 0;
-                if (valid) {
-                    w_out[(size_t)t * n + j] = ws;                // the snapshot
-                    if (HAS_LAST) at_rows[(size_t)t * n + j] = j == k0 + t ? -1 : lp[tq];
-                    if (HAS_HOPS) wh_out[(size_t)t * n + j] = hws;
-                }
-                if (j == k0 + t) ws = qnan<T>();                  // skip j == k
-                s_dline[t][lane] = wd;
-                s_sline[t][lane] = ws;
-                if (HAS_HOPS) { s_dh[t][lane] = hwd; s_sh[t][lane] = hws; }
-                // column t of this wave's rows: SB independent cross-lane reads first
-                T cv[SB];
-                int32_t ch[SB];
-#pragma unroll
-                for (int q = 0; q < SB; ++q) {
-                    cv[q] = readlane<T>(pd[q], t);
-                    ch[q] = HAS_HOPS ? readlane<int>(hd[q], t) : 0;
-                }
-#pragma unroll
-                for (int q = 0; q < SB; ++q) {
-                    if (q == tq) continue;                        // skip i == k
-                    relax_row(q, cv[q], ch[q], wd, ws, hwd, hws, t);
-                }
-            }
-        }
+        if (wave == b) serial_phase(b, nullptr);
         lds_barrier();
         if (wave > b) {            // earlier rows are past their own pivots: nothing needs them
 #pragma unroll
-            for (int tq = 0; tq < SB; ++tq) {
-                const int t = b * SB + tq;
-                if (t >= bt) continue;
-                const T wd = s_dline[t][lane], ws = s_sline[t][lane];
-                const int32_t hwd = HAS_HOPS ? s_dh[t][lane] : 0, hws = HAS_HOPS ? s_sh[t][lane] : 0;
-                T cv[SB];
-                int32_t ch[SB];
-#pragma unroll
-                for (int q = 0; q < SB; ++q) {
-                    cv[q] = readlane<T>(pd[q], t);
-                    ch[q] = HAS_HOPS ? readlane<int>(hd[q], t) : 0;
-                }
-#pragma unroll
-                for (int q = 0; q < SB; ++q) relax_row(q, cv[q], ch[q], wd, ws, hwd, hws, t);
-            }
+            for (int tq = 0; tq < SB; ++tq)
+                if (b * SB + tq < bt) apply_pivot(b * SB + tq);
         }
+    }
     }
 }
 
@@ -326,9 +388,10 @@ __global__ __launch_bounds__(PANEL_THREADS) void fused_rowpanel(const T *rows, i
 template <typename T, bool HAS_NEXT, bool HAS_HOPS> constexpr int colpanel_lds()
 {
     return B * 64 * (int)sizeof(T) + (HAS_NEXT ? B * 64 * 4 : 0) + B * B * (int)sizeof(T) +
-           (HAS_HOPS ? B * 64 * 4 + B * B * 4 : 0);
+           (HAS_HOPS ? B * 64 * 4 + B * B * 4 : 0) + PANEL_FLAG_BYTES;
 }
-template <typename T, bool HAS_NEXT, bool HAS_LAST, bool HAS_HOPS, bool OWN_D, bool MAXF = false>
+template <typename T, bool HAS_NEXT, bool HAS_LAST, bool HAS_HOPS, bool OWN_D, bool MAXF = false,
+          bool FLAGS = FWX_PANEL_FLAGS != 0>
 __device__ __forceinline__ void colpanel_body(char *smem, int bid, const T *rate, const int32_t *next, int rows,
                                               int n, int row0, int k0, int bt, const T *w, T *ct, int32_t *cnt,
                                               int ct_ld, const int32_t *last, int32_t *at_col,
@@ -376,107 +439,139 @@ __device__ __forceinline__ void colpanel_body(char *smem, int bid, const T *rate
             hdd[q] = (HAS_HOPS && c < bt && lane < bt) ? d_hops[(size_t)c * n + k0 + lane] : 0;
         }
     }
+    if constexpr (FLAGS)
+        panel_flags_init(reinterpret_cast<int *>(smem + colpanel_lds<T, HAS_NEXT, HAS_HOPS>() - PANEL_FLAG_BYTES));
     __syncthreads();
 
+    // the serial phase of this wave's sub-block b (see rowpanel_body)
+    auto serial_phase = [&](int b, int *flag) {
+#pragma unroll
+        for (int tq = 0; tq < SB; ++tq) {
+            const int t = b * SB + tq;
+            if (t >= bt) continue;
+            // ---- the diagonal block: pivot row t at time t (NaN at its own column: skip j == k,
+            // which also hides the stale diagonal entry), then this wave's other rows
+            T wd = T(0);
+            int32_t hwd = 0;
+            if (OWN_D) {
+                wd = pd[tq];
+                if (lane == t) wd = qnan<T>();
+                hwd = HAS_HOPS ? hdd[tq] : 0;
+                s_wd[t][lane] = wd;
+                if (HAS_HOPS) s_wdh[t][lane] = hwd;
+            }
+            // ---- the column lines
+            T c = d[tq];
+            const int32_t cn = nx[tq];
+            const int32_t hc = hd[tq];
+            if (gi == k0 + t) c = qnan<T>();                  // skip i == k
+            s_line[t][lane] = c;
+            if (HAS_NEXT) s_nline[t][lane] = cn;
+            if (HAS_HOPS) s_hline[t][lane] = hc;
+            if (flag) panel_flag_raise(flag, t);
+            if (valid) {
+                ct[(size_t)t * ct_ld + il] = c;
+                if (HAS_NEXT) cnt[(size_t)t * ct_ld + il] = cn;
+                if (HAS_LAST) at_col[(size_t)il * n + k0 + t] = gi == k0 + t ? -1 : lp[tq];
+                if (HAS_HOPS) cht[(size_t)t * ct_ld + il] = hc;
+            }
+            if (OWN_D) {
+                T cv[SB];
+                int32_t chv[SB];
+#pragma unroll
+                for (int q = 0; q < SB; ++q) {
+                    cv[q] = readlane<T>(pd[q], t);
+                    chv[q] = HAS_HOPS ? readlane<int>(hdd[q], t) : 0;
+                }
+#pragma unroll
+                for (int q = 0; q < SB; ++q) {
+                    if (q == tq) continue;                    // skip i == k
+                    const T cd = cv[q] * wd;
+                    if (MAXF) { pd[q] = fmax_t(pd[q], cd); continue; }
+                    const bool ud = pd[q] < cd;
+                    pd[q] = ud ? cd : pd[q];
+                    if (HAS_HOPS) hdd[q] = ud ? (int32_t)((uint32_t)chv[q] + (uint32_t)hwd) : hdd[q];
+                }
+            }
+#pragma unroll
+            for (int q = 0; q < SB; ++q) {
+                if (q == tq) continue;                        // skip j == k
+                // D_t[k0+t][k0 + b*SB + q]: lane b*SB+q of the pivot row just published
+                const T wv = OWN_D ? readlane<T>(wd, b * SB + q) : s_wd[t][b * SB + q];
+                const int32_t wvh = !HAS_HOPS ? 0 : OWN_D ? readlane<int>(hwd, b * SB + q) : s_wdh[t][b * SB + q];
+                const T cand = c * wv;
+                if (MAXF) { d[q] = fmax_t(d[q], cand); continue; }
+                const bool up = d[q] < cand;
+                d[q] = up ? cand : d[q];
+                if (HAS_NEXT) nx[q] = up ? cn : nx[q];
+                if (HAS_LAST) lp[q] = up ? k0 + t : lp[q];
+                if (HAS_HOPS) hd[q] = up ? (int32_t)((uint32_t)hc + (uint32_t)wvh) : hd[q];
+            }
+        }
+    };
+    // published pivot t onto this wave's lines (columns left of the sub-block have been snapshotted already; rows
+    // above it are past their own pivots too)
+    auto apply_pivot = [&](int t) {
+        if (OWN_D) {
+            const T wd = s_wd[t][lane];
+            const int32_t hwd = HAS_HOPS ? s_wdh[t][lane] : 0;
+#pragma unroll
+            for (int q = 0; q < SB; ++q) {
+                const T cd = readlane<T>(pd[q], t) * wd;
+                if (MAXF) { pd[q] = fmax_t(pd[q], cd); continue; }
+                const int32_t chv = HAS_HOPS ? readlane<int>(hdd[q], t) : 0;
+                const bool ud = pd[q] < cd;
+                pd[q] = ud ? cd : pd[q];
+                if (HAS_HOPS) hdd[q] = ud ? (int32_t)((uint32_t)chv + (uint32_t)hwd) : hdd[q];
+            }
+        }
+        const T c = s_line[t][lane];
+        const int32_t cn = HAS_NEXT ? s_nline[t][lane] : 0;
+        const int32_t hc = HAS_HOPS ? s_hline[t][lane] : 0;
+#pragma unroll
+        for (int q = 0; q < SB; ++q) {
+            const T cand = c * s_wd[t][wave * SB + q];
+            if (MAXF) { d[q] = fmax_t(d[q], cand); continue; }
+            const bool up = d[q] < cand;
+            d[q] = up ? cand : d[q];
+            if (HAS_NEXT) nx[q] = up ? cn : nx[q];
+            if (HAS_LAST) lp[q] = up ? k0 + t : lp[q];
+            if (HAS_HOPS) hd[q] = up ? (int32_t)((uint32_t)hc + (uint32_t)s_wdh[t][wave * SB + q]) : hd[q];
+        }
+    };
+    if constexpr (FLAGS) {
+    int *flag = reinterpret_cast<int *>(smem + colpanel_lds<T, HAS_NEXT, HAS_HOPS>() - PANEL_FLAG_BYTES);
+    // (the flags were initialised before the barrier above)
+#pragma unroll 1
+    for (int b = 0; b + 1 < wave; ++b) {
+        if (b * SB >= bt) break;                   // uniform
+        panel_flag_wait(flag, min(b * SB + SB, bt) - 1);
+#pragma unroll
+        for (int tq = 0; tq < SB; ++tq)
+            if (b * SB + tq < bt) apply_pivot(b * SB + tq);
+    }
+    if (wave > 0 && (wave - 1) * SB < bt) {
+#pragma unroll
+        for (int tq = 0; tq < SB; ++tq) {
+            const int t = (wave - 1) * SB + tq;
+            if (t >= bt) continue;
+            panel_flag_wait(flag, t);
+            apply_pivot(t);
+        }
+    }
+    if (wave * SB < bt) serial_phase(wave, flag);
+    } else {
 #pragma unroll 1
     for (int b = 0; b < B / SB; ++b) {
         if (b * SB >= bt) continue;
-        if (wave == b) {
-#pragma unroll
-            for (int tq = 0; tq < SB; ++tq) {
-                const int t = b * SB + tq;
-                if (t >= bt) continue;
-                // ---- the diagonal block: pivot row t at time t (NaN at its own column: skip j == k,
-                // which also hides the stale diagonal entry), then this wave's other rows
-                T wd = T(0);
-                int32_t hwd = 0;
-                if (OWN_D) {
-                    wd = pd[tq];
-                    if (lane == t) wd = qnan<T>();
-                    hwd = HAS_HOPS ? hdd[tq] : 0;
-                    s_wd[t][lane] = wd;
-                    if (HAS_HOPS) s_wdh[t][lane] = hwd;
-                    T cv[SB];
-                    int32_t chv[SB];
-#pragma unroll
-                    for (int q = 0; q < SB; ++q) {
-                        cv[q] = readlane<T>(pd[q], t);
-                        chv[q] = HAS_HOPS ? readlane<int>(hdd[q], t) : 0;
-                    }
-#pragma unroll
-                    for (int q = 0; q < SB; ++q) {
-                        if (q == tq) continue;                    // skip i == k
-                        const T cd = cv[q] * wd;
-                        if (MAXF) { pd[q] = fmax_t(pd[q], cd); continue; }
-                        const bool ud = pd[q] < cd;
-                        pd[q] = ud ? cd : pd[q];
-                        if (HAS_HOPS) hdd[q] = ud ? (int32_t)((uint32_t)chv[q] + (uint32_t)hwd) : hdd[q];
-                    }
-                }
-                // ---- the column lines
-                T c = d[tq];
-                const int32_t cn = nx[tq];
-                const int32_t hc = hd[tq];
-                if (gi == k0 + t) c = qnan<T>();                  // skip i == k
-                s_line[t][lane] = c;
-                if (HAS_NEXT) s_nline[t][lane] = cn;
-                if (HAS_HOPS) s_hline[t][lane] = hc;
-                if (valid) {
-                    ct[(size_t)t * ct_ld + il] = c;
-                    if (HAS_NEXT) cnt[(size_t)t * ct_ld + il] = cn;
-                    if (HAS_LAST) at_col[(size_t)il * n + k0 + t] = gi == k0 + t ? -1 : lp[tq];
-                    if (HAS_HOPS) cht[(size_t)t * ct_ld + il] = hc;
-                }
-#pragma unroll
-                for (int q = 0; q < SB; ++q) {
-                    if (q == tq) continue;                        // skip j == k
-                    // D_t[k0+t][k0 + b*SB + q]: lane b*SB+q of the pivot row just published
-                    const T wv = OWN_D ? readlane<T>(wd, b * SB + q) : s_wd[t][b * SB + q];
-                    const int32_t wvh = !HAS_HOPS ? 0 : OWN_D ? readlane<int>(hwd, b * SB + q) : s_wdh[t][b * SB + q];
-                    const T cand = c * wv;
-                    if (MAXF) { d[q] = fmax_t(d[q], cand); continue; }
-                    const bool up = d[q] < cand;
-                    d[q] = up ? cand : d[q];
-                    if (HAS_NEXT) nx[q] = up ? cn : nx[q];
-                    if (HAS_LAST) lp[q] = up ? k0 + t : lp[q];
-                    if (HAS_HOPS) hd[q] = up ? (int32_t)((uint32_t)hc + (uint32_t)wvh) : hd[q];
-                }
-            }
-        }
+        if (wave == b) serial_phase(b, nullptr);
         lds_barrier();
-        if (wave > b) {            // columns left of the sub-block have been snapshotted already
+        if (wave > b) {
 #pragma unroll
-            for (int tq = 0; tq < SB; ++tq) {
-                const int t = b * SB + tq;
-                if (t >= bt) continue;
-                if (OWN_D) {       // rows above the sub-block are past their own pivots too
-                    const T wd = s_wd[t][lane];
-                    const int32_t hwd = HAS_HOPS ? s_wdh[t][lane] : 0;
-#pragma unroll
-                    for (int q = 0; q < SB; ++q) {
-                        const T cd = readlane<T>(pd[q], t) * wd;
-                        if (MAXF) { pd[q] = fmax_t(pd[q], cd); continue; }
-                        const int32_t chv = HAS_HOPS ? readlane<int>(hdd[q], t) : 0;
-                        const bool ud = pd[q] < cd;
-                        pd[q] = ud ? cd : pd[q];
-                        if (HAS_HOPS) hdd[q] = ud ? (int32_t)((uint32_t)chv + (uint32_t)hwd) : hdd[q];
-                    }
-                }
-                const T c = s_line[t][lane];
-                const int32_t cn = HAS_NEXT ? s_nline[t][lane] : 0;
-                const int32_t hc = HAS_HOPS ? s_hline[t][lane] : 0;
-#pragma unroll
-                for (int q = 0; q < SB; ++q) {
-                    const T cand = c * s_wd[t][wave * SB + q];
-                    if (MAXF) { d[q] = fmax_t(d[q], cand); continue; }
-                    const bool up = d[q] < cand;
-                    d[q] = up ? cand : d[q];
-                    if (HAS_NEXT) nx[q] = up ? cn : nx[q];
-                    if (HAS_LAST) lp[q] = up ? k0 + t : lp[q];
-                    if (HAS_HOPS) hd[q] = up ? (int32_t)((uint32_t)hc + (uint32_t)s_wdh[t][wave * SB + q]) : hd[q];
-                }
-            }
+            for (int tq = 0; tq < SB; ++tq)
+                if (b * SB + tq < bt) apply_pivot(b * SB + tq);
         }
+    }
     }
 }
 
@@ -505,13 +600,16 @@ __global__ __launch_bounds__(PANEL_THREADS) void fused_panels(int row_wgs, const
 {
     constexpr int RL = rowpanel_lds<T, HAS_HOPS>(), CL = colpanel_lds<T, HAS_NEXT, HAS_HOPS>();
     __shared__ __attribute__((aligned(16))) char smem[RL > CL ? RL : CL];
+    // flags everywhere but the f32 max-form (rates only, inside the domain) panels: their pivots are so cheap that
+    // the polling costs more than the overlap gives (N = 1024: 0.47 -> 0.48 ms; with next-hops 0.68 -> 0.61)
+    constexpr bool FL = FWX_PANEL_FLAGS != 0 && !(MAXF && sizeof(T) == 4);
     const size_t prow = (size_t)k0 * n;            // the pivot rows
     if ((int)blockIdx.x < row_wgs) {               // workgroup-uniform
-        rowpanel_body<T, HAS_LAST, HAS_HOPS, MAXF>(smem, (int)blockIdx.x, rate + prow, n, k0, bt, w_out,
+        rowpanel_body<T, HAS_LAST, HAS_HOPS, MAXF, FL>(smem, (int)blockIdx.x, rate + prow, n, k0, bt, w_out,
                                              HAS_LAST ? last + prow : nullptr, HAS_LAST ? at_row + prow : nullptr,
                                              HAS_HOPS ? hops + prow : nullptr, wh_out);
     } else {
-        colpanel_body<T, HAS_NEXT, HAS_LAST, HAS_HOPS, true, MAXF>(smem, (int)blockIdx.x - row_wgs, rate, next, n, n, 0,
+        colpanel_body<T, HAS_NEXT, HAS_LAST, HAS_HOPS, true, MAXF, FL>(smem, (int)blockIdx.x - row_wgs, rate, next, n, n, 0,
                                                              k0, bt, nullptr, ct, cnt, ct_ld, last, at_col, hops,
                                                              nullptr, cht, rate + prow,
                                                              HAS_HOPS ? hops + prow : nullptr);
