@@ -272,6 +272,8 @@ __device__ __forceinline__ void rowpanel_body(char *smem, int bid, const T *rows
     // the serial phase of this wave's sub-block b: pivot by pivot, each line published (and, with flags, announced)
     // before the wave's other rows take the pivot
     auto serial_phase = [&](int b, int *flag) {
+        T snap_v[SB];                                  // the snapshots: stored after the chain's four steps
+        int32_t snap_l[SB], snap_h[SB];
 #pragma unroll
         for (int tq = 0; tq < SB; ++tq) {
             const int t = b * SB + tq;
@@ -289,11 +291,9 @@ __device__ __forceinline__ void rowpanel_body(char *smem, int bid, const T *rows
             s_sline[t][lane] = ws;
             if (HAS_HOPS) { s_dh[t][lane] = hwd; s_sh[t][lane] = hws; }
             if (flag) panel_flag_raise(flag, t);
-            if (valid) {
-                w_out[(size_t)t * n + j] = snap;
-                if (HAS_LAST) at_rows[(size_t)t * n + j] = j == k0 + t ? -1 : lp[tq];
-                if (HAS_HOPS) wh_out[(size_t)t * n + j] = hws;
-            }
+            snap_v[tq] = snap;
+            snap_l[tq] = HAS_LAST ? (j == k0 + t ? -1 : lp[tq]) : 0;
+            snap_h[tq] = hws;
             // column t of this wave's rows: SB independent cross-lane reads first
             T cv[SB];
             int32_t ch[SB];
@@ -306,6 +306,16 @@ __device__ __forceinline__ void rowpanel_body(char *smem, int bid, const T *rows
             for (int q = 0; q < SB; ++q) {
                 if (q == tq) continue;                        // skip i == k
                 relax_row(q, cv[q], ch[q], wd, ws, hwd, hws, t);
+            }
+        }
+        if (valid) {
+#pragma unroll
+            for (int tq = 0; tq < SB; ++tq) {
+                const int t = b * SB + tq;
+                if (t >= bt) continue;
+                w_out[(size_t)t * n + j] = snap_v[tq];
+                if (HAS_LAST) at_rows[(size_t)t * n + j] = snap_l[tq];
+                if (HAS_HOPS) wh_out[(size_t)t * n + j] = snap_h[tq];
             }
         }
     };
@@ -445,6 +455,8 @@ __device__ __forceinline__ void colpanel_body(char *smem, int bid, const T *rate
 
     // the serial phase of this wave's sub-block b (see rowpanel_body)
     auto serial_phase = [&](int b, int *flag) {
+        T snap_c[SB];                                  // the snapshots: stored after the chain's four steps
+        int32_t snap_n[SB], snap_l[SB], snap_h[SB];
 #pragma unroll
         for (int tq = 0; tq < SB; ++tq) {
             const int t = b * SB + tq;
@@ -469,12 +481,10 @@ __device__ __forceinline__ void colpanel_body(char *smem, int bid, const T *rate
             if (HAS_NEXT) s_nline[t][lane] = cn;
             if (HAS_HOPS) s_hline[t][lane] = hc;
             if (flag) panel_flag_raise(flag, t);
-            if (valid) {
-                ct[(size_t)t * ct_ld + il] = c;
-                if (HAS_NEXT) cnt[(size_t)t * ct_ld + il] = cn;
-                if (HAS_LAST) at_col[(size_t)il * n + k0 + t] = gi == k0 + t ? -1 : lp[tq];
-                if (HAS_HOPS) cht[(size_t)t * ct_ld + il] = hc;
-            }
+            snap_c[tq] = c;
+            snap_n[tq] = cn;
+            snap_l[tq] = HAS_LAST ? (gi == k0 + t ? -1 : lp[tq]) : 0;
+            snap_h[tq] = hc;
             if (OWN_D) {
                 T cv[SB];
                 int32_t chv[SB];
@@ -506,6 +516,17 @@ __device__ __forceinline__ void colpanel_body(char *smem, int bid, const T *rate
                 if (HAS_NEXT) nx[q] = up ? cn : nx[q];
                 if (HAS_LAST) lp[q] = up ? k0 + t : lp[q];
                 if (HAS_HOPS) hd[q] = up ? (int32_t)((uint32_t)hc + (uint32_t)wvh) : hd[q];
+            }
+        }
+        if (valid) {
+#pragma unroll
+            for (int tq = 0; tq < SB; ++tq) {
+                const int t = b * SB + tq;
+                if (t >= bt) continue;
+                ct[(size_t)t * ct_ld + il] = snap_c[tq];
+                if (HAS_NEXT) cnt[(size_t)t * ct_ld + il] = snap_n[tq];
+                if (HAS_LAST) at_col[(size_t)il * n + k0 + t] = snap_l[tq];
+                if (HAS_HOPS) cht[(size_t)t * ct_ld + il] = snap_h[tq];
             }
         }
     };
