@@ -51,4 +51,7 @@ def main():
 
 
 if __name__ == "__main__":
-    main()
+    try:
+        main()
+    except BrokenPipeError:          # piped into `head`
+        pass
