@@ -108,8 +108,9 @@ struct FusedCols {
     static FusedCols except(int lo, int hi) { FusedCols c; c.skip_lo = lo; c.skip_hi = hi; return c; }
 };
 // True if the main launch these arguments select leaves no room for a panel workgroup when ONE of its own
-// workgroups retires (f32 with next-hops on 64 x 64 tiles: four workgroups per CU at 128 registers free 128 per
-// SIMD, a panel workgroup is four waves per SIMD at 48): the panels of the look-ahead chain then wait for the
+// workgroups retires (f32 with next-hops on 64 x 64 tiles: four workgroups per CU at 128 registers and 36.5 KB of
+// LDS each -- the hole one of them leaves is smaller than a panel workgroup's 48 KB, and before round 4's panel
+// rewrite also than its 4 x 48 registers per SIMD): the panels of the look-ahead chain then wait for the
 // launch's tail.  A double-pass schedule issues such a main launch as two halves -- the first one's tail lets the
 // chain's first panel in, the second one's the other (fused_range in fwx_api.hip, profiles/r04_timeline_*).
 template <typename T> bool fused_main_starves_panels(const FusedArgs<T> &a);
