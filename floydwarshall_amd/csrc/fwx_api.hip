@@ -216,7 +216,10 @@ int fused_range(T *rate, int32_t *next, int32_t *hops, int n, int k_begin, int k
         };
         auto panels4 = [&](int q, hipStream_t st) {
             bind4(q, 1);
-            return fwx::launch_fused_panels<T>(a, w4 + (size_t)set_of(q) * Bq * n, wh_of(q), st);
+            a.side = st != s;                       // beside a main launch: the panel kernels may pick a leaner form
+            const hipError_t e = fwx::launch_fused_panels<T>(a, w4 + (size_t)set_of(q) * Bq * n, wh_of(q), st);
+            a.side = false;
+            return e;
         };
         // pivots of `blocks` blocks from block q onto the rows [lo, hi) (all columns) and the columns
         // [lo, hi) (the other rows)
@@ -249,12 +252,13 @@ int fused_range(T *rate, int32_t *next, int32_t *hops, int n, int k_begin, int k
                 }
                 FWX_HIP(hipEventRecord(side.panel_done, side.s));
                 bind4(q, 2);
-                // a main launch whose retiring workgroups leave no room for a panel workgroup goes out as two
-                // halves: the chain's panels get in at each half's tail instead of at the end of the whole launch
-                // (N = 8192 + next-hops: gap between main launches 77 -> 20 us; FWX_SPLIT_MAIN=0: A/B)
+                // a main launch whose retiring workgroups leave no room for a panel workgroup -- and for which the panel
+                // kernels have no form that fits the hole (the path trace) -- goes out as two halves: the chain's
+                // panels get in at each half's tail instead of at the end of the whole launch (N = 8192 + next-hops:
+                // gap between main launches 77 -> 20 us; FWX_SPLIT_MAIN=0: A/B)
                 static const bool split_ok = [] { const char *e = getenv("FWX_SPLIT_MAIN"); return !(e && *e == '0'); }();
                 const int h = n / 2 / 128 * 128;
-                if (split_ok && h > 0 && fwx::fused_main_starves_panels<T>(a)) {
+                if (split_ok && h > 0 && fwx::fused_main_starves_panels<T>(a) && !fwx::fused_panels_fit_beside<T>(a)) {
                     FWX_HIP(fwx::launch_fused_main<T>(a, 0, h, s, x_lo, x_hi, fwx::FusedCols::except(x_lo, x_hi)));
                     FWX_HIP(fwx::launch_fused_main<T>(a, h, n, s, x_lo, x_hi, fwx::FusedCols::except(x_lo, x_hi)));
                 } else {

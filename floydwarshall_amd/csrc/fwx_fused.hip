@@ -395,33 +395,41 @@ __global__ __launch_bounds__(PANEL_THREADS) void fused_rowpanel(const T *rows, i
 // hops d_hops; lanes = block columns, exactly as fused_rowpanel does) TOGETHER with its column
 // lines, instead of reading the block columns of a finished snapshot panel W: the column panel then
 // does not depend on the row panel of its pass, and the two can share one launch (fused_panels).
-template <typename T, bool HAS_NEXT, bool HAS_HOPS> constexpr int colpanel_lds()
+// RW = rows per column workgroup: 64, or 32 -- half the lanes mirror the other half, twice the workgroups, and the
+// lines of the published pivot columns are 32 wide: 32.25 KB of LDS instead of 48.25 (f32 with next-hops), which
+// fits the hole ONE retiring workgroup of the 64 x 64 fused_main_arg leaves (LDS is handed out in one piece:
+// profiles/r04_panels_32_rows.txt)
+template <typename T, bool HAS_NEXT, bool HAS_HOPS, int RW = 64> constexpr int colpanel_lds()
 {
-    return B * 64 * (int)sizeof(T) + (HAS_NEXT ? B * 64 * 4 : 0) + B * B * (int)sizeof(T) +
-           (HAS_HOPS ? B * 64 * 4 + B * B * 4 : 0) + PANEL_FLAG_BYTES;
+    return B * RW * (int)sizeof(T) + (HAS_NEXT ? B * RW * 4 : 0) + B * B * (int)sizeof(T) +
+           (HAS_HOPS ? B * RW * 4 + B * B * 4 : 0) + PANEL_FLAG_BYTES;
 }
 template <typename T, bool HAS_NEXT, bool HAS_LAST, bool HAS_HOPS, bool OWN_D, bool MAXF = false,
-          bool FLAGS = FWX_PANEL_FLAGS != 0>
+          bool FLAGS = FWX_PANEL_FLAGS != 0, int RW = 64>
 __device__ __forceinline__ void colpanel_body(char *smem, int bid, const T *rate, const int32_t *next, int rows,
                                               int n, int row0, int k0, int bt, const T *w, T *ct, int32_t *cnt,
                                               int ct_ld, const int32_t *last, int32_t *at_col,
                                               const int32_t *hops, const int32_t *wh, int32_t *cht,
                                               const T *d_rows, const int32_t *d_hops)
 {
-    typedef T line_t[64];
-    typedef int32_t iline_t[64];
+    static_assert(RW == 64 || RW == 32, "rows per column workgroup");
+    typedef T line_t[RW];                          // lines of the workgroup's rows
+    typedef int32_t iline_t[RW];
+    typedef T dline_t[64];                         // lines of the diagonal block
+    typedef int32_t idline_t[64];
     __builtin_amdgcn_s_setprio(3);                 // the panels ARE the serial chain: first in line on their SIMD
     line_t *s_line = (line_t *)smem;               // published pivot columns (time-t, NaN at i==k)
-    line_t *s_wd = s_line + B;                     // s_wd[t][c] = D_t[k0+t][k0+c]
+    dline_t *s_wd = (dline_t *)(s_line + B);       // s_wd[t][c] = D_t[k0+t][k0+c]
     iline_t *s_nline = (iline_t *)(s_wd + B);      // (HAS_NEXT)
     iline_t *s_hline = s_nline + (HAS_NEXT ? B : 0);   // hops of the published pivot columns (HAS_HOPS)
-    iline_t *s_wdh = s_hline + B;                  // hops of D_t[k0+t][k0+c]
+    idline_t *s_wdh = (idline_t *)(s_hline + B);   // hops of D_t[k0+t][k0+c]
     static_assert(B == 64, "s_wd rows are 64 wide");
     const int lane = threadIdx.x & 63;
+    const int rl = lane & (RW - 1);                // this lane's row of the workgroup (lanes RW.. mirror 0..RW-1)
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int il = bid * 64 + lane;
-    const bool valid = il < rows;
-    const int ic = valid ? il : rows - 1;
+    const int il = bid * RW + rl;
+    const bool valid = il < rows && lane < RW;     // (the mirror lanes compute the same values and store nothing)
+    const int ic = il < rows ? il : rows - 1;
     const int gi = row0 + ic;
 
     if (!OWN_D) {
@@ -450,7 +458,7 @@ __device__ __forceinline__ void colpanel_body(char *smem, int bid, const T *rate
         }
     }
     if constexpr (FLAGS)
-        panel_flags_init(reinterpret_cast<int *>(smem + colpanel_lds<T, HAS_NEXT, HAS_HOPS>() - PANEL_FLAG_BYTES));
+        panel_flags_init(reinterpret_cast<int *>(smem + colpanel_lds<T, HAS_NEXT, HAS_HOPS, RW>() - PANEL_FLAG_BYTES));
     __syncthreads();
 
     // the serial phase of this wave's sub-block b (see rowpanel_body)
@@ -477,9 +485,9 @@ __device__ __forceinline__ void colpanel_body(char *smem, int bid, const T *rate
             const int32_t cn = nx[tq];
             const int32_t hc = hd[tq];
             if (gi == k0 + t) c = qnan<T>();                  // skip i == k
-            s_line[t][lane] = c;
-            if (HAS_NEXT) s_nline[t][lane] = cn;
-            if (HAS_HOPS) s_hline[t][lane] = hc;
+            s_line[t][rl] = c;
+            if (HAS_NEXT) s_nline[t][rl] = cn;
+            if (HAS_HOPS) s_hline[t][rl] = hc;
             if (flag) panel_flag_raise(flag, t);
             snap_c[tq] = c;
             snap_n[tq] = cn;
@@ -546,9 +554,9 @@ __device__ __forceinline__ void colpanel_body(char *smem, int bid, const T *rate
                 if (HAS_HOPS) hdd[q] = ud ? (int32_t)((uint32_t)chv + (uint32_t)hwd) : hdd[q];
             }
         }
-        const T c = s_line[t][lane];
-        const int32_t cn = HAS_NEXT ? s_nline[t][lane] : 0;
-        const int32_t hc = HAS_HOPS ? s_hline[t][lane] : 0;
+        const T c = s_line[t][rl];
+        const int32_t cn = HAS_NEXT ? s_nline[t][rl] : 0;
+        const int32_t hc = HAS_HOPS ? s_hline[t][rl] : 0;
 #pragma unroll
         for (int q = 0; q < SB; ++q) {
             const T cand = c * s_wd[t][wave * SB + q];
@@ -561,7 +569,7 @@ __device__ __forceinline__ void colpanel_body(char *smem, int bid, const T *rate
         }
     };
     if constexpr (FLAGS) {
-    int *flag = reinterpret_cast<int *>(smem + colpanel_lds<T, HAS_NEXT, HAS_HOPS>() - PANEL_FLAG_BYTES);
+    int *flag = reinterpret_cast<int *>(smem + colpanel_lds<T, HAS_NEXT, HAS_HOPS, RW>() - PANEL_FLAG_BYTES);
     // (the flags were initialised before the barrier above)
 #pragma unroll 1
     for (int b = 0; b + 1 < wave; ++b) {
@@ -645,13 +653,14 @@ __global__ __launch_bounds__(PANEL_THREADS) void fused_panels(int row_wgs, const
 // main grid's tail (772 us beside the main launch against 30 us alone, gpurun_out/r03_final_prof_next),
 // and with two passes per main launch the side chain -- two panels per pair -- then ends after it.
 // (amdgpu_num_vgpr counts HALF the unified register file of gfx950: 24 -> 48.)
-template <bool HAS_LAST>
+// RW = 32: column workgroups of 32 rows (see colpanel_lds), twice as many -- 32.25 KB of LDS per workgroup
+template <bool HAS_LAST, int RW = 64>
 __global__ __launch_bounds__(PANEL_THREADS) __attribute__((amdgpu_num_vgpr(24)))
 void fused_panels_next_f32(int row_wgs, const float *rate, const int32_t *next, int n, int k0, int bt, float *w_out,
                            float *ct, int32_t *cnt, int ct_ld, const int32_t *last, int32_t *at_row,
                            int32_t *at_col)
 {
-    constexpr int RL = rowpanel_lds<float, false>(), CL = colpanel_lds<float, true, false>();
+    constexpr int RL = rowpanel_lds<float, false>(), CL = colpanel_lds<float, true, false, RW>();
     __shared__ __attribute__((aligned(16))) char smem[RL > CL ? RL : CL];
     const size_t prow = (size_t)k0 * n;
     if ((int)blockIdx.x < row_wgs)                 // workgroup-uniform
@@ -659,9 +668,9 @@ void fused_panels_next_f32(int row_wgs, const float *rate, const int32_t *next, 
                                                      HAS_LAST ? last + prow : nullptr,
                                                      HAS_LAST ? at_row + prow : nullptr, nullptr, nullptr);
     else
-        colpanel_body<float, true, HAS_LAST, false, true, false>(smem, (int)blockIdx.x - row_wgs, rate, next, n, n, 0,
-                                                                 k0, bt, nullptr, ct, cnt, ct_ld, last, at_col,
-                                                                 nullptr, nullptr, nullptr, rate + prow, nullptr);
+        colpanel_body<float, true, HAS_LAST, false, true, false, FWX_PANEL_FLAGS != 0, RW>(
+            smem, (int)blockIdx.x - row_wgs, rate, next, n, n, 0, k0, bt, nullptr, ct, cnt, ct_ld, last, at_col,
+            nullptr, nullptr, nullptr, rate + prow, nullptr);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -2270,6 +2279,17 @@ template <> bool fused_main_starves_panels<float>(const FusedArgs<float> &a)
     return a.nonneg && !a.updates && a.next && small_tiles_arg(a.n, a.rows);
 }
 template <> bool fused_main_starves_panels<double>(const FusedArgs<double> &) { return false; }
+static bool panels_32_rows_enabled()
+{
+    static const bool on = [] { const char *e = getenv("FWX_PANELS_32_ROWS"); return !(e && *e == '0'); }();
+    static const bool tight = [] { const char *e = getenv("FWX_PANELS_TIGHT"); return !(e && *e == '0'); }();
+    return on && tight;
+}
+template <> bool fused_panels_fit_beside<float>(const FusedArgs<float> &a)
+{
+    return panels_32_rows_enabled() && a.next && !a.hops && !a.plog.last && fused_main_starves_panels(a);
+}
+template <> bool fused_panels_fit_beside<double>(const FusedArgs<double> &) { return false; }
 
 // f32, rates only, no update counting, domain verified by the caller: the max3 kernel.
 static bool launch_max_form(const FusedArgs<float> &a, dim3 grid, dim3 block, int skip_lo,
@@ -2555,6 +2575,15 @@ hipError_t launch_fused_panels(const FusedArgs<T> &a, T *w_out, int32_t *wh_out,
     // f32 with next-hops, no hops: the form that fits beside two fused_main_arg workgroups (FWX_PANELS_TIGHT=0: A/B)
     static const bool tight = [] { const char *e = getenv("FWX_PANELS_TIGHT"); return !(e && *e == '0'); }();
     if constexpr (sizeof(T) == 4) {
+        // (a.side:) beside a main launch whose retiring workgroups leave 36.5 KB holes (the 64 x 64 fused_main_arg): column
+        // workgroups of 32 rows, 32.25 KB each (FWX_PANELS_32_ROWS=0: A/B).  With the path trace the kernel needs 36
+        // registers, 4 x 40 > the 128 a retiring main workgroup frees: no point, the 64-row form stays
+        if (a.side && fused_panels_fit_beside(a)) {
+            const dim3 g32((unsigned)(row_wgs + (a.n + 31) / 32));
+            hipLaunchKernelGGL((fused_panels_next_f32<false, 32>), g32, block, 0, s, row_wgs, a.rate, a.next, a.n, a.k0,
+                               a.bt, w_out, a.ct, a.cnt, a.ct_ld, nullptr, nullptr, nullptr);
+            return hipGetLastError();
+        }
         if (tight && a.next && !a.hops) {
             if (a.plog.last)
                 hipLaunchKernelGGL(fused_panels_next_f32<true>, grid, block, 0, s, row_wgs, a.rate, a.next, a.n, a.k0,

@@ -80,7 +80,8 @@ template <typename T> struct FusedArgs {
                            // and not NaN and, if next is carried, no positive rate lacks a path:
                            // the max-form kernels may run (f32: rates only, or rates + next + trace)
     PathLog plog = PathLog();   // path trace (needs next): rows x n like rate / next, LOCAL rows
-    bool side = false;     // launch_fused_main: a launch of the look-ahead chain beside a main launch (the next
+    bool side = false;     // launch_fused_panels: launched beside a main launch (may pick a form that fits its holes);
+                           // launch_fused_main: a launch of the look-ahead chain beside a main launch (the next
                            // blocks' rows and columns) -- its waves run at raised priority (s_setprio 2; the
                            // panel kernels always run at 3), because the chain, not the sweep, bounds mid sizes
 };
@@ -114,6 +115,10 @@ struct FusedCols {
 // launch's tail.  A double-pass schedule issues such a main launch as two halves -- the first one's tail lets the
 // chain's first panel in, the second one's the other (fused_range in fwx_api.hip, profiles/r04_timeline_*).
 template <typename T> bool fused_main_starves_panels(const FusedArgs<T> &a);
+// ... unless launch_fused_panels has a form for these arguments that fits the hole (a.side set: f32 with next-hops,
+// no trace, no hops -- column workgroups of 32 rows, 32.25 KB of LDS and 32 registers): then the main launch stays
+// whole and the chain runs beside it.
+template <typename T> bool fused_panels_fit_beside(const FusedArgs<T> &a);
 template <typename T>
 hipError_t launch_fused_main(const FusedArgs<T> &a, int r_lo, int r_hi, hipStream_t s,
                              int skip_lo = 0, int skip_hi = 0, FusedCols cols = FusedCols());
