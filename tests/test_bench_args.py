@@ -200,3 +200,12 @@ def test_after_the_line_is_printed_a_hung_final_barrier_only_ends_the_process():
             break
         time.sleep(0.1)
     assert codes == [0] and out.getvalue() == ""
+
+
+def test_digest_of_row_slabs_equals_the_digest_of_the_matrix():
+    """run_dist digests the ranks' slabs in row order instead of concatenating a 1 GiB matrix: same digest."""
+    import numpy as np
+    import bench
+    a = np.random.default_rng(5).random((37, 11)).astype(np.float32)
+    assert bench.digest([a[:5], a[5:20], a[20:]]) == bench.digest(a)
+    assert bench.digest([a[:5], a[5:20], a[20:36]]) != bench.digest(a)
