@@ -92,7 +92,10 @@ constexpr int kDoublePassMinN = 6144;    // FWX_DOUBLE_PASS_MIN_N overrides
 // ... and with next-hops (the arg kernels; + trace, + hops), f32 only: FWX_DOUBLE_PASS_NEXT_MIN_N overrides.
 // (f64: the two-pass fused_main_arg_f64 is SLOWER than two launches, N = 16384 + next 486 -> 499 ms on
 // one box -- tools/runs/r03_run33.sh --, so f64 stays on the single pass unless the variable asks)
-constexpr int kDoublePassNextMinN = 8192;
+// (round 4, after the panel flags and the 32-row column panels: tools/runs/r04_run42.sh, single / double pass, ms:
+//  + next 4096 5.8 / 6.0, 5120 9.9 / 9.7, 6144 16.2 / 16.0, 7168 24.3 / 23.8; + trace 4096 6.3 / 6.8, 6144 21.0 /
+//  17.9, 7168 32.0 / 26.1 -- the threshold was 8192)
+constexpr int kDoublePassNextMinN = 5120;
 // FWX_LOOKAHEAD_MIN_N / FWX_SYMMETRIC_MIN_N override the thresholds (tests force each schedule at
 // small sizes, tuning runs switch one off with a huge value); read on every solve.
 static int env_threshold(const char *name, int dflt)

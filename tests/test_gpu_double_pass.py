@@ -1,7 +1,7 @@
 """The double-pass schedule (fused_range in csrc/fwx_api.hip): the max-form main kernels (rates only)
 and the arg kernels (rates + next-hops, + path trace, + hops) apply TWO passes = 128 pivots per launch,
 the side stream keeps two passes' worth of panels ahead.  By default from N = 6144 (rates only) and
-N = 8192 (with next-hops) on; FWX_DOUBLE_PASS_MIN_N=0 / FWX_DOUBLE_PASS_NEXT_MIN_N=0 force it here at
+N = 5120 (with next-hops) on; FWX_DOUBLE_PASS_MIN_N=0 / FWX_DOUBLE_PASS_NEXT_MIN_N=0 force it here at
 sizes the oracle solves in seconds: even / odd numbers of 64-blocks, ragged tails, matrix orders that
 are no multiple of the tile, aligned pivot ranges, ties / sparse / overflowing inputs, f32 and f64.
 Bit for bit, exact `_path` lists included."""
