@@ -653,7 +653,10 @@ __global__ __launch_bounds__(PANEL_THREADS) void fused_panels(int row_wgs, const
 // main grid's tail (772 us beside the main launch against 30 us alone, gpurun_out/r03_final_prof_next),
 // and with two passes per main launch the side chain -- two panels per pair -- then ends after it.
 // (amdgpu_num_vgpr counts HALF the unified register file of gfx950: 24 -> 48.)
-// RW = 32: column workgroups of 32 rows (see colpanel_lds), twice as many -- 32.25 KB of LDS per workgroup
+// Since round 4 (flags instead of barriers, snapshot stores after the serial phase) the bodies need 32 / 36
+// registers with or without this cap; the kernel stays as the place where the budget is ENFORCED, and as the
+// carrier of RW = 32: column workgroups of 32 rows (see colpanel_lds), twice as many -- 32.25 KB of LDS and 32
+// registers per workgroup, which fits the hole one retiring workgroup of the 64 x 64 fused_main_arg leaves.
 template <bool HAS_LAST, int RW = 64>
 __global__ __launch_bounds__(PANEL_THREADS) __attribute__((amdgpu_num_vgpr(24)))
 void fused_panels_next_f32(int row_wgs, const float *rate, const int32_t *next, int n, int k0, int bt, float *w_out,
