@@ -10,6 +10,11 @@ uint64_t fwo_relax_mt_f32(int32_t, float *, int32_t *, int32_t *, int32_t, int32
 uint64_t fwo_relax_mt_f64(int32_t, double *, int32_t *, int32_t *, int32_t, int32_t, int32_t);
 int fwo_copy_per_k_f64(int32_t, double *, int32_t *, int32_t *);
 int32_t fwo_follow_path(int32_t, const int32_t *, int32_t, int32_t, int32_t *, int32_t);
+/* oracle/fw_oracle_fast.c: the chunk-pre-check twin and the pivot-tiled form */
+uint64_t fwo_relax_mt_fast_f64(int32_t, double *, int32_t *, int32_t *, int32_t, int32_t, int32_t);
+uint64_t fwo_relax_mt_fast_f32(int32_t, float *, int32_t *, int32_t *, int32_t, int32_t, int32_t);
+int64_t fwo_relax_mt_tiled_f64(int32_t, double *, int32_t *, int32_t *, int32_t, int32_t, int32_t, int32_t);
+int64_t fwo_relax_mt_tiled_f32(int32_t, float *, int32_t *, int32_t *, int32_t, int32_t, int32_t, int32_t);
 
 int main(void)
 {
@@ -57,6 +62,24 @@ int main(void)
         fwo_relax_mt_f64(n, r2, nx2, hp2, 0, n, 5);
         for (size_t q = 0; q < nn; ++q)
             if (r[q] != r2[q] || nx[q] != nx2[q] || hp[q] != hp2[q]) return 5;
+        /* the fast twins against the plain loop's result (r, nx, hp), f64 with next + hops: odd thread counts, a
+         * tile that does not divide n */
+        for (int variant = 0; variant < 2; ++variant) {
+            s = 12345u + n;
+            for (int i = 0; i < n; ++i)
+                for (int j = 0; j < n; ++j) {
+                    s = s * 1664525u + 1013904223u;
+                    double v = i == j ? 0.0 : 0.05 + 0.95 * (s >> 8) / 16777216.0;
+                    if ((s & 63) == 0) v = 0.0;
+                    r2[i * n + j] = v;
+                    nx2[i * n + j] = (v > 0) ? j : -1;
+                    hp2[i * n + j] = v > 0;
+                }
+            if (variant == 0) fwo_relax_mt_fast_f64(n, r2, nx2, hp2, 0, n, 3);
+            else if (fwo_relax_mt_tiled_f64(n, r2, nx2, hp2, 0, n, 3, 5) < 0) return 6;
+            for (size_t q = 0; q < nn; ++q)
+                if (r[q] != r2[q] || nx[q] != nx2[q] || hp[q] != hp2[q]) return 7 + variant;
+        }
         free(r); free(r2); free(f); free(f2); free(nx); free(hp); free(nx2); free(hp2); free(path);
     }
     puts("oracle sanitize ok");

@@ -36,7 +36,7 @@ def test_host_mirror_cpu_code_under_asan_ubsan(tmp_path):
 def test_oracle_c_under_asan_ubsan(tmp_path):
     exe = str(tmp_path / "oracle_sanitize")
     subprocess.run(["gcc", "-std=gnu11", "-Wall", "-Wextra", "-ffp-contract=off", "-pthread"] + SAN +
-                   [os.path.join(ROOT, "oracle", "fw_oracle.c"),
+                   [os.path.join(ROOT, "oracle", "fw_oracle.c"), os.path.join(ROOT, "oracle", "fw_oracle_fast.c"),
                     os.path.join(ROOT, "tests", "native", "oracle_sanitize_main.c"),
                     "-o", exe, "-lpthread"], check=True)
     r = _run(exe)
